@@ -1,0 +1,32 @@
+# Builds everything in-tree (the .so files travel to the GPU box with the snapshot):
+#   ouster_sdk_amd/lib/libouster_hip.so        HIP kernels + C ABI (include/ouster_hip.h), gfx950
+#   ouster_sdk_amd/lib/libouster_core_amd.so   C++ host API (include/ouster/core/*.h) over the C ABI
+#   oracle/_build/libouster_oracle.so          CPU oracle (test infrastructure only)
+HIPCC ?= hipcc
+CXX ?= g++
+LIB := ouster_sdk_amd/lib
+CSRC := ouster_sdk_amd/csrc
+HOST_SRC := $(wildcard $(CSRC)/host/*.cpp)
+HIP_SRC := $(CSRC)/ouster_hip_kernels.hip $(CSRC)/ouster_hip_capi.hip
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result
+CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -I$(CSRC)/host
+
+all: $(LIB)/libouster_hip.so $(LIB)/libouster_core_amd.so oracle
+
+$(LIB)/libouster_hip.so: $(HIP_SRC) $(CSRC)/ouster_hip_dev.h include/ouster_hip.h
+	mkdir -p $(LIB)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+$(LIB)/libouster_core_amd.so: $(HOST_SRC) $(wildcard include/ouster/core/*.h include/ouster/hip/*.h) $(CSRC)/host/host_internal.h $(LIB)/libouster_hip.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -louster_hip -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -C oracle -s
+
+cpptests: $(LIB)/libouster_core_amd.so
+	$(MAKE) -C tests/cpp -s
+
+clean:
+	rm -rf $(LIB) oracle/_build tests/cpp/_build
+
+.PHONY: all oracle clean cpptests

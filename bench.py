@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpoints/s projected (decode + destagger + cartesian), 128x2048 dual return.
+
+A "step" = one pass of the fused hot path over a resident batch of synthetic frames:
+  wire packets (HBM) -> 8 staggered planes + 4 destaggered planes + 2 x XYZ f32 (HBM),
+i.e. FrameBatcher + destagger<T> + XYZLutT<float>::operator() of the reference for every
+frame of the batch (BASELINE.json configs[2]: OS-2-128 2048x128 RNG15_RFL8_NIR8 dual return).
+A "point" is one (pixel, return) with XYZ produced: 524288 per frame.
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by torch.distributed.run, one rank per GPU; frames are independent, so
+ranks shard the batch with no data-path collective ("weak": per-GPU work fixed).  Rank 0
+prints ONE JSON line with the whole-job rate, the roofline of the dominant kernel
+(k_decode, timed with HIP events on its stream) and the CPU baseline (the oracle's
+restatement of the reference loops, timed on this box's host cores, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W, CPP = 128, 2048, 16
+PROFILE = "RNG15_RFL8_NIR8_DUAL"
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# wire layout of the benchmark profile (bit_start, bit_size, upshift) -- parsing.cpp:304-315
+DUAL_LB_BITS = {"RANGE": (0, 15, 3), "FLAGS": (15, 1, 0), "REFLECTIVITY": (16, 8, 0),
+                "NEAR_IR": (24, 8, 4), "RANGE2": (32, 15, 3), "FLAGS2": (47, 1, 0),
+                "REFLECTIVITY2": (48, 8, 0), "WINDOW": (56, 8, 0)}
+DESTAGGERED = ["RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"]
+
+
+def synth_calibration():
+    """OS-2-128 style calibration."""
+    alt = np.linspace(21.0, -21.0, H)
+    az = np.tile(np.array([4.2, 1.4, -1.4, -4.2]), H // 4)
+    shifts = np.round(az / 360.0 * W).astype(np.int32)
+    b2l = np.eye(4)
+    b2l[0, 3] = 13.762
+    l2s = np.array([[-1, 0, 0, 0], [0, -1, 0, 0], [0, 0, 1, 36.18], [0, 0, 0, 1]], dtype=np.float64)
+    return alt, az, shifts, b2l, l2s
+
+
+def synth_packets(n_frames: int, seed: int = 0xDEADBEEF, zero_frac: float = 0.3) -> np.ndarray:
+    """Wire packets of n_frames random dual-return frames, [n, 128, 16640] uint8.
+    Numpy bit packing of the RNG15_RFL8_NIR8_DUAL layout with STANDARD headers
+    (packet header: type u16 | frame_id u16 | init_id u24 | prod_sn u40; column header:
+    timestamp u64 | measurement_id u16 | status u16) -- independent of oracle/ and of the
+    library under test."""
+    col_size = 12 + H * 8
+    pkt_size = 32 + CPP * col_size + 32
+    ppf = W // CPP
+    out = np.zeros((n_frames, ppf, pkt_size), dtype=np.uint8)
+    for f in range(n_frames):
+        rng = np.random.default_rng(seed + f)
+        px = np.zeros((W, H), dtype=np.uint64)  # column major like the wire
+        for name, (start, size, up) in DUAL_LB_BITS.items():
+            v = rng.integers(0, 1 << size, size=(W, H), dtype=np.uint64)
+            if name in ("RANGE", "RANGE2"):
+                v[rng.random((W, H)) < zero_frac] = 0
+            px |= v << np.uint64(start)
+        cols = np.zeros((W, col_size), dtype=np.uint8)
+        cols[:, 0:8] = (1000 + np.arange(W, dtype=np.uint64)).view(np.uint8).reshape(W, 8)
+        cols[:, 8:10] = np.arange(W, dtype=np.uint16).view(np.uint8).reshape(W, 2)
+        cols[:, 10] = 1
+        cols[:, 12:] = px.view(np.uint8).reshape(W, H * 8)
+        out[f, :, 32:32 + CPP * col_size] = cols.reshape(ppf, CPP * col_size)
+        hdr = np.zeros(32, dtype=np.uint8)
+        hdr[0] = 1
+        hdr[2:4] = np.frombuffer(np.uint16((700 + f) & 0xFFFF).tobytes(), np.uint8)
+        hdr[4:7] = [0x56, 0x34, 0x12]
+        hdr[7:12] = [0x55, 0x44, 0x33, 0x22, 0x11]
+        out[f, :, :32] = hdr
+    return out
+
+
+def algorithmic_bytes_per_frame() -> int:
+    """SURVEY.md 8(d), config 3, f32 XYZ, separable LUT tables (no LUT bytes)."""
+    pkts = (W // CPP) * (32 + CPP * (12 + H * 8) + 32)          # 2 129 920
+    planes = H * W * 15                                           # 8 planes, 15 B/px
+    dst = H * W * 10                                              # RANGE,RANGE2,REFL,REFL2
+    xyz = 2 * H * W * 3 * 4                                       # two returns, f32
+    return pkts + planes + dst + xyz                              # 14 974 976
+
+
+def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 12.0):
+    """The oracle's restatement of the reference CPU path on a bounded sample."""
+    from oracle import oracle as O
+    import ctypes as C
+    O.build()
+    cal = O.synthetic_calib(h=H, w=W, profile=PROFILE)
+    pf = cal.packet_format()
+    ldir, lofs = cal.xyz_lut(False)
+    n = pool.shape[0]
+    flat = np.ascontiguousarray(pool)
+    sh = np.ascontiguousarray(shifts, dtype=np.int32)
+    cks = C.c_uint64()
+
+    def run(reps, threads, f64):
+        return O.lib().ora_bench_hot_path(C.byref(pf), 1, flat.ctypes.data, n, W // CPP,
+                                          sh.ctypes.data, ldir.ctypes.data, lofs.ctypes.data,
+                                          int(f64), reps, threads, C.byref(cks))
+
+    t1 = run(1, 1, True)                                   # calibrate
+    reps = max(1, int(target_s / max(t1, 1e-3)))
+    t = run(reps, 1, True)
+    pts = n * reps * H * W * 2
+    cores = os.cpu_count() or 1
+    res = {"value": pts / t / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port",
+           "sample": f"{n} frames x {reps} passes, FrameBatcher(block path)+destagger x4+"
+                     f"cartesianT<double> x2 (the reference's default single-threaded path), "
+                     f"{t:.1f} s"}
+    if cores > 1:  # all host cores, frames in parallel (informational)
+        ta = run(max(1, reps // 2) * min(cores, 8) // 4 + 1, cores, True)
+        ra = max(1, reps // 2) * min(cores, 8) // 4 + 1
+        res["all_cores"] = {"value": n * ra * H * W * 2 / ta / 1e6, "cores": cores}
+    tf = run(max(1, reps // 2), 1, False)
+    res["f32_variant"] = {"value": n * max(1, reps // 2) * H * W * 2 / tf / 1e6, "cores": 1}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--exchange", action="store_true",
+                    help="also time RCCL scatter of packets / gather of XYZ (reported separately)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ouster_sdk_amd.device import HotPath
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    alt, az, shifts, b2l, l2s = synth_calibration()
+    hp = HotPath(PROFILE, H, W, CPP)
+    hp.set_pixel_shift_by_row(shifts)
+    hp.add_lut(b2l, l2s, az, alt)
+
+    pool = synth_packets(args.pool, seed=0xDEADBEEF + 1000 * rank)
+    F = args.frames
+    d_pool = torch.from_numpy(pool).cuda()
+    packets = d_pool.repeat((F + args.pool - 1) // args.pool, 1, 1)[:F].contiguous()
+    out = hp.alloc_outputs(F, destagger=DESTAGGERED, xyz=["RANGE", "RANGE2"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        hp.decode(packets, out)
+    torch.cuda.synchronize()
+    barrier()
+    hp.ctx.timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hp.decode(packets, out)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    kern_ms, n_launch = hp.ctx.timing_read()
+    hp.ctx.timing(False)
+
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    exchange = None
+    if args.exchange and world > 1:
+        # the only real exchange step of the path: rank 0 scatters raw packets, gathers XYZ
+        xyz = out["xyz:RANGE"]
+        torch.cuda.synchronize(); barrier()
+        e0 = time.perf_counter()
+        recv = torch.empty_like(packets)
+        dist.scatter(recv, [packets for _ in range(world)] if rank == 0 else None, src=0)
+        gl = [torch.empty_like(xyz) for _ in range(world)] if rank == 0 else None
+        dist.gather(xyz, gl, dst=0)
+        torch.cuda.synchronize(); barrier()
+        exchange = {"scatter_packets_gather_xyz_ms": (time.perf_counter() - e0) * 1e3}
+
+    points_per_step = F * H * W * 2 * world
+    value = points_per_step * args.steps / elapsed / 1e6
+    bytes_per_launch = algorithmic_bytes_per_frame() * F
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    if rank == 0:
+        line = {
+            "metric": "Mpoints/sec projected (decode+destagger+cartesian), 128x2048 dual-return",
+            "value": round(value, 1), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32+f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: OS-2-128 2048x128 RNG15_RFL8_NIR8_DUAL dual return",
+                       "frames_per_step_per_gpu": F, "points_per_frame": H * W * 2,
+                       "outputs": "8 planes + 4 destaggered planes + 2x XYZ f32 + column headers",
+                       "sharding": f"frames x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_decode<SpecDualLB,64,sep-f32>",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernel_ms_avg": round(kern_ms, 4), "launches_timed": n_launch},
+            "cpu_baseline": None,
+        }
+        if exchange:
+            line["exchange"] = exchange
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(pool, shifts)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,305 @@
+// lidar_frame.h -- LidarFrame, FrameBatcher, destagger.
+//
+// Public surface follows the reference ouster_core/include/ouster/core/lidar_frame.h
+// (LidarFrame :124-821, destagger :917-935, FrameBatcher :966-1145) and
+// ouster_core/include/ouster/core/field.h (Field).  LidarFrame stays a host container of
+// named row-major H x W planes (calloc'd, value semantics); what changes is who fills it:
+// FrameBatcher collects a frame's packets and decodes them on the GPU in one launch,
+// destagger<T>() runs the HIP kernel.  Device-resident, batched variants that avoid the
+// PCIe round trip live in ouster/hip/device_batch.h.
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <queue>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ouster/core/packet.h"
+#include "ouster/core/types.h"
+
+namespace ouster {
+namespace sdk {
+namespace core {
+
+enum class FieldClass { NONE = 0, PIXEL_FIELD = 1, COLUMN_FIELD = 2, PACKET_FIELD = 3, FRAME_FIELD = 4 };
+
+/** Name, element type and extra dimensions of a LidarFrame field (lidar_frame.h:36-74). */
+struct FieldType {
+    std::string name;
+    ChanFieldType element_type = ChanFieldType::VOID;
+    std::vector<size_t> extra_dims;
+    FieldClass field_class = FieldClass::PIXEL_FIELD;
+    FieldType() = default;
+    FieldType(std::string n, ChanFieldType t, std::vector<size_t> extra = {},
+              FieldClass c = FieldClass::PIXEL_FIELD)
+        : name(std::move(n)), element_type(t), extra_dims(std::move(extra)), field_class(c) {}
+    bool operator==(const FieldType& o) const {
+        return name == o.name && element_type == o.element_type && extra_dims == o.extra_dims &&
+               field_class == o.field_class;
+    }
+    bool operator<(const FieldType& o) const { return name < o.name; }
+};
+using LidarFrameFieldTypes = std::vector<FieldType>;
+
+/** Owning, zero-initialised, typed n-d buffer (field.h:828-905, field.cpp:247-296). */
+class Field {
+   public:
+    Field() = default;
+    Field(ChanFieldType tag, std::vector<size_t> shape, FieldClass c = FieldClass::NONE);
+    Field(const Field& o);
+    Field(Field&& o) noexcept;
+    Field& operator=(Field o) noexcept;
+    ~Field();
+
+    ChanFieldType tag() const { return tag_; }
+    const std::vector<size_t>& shape() const { return shape_; }
+    FieldClass field_class() const { return class_; }
+    size_t element_size() const { return field_type_size(tag_); }
+    size_t size() const { return count_; }   ///< number of elements
+    size_t bytes() const { return count_ * element_size(); }
+    void* get() { return ptr_; }
+    const void* get() const { return ptr_; }
+    /** Typed pointer. @throw std::invalid_argument on element type mismatch. */
+    template <typename T> T* get() {
+        check<T>();
+        return static_cast<T*>(ptr_);
+    }
+    template <typename T> const T* get() const {
+        check<T>();
+        return static_cast<const T*>(ptr_);
+    }
+    /** 2-D typed view. @throw std::invalid_argument on type / rank mismatch. */
+    template <typename T> ImgRef<T> img() {
+        check<T>();
+        if (shape_.size() != 2) throw std::invalid_argument("Field: cannot convert to 2d image");
+        return ImgRef<T>(static_cast<T*>(ptr_), shape_[0], shape_[1]);
+    }
+    template <typename T> ImgRef<const T> img() const {
+        check<T>();
+        if (shape_.size() != 2) throw std::invalid_argument("Field: cannot convert to 2d image");
+        return ImgRef<const T>(static_cast<const T*>(ptr_), shape_[0], shape_[1]);
+    }
+    void set_zero();
+    bool operator==(const Field& o) const;
+    bool operator!=(const Field& o) const { return !(*this == o); }
+
+   private:
+    template <typename T> void check() const {
+        if (FieldTag<T>::tag != tag_)
+            throw std::invalid_argument("Field: ineligible dereference type");
+    }
+    ChanFieldType tag_ = ChanFieldType::VOID;
+    std::vector<size_t> shape_;
+    FieldClass class_ = FieldClass::NONE;
+    size_t count_ = 0;
+    void* ptr_ = nullptr;
+};
+
+/** 1-D header view (stands in for the Eigen headers returned by the reference). */
+template <typename T>
+class HeaderRef {
+   public:
+    HeaderRef(T* p, size_t n) : p_(p), n_(n) {}
+    T* data() const { return p_; }
+    size_t size() const { return n_; }
+    size_t rows() const { return n_; }
+    T& operator[](size_t i) const { return p_[i]; }
+    T& operator()(size_t i) const { return p_[i]; }
+    void setZero() const { for (size_t i = 0; i < n_; ++i) p_[i] = T{}; }
+    size_t count() const {  ///< number of non-zero entries
+        size_t c = 0;
+        for (size_t i = 0; i < n_; ++i) c += p_[i] != T{};
+        return c;
+    }
+   private:
+    T* p_;
+    size_t n_;
+};
+
+/** Default planes of a profile / data format (lidar_frame.cpp:73-259, :1038-1117). */
+LidarFrameFieldTypes get_field_types(UDPProfileLidar profile);
+LidarFrameFieldTypes get_field_types(const DataFormat& format, const Version& fw_version);
+LidarFrameFieldTypes get_field_types(const SensorInfo& info);
+
+class LidarFrame {
+   public:
+    size_t w{0};
+    size_t h{0};
+    int64_t frame_id{-1};
+    uint64_t frame_status{0};
+    uint16_t shutdown_countdown{0};
+    uint16_t shot_limiting_countdown{0};
+    std::shared_ptr<SensorInfo> sensor_info;
+
+    LidarFrame();
+    LidarFrame(const LidarFrame&);
+    LidarFrame(LidarFrame&&) noexcept;
+    LidarFrame& operator=(const LidarFrame&);
+    LidarFrame& operator=(LidarFrame&&) noexcept;
+    ~LidarFrame();
+
+    explicit LidarFrame(const DataFormat& format);
+    explicit LidarFrame(const SensorInfo& info);
+    explicit LidarFrame(std::shared_ptr<SensorInfo> info);
+    LidarFrame(std::shared_ptr<SensorInfo> info, const LidarFrameFieldTypes& field_types);
+    /** @throw std::invalid_argument for zero dims / zero columns_per_packet. */
+    LidarFrame(size_t h, size_t w, const LidarFrameFieldTypes& field_types,
+               size_t columns_per_packet = DEFAULT_COLUMNS_PER_PACKET);
+    LidarFrame(size_t h, size_t w, UDPProfileLidar profile,
+               size_t columns_per_packet = DEFAULT_COLUMNS_PER_PACKET);
+
+    /** @throw std::out_of_range if the field does not exist (lidar_frame.cpp:422-436). */
+    Field& field(const std::string& name);
+    const Field& field(const std::string& name) const;
+    template <typename T> ImgRef<T> field(const std::string& name) { return field(name).img<T>(); }
+    template <typename T> ImgRef<const T> field(const std::string& name) const {
+        return field(name).img<T>();
+    }
+    bool has_field(const std::string& name) const;
+    Field& add_field(const FieldType& type);
+    Field& add_field(const std::string& name, ChanFieldType type, std::vector<size_t> extra_dims = {},
+                     FieldClass c = FieldClass::PIXEL_FIELD);
+    Field del_field(const std::string& name);
+    std::map<std::string, Field>& fields() { return fields_; }
+    const std::map<std::string, Field>& fields() const { return fields_; }
+    LidarFrameFieldTypes field_types() const;
+
+    HeaderRef<uint64_t> timestamp() { return {timestamp_.get<uint64_t>(), w}; }
+    HeaderRef<const uint64_t> timestamp() const { return {timestamp_.get<uint64_t>(), w}; }
+    HeaderRef<uint16_t> measurement_id() { return {measurement_id_.get<uint16_t>(), w}; }
+    HeaderRef<const uint16_t> measurement_id() const { return {measurement_id_.get<uint16_t>(), w}; }
+    HeaderRef<uint32_t> status() { return {status_.get<uint32_t>(), w}; }
+    HeaderRef<const uint32_t> status() const { return {status_.get<uint32_t>(), w}; }
+    HeaderRef<uint64_t> packet_timestamp() { return {packet_timestamp_.get<uint64_t>(), packet_count_}; }
+    HeaderRef<const uint64_t> packet_timestamp() const {
+        return {packet_timestamp_.get<uint64_t>(), packet_count_};
+    }
+    HeaderRef<uint8_t> alert_flags() { return {alert_flags_.get<uint8_t>(), packet_count_}; }
+    HeaderRef<const uint8_t> alert_flags() const { return {alert_flags_.get<uint8_t>(), packet_count_}; }
+    /** per-column 4x4 poses, identity initialised (lidar_frame.cpp:353-358) */
+    Field& body_to_world() { return body_to_world_; }
+    const Field& body_to_world() const { return body_to_world_; }
+    size_t packet_count() const { return packet_count_; }
+
+    ThermalShutdownStatus thermal_shutdown() const {
+        return static_cast<ThermalShutdownStatus>(frame_status & 0x0f);
+    }
+    ShotLimitingStatus shot_limiting() const {
+        return static_cast<ShotLimitingStatus>((frame_status & 0xf0) >> 4);
+    }
+    /** true when every column in `window` has status bit 0 set */
+    bool complete(ColumnWindow window) const;
+
+    bool equals(const LidarFrame& other) const;
+
+   private:
+    Field timestamp_, measurement_id_, status_, packet_timestamp_, body_to_world_, alert_flags_;
+    std::map<std::string, Field> fields_;
+    size_t packet_count_{0};
+};
+
+bool operator==(const LidarFrame& a, const LidarFrame& b);
+inline bool operator!=(const LidarFrame& a, const LidarFrame& b) { return !(a == b); }
+
+// ---------------------------------------------------------------------------------------
+// destagger / stagger (lidar_frame.h:917-935, impl/lidar_frame_impl.h:733-989): GPU-backed
+// ---------------------------------------------------------------------------------------
+namespace impl {
+/** elem_bytes = sizeof(T) * trailing dims.  Throws the reference's std::invalid_argument
+ * messages for size mismatches. */
+void destagger_bytes(const void* img, void* out, size_t h, size_t w, size_t elem_bytes,
+                     const std::vector<int>& pixel_shift_by_row, bool inverse, size_t out_h,
+                     size_t out_w);
+}  // namespace impl
+
+template <typename T>
+inline void destagger_into(const ImgRef<const T>& img, const std::vector<int>& pixel_shift_by_row,
+                           bool inverse, ImgRef<T> destaggered) {
+    impl::destagger_bytes(img.data(), destaggered.data(), img.rows(), img.cols(), sizeof(T),
+                          pixel_shift_by_row, inverse, destaggered.rows(), destaggered.cols());
+}
+
+template <typename T>
+inline img_t<T> destagger(const ImgRef<const T>& img, const std::vector<int>& pixel_shift_by_row,
+                          bool inverse = false) {
+    img_t<T> out(img.rows(), img.cols());
+    destagger_into<T>(img, pixel_shift_by_row, inverse, ImgRef<T>(out));
+    return out;
+}
+template <typename T>
+inline img_t<T> destagger(const img_t<T>& img, const std::vector<int>& pixel_shift_by_row,
+                          bool inverse = false) {
+    return destagger<T>(ImgRef<const T>(img), pixel_shift_by_row, inverse);
+}
+
+template <typename T>
+inline img_t<T> destagger(const SensorInfo& info, const ImgRef<const T>& img, bool inverse = false) {
+    if (img.rows() != info.format.pixels_per_column || img.cols() != info.format.columns_per_frame ||
+        img.rows() != info.format.pixel_shift_by_row.size())
+        throw std::invalid_argument{"Image resolution must match SensorInfo."};
+    return destagger<T>(img, info.format.pixel_shift_by_row, inverse);
+}
+template <typename T>
+inline img_t<T> destagger(const SensorInfo& info, const img_t<T>& img, bool inverse = false) {
+    return destagger<T>(info, ImgRef<const T>(img), inverse);
+}
+template <typename T>
+inline img_t<T> stagger(const SensorInfo& info, const img_t<T>& img) {
+    return destagger<T>(info, img, true);
+}
+/** Destagger a whole Field (any element type, trailing dims allowed; field.cpp:329-340). */
+Field destagger(const SensorInfo& info, const Field& field, bool inverse = false);
+
+/** Column of the staggered image a destaggered pixel came from (lidar_frame.cpp:893-905). */
+uint64_t column_timestamp_at_destaggered_pixel(const LidarFrame& frame, const SensorInfo& info,
+                                               size_t row, size_t col);
+
+// ---------------------------------------------------------------------------------------
+// FrameBatcher (lidar_frame.h:966-1145, lidar_frame.cpp:1248-1959; lidar packets only)
+// ---------------------------------------------------------------------------------------
+class FrameBatcher {
+   public:
+    PacketFormat pf;
+
+    explicit FrameBatcher(const SensorInfo& info);
+    explicit FrameBatcher(const std::shared_ptr<SensorInfo>& info);
+    FrameBatcher(const FrameBatcher&) = delete;
+    FrameBatcher& operator=(const FrameBatcher&) = delete;
+    FrameBatcher(FrameBatcher&&) noexcept;
+    ~FrameBatcher();
+
+    /**
+     * Add a packet to the frame; returns true when `lidar_frame` is ready.  The frame's
+     * planes and column headers are written when the frame completes (one GPU decode per
+     * frame); packet_timestamp / alert_flags / frame-level values are updated per packet
+     * exactly as the reference does.
+     * @throw std::invalid_argument("unexpected frame dimensions") etc. as the reference
+     * @throw std::runtime_error for a non-increasing FUSA frame id
+     */
+    bool batch(const Packet& packet, LidarFrame& lidar_frame);
+    bool operator()(const Packet& packet, LidarFrame& lidar_frame) { return batch(packet, lidar_frame); }
+    void reset();
+    size_t batched_packets() const;
+    size_t dropped_packets() const;
+    void set_max_cache_size(size_t n);
+    size_t get_max_cache_size() const;
+
+   private:
+    struct State;
+    std::unique_ptr<State> s_;
+};
+
+namespace impl {
+/** LidarFrame -> wire packets (test-side "fake sensor", impl/lidar_frame_impl.h:435-531). */
+std::vector<LidarPacket> frame_to_packets(const LidarFrame& frame,
+                                          std::shared_ptr<PacketFormat> packet_format,
+                                          uint32_t init_id, uint64_t prod_sn);
+}  // namespace impl
+
+}  // namespace core
+}  // namespace sdk
+}  // namespace ouster

@@ -1,0 +1,244 @@
+/*
+ * ouster_hip.h -- C ABI of the MI355X (gfx950) implementation of the Ouster
+ * SDK's per-pixel hot path:
+ *     packet-format field decode -> LidarFrame planes, destagger, cartesian.
+ *
+ * This is the drop-in boundary.  The reference (ouster-sdk 1.0.1) has no C ABI
+ * for this path -- its boundary is the C++ API of ouster_core -- so each entry
+ * point below names the reference C++ interface it replaces (paths relative to
+ * the reference checkout).  The C++ classes in include/ouster/core/ (same names
+ * and semantics as the reference: PacketFormat, LidarFrame, FrameBatcher,
+ * destagger<T>, XYZLutT<T>, cartesian) are thin host code over these calls; see
+ * INTEGRATION.md for the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns OUSTER_HIP_OK (0) or a negative error code and
+ *     never throws; ouster_hip_last_error() returns a thread-local message.
+ *   - all "device" pointers are HIP device pointers on the context's GPU; all
+ *     work is ordered on the context's stream (ouster_hip_ctx_stream) and is
+ *     asynchronous unless stated otherwise; call ouster_hip_sync() to wait.
+ *   - plain pointers and sizes only; no C++/torch types.
+ */
+#ifndef OUSTER_HIP_H
+#define OUSTER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OUSTER_HIP_OK 0
+#define OUSTER_HIP_ERR_INVALID_ARGUMENT (-1) /* maps to std::invalid_argument */
+#define OUSTER_HIP_ERR_RUNTIME (-2)          /* HIP runtime failure -> std::runtime_error */
+#define OUSTER_HIP_ERR_NO_DEVICE (-3)
+#define OUSTER_HIP_ERR_UNSUPPORTED (-4)
+
+#define OUSTER_HIP_MAX_FIELDS 32
+
+/* element type tags == ouster::sdk::core::ChanFieldType
+ * (ouster_core/include/ouster/core/chanfield.h:111-128) */
+#define OUSTER_HIP_U8 1
+#define OUSTER_HIP_U16 2
+#define OUSTER_HIP_U32 3
+#define OUSTER_HIP_U64 4
+#define OUSTER_HIP_F32 9
+#define OUSTER_HIP_F64 10
+#define OUSTER_HIP_F16 12
+
+typedef struct ouster_hip_ctx ouster_hip_ctx;
+typedef struct ouster_hip_format ouster_hip_format;
+typedef struct ouster_hip_lut ouster_hip_lut;
+
+/* One bit-field: POD mirror of ouster::sdk::core::FieldDecodeInfo
+ * (ouster_core/include/ouster/core/field_decode_info.h:24-54):
+ *   value = ((*(u64*)(base + offset)) & mask) >> shift   (shift<0: << -shift) */
+typedef struct ouster_hip_bits {
+    uint64_t mask;
+    uint32_t offset;
+    int32_t shift;
+} ouster_hip_bits;
+
+/* One decoded channel field and the LidarFrame plane it lands in.
+ * dst_elem_size = sizeof(plane element) * extra dims (1,2,4,8; 6 for the
+ * packed 3 x float16 RGB plane, impl/lidar_frame_impl.h:36-40).  The decoded
+ * 64-bit word is truncated little-endian to dst_elem_size bytes exactly as
+ * FieldDecodeInfo::get<T> does. */
+typedef struct ouster_hip_field_desc {
+    ouster_hip_bits bits;    /* offset is relative to the pixel's channel data */
+    uint32_t dst_elem_size;
+    uint32_t f16_nan_fill;   /* !=0: "zero" for this plane is 0x7e00 per 16-bit lane
+                                (ouster_core/src/lidar_frame.cpp:1397-1401) */
+} ouster_hip_field_desc;
+
+/* Packet geometry + bit layout: POD mirror of ouster::sdk::core::PacketFormat
+ * (ouster_core/include/ouster/core/types.h:137-160, src/parsing.cpp:453-538).
+ * Covers the built-in profiles and anything add_custom_profile() registers
+ * (ouster_core/include/ouster/core/profile_extension.h:52-55). */
+typedef struct ouster_hip_format_desc {
+    uint32_t pixels_per_column;   /* H */
+    uint32_t columns_per_packet;
+    uint32_t columns_per_frame;   /* W */
+    uint32_t packet_header_size;
+    uint32_t col_header_size;
+    uint32_t channel_data_size;
+    uint32_t col_footer_size;
+    uint32_t packet_footer_size;
+    uint32_t col_size;
+    uint32_t lidar_packet_size;
+    /* column header fields, offsets relative to the column start */
+    ouster_hip_bits col_timestamp;
+    ouster_hip_bits col_measurement_id;
+    ouster_hip_bits col_status;
+    /* packet header fields, offsets relative to the packet start */
+    ouster_hip_bits frame_id;
+    ouster_hip_bits alert_flags;
+    ouster_hip_bits thermal_shutdown;
+    ouster_hip_bits shot_limiting;
+    ouster_hip_bits countdown_thermal_shutdown;
+    ouster_hip_bits countdown_shot_limiting;
+    uint32_t n_fields;
+    uint32_t reserved;
+    ouster_hip_field_desc fields[OUSTER_HIP_MAX_FIELDS];
+} ouster_hip_format_desc;
+
+/* Sensor calibration for the XYZ lookup table: the arguments of
+ * impl::make_xyz_lut (ouster_core/include/ouster/core/xyzlut.h:53-56).
+ * Matrices are 4x4 row-major.  n_angles is either H (OS sensors: per-beam
+ * angles) or W*H (DF sensors: per-pixel angles, xyzlut.cpp:49-59). */
+typedef struct ouster_hip_calib {
+    uint32_t w, h;
+    double range_unit;
+    double beam_to_lidar_transform[16];
+    double transform[16];
+    const double* azimuth_angles_deg;
+    const double* altitude_angles_deg;
+    size_t n_angles;
+} ouster_hip_calib;
+
+/* frame-level values latched from the first packet of a frame
+ * (FrameBatcher::start_frame, ouster_core/src/lidar_frame.cpp:1709-1741) */
+typedef struct ouster_hip_frame_meta {
+    int64_t frame_id;          /* -1 if the frame has no packets */
+    uint64_t frame_status;     /* thermal&0xf | (shot&0xf)<<4, lidar_frame.cpp:1310-1323 */
+    uint16_t shutdown_countdown;
+    uint16_t shot_limiting_countdown;
+    uint32_t n_valid_columns;  /* columns written (not part of the reference struct) */
+} ouster_hip_frame_meta;
+
+/* Device output pointers of one batched decode.  Every array is dense over
+ * the batch: plane i is [n_frames][H][W] elements of fields[i].dst_elem_size
+ * bytes, row-major like Field (ouster_core/include/ouster/core/field.h:828-905).
+ * Any pointer may be NULL to skip that output. */
+typedef struct ouster_hip_frame_out {
+    void* planes[OUSTER_HIP_MAX_FIELDS];       /* staggered planes               */
+    void* destaggered[OUSTER_HIP_MAX_FIELDS];  /* destagger(plane) fused in       */
+    uint64_t* timestamp;        /* [n_frames][W]      LidarFrame::timestamp()      */
+    uint16_t* measurement_id;   /* [n_frames][W]      LidarFrame::measurement_id() */
+    uint32_t* status;           /* [n_frames][W]      LidarFrame::status()         */
+    uint64_t* packet_timestamp; /* [n_frames][W/cpp]  needs host_timestamps        */
+    uint8_t* alert_flags;       /* [n_frames][W/cpp]  only touched where a packet exists */
+    ouster_hip_frame_meta* frame_meta; /* [n_frames] */
+    /* cartesian fused in: xyz[k] = lut(plane of field xyz_field[k]); [n_frames][H*W][3] */
+    void* xyz[2];
+    int32_t xyz_field[2];       /* index into fields[]; -1 = unused */
+    int32_t xyz_dtype;          /* OUSTER_HIP_F32 or OUSTER_HIP_F64 */
+    int32_t reserved;
+} ouster_hip_frame_out;
+
+/* ---- context ------------------------------------------------------------ */
+/* stream: an existing hipStream_t to order on (e.g. torch's current stream),
+ * or NULL to let the context create and own a non-blocking stream. */
+int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out);
+void ouster_hip_ctx_destroy(ouster_hip_ctx* ctx);
+void* ouster_hip_ctx_stream(ouster_hip_ctx* ctx);
+int ouster_hip_sync(ouster_hip_ctx* ctx);
+const char* ouster_hip_last_error(void);
+const char* ouster_hip_version(void);
+
+/* ---- packet format -> device descriptor ---------------------------------- */
+/* Replaces constructing ouster::sdk::core::PacketFormat for device use
+ * (ouster_core/src/parsing.cpp:600-626). */
+int ouster_hip_format_create(ouster_hip_ctx* ctx, const ouster_hip_format_desc* desc,
+                             ouster_hip_format** out);
+void ouster_hip_format_destroy(ouster_hip_format* fmt);
+
+/* ---- XYZ lookup table ---------------------------------------------------- */
+/* Replaces impl::make_xyz_lut(w,h,range_unit,b2l,transform,az,alt)
+ * (ouster_core/src/xyzlut.cpp:11-89).  Per-beam (n_angles == h) calibrations
+ * are kept as separable per-beam x per-column tables (the LUT is never
+ * materialised on the device); per-pixel calibrations fall back to a full
+ * double LUT.  Returns INVALID_ARGUMENT for the same dimension errors the
+ * reference throws for (xyzlut.cpp:14-21). */
+int ouster_hip_lut_create(ouster_hip_ctx* ctx, const ouster_hip_calib* calib,
+                          ouster_hip_lut** out);
+/* Replaces XYZLutT<T>(direction, offset, h, w) (xyzlut.h:134-135): adopt
+ * caller-provided host arrays [n][3] of dtype F32 or F64 (copied to the device). */
+int ouster_hip_lut_create_from_arrays(ouster_hip_ctx* ctx, const void* direction,
+                                      const void* offset, uint32_t h, uint32_t w,
+                                      int dtype, ouster_hip_lut** out);
+/* Host copy of the full double LUT, [w*h][3] each == XYZLut::direction/offset
+ * (xyzlut.h:82-89). */
+int ouster_hip_lut_export(const ouster_hip_lut* lut, double* direction, double* offset);
+void ouster_hip_lut_destroy(ouster_hip_lut* lut);
+
+/* ---- batched decode (+ fused destagger + fused cartesian) ---------------- */
+/* Replaces a sequence of FrameBatcher::batch(packet, frame) calls
+ * (ouster_core/src/lidar_frame.cpp:1824-1884; pixel work :1422-1576, which
+ * calls PacketFormat::block_field / col_field, src/parsing.cpp:628-675),
+ * optionally followed by destagger<T>() (impl/lidar_frame_impl.h:733-760) and
+ * XYZLutT::operator() (xyzlut.h:139-150) on the result.
+ *
+ * packets: device buffer laid out [n_frames][slots_per_frame][packet_stride]
+ *   bytes; packet_stride >= lidar_packet_size.  packet_counts (HOST array,
+ *   nullable) gives the number of slots actually filled per frame (NULL: all).
+ *   Packets of a frame may be in any order; a frame's result is "all planes and
+ *   column headers zero, then every received column with status&1 and
+ *   measurement_id < W written at its measurement_id" -- the memset-then-scatter
+ *   equivalent of the reference's incremental zero-fill.
+ *   When two received columns carry the same measurement_id the one later in
+ *   the buffer wins (the reference: the one batched later).
+ * host_timestamps: device array [n_frames][slots_per_frame] of
+ *   Packet::host_timestamp values, or NULL (packet_timestamp is then not written).
+ * pixel_shift_by_row: HOST array [H] (needed iff any destaggered[] is set).
+ * luts: HOST array of n_luts LUT handles; frame f uses luts[f % n_luts]
+ *   (multi-sensor batches interleave sensors); NULL iff no xyz output. */
+int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt,
+                      const uint8_t* packets, size_t packet_stride,
+                      uint32_t slots_per_frame, const uint32_t* packet_counts,
+                      uint32_t n_frames, const uint64_t* host_timestamps,
+                      const ouster_hip_frame_out* out,
+                      const int32_t* pixel_shift_by_row,
+                      const ouster_hip_lut* const* luts, uint32_t n_luts);
+
+/* ---- standalone destagger ------------------------------------------------ */
+/* Replaces destagger_into<T>(img, pixel_shift_by_row, inverse, out)
+ * (impl/lidar_frame_impl.h:733-760, N-d variant :776-811): n_images images of
+ * h x w elements of elem_bytes bytes (element = T times trailing dims).
+ * shifts: HOST array; n_shifts != h -> INVALID_ARGUMENT ("image height does
+ * not match shifts size"). */
+int ouster_hip_destagger(ouster_hip_ctx* ctx, const void* src, void* dst, uint32_t h,
+                         uint32_t w, uint32_t elem_bytes, const int32_t* shifts,
+                         uint32_t n_shifts, int inverse, uint32_t n_images);
+
+/* ---- standalone cartesian ------------------------------------------------ */
+/* Replaces impl::cartesianT<T>(points, range, direction, offset)
+ * (impl/cartesian.h:36-66) / XYZLutT<T>::operator()(range) / cartesian():
+ * range [n_images][h*w] u32 (staggered) -> xyz [n_images][h*w][3] of
+ * xyz_dtype (F32 or F64). */
+int ouster_hip_cartesian(ouster_hip_ctx* ctx, const ouster_hip_lut* lut,
+                         const uint32_t* range, void* xyz, int xyz_dtype,
+                         uint32_t n_images);
+
+/* ---- instrumentation ------------------------------------------------------ */
+/* Average duration in ms of the dominant decode kernel over the launches made
+ * since the last reset, measured with HIP events on the context's stream
+ * (enabled by ouster_hip_timing_enable; adds two event records per launch). */
+int ouster_hip_timing_enable(ouster_hip_ctx* ctx, int on);
+int ouster_hip_timing_read(ouster_hip_ctx* ctx, double* avg_ms, uint32_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OUSTER_HIP_H */

@@ -174,6 +174,7 @@ def lib():
     L.ora_batcher_force_col_path.argtypes = [C.c_void_p, C.c_int]
     L.ora_batcher_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64,
                                     C.POINTER(FrameS)]
+    L.ora_batcher_finalize.argtypes = [C.c_void_p, C.POINTER(FrameS)]
     L.ora_batcher_dropped.restype = C.c_uint64
     L.ora_batcher_dropped.argtypes = [C.c_void_p]
     L.ora_frame_to_packets.argtypes = [C.POINTER(FrameS), C.POINTER(PF), C.c_uint32,
@@ -367,6 +368,9 @@ class Batcher:
         if rc < 0:
             raise RuntimeError(f"batch failed ({rc})")
         return bool(rc)
+
+    def finalize(self, frame: Frame):
+        lib().ora_batcher_finalize(self._b, frame._f)
 
     @property
     def dropped(self) -> int:

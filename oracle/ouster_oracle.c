@@ -904,6 +904,14 @@ static int batch_with_caching(ora_batcher* b, const uint8_t* pkt, size_t len, ui
     return 0;
 }
 
+/* Test helper: release the frame being assembled the way batch() does when it gives up
+ * waiting (finalize_frame, lidar_frame.cpp:1905-1927): zero the tail past the last
+ * received column.  The reference has no public entry for this; it happens inside
+ * batch_with_caching / handle_init_id_change. */
+int ora_batcher_finalize(ora_batcher* b, ora_frame* fr) {
+    return finalize_frame(b, fr, -1);
+}
+
 /* batch(): lidar_frame.cpp:1824-1884; handle_init_id_change :1795-1822.
  * The frame's sensor_info->init_id is taken equal to the batcher's constructor
  * init id (single-sensor use). */

@@ -179,6 +179,8 @@ void ora_batcher_force_col_path(ora_batcher* b, int on);
 int ora_batcher_batch(ora_batcher* b, const uint8_t* packet, size_t len,
                       uint64_t host_timestamp, ora_frame* frame);
 uint64_t ora_batcher_dropped(const ora_batcher* b);
+/* test helper: finalize_frame() of the frame in progress (tail zero-fill) */
+int ora_batcher_finalize(ora_batcher* b, ora_frame* frame);
 
 /* ---- frame -> packets (test-side packet synthesis) ---- */
 /* writes up to n_packets packets of pf->lidar_packet_size bytes into out,

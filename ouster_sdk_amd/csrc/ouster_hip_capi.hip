@@ -1,0 +1,717 @@
+// ouster_hip_capi.hip -- host side of the C ABI declared in include/ouster_hip.h.
+// Owns the context (stream, scratch), turns format / calibration descriptions into
+// device tables and launches the kernels of ouster_hip_kernels.hip.  No compute happens
+// on the host except the one-off XYZ table construction (make_xyz_lut is a one-off in the
+// reference too: ouster_core/src/xyzlut.cpp:11-89, cached per sensor in sensor_info.cpp:260-275).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ouster_hip_dev.h"
+
+using namespace ouster_hip_dev;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(OUSTER_HIP_ERR_RUNTIME, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 2;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            return -1;
+        }
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct ouster_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf map, offsets, luts, counts;
+    std::vector<int32_t> offsets_host;   // cache key of `offsets`
+    std::vector<LutDev> luts_host;       // cache key of `luts`
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+};
+
+struct ouster_hip_format {
+    ouster_hip_format_desc desc;
+    Geometry g;
+    int spec_id = SPEC_GENERIC;
+    int8_t spec_of_desc[OUSTER_HIP_MAX_FIELDS];
+    int spec_nf = 0, spec_r1 = -1, spec_r2 = -1;
+};
+
+struct ouster_hip_lut {
+    ouster_hip_ctx* ctx = nullptr;
+    uint32_t w = 0, h = 0;
+    bool separable = false;
+    LutDev dev{};
+    void *d_beam = nullptr, *d_col = nullptr, *d_dir = nullptr, *d_ofs = nullptr;
+    // host copy of the full double LUT for ouster_hip_lut_export
+    std::vector<double> direction, offset;
+};
+
+// ---------------------------------------------------------------------------------------
+// host math: impl::make_xyz_lut (ouster_core/src/xyzlut.cpp:11-89), full LUT in double
+// ---------------------------------------------------------------------------------------
+static void host_full_lut(const ouster_hip_calib& c, std::vector<double>& direction,
+                          std::vector<double>& offset) {
+    const size_t w = c.w, h = c.h;
+    direction.assign(w * h * 3, 0.0);
+    offset.assign(w * h * 3, 0.0);
+    const double* b2l = c.beam_to_lidar_transform;
+    const double* tf = c.transform;
+    const double bx = b2l[3], bz = b2l[11];
+    double n = bx;
+    if (bz != 0) n = std::sqrt(std::pow(bx, 2) + std::pow(bz, 2));
+    const bool per_beam = (c.n_angles == h);
+    const double step = M_PI * 2.0 / static_cast<double>(w);
+    for (size_t row = 0; row < h; ++row) {
+        for (size_t col = 0; col < w; ++col) {
+            const size_t i = row * w + col;
+            double enc, azi, alt;
+            if (per_beam) {
+                enc = 2.0 * M_PI - static_cast<double>(col) * step;
+                azi = -c.azimuth_angles_deg[row] * M_PI / 180.0;
+                alt = c.altitude_angles_deg[row] * M_PI / 180.0;
+            } else {
+                enc = 0;
+                azi = c.azimuth_angles_deg[i] * M_PI / 180.0;
+                alt = c.altitude_angles_deg[i] * M_PI / 180.0;
+            }
+            const double d[3] = {std::cos(enc + azi) * std::cos(alt),
+                                 std::sin(enc + azi) * std::cos(alt), std::sin(alt)};
+            const double o[3] = {std::cos(enc) * bx - d[0] * n, std::sin(enc) * bx - d[1] * n,
+                                 -d[2] * n + bz};
+            for (int r = 0; r < 3; ++r) {
+                double dd = 0, oo = 0;
+                for (int k = 0; k < 3; ++k) {
+                    dd += d[k] * tf[r * 4 + k];
+                    oo += o[k] * tf[r * 4 + k];
+                }
+                oo += tf[r * 4 + 3];
+                direction[i * 3 + r] = dd * c.range_unit;
+                offset[i * 3 + r] = oo * c.range_unit;
+            }
+        }
+    }
+}
+
+// separable form of the same table: see the derivation in DESIGN.md ("XYZ tables")
+static void host_separable_tables(const ouster_hip_calib& c, std::vector<double>& beam,
+                                  std::vector<double>& col, double& n_out) {
+    const size_t w = c.w, h = c.h;
+    const double* b2l = c.beam_to_lidar_transform;
+    const double* tf = c.transform;
+    const double ru = c.range_unit;
+    const double bx = b2l[3], bz = b2l[11];
+    double n = bx;
+    if (bz != 0) n = std::sqrt(std::pow(bx, 2) + std::pow(bz, 2));
+    n_out = n;
+    auto rot = [&](const double v[3], double out[3]) {
+        for (int r = 0; r < 3; ++r)
+            out[r] = v[0] * tf[r * 4 + 0] + v[1] * tf[r * 4 + 1] + v[2] * tf[r * 4 + 2];
+    };
+    beam.assign(h * 9, 0.0);
+    for (size_t row = 0; row < h; ++row) {
+        const double azi = -c.azimuth_angles_deg[row] * M_PI / 180.0;
+        const double alt = c.altitude_angles_deg[row] * M_PI / 180.0;
+        const double A = std::cos(azi) * std::cos(alt), B = std::sin(azi) * std::cos(alt),
+                     Cc = std::sin(alt);
+        const double u[3] = {A, B, 0}, v[3] = {-B, A, 0}, wv[3] = {0, 0, Cc};
+        double ru_[3];
+        rot(u, ru_);
+        for (int k = 0; k < 3; ++k) beam[row * 9 + k] = ru_[k] * ru;
+        rot(v, ru_);
+        for (int k = 0; k < 3; ++k) beam[row * 9 + 3 + k] = ru_[k] * ru;
+        rot(wv, ru_);
+        for (int k = 0; k < 3; ++k) beam[row * 9 + 6 + k] = ru_[k] * ru;
+    }
+    col.assign(w * 5, 0.0);
+    const double step = M_PI * 2.0 / static_cast<double>(w);
+    for (size_t cc = 0; cc < w; ++cc) {
+        const double enc = 2.0 * M_PI - static_cast<double>(cc) * step;
+        const double cx = std::cos(enc), sx = std::sin(enc);
+        const double o[3] = {cx * bx, sx * bx, bz};
+        double ro[3];
+        rot(o, ro);
+        col[cc * 5 + 0] = cx;
+        col[cc * 5 + 1] = sx;
+        for (int k = 0; k < 3; ++k) col[cc * 5 + 2 + k] = (ro[k] + tf[k * 4 + 3]) * ru;
+    }
+}
+
+static void fill_geometry(const ouster_hip_format_desc& d, Geometry& g) {
+    g.pixels_per_column = d.pixels_per_column;
+    g.columns_per_packet = d.columns_per_packet;
+    g.columns_per_frame = d.columns_per_frame;
+    g.packet_header_size = d.packet_header_size;
+    g.col_header_size = d.col_header_size;
+    g.channel_data_size = d.channel_data_size;
+    g.col_footer_size = d.col_footer_size;
+    g.packet_footer_size = d.packet_footer_size;
+    g.col_size = d.col_size;
+    g.lidar_packet_size = d.lidar_packet_size;
+    g.col_timestamp = d.col_timestamp;
+    g.col_measurement_id = d.col_measurement_id;
+    g.col_status = d.col_status;
+    g.frame_id = d.frame_id;
+    g.alert_flags = d.alert_flags;
+    g.thermal_shutdown = d.thermal_shutdown;
+    g.shot_limiting = d.shot_limiting;
+    g.countdown_thermal_shutdown = d.countdown_thermal_shutdown;
+    g.countdown_shot_limiting = d.countdown_shot_limiting;
+}
+
+extern "C" {
+
+const char* ouster_hip_last_error(void) { return g_err.c_str(); }
+const char* ouster_hip_version(void) { return "ouster_hip 0.1 (gfx950)"; }
+
+int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
+    if (!out) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(OUSTER_HIP_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    ouster_hip_ctx* c = new (std::nothrow) ouster_hip_ctx();
+    if (!c) return fail(OUSTER_HIP_ERR_RUNTIME, "out of memory");
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return fail(OUSTER_HIP_ERR_RUNTIME, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return OUSTER_HIP_OK;
+}
+
+void ouster_hip_ctx_destroy(ouster_hip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->map.release();
+    c->offsets.release();
+    c->luts.release();
+    c->counts.release();
+    for (auto& p : c->ev_pool) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* ouster_hip_ctx_stream(ouster_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int ouster_hip_sync(ouster_hip_ctx* c) {
+    if (!c) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OUSTER_HIP_OK;
+}
+
+// ---- format ----------------------------------------------------------------------------
+int ouster_hip_format_create(ouster_hip_ctx* ctx, const ouster_hip_format_desc* d,
+                             ouster_hip_format** out) {
+    if (!ctx || !d || !out) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->pixels_per_column == 0)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unexpected pixels_per_column: 0");
+    if (d->columns_per_packet == 0)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unexpected columns_per_packet: 0");
+    if (d->columns_per_frame == 0)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unexpected columns_per_frame: 0");
+    if (d->n_fields > OUSTER_HIP_MAX_FIELDS)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "too many fields (%u)", d->n_fields);
+    if (d->col_size != d->col_header_size + d->pixels_per_column * d->channel_data_size +
+                           d->col_footer_size ||
+        d->lidar_packet_size != d->packet_header_size + d->columns_per_packet * d->col_size +
+                                    d->packet_footer_size)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "inconsistent packet geometry");
+    if (d->lidar_packet_size > 65535)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "lidar_packet_size cannot exceed 65535");
+    if ((d->col_size & 3) || (d->packet_header_size & 3) || (d->lidar_packet_size & 3))
+        return fail(OUSTER_HIP_ERR_UNSUPPORTED, "packet geometry must be 4-byte granular");
+    for (uint32_t i = 0; i < d->n_fields; ++i) {
+        const uint32_t e = d->fields[i].dst_elem_size;
+        if (!(e == 1 || e == 2 || e == 4 || e == 6 || e == 8))
+            return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "field %u: unsupported element size %u", i, e);
+    }
+    ouster_hip_format* f = new (std::nothrow) ouster_hip_format();
+    if (!f) return fail(OUSTER_HIP_ERR_RUNTIME, "out of memory");
+    f->desc = *d;
+    fill_geometry(*d, f->g);
+    // match against the compile-time specialisations
+    f->spec_id = SPEC_GENERIC;
+    for (int sid = SPEC_DUAL_LB; sid <= SPEC_LEGACY && f->spec_id == SPEC_GENERIC; ++sid) {
+        int nf, r1, r2;
+        uint32_t chan;
+        const FieldC* sf = spec_fields(sid, &nf, &chan, &r1, &r2);
+        if (chan != d->channel_data_size || (d->col_header_size & 3) || d->n_fields == 0) continue;
+        bool ok = true;
+        int8_t map[OUSTER_HIP_MAX_FIELDS];
+        uint32_t used = 0;
+        for (uint32_t i = 0; i < d->n_fields && ok; ++i) {
+            const auto& fd = d->fields[i];
+            int hit = -1;
+            for (int k = 0; k < nf; ++k)
+                if (!(used & (1u << k)) && sf[k].offset == fd.bits.offset &&
+                    sf[k].mask == fd.bits.mask && sf[k].shift == fd.bits.shift &&
+                    sf[k].elem == fd.dst_elem_size && !fd.f16_nan_fill) {
+                    hit = k;
+                    break;
+                }
+            if (hit < 0) ok = false;
+            else { used |= 1u << hit; map[i] = (int8_t)hit; }
+        }
+        if (ok) {
+            f->spec_id = sid;
+            memcpy(f->spec_of_desc, map, sizeof map);
+            f->spec_nf = nf;
+            f->spec_r1 = r1;
+            f->spec_r2 = r2;
+        }
+    }
+    *out = f;
+    return OUSTER_HIP_OK;
+}
+
+void ouster_hip_format_destroy(ouster_hip_format* f) { delete f; }
+
+// ---- lut -------------------------------------------------------------------------------
+static int upload(void** dptr, const void* src, size_t bytes, hipStream_t st) {
+    if (hipMalloc(dptr, bytes) != hipSuccess) return -1;
+    if (hipMemcpyAsync(*dptr, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    return hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
+}
+
+int ouster_hip_lut_create(ouster_hip_ctx* ctx, const ouster_hip_calib* c, ouster_hip_lut** out) {
+    if (!ctx || !c || !out) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (c->w == 0 || c->h == 0)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "lut dimensions must be greater than zero");
+    const size_t hw = (size_t)c->w * c->h;
+    if ((c->n_angles != c->h && c->n_angles != hw) || !c->azimuth_angles_deg ||
+        !c->altitude_angles_deg)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unexpected frame dimensions");
+    HIP_TRY(hipSetDevice(ctx->device));
+    ouster_hip_lut* L = new (std::nothrow) ouster_hip_lut();
+    if (!L) return fail(OUSTER_HIP_ERR_RUNTIME, "out of memory");
+    L->ctx = ctx;
+    L->w = c->w;
+    L->h = c->h;
+    host_full_lut(*c, L->direction, L->offset);
+    int rc = 0;
+    if (c->n_angles == c->h) {
+        std::vector<double> beam, col;
+        double n;
+        host_separable_tables(*c, beam, col, n);
+        L->separable = true;
+        rc |= upload(&L->d_beam, beam.data(), beam.size() * 8, ctx->stream);
+        rc |= upload(&L->d_col, col.data(), col.size() * 8, ctx->stream);
+        L->dev.beam_tab = (const double*)L->d_beam;
+        L->dev.col_tab = (const double*)L->d_col;
+        L->dev.n = n;
+        L->dev.full_dtype = 0;
+    } else {
+        rc |= upload(&L->d_dir, L->direction.data(), hw * 24, ctx->stream);
+        rc |= upload(&L->d_ofs, L->offset.data(), hw * 24, ctx->stream);
+        L->dev.full_dir = L->d_dir;
+        L->dev.full_ofs = L->d_ofs;
+        L->dev.full_dtype = OUSTER_HIP_F64;
+    }
+    if (rc) {
+        ouster_hip_lut_destroy(L);
+        return fail(OUSTER_HIP_ERR_RUNTIME, "LUT upload failed");
+    }
+    *out = L;
+    return OUSTER_HIP_OK;
+}
+
+int ouster_hip_lut_create_from_arrays(ouster_hip_ctx* ctx, const void* direction,
+                                      const void* offset, uint32_t h, uint32_t w, int dtype,
+                                      ouster_hip_lut** out) {
+    if (!ctx || !direction || !offset || !out)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (w == 0 || h == 0)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "lut dimensions must be greater than zero");
+    if (dtype != OUSTER_HIP_F32 && dtype != OUSTER_HIP_F64)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "LUT dtype must be F32 or F64");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t hw = (size_t)w * h, es = dtype == OUSTER_HIP_F32 ? 4 : 8;
+    ouster_hip_lut* L = new (std::nothrow) ouster_hip_lut();
+    if (!L) return fail(OUSTER_HIP_ERR_RUNTIME, "out of memory");
+    L->ctx = ctx;
+    L->w = w;
+    L->h = h;
+    L->direction.resize(hw * 3);
+    L->offset.resize(hw * 3);
+    for (size_t i = 0; i < hw * 3; ++i) {
+        L->direction[i] = es == 4 ? (double)((const float*)direction)[i] : ((const double*)direction)[i];
+        L->offset[i] = es == 4 ? (double)((const float*)offset)[i] : ((const double*)offset)[i];
+    }
+    int rc = upload(&L->d_dir, direction, hw * 3 * es, ctx->stream);
+    rc |= upload(&L->d_ofs, offset, hw * 3 * es, ctx->stream);
+    if (rc) {
+        ouster_hip_lut_destroy(L);
+        return fail(OUSTER_HIP_ERR_RUNTIME, "LUT upload failed");
+    }
+    L->dev.full_dir = L->d_dir;
+    L->dev.full_ofs = L->d_ofs;
+    L->dev.full_dtype = dtype;
+    *out = L;
+    return OUSTER_HIP_OK;
+}
+
+int ouster_hip_lut_export(const ouster_hip_lut* L, double* direction, double* offset) {
+    if (!L || !direction || !offset) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    memcpy(direction, L->direction.data(), L->direction.size() * 8);
+    memcpy(offset, L->offset.data(), L->offset.size() * 8);
+    return OUSTER_HIP_OK;
+}
+
+void ouster_hip_lut_destroy(ouster_hip_lut* L) {
+    if (!L) return;
+    if (L->ctx) (void)hipSetDevice(L->ctx->device);
+    if (L->d_beam) (void)hipFree(L->d_beam);
+    if (L->d_col) (void)hipFree(L->d_col);
+    if (L->d_dir) (void)hipFree(L->d_dir);
+    if (L->d_ofs) (void)hipFree(L->d_ofs);
+    delete L;
+}
+
+// ---- helpers for per-call device tables -------------------------------------------------
+// destination column offset per row with the reference's exact arithmetic:
+//   offset = (w + sign*shift % w) % w   with w a size_t, i.e. `sign*shift` is converted to
+//   an unsigned 64-bit value BEFORE the modulo (impl/lidar_frame_impl.h:737-756).
+static void dest_offsets(const int32_t* shifts, uint32_t h, uint32_t w, int inverse,
+                         std::vector<int32_t>& out) {
+    out.resize(h);
+    const int sign = inverse ? -1 : +1;
+    const size_t ws = w;
+    for (uint32_t u = 0; u < h; ++u) {
+        const size_t x = (size_t)(long long)(sign * shifts[u]);
+        out[u] = (int32_t)((ws + x % ws) % ws);
+    }
+}
+
+static int ensure_offsets(ouster_hip_ctx* c, const std::vector<int32_t>& off) {
+    if (off == c->offsets_host && c->offsets.p) return 0;
+    if (c->offsets.ensure(off.size() * 4)) return -1;
+    if (hipMemcpyAsync(c->offsets.p, off.data(), off.size() * 4, hipMemcpyHostToDevice,
+                       c->stream) != hipSuccess)
+        return -1;
+    // the source vector must outlive the (possibly staged) copy
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    c->offsets_host = off;
+    return 0;
+}
+
+static int ensure_luts(ouster_hip_ctx* c, const std::vector<LutDev>& l) {
+    bool same = c->luts.p && l.size() == c->luts_host.size() &&
+                memcmp(l.data(), c->luts_host.data(), l.size() * sizeof(LutDev)) == 0;
+    if (same) return 0;
+    if (c->luts.ensure(l.size() * sizeof(LutDev))) return -1;
+    if (hipMemcpyAsync(c->luts.p, l.data(), l.size() * sizeof(LutDev), hipMemcpyHostToDevice,
+                       c->stream) != hipSuccess)
+        return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    c->luts_host = l;
+    return 0;
+}
+
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- decode ------------------------------------------------------------------------------
+int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const uint8_t* packets,
+                      size_t packet_stride, uint32_t slots_per_frame,
+                      const uint32_t* packet_counts, uint32_t n_frames,
+                      const uint64_t* host_timestamps, const ouster_hip_frame_out* out,
+                      const int32_t* pixel_shift_by_row, const ouster_hip_lut* const* luts,
+                      uint32_t n_luts) {
+    if (!ctx || !fmt || !out) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_frames == 0) return OUSTER_HIP_OK;
+    if (!packets) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "packets is NULL");
+    const Geometry& g = fmt->g;
+    const uint32_t W = g.columns_per_frame, H = g.pixels_per_column;
+    if (packet_stride < g.lidar_packet_size || (packet_stride & 3) || ((uintptr_t)packets & 3))
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT,
+                    "packet_stride must be >= lidar_packet_size and 4-byte granular");
+    if ((uint64_t)slots_per_frame * g.columns_per_packet > 0x7fffffffull || slots_per_frame == 0)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "bad slots_per_frame");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    const uint32_t nf = fmt->desc.n_fields;
+    bool any_dst = false, any_xyz = (out->xyz[0] || out->xyz[1]);
+    for (uint32_t i = 0; i < nf; ++i) any_dst |= out->destaggered[i] != nullptr;
+    if (any_dst && !pixel_shift_by_row)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "image height does not match shifts size");
+    if (any_xyz) {
+        if (!luts || n_luts == 0) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "xyz output needs a LUT");
+        if (out->xyz_dtype != OUSTER_HIP_F32 && out->xyz_dtype != OUSTER_HIP_F64)
+            return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "xyz_dtype must be F32 or F64");
+        for (int k = 0; k < 2; ++k) {
+            if (!out->xyz[k]) continue;
+            const int xf = out->xyz_field[k];
+            if (xf < 0 || (uint32_t)xf >= nf || fmt->desc.fields[xf].dst_elem_size != 4)
+                return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT,
+                            "xyz_field[%d] must name a 32-bit range field", k);
+        }
+        for (uint32_t i = 0; i < n_luts; ++i)
+            if (!luts[i] || luts[i]->w != W || luts[i]->h != H)
+                return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unexpected image dimensions");
+    }
+
+    // ---- scratch: column map, destagger offsets, LUT descriptors, packet counts
+    const size_t map_bytes = (size_t)n_frames * W * 4;
+    if (ctx->map.ensure(map_bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(map) failed");
+    HIP_TRY(hipMemsetAsync(ctx->map.p, 0xFF, map_bytes, st));
+    const uint32_t n_packets_out = W / g.columns_per_packet;
+    if (out->packet_timestamp && host_timestamps)  // start_frame zeroes it (lidar_frame.cpp:1719)
+        HIP_TRY(hipMemsetAsync(out->packet_timestamp, 0, (size_t)n_frames * n_packets_out * 8, st));
+    const uint32_t* d_counts = nullptr;
+    if (packet_counts) {
+        for (uint32_t f = 0; f < n_frames; ++f)
+            if (packet_counts[f] > slots_per_frame)
+                return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "packet_counts[%u] > slots_per_frame", f);
+        if (ctx->counts.ensure((size_t)n_frames * 4))
+            return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(counts) failed");
+        HIP_TRY(hipMemcpyAsync(ctx->counts.p, packet_counts, (size_t)n_frames * 4,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        d_counts = (const uint32_t*)ctx->counts.p;
+    }
+    if (any_dst) {
+        std::vector<int32_t> off;
+        dest_offsets(pixel_shift_by_row, H, W, 0, off);
+        if (ensure_offsets(ctx, off)) return fail(OUSTER_HIP_ERR_RUNTIME, "offset upload failed");
+    }
+    int xyzm = 0;
+    if (any_xyz) {
+        std::vector<LutDev> l(n_luts);
+        bool all_sep = true;
+        for (uint32_t i = 0; i < n_luts; ++i) {
+            l[i] = luts[i]->dev;
+            all_sep &= luts[i]->separable;
+        }
+        bool none_sep = true;
+        for (uint32_t i = 0; i < n_luts; ++i) none_sep &= !luts[i]->separable;
+        if (!all_sep && !none_sep)
+            return fail(OUSTER_HIP_ERR_UNSUPPORTED, "cannot mix separable and full LUTs in one batch");
+        if (ensure_luts(ctx, l)) return fail(OUSTER_HIP_ERR_RUNTIME, "LUT descriptor upload failed");
+        xyzm = all_sep ? (out->xyz_dtype == OUSTER_HIP_F32 ? 1 : 2) : 3;
+    }
+
+    // ---- k_colmap
+    ColmapArgs ca{};
+    ca.g = g;
+    ca.packets = packets;
+    ca.packet_stride = packet_stride;
+    ca.slots_per_frame = slots_per_frame;
+    ca.n_packets_out = n_packets_out;
+    ca.packet_counts = d_counts;
+    ca.host_timestamps = host_timestamps;
+    ca.map = (int32_t*)ctx->map.p;
+    ca.packet_timestamp = out->packet_timestamp;
+    ca.alert_flags = out->alert_flags;
+    ca.frame_meta = out->frame_meta;
+    HIP_TRY(launch_colmap(ca, n_frames, st));
+
+    // ---- k_decode
+    DecodeArgs da{};
+    da.g = g;
+    da.packets = packets;
+    da.packet_stride = packet_stride;
+    da.slots_per_frame = slots_per_frame;
+    da.n_frames = n_frames;
+    da.map = (const int32_t*)ctx->map.p;
+    da.dst_offsets = (const int32_t*)ctx->offsets.p;
+    da.luts = (const LutDev*)ctx->luts.p;
+    da.n_luts = n_luts ? n_luts : 1;
+    da.n_fields = nf;
+    da.any_destagger = any_dst;
+    da.timestamp = out->timestamp;
+    da.measurement_id = out->measurement_id;
+    da.status = out->status;
+    da.xyz[0] = out->xyz[0];
+    da.xyz[1] = out->xyz[1];
+    da.xyz_field[0] = out->xyz[0] ? out->xyz_field[0] : -1;
+    da.xyz_field[1] = out->xyz[1] ? out->xyz_field[1] : -1;
+    da.xyz_dtype = out->xyz_dtype;
+    bool vec_ok = (W % 4 == 0);
+    const size_t npx = (size_t)H * W;
+    for (uint32_t i = 0; i < nf; ++i) {
+        da.planes[i] = out->planes[i];
+        da.destaggered[i] = out->destaggered[i];
+        da.bits[i] = fmt->desc.fields[i].bits;
+        da.elem[i] = (uint8_t)fmt->desc.fields[i].dst_elem_size;
+        da.f16_nan[i] = fmt->desc.fields[i].f16_nan_fill ? 1 : 0;
+        const size_t fstride = npx * da.elem[i];
+        if (out->planes[i]) vec_ok &= al16(out->planes[i]) && (fstride % 16 == 0);
+        // destaggered stores are unaligned-capable; only 4-byte stores of sub-dword
+        // elements need the element alignment the caller already guarantees
+    }
+    const size_t xes = out->xyz_dtype == OUSTER_HIP_F64 ? 8 : 4;
+    for (int k = 0; k < 2; ++k)
+        if (out->xyz[k]) vec_ok &= al16(out->xyz[k]) && ((npx * 3 * xes) % 16 == 0);
+    da.vec_ok = vec_ok;
+
+    int spec = fmt->spec_id;
+    if (spec != SPEC_GENERIC) {
+        for (int k = 0; k < 16; ++k) da.desc_of_spec[k] = -1;
+        for (uint32_t i = 0; i < nf; ++i) da.desc_of_spec[fmt->spec_of_desc[i]] = (int8_t)i;
+        // the compile-time kernels take the xyz ranges from their RANGE / RANGE2 slots
+        if (out->xyz[0] && fmt->spec_of_desc[out->xyz_field[0]] != fmt->spec_r1) spec = SPEC_GENERIC;
+        if (out->xyz[1] && fmt->spec_of_desc[out->xyz_field[1]] != fmt->spec_r2) spec = SPEC_GENERIC;
+    }
+
+    // tile width: widest tile that still lets two workgroups share a CU's 160 KiB LDS
+    int tile = 0;
+    for (int t : {64, 32, 16})
+        if (decode_lds_bytes(g, t) <= 80 * 1024) { tile = t; break; }
+    if (!tile)
+        for (int t : {64, 32, 16})
+            if (decode_lds_bytes(g, t) <= 160 * 1024) { tile = t; break; }
+    if (!tile) return fail(OUSTER_HIP_ERR_UNSUPPORTED, "column of %u bytes does not fit in LDS", g.col_size);
+    da.tiles_per_frame = (W + tile - 1) / tile;
+    da.xcd_map = n_frames >= 8 ? 1u : 0u;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            ctx->ev_pool.emplace_back(a, b);
+        }
+        e0 = ctx->ev_pool[ctx->ev_used].first;
+        e1 = ctx->ev_pool[ctx->ev_used].second;
+        ctx->ev_used++;
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    HIP_TRY(launch_decode(da, spec, tile, xyzm, st));
+    if (e1) HIP_TRY(hipEventRecord(e1, st));
+    return OUSTER_HIP_OK;
+}
+
+// ---- standalone destagger -----------------------------------------------------------------
+int ouster_hip_destagger(ouster_hip_ctx* ctx, const void* src, void* dst, uint32_t h, uint32_t w,
+                         uint32_t elem_bytes, const int32_t* shifts, uint32_t n_shifts,
+                         int inverse, uint32_t n_images) {
+    if (!ctx || !shifts) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_shifts != h)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "image height does not match shifts size");
+    if (n_images == 0 || h == 0 || w == 0) return OUSTER_HIP_OK;
+    if (!src || !dst || src == dst) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "bad image pointers");
+    if (elem_bytes == 0) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "elem_bytes is 0");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<int32_t> off;
+    dest_offsets(shifts, h, w, inverse, off);
+    if (ensure_offsets(ctx, off)) return fail(OUSTER_HIP_ERR_RUNTIME, "offset upload failed");
+    DestaggerArgs a{};
+    a.src = src;
+    a.dst = dst;
+    a.h = h;
+    a.w = w;
+    a.elem = elem_bytes;
+    a.offsets = (const int32_t*)ctx->offsets.p;
+    HIP_TRY(launch_destagger(a, n_images, ctx->stream));
+    return OUSTER_HIP_OK;
+}
+
+// ---- standalone cartesian -------------------------------------------------------------------
+int ouster_hip_cartesian(ouster_hip_ctx* ctx, const ouster_hip_lut* lut, const uint32_t* range,
+                         void* xyz, int xyz_dtype, uint32_t n_images) {
+    if (!ctx || !lut) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (xyz_dtype != OUSTER_HIP_F32 && xyz_dtype != OUSTER_HIP_F64)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "xyz_dtype must be F32 or F64");
+    if (n_images == 0) return OUSTER_HIP_OK;
+    if (!range || !xyz) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL image pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    CartesianArgs a{};
+    a.lut = lut->dev;
+    a.range = range;
+    a.xyz = xyz;
+    a.w = lut->w;
+    a.h = lut->h;
+    a.n_images = n_images;
+    a.xyz_dtype = xyz_dtype;
+    const size_t npx = (size_t)lut->w * lut->h;
+    a.vec_ok = al16(range) && al16(xyz) && (npx % 4 == 0);
+    const int mode = lut->separable ? (xyz_dtype == OUSTER_HIP_F32 ? 1 : 2) : 3;
+    HIP_TRY(launch_cartesian(a, mode, ctx->stream));
+    return OUSTER_HIP_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+int ouster_hip_timing_enable(ouster_hip_ctx* ctx, int on) {
+    if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    ctx->timing = on != 0;
+    ctx->ev_used = 0;
+    return OUSTER_HIP_OK;
+}
+
+int ouster_hip_timing_read(ouster_hip_ctx* ctx, double* avg_ms, uint32_t* n_launches) {
+    if (!ctx || !avg_ms) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double total = 0;
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+        total += ms;
+    }
+    *avg_ms = ctx->ev_used ? total / (double)ctx->ev_used : 0.0;
+    if (n_launches) *n_launches = (uint32_t)ctx->ev_used;
+    ctx->ev_used = 0;
+    return OUSTER_HIP_OK;
+}
+
+}  // extern "C"

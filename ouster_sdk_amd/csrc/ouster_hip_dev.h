@@ -1,0 +1,109 @@
+// ouster_hip_dev.h -- kernel argument blocks shared by the kernels and the C ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "../../include/ouster_hip.h"
+
+namespace ouster_hip_dev {
+
+enum SpecId { SPEC_GENERIC = 0, SPEC_DUAL_LB, SPEC_LB, SPEC_SINGLE, SPEC_DUAL, SPEC_LEGACY };
+
+struct Geometry {
+    uint32_t pixels_per_column, columns_per_packet, columns_per_frame;
+    uint32_t packet_header_size, col_header_size, channel_data_size, col_footer_size,
+        packet_footer_size, col_size, lidar_packet_size;
+    ouster_hip_bits col_timestamp, col_measurement_id, col_status;
+    ouster_hip_bits frame_id, alert_flags, thermal_shutdown, shot_limiting,
+        countdown_thermal_shutdown, countdown_shot_limiting;
+};
+
+// device view of one XYZ lookup table
+struct LutDev {
+    const double* beam_tab;  // [h][9]  U(3) V(3) Wb(3), x range_unit, rotated   (separable mode)
+    const double* col_tab;   // [w][5]  cos(theta_e) sin(theta_e) Kc(3)           (separable mode)
+    const void* full_dir;    // [w*h][3] full LUT (full mode)
+    const void* full_ofs;
+    double n;                // beam_to_lidar euclidean distance (raw range units)
+    int32_t full_dtype;      // OUSTER_HIP_F32 / F64 for full_dir/full_ofs, 0 when separable
+    int32_t pad;
+};
+
+struct ColmapArgs {
+    Geometry g;
+    const uint8_t* packets;
+    size_t packet_stride;
+    uint32_t slots_per_frame;
+    uint32_t n_packets_out;  // W / cpp
+    const uint32_t* packet_counts;  // device, nullable
+    const uint64_t* host_timestamps;
+    int32_t* map;  // [n_frames][W], pre-set to -1
+    uint64_t* packet_timestamp;
+    uint8_t* alert_flags;
+    ouster_hip_frame_meta* frame_meta;
+};
+
+struct DecodeArgs {
+    Geometry g;
+    const uint8_t* packets;
+    size_t packet_stride;
+    uint32_t slots_per_frame;
+    uint32_t n_frames;
+    uint32_t tiles_per_frame;
+    uint32_t xcd_map;        // 1: blockIdx -> (frame, tile) keeps a frame on one XCD
+    uint32_t vec_ok;         // W % 4 == 0 and all output bases/strides 16 B aligned
+    uint32_t any_destagger;
+    const int32_t* map;          // [n_frames][W]
+    const int32_t* dst_offsets;  // [H] destination column offset per row (device)
+    const LutDev* luts;          // [n_luts] (device)
+    uint32_t n_luts;
+    uint32_t n_fields;
+    void* planes[OUSTER_HIP_MAX_FIELDS];
+    void* destaggered[OUSTER_HIP_MAX_FIELDS];
+    ouster_hip_bits bits[OUSTER_HIP_MAX_FIELDS];
+    uint8_t elem[OUSTER_HIP_MAX_FIELDS];
+    uint8_t f16_nan[OUSTER_HIP_MAX_FIELDS];
+    int8_t desc_of_spec[16];  // static spec field k -> index into planes[] (-1: not requested)
+    uint64_t* timestamp;
+    uint16_t* measurement_id;
+    uint32_t* status;
+    void* xyz[2];
+    int32_t xyz_field[2];
+    int32_t xyz_dtype;
+};
+
+struct DestaggerArgs {
+    const void* src;
+    void* dst;
+    uint32_t h, w, elem;
+    const int32_t* offsets;  // [h] device, reference arithmetic applied on the host
+};
+
+struct CartesianArgs {
+    LutDev lut;
+    const uint32_t* range;
+    void* xyz;
+    uint32_t w, h, n_images;
+    int32_t xyz_dtype;
+    uint32_t vec_ok;
+};
+
+// one compile-time field of a standard profile (see the Spec* tables in the kernels file)
+struct FieldC {
+    uint32_t offset;
+    uint64_t mask;
+    int32_t shift;
+    uint32_t elem;
+};
+const FieldC* spec_fields(int spec_id, int* nf, uint32_t* chan, int* r1, int* r2);
+
+size_t decode_lds_bytes(const Geometry& g, int tile);
+hipError_t launch_colmap(const ColmapArgs& a, uint32_t n_frames, hipStream_t st);
+hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, hipStream_t st);
+hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st);
+hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
+
+}  // namespace ouster_hip_dev

@@ -1,0 +1,818 @@
+// ouster_hip_kernels.hip -- CDNA4 (gfx950) kernels for the Ouster per-pixel hot path.
+//
+//   k_colmap    column headers -> per-frame "destination column -> source column" map
+//   k_decode    fused field decode (+ destagger + cartesian), one workgroup per
+//               64/32/16-column tile of one frame
+//   k_destagger standalone per-row circular shift
+//   k_cartesian standalone range image -> XYZ
+//
+// What the kernels compute is defined by the reference loops
+//   PacketFormat::col_field/block_field      ouster_core/src/parsing.cpp:628-675
+//   FieldDecodeInfo::get                     ouster_core/include/ouster/core/field_decode_info.h:41-54
+//   FrameBatcher::parse_by_col/_by_block     ouster_core/src/lidar_frame.cpp:1422-1528
+//   destagger_into<T>                        ouster_core/include/ouster/core/impl/lidar_frame_impl.h:733-760
+//   impl::make_xyz_lut / cartesianT<T>       ouster_core/src/xyzlut.cpp:11-89, impl/cartesian.h:36-66
+// How they compute it is MI355X-specific; see DESIGN.md.
+//
+// Memory-bound byte/bit work: no MFMA anywhere.  The wire format is column
+// major (one column = H consecutive pixels), the LidarFrame planes are row
+// major H x W, so each workgroup stages a tile of columns in LDS with wide
+// coalesced loads and then walks it row-wise, 4 consecutive columns per lane,
+// so that every global store is a 16 B (u32 planes / xyz) or packed (u8/u16
+// planes) vector store of a contiguous row segment.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ouster_hip_dev.h"
+
+namespace ouster_hip_dev {
+
+// ------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t apply_bits(uint64_t word, uint64_t mask, int shift) {
+    word &= mask;
+    if (shift > 0) word >>= shift;
+    else if (shift < 0) word <<= -shift;
+    return word;
+}
+
+__device__ __forceinline__ uint64_t funnel3(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t sh) {
+    uint64_t lo = ((uint64_t)d1 << 32) | d0;
+    uint64_t v = lo >> sh;
+    if (sh) v |= ((uint64_t)d2) << (64 - sh);
+    return v;
+}
+
+// 64-bit little-endian window at an arbitrary byte address in global memory
+__device__ __forceinline__ uint64_t window_global(const uint8_t* p) {
+    uintptr_t a = (uintptr_t)p;
+    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+    uint32_t sh = (uint32_t)(a & 3) * 8;
+    uint32_t d0 = q[0], d1 = q[1];
+    uint32_t d2 = sh ? q[2] : 0u;
+    return funnel3(d0, d1, d2, sh);
+}
+
+// same, from the LDS tile (byte offset into the tile)
+__device__ __forceinline__ uint64_t window_lds(const uint32_t* tile, uint32_t byte_off) {
+    const uint32_t* q = tile + (byte_off >> 2);
+    uint32_t sh = (byte_off & 3) * 8;
+    return funnel3(q[0], q[1], q[2], sh);
+}
+
+__device__ __forceinline__ uint64_t trunc_elem(uint64_t v, uint32_t elem) {
+    return elem >= 8 ? v : (v & ((1ull << (elem * 8)) - 1));
+}
+
+// unaligned-capable vector stores (gfx950 global stores only need the HW
+// "unaligned access mode", which amdhsa enables; the compiler emits single
+// global_store_dword{,x2,x4} for these packed types)
+struct __attribute__((packed, aligned(1))) pk4 { uint32_t a; };
+struct __attribute__((packed, aligned(1))) pk8 { uint32_t a, b; };
+struct __attribute__((packed, aligned(1))) pk16 { uint32_t a, b, c, d; };
+
+__device__ __forceinline__ void st4(void* p, uint32_t a) { ((pk4*)p)->a = a; }
+__device__ __forceinline__ void st8(void* p, uint32_t a, uint32_t b) {
+    pk8 v{a, b};
+    *((pk8*)p) = v;
+}
+__device__ __forceinline__ void st16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    pk16 v{a, b, c, d};
+    *((pk16*)p) = v;
+}
+
+// store 4 consecutive elements of `elem` bytes each starting at byte pointer p
+__device__ __forceinline__ void store4(uint8_t* p, const uint64_t v[4], uint32_t elem) {
+    switch (elem) {
+        case 1:
+            st4(p, (uint32_t)(v[0] & 0xff) | ((uint32_t)(v[1] & 0xff) << 8) |
+                       ((uint32_t)(v[2] & 0xff) << 16) | ((uint32_t)(v[3] & 0xff) << 24));
+            break;
+        case 2:
+            st8(p, (uint32_t)(v[0] & 0xffff) | ((uint32_t)(v[1] & 0xffff) << 16),
+                (uint32_t)(v[2] & 0xffff) | ((uint32_t)(v[3] & 0xffff) << 16));
+            break;
+        case 4:
+            st16(p, (uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
+            break;
+        case 6: {
+            // 4 x 48 bit, little endian, 24 contiguous bytes
+            uint64_t a = (v[0] & 0xffffffffffffull) | (v[1] << 48);
+            uint64_t b = ((v[1] >> 16) & 0xffffffffull) | (v[2] << 32);
+            uint64_t c = ((v[2] >> 32) & 0xffffull) | (v[3] << 16);
+            st8(p, (uint32_t)a, (uint32_t)(a >> 32));
+            st8(p + 8, (uint32_t)b, (uint32_t)(b >> 32));
+            st8(p + 16, (uint32_t)c, (uint32_t)(c >> 32));
+            break;
+        }
+        default:  // 8
+            st16(p, (uint32_t)v[0], (uint32_t)(v[0] >> 32), (uint32_t)v[1], (uint32_t)(v[1] >> 32));
+            st16(p + 16, (uint32_t)v[2], (uint32_t)(v[2] >> 32), (uint32_t)v[3],
+                 (uint32_t)(v[3] >> 32));
+    }
+}
+
+__device__ __forceinline__ void store1(uint8_t* p, uint64_t v, uint32_t elem) {
+    switch (elem) {
+        case 1: *p = (uint8_t)v; break;
+        case 2: *(uint16_t*)p = (uint16_t)v; break;
+        case 4: *(uint32_t*)p = (uint32_t)v; break;
+        case 6:
+            *(uint16_t*)p = (uint16_t)v;
+            *(uint16_t*)(p + 2) = (uint16_t)(v >> 16);
+            *(uint16_t*)(p + 4) = (uint16_t)(v >> 32);
+            break;
+        default: *(uint64_t*)p = v;
+    }
+}
+
+__device__ __forceinline__ uint64_t zero_value(uint32_t f16_nan) {
+    return f16_nan ? 0x7e007e007e007e00ull : 0ull;
+}
+
+// ------------------------------------------------------------------------------------
+// k_colmap: one thread per received column slot.
+//   map[f][m_id] = max over received valid columns of (slot index)   ("last in buffer wins")
+//   + packet level outputs + frame meta
+// Semantics: FrameBatcher::parse_by_col, ouster_core/src/lidar_frame.cpp:1422-1466
+//   (m_id >= W dropped :1432-1434, invalid status dropped :1447-1450) and
+//   batch_lidar_packet :1534-1539 (packet_timestamp / alert_flags per packet),
+//   start_frame :1709-1741 (frame meta from the first packet).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colmap(ColmapArgs a) {
+    const uint32_t cpp = a.g.columns_per_packet;
+    const uint32_t slots = a.slots_per_frame * cpp;
+    const uint32_t f = blockIdx.y;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t count = a.packet_counts ? a.packet_counts[f] : a.slots_per_frame;
+    if (s == 0 && a.frame_meta) {
+        ouster_hip_frame_meta m;
+        m.frame_id = -1; m.frame_status = 0; m.shutdown_countdown = 0;
+        m.shot_limiting_countdown = 0; m.n_valid_columns = 0;
+        if (count > 0) {
+            const uint8_t* pkt = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
+            m.frame_id = (int64_t)(uint32_t)apply_bits(window_global(pkt + a.g.frame_id.offset),
+                                                        a.g.frame_id.mask, a.g.frame_id.shift);
+            uint8_t th = (uint8_t)apply_bits(window_global(pkt + a.g.thermal_shutdown.offset),
+                                             a.g.thermal_shutdown.mask, a.g.thermal_shutdown.shift);
+            uint8_t sl = (uint8_t)apply_bits(window_global(pkt + a.g.shot_limiting.offset),
+                                             a.g.shot_limiting.mask, a.g.shot_limiting.shift);
+            m.frame_status = (uint64_t)(th & 0x0f) | ((uint64_t)(sl & 0x0f) << 4);
+            m.shutdown_countdown = (uint16_t)apply_bits(
+                window_global(pkt + a.g.countdown_thermal_shutdown.offset),
+                a.g.countdown_thermal_shutdown.mask, a.g.countdown_thermal_shutdown.shift);
+            m.shot_limiting_countdown = (uint16_t)apply_bits(
+                window_global(pkt + a.g.countdown_shot_limiting.offset),
+                a.g.countdown_shot_limiting.mask, a.g.countdown_shot_limiting.shift);
+        }
+        a.frame_meta[f] = m;
+    }
+    if (s >= slots) return;
+    const uint32_t p = s / cpp, icol = s - p * cpp;
+    if (p >= count) return;
+    const uint8_t* pkt = a.packets + ((size_t)f * a.slots_per_frame + p) * a.packet_stride;
+    const uint8_t* col = pkt + a.g.packet_header_size + (size_t)icol * a.g.col_size;
+    const uint32_t m_id = (uint16_t)apply_bits(window_global(col + a.g.col_measurement_id.offset),
+                                               a.g.col_measurement_id.mask,
+                                               a.g.col_measurement_id.shift);
+    const uint32_t status = (uint32_t)apply_bits(window_global(col + a.g.col_status.offset),
+                                                 a.g.col_status.mask, a.g.col_status.shift);
+    if (icol == 0) {
+        const uint32_t packet_id = m_id / cpp;
+        if (packet_id < a.n_packets_out) {
+            if (a.packet_timestamp && a.host_timestamps)
+                a.packet_timestamp[(size_t)f * a.n_packets_out + packet_id] =
+                    a.host_timestamps[(size_t)f * a.slots_per_frame + p];
+            if (a.alert_flags)
+                a.alert_flags[(size_t)f * a.n_packets_out + packet_id] = (uint8_t)apply_bits(
+                    window_global(pkt + a.g.alert_flags.offset), a.g.alert_flags.mask,
+                    a.g.alert_flags.shift);
+        }
+    }
+    if ((status & 1u) && m_id < a.g.columns_per_frame)
+        atomicMax(&a.map[(size_t)f * a.g.columns_per_frame + m_id], (int32_t)s);
+}
+
+// ------------------------------------------------------------------------------------
+// global -> LDS staging of one contiguous byte range, all threads of the block
+// ------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__device__ __forceinline__ void stage_range(uint32_t* lds_tile, uint32_t lds_byte_off,
+                                            const uint8_t* __restrict__ src, uint32_t nbytes,
+                                            uint32_t tid) {
+    if ((((uintptr_t)src | lds_byte_off | nbytes) & 15u) == 0) {
+        const u32x4* s = (const u32x4*)src;
+        u32x4* d = (u32x4*)(lds_tile + (lds_byte_off >> 2));
+        const uint32_t n = nbytes >> 4;
+#pragma unroll 4
+        for (uint32_t i = tid; i < n; i += NT) d[i] = __builtin_nontemporal_load(s + i);
+    } else {  // packets are 4-byte granular (parsing.cpp:459-469), so is everything in them
+        const uint32_t* s = (const uint32_t*)src;
+        uint32_t* d = lds_tile + (lds_byte_off >> 2);
+        const uint32_t n = nbytes >> 2;
+#pragma unroll 4
+        for (uint32_t i = tid; i < n; i += NT) d[i] = s[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// static field tables for the standard profiles (bit layouts: parsing.cpp:170-363,
+// plane element sizes: lidar_frame.cpp:73-187).  A runtime format descriptor is
+// matched against these at format_create; anything else runs the generic spec.
+// ------------------------------------------------------------------------------------
+struct SpecDualLB {  // RNG15_RFL8_NIR8_DUAL / FUSA_RNG15_RFL8_NIR8_DUAL, 8 B/px
+    static constexpr bool is_static = true;
+    static constexpr uint32_t chan = 8;
+    static constexpr int nf = 8;
+    static constexpr int range_idx = 0, range2_idx = 4;
+    static constexpr FieldC f[8] = {{0, 0x7fff, -3, 4}, {1, 0x80, 7, 1},  {2, 0xff, 0, 1},
+                                    {3, 0xff, -4, 2},   {4, 0x7fff, -3, 4}, {5, 0x80, 7, 1},
+                                    {6, 0xff, 0, 1},    {7, 0xff, 0, 1}};
+};
+struct SpecLB {  // RNG15_RFL8_NIR8, 4 B/px
+    static constexpr bool is_static = true;
+    static constexpr uint32_t chan = 4;
+    static constexpr int nf = 4;
+    static constexpr int range_idx = 0, range2_idx = -1;
+    static constexpr FieldC f[4] = {{0, 0x7fff, -3, 4}, {1, 0x80, 7, 1}, {2, 0xff, 0, 1},
+                                    {3, 0xff, -4, 2}};
+};
+struct SpecSingle {  // RNG19_RFL8_SIG16_NIR16, 12 B/px
+    static constexpr bool is_static = true;
+    static constexpr uint32_t chan = 12;
+    static constexpr int nf = 6;
+    static constexpr int range_idx = 0, range2_idx = -1;
+    static constexpr FieldC f[6] = {{0, 0x7ffff, 0, 4}, {2, 0xf8, 3, 1},   {4, 0xff, 0, 1},
+                                    {6, 0xffff, 0, 2},  {8, 0xffff, 0, 2}, {11, 0xff, 0, 1}};
+};
+struct SpecDual {  // RNG19_RFL8_SIG16_NIR16_DUAL, 16 B/px
+    static constexpr bool is_static = true;
+    static constexpr uint32_t chan = 16;
+    static constexpr int nf = 10;
+    static constexpr int range_idx = 0, range2_idx = 3;
+    static constexpr FieldC f[10] = {{0, 0x7ffff, 0, 4},  {2, 0xf8, 3, 1},   {3, 0xff, 0, 1},
+                                     {4, 0x7ffff, 0, 4},  {6, 0xf8, 3, 1},   {7, 0xff, 0, 1},
+                                     {8, 0xffff, 0, 2},   {10, 0xffff, 0, 2}, {12, 0xffff, 0, 2},
+                                     {15, 0xff, 0, 1}};
+};
+struct SpecLegacy {  // LEGACY, 12 B/px
+    static constexpr bool is_static = true;
+    static constexpr uint32_t chan = 12;
+    static constexpr int nf = 5;
+    static constexpr int range_idx = 0, range2_idx = -1;
+    static constexpr FieldC f[5] = {{0, 0xfffff, 0, 4}, {3, 0xf0, 4, 1}, {4, 0xff, 0, 1},
+                                    {6, 0xffff, 0, 2},  {8, 0xffff, 0, 2}};
+};
+struct SpecGeneric {  // everything else: descriptors read from the kernel arguments
+    static constexpr bool is_static = false;
+    static constexpr uint32_t chan = 0;
+    static constexpr int nf = 0;
+    static constexpr int range_idx = -1, range2_idx = -1;
+};
+
+const FieldC* spec_fields(int spec_id, int* nf, uint32_t* chan, int* r1, int* r2) {
+    switch (spec_id) {
+        case SPEC_DUAL_LB: *nf = SpecDualLB::nf; *chan = SpecDualLB::chan; *r1 = 0; *r2 = 4; return SpecDualLB::f;
+        case SPEC_LB: *nf = SpecLB::nf; *chan = SpecLB::chan; *r1 = 0; *r2 = -1; return SpecLB::f;
+        case SPEC_SINGLE: *nf = SpecSingle::nf; *chan = SpecSingle::chan; *r1 = 0; *r2 = -1; return SpecSingle::f;
+        case SPEC_DUAL: *nf = SpecDual::nf; *chan = SpecDual::chan; *r1 = 0; *r2 = 3; return SpecDual::f;
+        case SPEC_LEGACY: *nf = SpecLegacy::nf; *chan = SpecLegacy::chan; *r1 = 0; *r2 = -1; return SpecLegacy::f;
+        default: *nf = 0; *chan = 0; *r1 = *r2 = -1; return nullptr;
+    }
+}
+
+// compile-time field extraction from the pixel's dwords held in registers
+template <class S, int K, int CW>
+__device__ __forceinline__ uint64_t extract_static(const uint32_t (&w)[CW]) {
+    constexpr uint32_t off = S::f[K].offset;
+    constexpr uint32_t i0 = off / 4, sh = (off % 4) * 8;
+    uint64_t lo = w[i0];
+    if constexpr (i0 + 1 < CW) lo |= (uint64_t)w[i0 + 1] << 32;
+    uint64_t win = lo >> sh;
+    if constexpr (sh != 0 && i0 + 2 < CW) win |= (uint64_t)w[i0 + 2] << (64 - sh);
+    return trunc_elem(apply_bits(win, S::f[K].mask, S::f[K].shift), S::f[K].elem);
+}
+
+// ------------------------------------------------------------------------------------
+// XYZ projection of 4 consecutive pixels of one row.
+//   separable tables (per-beam x per-column, double math, one rounding on store):
+//     dir  = cx*U + sx*V + Wb          (already x range_unit and rotated by `transform`)
+//     xyz  = (r - n) * dir + Kc        (Kc: per-column part of the offset)
+//   == r*direction + offset of make_xyz_lut (xyzlut.cpp:63-86) up to ~1e-13 m.
+//   full LUT (user arrays / per-pixel angle sensors): xyz = r*dir + ofs in the
+//   LUT's own precision, as cartesianT<T> does (cartesian.h:53-65).
+// ------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void store_xyz4(T* dst, const double (&p)[4][3]);
+
+template <>
+__device__ __forceinline__ void store_xyz4<float>(float* dst, const double (&p)[4][3]) {
+    float4* d = (float4*)dst;  // 48 B, 16 B aligned (pixel index multiple of 4)
+    d[0] = make_float4((float)p[0][0], (float)p[0][1], (float)p[0][2], (float)p[1][0]);
+    d[1] = make_float4((float)p[1][1], (float)p[1][2], (float)p[2][0], (float)p[2][1]);
+    d[2] = make_float4((float)p[2][2], (float)p[3][0], (float)p[3][1], (float)p[3][2]);
+}
+template <>
+__device__ __forceinline__ void store_xyz4<double>(double* dst, const double (&p)[4][3]) {
+    double2* d = (double2*)dst;
+    d[0] = make_double2(p[0][0], p[0][1]);
+    d[1] = make_double2(p[0][2], p[1][0]);
+    d[2] = make_double2(p[1][1], p[1][2]);
+    d[3] = make_double2(p[2][0], p[2][1]);
+    d[4] = make_double2(p[2][2], p[3][0]);
+    d[5] = make_double2(p[3][1], p[3][2]);
+}
+
+template <class T>
+__device__ __forceinline__ void store_xyz1(T* dst, const double (&p)[3]) {
+    dst[0] = (T)p[0]; dst[1] = (T)p[1]; dst[2] = (T)p[2];
+}
+
+// full-LUT projection of one pixel; LT = LUT element type
+template <class LT>
+__device__ __forceinline__ void project_full(const LT* dir, const LT* ofs, size_t pix, uint32_t r,
+                                             double (&p)[3]) {
+    if (r == 0) { p[0] = p[1] = p[2] = 0.0; return; }
+    const LT rr = (LT)r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // separate multiply and add like a default (non-FMA) host build of cartesianT
+        LT m = rr * dir[pix * 3 + k];
+        asm volatile("" : "+v"(m));  // keep the compiler from contracting into an fma
+        p[k] = (double)(LT)(m + ofs[pix * 3 + k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_decode: fused decode + destagger + cartesian for one (frame, column tile)
+// ------------------------------------------------------------------------------------
+// XYZM: 0 no xyz, 1 separable tables -> f32, 2 separable -> f64, 3 full LUT (runtime dtypes)
+template <class S, int TILE, int XYZM>
+__global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
+    constexpr int NT = 256;
+    constexpr int LPR = TILE / 4;    // lanes per row segment
+    constexpr int RPP = NT / LPR;    // rows per pass of the workgroup
+    extern __shared__ __align__(16) uint32_t smem[];
+
+    // ---- which (frame, tile)?  XCD-aware: all tiles of a frame on one XCD so that
+    // neighbouring tiles' partial cache lines (destaggered rows, u8 planes) merge in
+    // that XCD's L2 before they are written back.  Block b is dispatched to XCD b%8.
+    uint32_t f, tile;
+    const uint32_t tpf = a.tiles_per_frame;
+    if (a.xcd_map) {
+        const uint32_t xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        f = (i / tpf) * 8u + xcd;
+        tile = i % tpf;
+        if (f >= a.n_frames) return;
+    } else {
+        f = blockIdx.x / tpf;
+        tile = blockIdx.x - f * tpf;
+    }
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = a.g.columns_per_frame, H = a.g.pixels_per_column;
+    const uint32_t cpp = a.g.columns_per_packet, col_size = a.g.col_size;
+    const uint32_t c0 = tile * TILE;
+
+    // ---- LDS carve-up (all offsets 16 B aligned)
+    uint32_t* s_tile = smem;                                    // TILE * col_size (+16) bytes
+    const uint32_t tile_bytes = (TILE * col_size + 16 + 15) & ~15u;
+    int32_t* s_src = (int32_t*)(smem + (tile_bytes >> 2));      // [TILE]
+    uint64_t* s_masks = (uint64_t*)(s_src + TILE);              // [0] valid, [1] group-ok
+    int32_t* s_off = (int32_t*)(s_masks + 2);                   // [H] destagger offsets
+    double* s_beam = (double*)(s_off + ((H + 3) & ~3u));        // [H][9] per-beam table
+
+    // ---- phase 0: source map of this tile
+    if (tid < TILE) {
+        const uint32_t c = c0 + tid;
+        int32_t src = (c < W) ? a.map[(size_t)f * W + c] : -1;
+        s_src[tid] = src;
+        const uint32_t j0 = tid - tid % cpp;  // first column of my packet group in the tile
+        // "group ok": my packet's cpp columns sit in order, packet-aligned, all present
+        int32_t head = __shfl(src, (int)(j0 & 63u));
+        bool grp = (TILE % cpp == 0) && src >= 0 && head >= 0 && (uint32_t)head % cpp == 0 &&
+                   src == head + (int32_t)(tid - j0);
+        uint64_t vb = __ballot(src >= 0);
+        uint64_t gb = __ballot(grp);
+        if (tid == 0) { s_masks[0] = vb; s_masks[1] = gb; }
+    }
+    if (a.any_destagger)
+        for (uint32_t r = tid; r < H; r += NT) s_off[r] = a.dst_offsets[r];
+    const LutDev lut = (XYZM != 0) ? a.luts[f % a.n_luts] : LutDev{};
+    if (XYZM == 1 || XYZM == 2)
+        for (uint32_t i = tid; i < H * 9; i += NT) s_beam[i] = lut.beam_tab[i];
+    __syncthreads();
+
+    // ---- phase 1: stage the tile's columns in LDS, column j at byte j*col_size
+    const uint64_t validmask = s_masks[0], groupmask = s_masks[1];
+    const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
+    if (TILE % cpp == 0) {
+        const uint32_t gbytes = cpp * col_size;
+        for (uint32_t j0 = 0; j0 < TILE; j0 += cpp) {
+            const uint64_t gm = (cpp >= 64 ? ~0ull : ((1ull << cpp) - 1)) << j0;
+            if ((groupmask & gm) == gm) {  // whole packet, one linear copy
+                const uint32_t p = (uint32_t)s_src[j0] / cpp;
+                stage_range<NT>(s_tile, j0 * col_size,
+                                fbase + (size_t)p * a.packet_stride + a.g.packet_header_size,
+                                gbytes, tid);
+            } else if (validmask & gm) {
+                for (uint32_t j = j0; j < j0 + cpp; ++j) {
+                    const int32_t s = s_src[j];
+                    if (s < 0) continue;
+                    const uint32_t p = (uint32_t)s / cpp, ic = (uint32_t)s - p * cpp;
+                    stage_range<NT>(s_tile, j * col_size,
+                                    fbase + (size_t)p * a.packet_stride +
+                                        a.g.packet_header_size + (size_t)ic * col_size,
+                                    col_size, tid);
+                }
+            }
+        }
+    } else {
+        for (uint32_t j = 0; j < TILE; ++j) {
+            const int32_t s = s_src[j];
+            if (s < 0) continue;
+            const uint32_t p = (uint32_t)s / cpp, ic = (uint32_t)s - p * cpp;
+            stage_range<NT>(s_tile, j * col_size,
+                            fbase + (size_t)p * a.packet_stride + a.g.packet_header_size +
+                                (size_t)ic * col_size,
+                            col_size, tid);
+        }
+    }
+    if (tid < 4) s_tile[(TILE * col_size >> 2) + tid] = 0;  // slack read by 64-bit windows
+    __syncthreads();
+
+    // ---- phase 2a: column headers (timestamp / measurement_id / status), one lane per column
+    if (tid < TILE && c0 + tid < W) {
+        const uint32_t c = c0 + tid;
+        const bool v = (validmask >> tid) & 1;
+        const uint32_t cb = tid * col_size;
+        if (a.timestamp)
+            a.timestamp[(size_t)f * W + c] =
+                v ? apply_bits(window_lds(s_tile, cb + a.g.col_timestamp.offset),
+                               a.g.col_timestamp.mask, a.g.col_timestamp.shift) : 0ull;
+        if (a.measurement_id) a.measurement_id[(size_t)f * W + c] = v ? (uint16_t)c : (uint16_t)0;
+        if (a.status)
+            a.status[(size_t)f * W + c] =
+                v ? (uint32_t)apply_bits(window_lds(s_tile, cb + a.g.col_status.offset),
+                                         a.g.col_status.mask, a.g.col_status.shift) : 0u;
+    }
+
+    // ---- phase 2b: pixels.  lane = (row within pass, quad of 4 consecutive columns)
+    const uint32_t q = tid % LPR, ty = tid / LPR;
+    const uint32_t jq = q * 4;                 // first of my 4 columns inside the tile
+    const uint32_t col = c0 + jq;              // ... inside the frame
+    const uint32_t vq = (uint32_t)(validmask >> jq) & 0xfu;
+    const bool vec = a.vec_ok && (col + 3 < W);
+    if (col >= W) return;
+    const uint32_t ncol = (W - col) < 4 ? (W - col) : 4;  // <4 only when W%4 != 0
+    const uint32_t hdr = a.g.col_header_size;
+    const size_t plane_px = (size_t)H * W;
+
+    // per-column constants of the separable LUT for my 4 columns
+    double cx[4], sx[4], kc[4][3];
+    if (XYZM == 1 || XYZM == 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t cc = (col + c < W) ? col + c : W - 1;
+            const double* t = lut.col_tab + (size_t)cc * 5;
+            cx[c] = t[0]; sx[c] = t[1]; kc[c][0] = t[2]; kc[c][1] = t[3]; kc[c][2] = t[4];
+        }
+    }
+
+    for (uint32_t r = ty; r < H; r += RPP) {
+        const size_t rowpix = (size_t)r * W + col;  // pixel index of my first column
+        uint32_t doff = 0;                          // destaggered column of my first column
+        bool dvec = false;
+        if (a.any_destagger) {
+            doff = col + (uint32_t)s_off[r];
+            if (doff >= W) doff -= W;
+            dvec = vec && (doff + 3 < W);
+        }
+        uint32_t rng[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+
+        if constexpr (S::is_static) {
+            constexpr int CW = S::chan / 4;
+            uint32_t w[4][CW];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t* px = s_tile + (((jq + c) * col_size + hdr + r * S::chan) >> 2);
+#pragma unroll
+                for (int k = 0; k < CW; ++k) w[c][k] = px[k];
+            }
+            auto do_field = [&](auto kc_) {
+                constexpr int K = decltype(kc_)::value;
+                const int di = a.desc_of_spec[K];
+                if (di < 0) return;
+                uint64_t v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    v[c] = ((vq >> c) & 1) ? extract_static<S, K, CW>(w[c])
+                                           : trunc_elem(zero_value(a.f16_nan[di]), S::f[K].elem);
+                if (K == S::range_idx) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
+                if (K == S::range2_idx) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
+                constexpr uint32_t e = S::f[K].elem;
+                uint8_t* pl = (uint8_t*)a.planes[di];
+                if (pl) {
+                    uint8_t* d = pl + ((size_t)f * plane_px + rowpix) * e;
+                    if (vec) store4(d, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) store1(d + c * e, v[c], e);
+                }
+                uint8_t* dp = (uint8_t*)a.destaggered[di];
+                if (dp) {
+                    uint8_t* drow = dp + ((size_t)f * plane_px + (size_t)r * W) * e;
+                    if (dvec) store4(drow + (size_t)doff * e, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) {
+                        uint32_t dc = doff + c; if (dc >= W) dc -= W;
+                        store1(drow + (size_t)dc * e, v[c], e);
+                    }
+                }
+            };
+            [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+                (do_field(std::integral_constant<int, Ks>{}), ...);
+            }(std::make_integer_sequence<int, S::nf>{});
+        } else {
+            const uint32_t chan = a.g.channel_data_size;
+            for (uint32_t i = 0; i < a.n_fields; ++i) {
+                const bool want_xyz = (XYZM != 0) && ((int)i == a.xyz_field[0] || (int)i == a.xyz_field[1]);
+                uint8_t* pl = (uint8_t*)a.planes[i];
+                uint8_t* dp = (uint8_t*)a.destaggered[i];
+                if (!pl && !dp && !want_xyz) continue;
+                const uint32_t e = a.elem[i];
+                uint64_t v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t bo = (jq + c) * col_size + hdr + r * chan + a.bits[i].offset;
+                    v[c] = ((vq >> c) & 1)
+                               ? trunc_elem(apply_bits(window_lds(s_tile, bo), a.bits[i].mask,
+                                                       a.bits[i].shift), e)
+                               : trunc_elem(zero_value(a.f16_nan[i]), e);
+                }
+                if ((int)i == a.xyz_field[0]) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
+                if ((int)i == a.xyz_field[1]) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
+                if (pl) {
+                    uint8_t* d = pl + ((size_t)f * plane_px + rowpix) * e;
+                    if (vec) store4(d, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) store1(d + c * e, v[c], e);
+                }
+                if (dp) {
+                    uint8_t* drow = dp + ((size_t)f * plane_px + (size_t)r * W) * e;
+                    if (dvec) store4(drow + (size_t)doff * e, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) {
+                        uint32_t dc = doff + c; if (dc >= W) dc -= W;
+                        store1(drow + (size_t)dc * e, v[c], e);
+                    }
+                }
+            }
+        }
+
+        if constexpr (XYZM == 1 || XYZM == 2) {
+            using XT = typename std::conditional<XYZM == 1, float, double>::type;
+            const double* b = s_beam + r * 9;
+            const double u0 = b[0], u1 = b[1], u2 = b[2], v0 = b[3], v1 = b[4], v2 = b[5],
+                         w0 = b[6], w1 = b[7], w2 = b[8];
+            double d[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                d[c][0] = fma(cx[c], u0, fma(sx[c], v0, w0));
+                d[c][1] = fma(cx[c], u1, fma(sx[c], v1, w1));
+                d[c][2] = fma(cx[c], u2, fma(sx[c], v2, w2));
+            }
+#pragma unroll
+            for (int ret = 0; ret < 2; ++ret) {
+                XT* out = (XT*)a.xyz[ret];
+                if (!out) continue;
+                double p[4][3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t rr = rng[ret][c];
+                    const double rm = (double)rr - lut.n;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) p[c][k] = rr ? fma(rm, d[c][k], kc[c][k]) : 0.0;
+                }
+                XT* dst = out + ((size_t)f * plane_px + rowpix) * 3;
+                if (vec) store_xyz4<XT>(dst, p);
+                else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<XT>(dst + c * 3, p[c]);
+            }
+        } else if constexpr (XYZM == 3) {
+#pragma unroll
+            for (int ret = 0; ret < 2; ++ret) {
+                if (!a.xyz[ret]) continue;
+                double p[4][3];
+                for (uint32_t c = 0; c < ncol; ++c) {
+                    if (lut.full_dtype == OUSTER_HIP_F32)
+                        project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs,
+                                            rowpix + c, rng[ret][c], p[c]);
+                    else
+                        project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs,
+                                             rowpix + c, rng[ret][c], p[c]);
+                }
+                if (a.xyz_dtype == OUSTER_HIP_F32) {
+                    float* dst = (float*)a.xyz[ret] + ((size_t)f * plane_px + rowpix) * 3;
+                    if (vec) store_xyz4<float>(dst, p);
+                    else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<float>(dst + c * 3, p[c]);
+                } else {
+                    double* dst = (double*)a.xyz[ret] + ((size_t)f * plane_px + rowpix) * 3;
+                    if (vec) store_xyz4<double>(dst, p);
+                    else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<double>(dst + c * 3, p[c]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_destagger: dst[img][u][(v + off[u]) % w] = src[img][u][v], element = elem bytes.
+// One workgroup per (row, image); lanes walk the DESTINATION row in 16 B chunks so every
+// store is an aligned, coalesced 16 B vector; the source bytes for a chunk start at an
+// arbitrary byte offset of the source row and are fetched with three aligned dword loads
+// per output dword pair (the row is L1/L2 resident after first touch).
+//   offset arithmetic: destagger_into, impl/lidar_frame_impl.h:753-759
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_destagger(DestaggerArgs a) {
+    const uint32_t u = blockIdx.x, img = blockIdx.y;
+    const size_t row_bytes = (size_t)a.w * a.elem;
+    const uint8_t* srow = (const uint8_t*)a.src + ((size_t)img * a.h + u) * row_bytes;
+    uint8_t* drow = (uint8_t*)a.dst + ((size_t)img * a.h + u) * row_bytes;
+    const size_t shift_bytes = (size_t)a.offsets[u] * a.elem;  // dst byte b <- src byte (b - shift) mod row
+    const bool fast = ((row_bytes & 15) == 0) && ((((uintptr_t)a.src | (uintptr_t)a.dst) & 15) == 0);
+    if (fast) {
+        const uint32_t nchunk = (uint32_t)(row_bytes >> 4);
+        for (uint32_t i = threadIdx.x; i < nchunk; i += blockDim.x) {
+            const size_t db = (size_t)i << 4;
+            size_t sb = db + row_bytes - shift_bytes;
+            if (sb >= row_bytes) sb -= row_bytes;
+            uint32_t o[4];
+            if (sb + 16 <= row_bytes) {
+                const uint32_t sh = (uint32_t)(sb & 3) * 8;
+                const uint32_t* q = (const uint32_t*)(srow + (sb & ~(size_t)3));
+                if (sh == 0) {
+                    o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
+                } else {
+                    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                    o[0] = (d0 >> sh) | (d1 << (32 - sh));
+                    o[1] = (d1 >> sh) | (d2 << (32 - sh));
+                    o[2] = (d2 >> sh) | (d3 << (32 - sh));
+                    o[3] = (d3 >> sh) | (d4 << (32 - sh));
+                }
+            } else {  // the chunk straddles the wrap point of the source row
+                uint8_t b[16];
+                for (int k = 0; k < 16; ++k) {
+                    size_t s = sb + k;
+                    if (s >= row_bytes) s -= row_bytes;
+                    b[k] = srow[s];
+                }
+                for (int k = 0; k < 4; ++k)
+                    o[k] = b[4 * k] | (b[4 * k + 1] << 8) | (b[4 * k + 2] << 16) |
+                           ((uint32_t)b[4 * k + 3] << 24);
+            }
+            *(uint4*)(drow + db) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        for (size_t b = threadIdx.x; b < row_bytes; b += blockDim.x) {
+            size_t s = b + row_bytes - shift_bytes;
+            if (s >= row_bytes) s -= row_bytes;
+            drow[b] = srow[s];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_cartesian: standalone range image -> xyz, 4 consecutive pixels per lane
+//   (cartesianT<T>, impl/cartesian.h:36-66)
+// ------------------------------------------------------------------------------------
+template <int MODE /*1 sep->f32, 2 sep->f64, 3 full*/>
+__global__ __launch_bounds__(256) void k_cartesian(CartesianArgs a) {
+    const uint32_t W = a.w, H = a.h;
+    const size_t npix = (size_t)W * H;
+    const size_t quads = (npix + 3) / 4;
+    const LutDev lut = a.lut;
+    for (size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qi < quads * a.n_images;
+         qi += (size_t)gridDim.x * blockDim.x) {
+        const size_t img = qi / quads, q = qi - img * quads;
+        const size_t pix = q * 4;
+        const uint32_t n = (npix - pix) < 4 ? (uint32_t)(npix - pix) : 4;
+        const uint32_t* rp = a.range + img * npix + pix;
+        uint32_t r[4] = {0, 0, 0, 0};
+        const bool vec = (n == 4) && a.vec_ok;
+        if (vec) { uint4 t = *(const uint4*)rp; r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+        else for (uint32_t c = 0; c < n; ++c) r[c] = rp[c];
+        double p[4][3];
+        if constexpr (MODE == 1 || MODE == 2) {
+            for (uint32_t c = 0; c < n; ++c) {
+                const size_t i = pix + c;
+                const uint32_t row = (uint32_t)(i / W), cc = (uint32_t)(i - (size_t)row * W);
+                const double* b = lut.beam_tab + (size_t)row * 9;
+                const double* t = lut.col_tab + (size_t)cc * 5;
+                const double cxx = t[0], sxx = t[1];
+                const double rm = (double)r[c] - lut.n;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double d = fma(cxx, b[k], fma(sxx, b[3 + k], b[6 + k]));
+                    p[c][k] = r[c] ? fma(rm, d, t[2 + k]) : 0.0;
+                }
+            }
+        } else {
+            for (uint32_t c = 0; c < n; ++c) {
+                if (lut.full_dtype == OUSTER_HIP_F32)
+                    project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs,
+                                        pix + c, r[c], p[c]);
+                else
+                    project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs,
+                                         pix + c, r[c], p[c]);
+            }
+        }
+        if (a.xyz_dtype == OUSTER_HIP_F32) {
+            float* dst = (float*)a.xyz + (img * npix + pix) * 3;
+            if (vec) store_xyz4<float>(dst, p);
+            else for (uint32_t c = 0; c < n; ++c) store_xyz1<float>(dst + c * 3, p[c]);
+        } else {
+            double* dst = (double*)a.xyz + (img * npix + pix) * 3;
+            if (vec) store_xyz4<double>(dst, p);
+            else for (uint32_t c = 0; c < n; ++c) store_xyz1<double>(dst + c * 3, p[c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launchers (host)
+// ------------------------------------------------------------------------------------
+size_t decode_lds_bytes(const Geometry& g, int tile) {
+    size_t tile_bytes = ((size_t)tile * g.col_size + 16 + 15) & ~(size_t)15;
+    size_t h4 = (g.pixels_per_column + 3) & ~3u;
+    return tile_bytes + (size_t)tile * 4 + 16 + h4 * 4 + (size_t)g.pixels_per_column * 9 * 8;
+}
+
+template <class S, int TILE>
+static hipError_t launch_decode_t(const DecodeArgs& a, int xyzm, dim3 grid, size_t lds,
+                                  hipStream_t st) {
+    void (*k)(DecodeArgs) = nullptr;
+    switch (xyzm) {
+        case 0: k = k_decode<S, TILE, 0>; break;
+        case 1: k = k_decode<S, TILE, 1>; break;
+        case 2: k = k_decode<S, TILE, 2>; break;
+        default: k = k_decode<S, TILE, 3>; break;
+    }
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <class S>
+static hipError_t launch_decode_s(const DecodeArgs& a, int tile, int xyzm, dim3 grid, size_t lds,
+                                  hipStream_t st) {
+    switch (tile) {
+        case 64: return launch_decode_t<S, 64>(a, xyzm, grid, lds, st);
+        case 32: return launch_decode_t<S, 32>(a, xyzm, grid, lds, st);
+        default: return launch_decode_t<S, 16>(a, xyzm, grid, lds, st);
+    }
+}
+
+hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, hipStream_t st) {
+    const uint32_t tpf = a.tiles_per_frame;
+    const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * tpf : a.n_frames * tpf;
+    const dim3 grid(nblocks);
+    const size_t lds = decode_lds_bytes(a.g, tile);
+    switch (spec_id) {
+        case SPEC_DUAL_LB: return launch_decode_s<SpecDualLB>(a, tile, xyzm, grid, lds, st);
+        case SPEC_LB: return launch_decode_s<SpecLB>(a, tile, xyzm, grid, lds, st);
+        case SPEC_SINGLE: return launch_decode_s<SpecSingle>(a, tile, xyzm, grid, lds, st);
+        case SPEC_DUAL: return launch_decode_s<SpecDual>(a, tile, xyzm, grid, lds, st);
+        case SPEC_LEGACY: return launch_decode_s<SpecLegacy>(a, tile, xyzm, grid, lds, st);
+        default: return launch_decode_s<SpecGeneric>(a, tile, xyzm, grid, lds, st);
+    }
+}
+
+hipError_t launch_colmap(const ColmapArgs& a, uint32_t n_frames, hipStream_t st) {
+    const uint32_t slots = a.slots_per_frame * a.g.columns_per_packet;
+    dim3 grid((slots + 255) / 256, n_frames);
+    hipLaunchKernelGGL(k_colmap, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st) {
+    dim3 grid(a.h, n_images);
+    hipLaunchKernelGGL(k_destagger, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st) {
+    const size_t quads = ((size_t)a.w * a.h + 3) / 4 * a.n_images;
+    size_t blocks = (quads + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks == 0) blocks = 1;
+    dim3 grid((uint32_t)blocks);
+    switch (mode) {
+        case 1: hipLaunchKernelGGL(k_cartesian<1>, grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(k_cartesian<2>, grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(k_cartesian<3>, grid, dim3(256), 0, st, a); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ouster_hip_dev

@@ -1,0 +1,171 @@
+"""torch-backed device buffers around the C ABI (plumbing: memory, streams, distribution).
+
+`HotPath` bundles a context, a format and optional LUTs for one sensor configuration and
+exposes the three operations of the path on torch CUDA(=HIP) tensors:
+
+    decode(packets)   -> dict of planes / destaggered planes / xyz / column headers
+    destagger(img)    -> destaggered image(s)
+    cartesian(range)  -> xyz
+
+All arithmetic happens in libouster_hip.so; torch only owns the HBM allocations and the
+stream the kernels are ordered on.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+
+_TORCH_OF_ELEM = {1: torch.uint8, 2: torch.uint16, 4: torch.uint32, 8: torch.uint64}
+
+
+def _u8(n):
+    return torch.empty(n, dtype=torch.uint8, device="cuda")
+
+
+class HotPath:
+    def __init__(self, profile: str, h: int, w: int, cpp: int = 16, header_type: int = 0,
+                 fields: Optional[Sequence[Tuple[str, int]]] = None, with_window: bool = True,
+                 device: Optional[int] = None, use_torch_stream: bool = True):
+        if not torch.cuda.is_available():
+            raise capi.OusterHipError("no MI355X visible: the hot path has no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else device
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream().cuda_stream if use_torch_stream else None
+        self.ctx = capi.Context(self.device, stream)
+        self.profile, self.h, self.w, self.cpp = profile, h, w, cpp
+        self.fields: List[Tuple[str, int]] = list(fields) if fields is not None else \
+            capi.default_planes(profile, with_window)
+        self.desc = capi.format_desc(profile, h, cpp, w, self.fields, header_type)
+        self.fmt = self.ctx.make_format(self.desc)
+        self.packet_size = self.desc.lidar_packet_size
+        self.luts: List[capi.Lut] = []
+        self.shifts: Optional[np.ndarray] = None
+
+    # -- configuration -----------------------------------------------------------------
+    def set_pixel_shift_by_row(self, shifts):
+        self.shifts = np.ascontiguousarray(shifts, dtype=np.int32)
+
+    def add_lut(self, beam_to_lidar, transform, az_deg, alt_deg, range_unit=0.001) -> capi.Lut:
+        lut = capi.Lut.from_calib(self.ctx, self.w, self.h, range_unit, beam_to_lidar, transform,
+                                  az_deg, alt_deg)
+        self.luts.append(lut)
+        return lut
+
+    def add_lut_arrays(self, direction, offset) -> capi.Lut:
+        lut = capi.Lut.from_arrays(self.ctx, direction, offset, self.h, self.w)
+        self.luts.append(lut)
+        return lut
+
+    def field_index(self, name: str) -> int:
+        for i, (n, _) in enumerate(self.fields):
+            if n == name:
+                return i
+        return -1
+
+    # -- output allocation ---------------------------------------------------------------
+    def alloc_outputs(self, n_frames: int, planes: Optional[Sequence[str]] = None,
+                      destagger: Sequence[str] = (), xyz: Sequence[str] = (),
+                      xyz_dtype=torch.float32, headers: bool = True) -> Dict[str, torch.Tensor]:
+        out: Dict[str, torch.Tensor] = {}
+        names = [n for n, _ in self.fields] if planes is None else list(planes)
+        for n, es in self.fields:
+            if n in names:
+                shape = (n_frames, self.h, self.w) if es != 6 else (n_frames, self.h, self.w, 3)
+                dt = _TORCH_OF_ELEM[es] if es != 6 else torch.uint16
+                out[n] = torch.empty(shape, dtype=dt, device="cuda")
+            if n in destagger:
+                shape = (n_frames, self.h, self.w) if es != 6 else (n_frames, self.h, self.w, 3)
+                dt = _TORCH_OF_ELEM[es] if es != 6 else torch.uint16
+                out["destaggered:" + n] = torch.empty(shape, dtype=dt, device="cuda")
+        for n in xyz:
+            out["xyz:" + n] = torch.empty((n_frames, self.h * self.w, 3), dtype=xyz_dtype,
+                                          device="cuda")
+        if headers:
+            out["timestamp"] = torch.empty((n_frames, self.w), dtype=torch.uint64, device="cuda")
+            out["measurement_id"] = torch.empty((n_frames, self.w), dtype=torch.uint16, device="cuda")
+            out["status"] = torch.empty((n_frames, self.w), dtype=torch.uint32, device="cuda")
+            out["frame_meta"] = torch.empty((n_frames, 24), dtype=torch.uint8, device="cuda")
+        return out
+
+    # -- the three operations --------------------------------------------------------------
+    def decode(self, packets: torch.Tensor, out: Dict[str, torch.Tensor],
+               packet_counts: Optional[np.ndarray] = None,
+               host_timestamps: Optional[torch.Tensor] = None):
+        """packets: uint8 CUDA tensor [n_frames, slots, packet_stride]."""
+        assert packets.is_cuda and packets.dtype == torch.uint8 and packets.is_contiguous()
+        n_frames, slots, stride = packets.shape
+        fo = capi.FrameOut()
+        fo.xyz_field[0] = fo.xyz_field[1] = -1
+        fo.xyz_dtype = capi.F32
+        any_dst = False
+        xyz_names = [k[4:] for k in out if k.startswith("xyz:")]
+        for i, (n, _) in enumerate(self.fields):
+            if n in out:
+                fo.planes[i] = out[n].data_ptr()
+            if "destaggered:" + n in out:
+                fo.destaggered[i] = out["destaggered:" + n].data_ptr()
+                any_dst = True
+        for k, n in enumerate(xyz_names[:2]):
+            t = out["xyz:" + n]
+            fo.xyz[k] = t.data_ptr()
+            fo.xyz_field[k] = self.field_index(n)
+            fo.xyz_dtype = capi.F32 if t.dtype == torch.float32 else capi.F64
+        for name in ("timestamp", "measurement_id", "status", "frame_meta", "packet_timestamp",
+                     "alert_flags"):
+            if name in out:
+                setattr(fo, name, out[name].data_ptr())
+        shifts_p = None
+        if any_dst:
+            if self.shifts is None:
+                raise ValueError("image height does not match shifts size")
+            shifts_p = self.shifts.ctypes.data
+        luts_arr = None
+        n_luts = 0
+        if xyz_names:
+            n_luts = len(self.luts)
+            luts_arr = (C.c_void_p * max(n_luts, 1))(*[l.h for l in self.luts])
+        counts_p = None
+        if packet_counts is not None:
+            packet_counts = np.ascontiguousarray(packet_counts, dtype=np.uint32)
+            counts_p = packet_counts.ctypes.data
+        capi.check(self.ctx.L.ouster_hip_decode(
+            self.ctx.h, self.fmt.h, packets.data_ptr(), stride, slots, counts_p, n_frames,
+            host_timestamps.data_ptr() if host_timestamps is not None else None, C.byref(fo),
+            shifts_p, luts_arr, n_luts))
+
+    def destagger(self, img: torch.Tensor, shifts=None, inverse: bool = False) -> torch.Tensor:
+        """img: CUDA tensor [n, h, w, ...] or [h, w, ...]; returns the destaggered copy."""
+        assert img.is_cuda and img.is_contiguous()
+        sh = np.ascontiguousarray(self.shifts if shifts is None else shifts, dtype=np.int32)
+        x = img
+        if img.dim() == 2:
+            n, h, w, extra = 1, img.shape[0], img.shape[1], 1
+        else:
+            n, h, w = img.shape[0], img.shape[1], img.shape[2]
+            extra = int(np.prod(img.shape[3:])) if img.dim() > 3 else 1
+        out = torch.empty_like(x)
+        capi.check(self.ctx.L.ouster_hip_destagger(self.ctx.h, x.data_ptr(), out.data_ptr(), h, w,
+                                                   img.element_size() * extra, sh.ctypes.data,
+                                                   sh.size, int(inverse), n))
+        return out
+
+    def cartesian(self, rng: torch.Tensor, lut: Optional[capi.Lut] = None,
+                  dtype=torch.float32) -> torch.Tensor:
+        """rng: uint32 CUDA tensor [n, h, w] or [h, w] -> [n, h*w, 3]."""
+        assert rng.is_cuda and rng.is_contiguous() and rng.dtype == torch.uint32
+        lut = lut or self.luts[0]
+        n = 1 if rng.dim() == 2 else rng.shape[0]
+        if rng.numel() != n * self.h * self.w:
+            raise ValueError("unexpected image dimensions")
+        xyz = torch.empty((n, self.h * self.w, 3), dtype=dtype, device="cuda")
+        capi.check(self.ctx.L.ouster_hip_cartesian(self.ctx.h, lut.h, rng.data_ptr(), xyz.data_ptr(),
+                                                   capi.F32 if dtype == torch.float32 else capi.F64, n))
+        return xyz
+
+    def sync(self):
+        self.ctx.sync()

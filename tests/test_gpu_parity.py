@@ -1,0 +1,320 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): bit-exact for every integer plane, column header and
+destaggered plane; |dXYZ| <= 1e-4 m for projected points (measured max is ~3e-5 m: one f32
+rounding of a value <= 525 m).  Mirrors the reference's tests:
+  tests/frame_batcher_test.cpp:548-692   snapshot captures through the batcher
+  tests/packet_format_test.cpp:218-406   synthetic encode -> decode identity, dropped packets
+  tests/frame_batcher_test.cpp:73-303    invalid columns / custom planes untouched
+  tests/destagger_test.cpp:135-210       destagger round trip, vs np.roll
+  tests/cartesian_test.cpp:53-99         float vs double projection
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import PCAPS, has_gpu
+
+pytestmark = pytest.mark.gpu
+
+if has_gpu():
+    import torch
+    from ouster_sdk_amd.device import HotPath
+
+XYZ_TOL = 1e-4  # metres, north_star tolerance
+
+CAPTURES = [
+    "OS-0-128-U1_v2.3.0_1024x10",
+    "OS-0-32-U1_v2.2.0_1024x10",
+    "OS-1-128_767798045_1024x10_20230712_120049",
+    "OS-2-128-U1_v2.3.0_1024x10",
+    "OS-2-32-U0_v2.0.0_1024x10",
+    "OS-1-32-G_v2.1.1_1024x10",
+    "crc_test",
+]
+PROFILE_NAME = {}
+
+
+def _pname(O, pid):
+    for k, v in O.PROFILES.items():
+        if v == pid:
+            return k
+    raise KeyError(pid)
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _oracle_frames(O, cal, pf, packets_by_frame, with_window):
+    """Run the oracle batcher on each frame's packets (in the given order)."""
+    frames = []
+    for pk in packets_by_frame:
+        fr = O.Frame.for_profile(cal.profile, cal.h, cal.w, cal.cpp, with_window=with_window)
+        fr.fill(0xAB)  # stale content must be overwritten or zeroed
+        b = O.Batcher(pf, init_id=O.lib().ora_init_id(pf, pk[0].ctypes.data) if len(pk) else 0,
+                      expected_packets=len(pk))
+        done = False
+        for i, p in enumerate(pk):
+            done = b.batch(p, 1 + i, fr)
+        if len(pk) == 0:
+            fr.fill(0)          # never started: the GPU path defines an empty frame as all zero
+        elif not done:
+            b.finalize(fr)      # released incomplete (duplicates / missing packets)
+        frames.append(fr)
+    return frames
+
+
+def _check_decode(O, cal, packets_by_frame, with_window, slots=None, xyz_dtype=None,
+                  use_extrinsics=False):
+    """Decode on the GPU and compare everything with the oracle."""
+    xyz_dtype = xyz_dtype or torch.float32
+    pf = cal.packet_format()
+    prof = _pname(O, cal.profile)
+    hp = HotPath(prof, cal.h, cal.w, cal.cpp, header_type=cal.header_type, with_window=with_window)
+    hp.set_pixel_shift_by_row(cal.pixel_shift_by_row)
+    hp.add_lut(cal.beam_to_lidar, cal.lut_transform(use_extrinsics), cal.beam_azimuth_angles,
+               cal.beam_altitude_angles)
+    n_frames = len(packets_by_frame)
+    slots = slots or max(len(p) for p in packets_by_frame)
+    host = np.zeros((n_frames, slots, pf.lidar_packet_size), dtype=np.uint8)
+    counts = np.zeros(n_frames, dtype=np.uint32)
+    for f, pk in enumerate(packets_by_frame):
+        host[f, :len(pk)] = pk
+        counts[f] = len(pk)
+    dev = torch.from_numpy(host).cuda()
+    names = [n for n, _ in hp.fields]
+    xyz_names = [n for n in ("RANGE", "RANGE2") if n in names]
+    dst_names = [n for n in ("RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2", "NEAR_IR") if n in names]
+    out = hp.alloc_outputs(n_frames, destagger=dst_names, xyz=xyz_names, xyz_dtype=xyz_dtype)
+    for t in out.values():
+        t.view(torch.uint8).fill_(0xCD)
+    hp.decode(dev, out, packet_counts=counts)
+    hp.sync()
+
+    ref = _oracle_frames(O, cal, pf, packets_by_frame, with_window)
+    ldir, lofs = cal.xyz_lut(use_extrinsics)
+    max_err = 0.0
+    for f, fr in enumerate(ref):
+        for n in names:
+            got = _np(out[n][f])
+            assert np.array_equal(got, fr.plane(n)), (f, n)
+        assert np.array_equal(_np(out["timestamp"][f]), fr.timestamp), f
+        assert np.array_equal(_np(out["measurement_id"][f]), fr.measurement_id), f
+        assert np.array_equal(_np(out["status"][f]), fr.status), f
+        for n in dst_names:
+            want = O.destagger(fr.plane(n), cal.pixel_shift_by_row)
+            assert np.array_equal(_np(out["destaggered:" + n][f]), want), (f, n)
+        for n in xyz_names:
+            want = O.cartesian(fr.plane(n), ldir, lofs)  # reference cartesian(): double
+            got = _np(out["xyz:" + n][f]).astype(np.float64)
+            err = np.abs(got - want).max()
+            max_err = max(max_err, err)
+            assert err <= XYZ_TOL, (f, n, err)
+            assert np.all(got[fr.plane(n).reshape(-1) == 0] == 0)
+        meta = _np(out["frame_meta"][f]).view(np.int64)
+        if len(packets_by_frame[f]):
+            assert meta[0] == fr.frame_id
+    return max_err
+
+
+@pytest.mark.parametrize("base", CAPTURES)
+def test_captures_match_oracle(oracle, base):
+    O = oracle
+    cal = O.calib_from_json(os.path.join(PCAPS, base + ".json"))
+    pf = cal.packet_format()
+    pk = O.lidar_packets_from_pcap(os.path.join(PCAPS, base + ".pcap"), pf)
+    assert len(pk) > 0
+    err = _check_decode(O, cal, [pk], with_window=False, slots=cal.w // cal.cpp)
+    assert err <= 4e-5
+
+
+@pytest.mark.parametrize("profile,h,w,hdr", [
+    ("RNG15_RFL8_NIR8_DUAL", 128, 2048, 0),
+    ("FUSA_RNG15_RFL8_NIR8_DUAL", 128, 1024, 1),
+    ("RNG19_RFL8_SIG16_NIR16", 128, 2048, 0),
+    ("RNG19_RFL8_SIG16_NIR16_DUAL", 128, 1024, 0),
+    ("RNG15_RFL8_NIR8", 64, 512, 0),
+    ("LEGACY", 64, 1024, 0),
+    ("FIVE_WORD_PIXEL", 32, 512, 0),
+    ("RNG19_RFL8_SIG16_NIR16_RGB16", 32, 512, 0),
+    ("RNG15_RFL8_NIR8_ZONE16", 16, 512, 0),
+])
+def test_synthetic_roundtrip(oracle, profile, h, w, hdr):
+    """encode -> GPU decode identity + oracle equality, 9 frames (exercises the XCD map)."""
+    O = oracle
+    cal = O.synthetic_calib(h=h, w=w, profile=profile, header_type=hdr)
+    packets, src = O.synth_packets(cal, 9, with_window=True)
+    err = _check_decode(O, cal, [packets[f] for f in range(9)], with_window=True)
+    assert err <= 4e-5
+
+
+def test_dropped_invalid_shuffled(oracle):
+    """Dropped packets, invalid columns, out-of-range m_id, shuffled order, duplicates."""
+    O = oracle
+    cal = O.synthetic_calib(h=128, w=1024, profile="RNG15_RFL8_NIR8_DUAL")
+    pf = cal.packet_format()
+    packets, _ = O.synth_packets(cal, 10)
+    rng = np.random.default_rng(7)
+    frames = []
+    for f in range(10):
+        pk = packets[f].copy()
+        keep = np.ones(len(pk), bool)
+        if f % 3 == 0:
+            keep[rng.integers(0, len(pk), 3)] = False      # dropped packets
+        if f % 3 == 1:  # invalid columns: clear status bit 0 (packet_format_test.cpp:374-382)
+            for p in rng.integers(0, len(pk), 4):
+                for c in rng.integers(0, 16, 5):
+                    off = pf.packet_header_size + c * pf.col_size + 10
+                    pk[p, off] &= 0xFE
+        if f == 5:  # one column claims a measurement id beyond the frame
+            off = pf.packet_header_size + 3 * pf.col_size + 8
+            pk[7, off:off + 2] = np.frombuffer(np.uint16(5000).tobytes(), np.uint8)
+        pk = pk[keep]
+        if f % 2 == 0:
+            pk = pk[rng.permutation(len(pk))]               # any order within a frame
+        if f == 9:
+            pk = np.concatenate([pk, pk[10:12]])            # duplicate packets (same data)
+        frames.append(pk)
+    frames.append(np.zeros((0, pf.lidar_packet_size), np.uint8))  # empty frame -> all zero
+    _check_decode(O, cal, frames, with_window=True, slots=70)
+
+
+def test_custom_profile_generic_kernel(oracle):
+    """add_custom_profile-style layout (tests/frame_batcher_test.cpp:676-704) through the
+    descriptor-driven kernel must equal the built-in profile's result."""
+    O = oracle
+    import ctypes as C
+    from ouster_sdk_amd import _capi as capi
+    cal = O.synthetic_calib(h=128, w=1024, profile="RNG15_RFL8_NIR8")
+    packets, _ = O.synth_packets(cal, 3)
+    hp = HotPath("RNG15_RFL8_NIR8", 128, 1024, 16)
+    # alternative encodings of the same bits: REFLECTIVITY read from byte 1 with mask 0xff00>>8, ...
+    alt = {"RANGE": (0, 0x7fff, -3), "FLAGS": (1, 0x80, 7), "REFLECTIVITY": (1, 0xff00, 8),
+           "NEAR_IR": (2, 0xff00, 4)}
+    desc = capi.FormatDesc.from_buffer_copy(hp.desc)
+    for i, (n, _) in enumerate(hp.fields):
+        desc.fields[i].bits.offset, desc.fields[i].bits.mask, desc.fields[i].bits.shift = alt[n]
+    fmt2 = hp.ctx.make_format(desc)
+    dev = torch.from_numpy(packets).cuda()
+    o1 = hp.alloc_outputs(3)
+    hp.decode(dev, o1)
+    hp.fmt, keep = fmt2, hp.fmt
+    o2 = hp.alloc_outputs(3)
+    hp.decode(dev, o2)
+    hp.sync()
+    for n, _ in hp.fields:
+        assert torch.equal(o1[n], o2[n]), n
+
+
+@pytest.mark.parametrize("dtype,w,extra", [
+    (np.uint8, 1024, 1), (np.uint16, 2048, 1), (np.uint32, 2048, 1), (np.uint64, 512, 1),
+    (np.float32, 1024, 1), (np.float64, 512, 1), (np.uint16, 512, 3), (np.uint32, 1000, 1),
+    (np.uint8, 999, 1),
+])
+def test_destagger_matches_oracle(oracle, dtype, w, extra):
+    O = oracle
+    h = 128
+    rng = np.random.default_rng(3)
+    shifts = rng.integers(-30, 31, h).astype(np.int32)  # destagger_test.cpp:123-133
+    shape = (4, h, w) if extra == 1 else (4, h, w, extra)
+    img = rng.integers(0, 255, size=shape).astype(dtype)
+    hp = HotPath("RNG15_RFL8_NIR8", h, 1024, 16)
+    d_img = torch.from_numpy(img.view(np.uint8).reshape(4, h, w, -1)).cuda()
+    for inverse in (False, True):
+        got = _np(hp.destagger(d_img, shifts, inverse=inverse)).view(dtype).reshape(shape)
+        for k in range(4):
+            want = O.destagger(img[k], shifts, inverse)
+            assert np.array_equal(got[k], want)
+            if (w & (w - 1)) == 0:  # power-of-two widths: equals np.roll (reference.py:131-158)
+                roll = np.stack([np.roll(img[k][u], (-1 if inverse else 1) * shifts[u], axis=0)
+                                 for u in range(h)])
+                assert np.array_equal(got[k], roll)
+    # round trip: stagger(destagger(x)) == x
+    back = hp.destagger(hp.destagger(d_img, shifts), shifts, inverse=True)
+    if (w & (w - 1)) == 0:
+        assert torch.equal(back, d_img)
+    with pytest.raises(ValueError, match="image height does not match shifts size"):
+        hp.destagger(d_img, shifts[:-1])
+
+
+def test_cartesian_standalone(oracle):
+    O = oracle
+    cal = O.synthetic_calib(h=128, w=1024, b2l_x=15.806)
+    ext = np.eye(4)
+    ext[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]
+    ext[:3, 3] = [1.5, -2.0, 0.25]
+    cal.extrinsic = ext
+    rng = np.random.default_rng(11)
+    r = rng.integers(0, 2 ** 19, size=(3, 128, 1024)).astype(np.uint32)
+    r[rng.random(r.shape) < 0.3] = 0
+    r[0, 0, :8] = 2 ** 19 - 8  # max range
+    ldir, lofs = cal.xyz_lut(True)
+    hp = HotPath("RNG15_RFL8_NIR8", 128, 1024, 16)
+    lut = hp.add_lut(cal.beam_to_lidar, cal.lut_transform(True), cal.beam_azimuth_angles,
+                     cal.beam_altitude_angles)
+    d, o = lut.export(1024, 128)
+    assert np.abs(d - ldir).max() < 1e-15 and np.abs(o - lofs).max() < 1e-12
+    dr = torch.from_numpy(r).cuda()
+    want = np.stack([O.cartesian(r[k], ldir, lofs) for k in range(3)])
+    g64 = _np(hp.cartesian(dr, dtype=torch.float64))
+    assert np.abs(g64 - want).max() < 1e-9            # separable tables vs full double LUT
+    g32 = _np(hp.cartesian(dr, dtype=torch.float32)).astype(np.float64)
+    assert np.abs(g32 - want).max() <= 4e-5
+    # user-supplied LUT arrays (XYZLutT<float> / XYZLutT<double> objects)
+    lut32 = hp.add_lut_arrays(ldir.astype(np.float32), lofs.astype(np.float32))
+    want32 = np.stack([O.cartesian(r[k], ldir.astype(np.float32), lofs.astype(np.float32))
+                       for k in range(3)])
+    got32 = _np(hp.cartesian(dr, lut=lut32, dtype=torch.float32))
+    assert np.array_equal(got32, want32)               # same f32 mul+add as cartesianT<float>
+    assert np.abs(got32.astype(np.float64) - want).max() <= XYZ_TOL
+    lut64 = hp.add_lut_arrays(ldir, lofs)
+    got64 = _np(hp.cartesian(dr, lut=lut64, dtype=torch.float64))
+    assert np.array_equal(got64, want)
+    with pytest.raises(ValueError):
+        hp.cartesian(dr[:, :64])
+
+
+def test_lut_dimension_errors(oracle):
+    hp = HotPath("RNG15_RFL8_NIR8", 128, 1024, 16)
+    az = np.zeros(128)
+    with pytest.raises(ValueError, match="unexpected frame dimensions"):
+        hp.add_lut(np.eye(4), np.eye(4), az[:-1], az[:-1])
+    with pytest.raises(ValueError, match="unexpected frame dimensions"):
+        hp.add_lut(np.eye(4), np.eye(4), az, az[:-1])
+
+
+def test_full_size_properties(oracle):
+    """BASELINE config 3 size (128x2048 dual, 64 frames): oracle-free invariants."""
+    O = oracle
+    cal = O.synthetic_calib(h=128, w=2048, profile="RNG15_RFL8_NIR8_DUAL")
+    packets, src = O.synth_packets(cal, 4)
+    n = 64
+    host = np.concatenate([packets] * (n // 4))
+    hp = HotPath("RNG15_RFL8_NIR8_DUAL", 128, 2048, 16)
+    hp.set_pixel_shift_by_row(cal.pixel_shift_by_row)
+    hp.add_lut(cal.beam_to_lidar, cal.lut_transform(False), cal.beam_azimuth_angles,
+               cal.beam_altitude_angles)
+    dev = torch.from_numpy(host).cuda()
+    out = hp.alloc_outputs(n, destagger=["RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"],
+                           xyz=["RANGE", "RANGE2"])
+    hp.decode(dev, out)
+    hp.sync()
+    # (1) decode(encode(x)) == x for every plane of every frame
+    for f in range(n):
+        for name, _ in hp.fields:
+            assert np.array_equal(_np(out[name][f]), src[f % 4].plane(name)), (f, name)
+    # (2) identical inputs -> identical outputs (frames repeat with period 4)
+    for k in ("xyz:RANGE", "xyz:RANGE2", "destaggered:RANGE", "destaggered:REFLECTIVITY2"):
+        assert torch.equal(out[k][:4].repeat((n // 4,) + (1,) * (out[k].dim() - 1)), out[k])
+    # (3) stagger(destaggered) == staggered plane
+    back = hp.destagger(out["destaggered:RANGE"], inverse=True)
+    assert torch.equal(back, out["RANGE"])
+    # (4) zero range <-> zero point; non-zero range within the sensor's reach
+    xyz = out["xyz:RANGE"].view(n, 128, 2048, 3)
+    zero = out["RANGE"].to(torch.int64) == 0
+    assert torch.all(xyz[zero] == 0)
+    norm = torch.linalg.vector_norm(xyz.double(), dim=-1)
+    rm = out["RANGE"].to(torch.float64) * 1e-3
+    assert torch.all((norm - rm).abs()[~zero] < 0.06)  # |p| ~ r up to the beam origin offset
