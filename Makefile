@@ -9,7 +9,8 @@ CSRC := ouster_sdk_amd/csrc
 HOST_SRC := $(wildcard $(CSRC)/host/*.cpp)
 HIP_SRC := $(CSRC)/ouster_hip_kernels.hip $(CSRC)/ouster_hip_capi.hip
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result
-CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -I$(CSRC)/host
+ROCM ?= /opt/rocm
+CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -I$(CSRC)/host -I$(ROCM)/include -D__HIP_PLATFORM_AMD__
 
 all: $(LIB)/libouster_hip.so $(LIB)/libouster_core_amd.so oracle
 
@@ -18,7 +19,7 @@ $(LIB)/libouster_hip.so: $(HIP_SRC) $(CSRC)/ouster_hip_dev.h include/ouster_hip.
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
 $(LIB)/libouster_core_amd.so: $(HOST_SRC) $(wildcard include/ouster/core/*.h include/ouster/hip/*.h) $(CSRC)/host/host_internal.h $(LIB)/libouster_hip.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -louster_hip -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -louster_hip -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle -s

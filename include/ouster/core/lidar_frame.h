@@ -288,8 +288,9 @@ class FrameBatcher {
     void set_max_cache_size(size_t n);
     size_t get_max_cache_size() const;
 
+    struct State;  ///< implementation detail (host state machine + staging + device buffers)
+
    private:
-    struct State;
     std::unique_ptr<State> s_;
 };
 

@@ -1,0 +1,323 @@
+// hip_runtime.cpp -- glue between the C++ host API and the C ABI (include/ouster_hip.h):
+// default context, error translation, staging buffers, and the GPU-backed implementations
+// of destagger, cartesian and the single-packet PacketFormat::col_field / block_field.
+//
+// There is deliberately no CPU fallback here: if the HIP library cannot create a context
+// (no GPU), every entry point throws std::runtime_error.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "host_internal.h"
+#include "ouster/core/lidar_frame.h"
+#include "ouster/core/xyzlut.h"
+#include "ouster/hip/device_buffer.h"
+
+namespace ouster {
+namespace sdk {
+namespace hip {
+
+void check(int rc) {
+    if (rc == OUSTER_HIP_OK) return;
+    const std::string msg = ouster_hip_last_error();
+    if (rc == OUSTER_HIP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+    throw std::runtime_error("ouster_hip: " + msg);
+}
+
+ouster_hip_ctx* default_ctx() {
+    static std::mutex mx;
+    static ouster_hip_ctx* ctx = nullptr;
+    std::lock_guard<std::mutex> lk(mx);
+    if (!ctx) check(ouster_hip_ctx_create(0, nullptr, &ctx));
+    return ctx;
+}
+
+static void hip_ok(hipError_t e, const char* what) {
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string("ouster_hip: ") + what + ": " + hipGetErrorString(e));
+}
+
+DeviceBuffer::DeviceBuffer(size_t bytes) { resize(bytes); }
+DeviceBuffer::~DeviceBuffer() {
+    if (p_) (void)hipFree(p_);
+}
+DeviceBuffer::DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) {
+    o.p_ = nullptr;
+    o.n_ = o.cap_ = 0;
+}
+DeviceBuffer& DeviceBuffer::operator=(DeviceBuffer&& o) noexcept {
+    std::swap(p_, o.p_);
+    std::swap(n_, o.n_);
+    std::swap(cap_, o.cap_);
+    return *this;
+}
+void DeviceBuffer::resize(size_t bytes) {
+    default_ctx();  // selects the device
+    if (bytes > cap_) {
+        if (p_) (void)hipFree(p_);
+        p_ = nullptr;
+        hip_ok(hipMalloc(&p_, bytes ? bytes : 1), "hipMalloc");
+        cap_ = bytes;
+    }
+    n_ = bytes;
+}
+void DeviceBuffer::upload(const void* src, size_t bytes, size_t offset) {
+    auto st = static_cast<hipStream_t>(ouster_hip_ctx_stream(default_ctx()));
+    hip_ok(hipMemcpyAsync(static_cast<uint8_t*>(p_) + offset, src, bytes, hipMemcpyHostToDevice, st),
+           "hipMemcpyAsync(H2D)");
+    hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
+}
+void DeviceBuffer::download(void* dst, size_t bytes, size_t offset) const {
+    auto st = static_cast<hipStream_t>(ouster_hip_ctx_stream(default_ctx()));
+    hip_ok(hipMemcpyAsync(dst, static_cast<const uint8_t*>(p_) + offset, bytes,
+                          hipMemcpyDeviceToHost, st),
+           "hipMemcpyAsync(D2H)");
+    hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
+}
+void DeviceBuffer::fill(int byte_value) {
+    auto st = static_cast<hipStream_t>(ouster_hip_ctx_stream(default_ctx()));
+    hip_ok(hipMemsetAsync(p_, byte_value, n_, st), "hipMemsetAsync");
+}
+
+}  // namespace hip
+
+namespace core {
+
+// ---------------------------------------------------------------------------------------
+// destagger (impl/lidar_frame_impl.h:733-811)
+// ---------------------------------------------------------------------------------------
+namespace impl {
+void destagger_bytes(const void* img, void* out, size_t h, size_t w, size_t elem_bytes,
+                     const std::vector<int>& shifts, bool inverse, size_t out_h, size_t out_w) {
+    if (shifts.size() != h) throw std::invalid_argument{"image height does not match shifts size"};
+    if (h != out_h || w != out_w)
+        throw std::invalid_argument{"image and destaggered must have the same shape"};
+    if (h == 0 || w == 0) return;
+    const size_t bytes = h * w * elem_bytes;
+    hip::DeviceBuffer src(bytes), dst(bytes);
+    src.upload(img, bytes);
+    std::vector<int32_t> sh(shifts.begin(), shifts.end());
+    hip::check(ouster_hip_destagger(hip::default_ctx(), src.data(), dst.data(),
+                                    static_cast<uint32_t>(h), static_cast<uint32_t>(w),
+                                    static_cast<uint32_t>(elem_bytes), sh.data(),
+                                    static_cast<uint32_t>(sh.size()), inverse ? 1 : 0, 1));
+    dst.download(out, bytes);
+}
+}  // namespace impl
+
+Field destagger(const SensorInfo& info, const Field& field, bool inverse) {
+    const auto& shape = field.shape();
+    if (shape.size() < 2 || shape[0] != info.format.pixels_per_column ||
+        shape[1] != info.format.columns_per_frame ||
+        shape[0] != info.format.pixel_shift_by_row.size())
+        throw std::invalid_argument{"Image resolution must match SensorInfo."};
+    Field out(field.tag(), shape, field.field_class());
+    size_t extra = 1;
+    for (size_t i = 2; i < shape.size(); ++i) extra *= shape[i];
+    impl::destagger_bytes(field.get(), out.get(), shape[0], shape[1], field.element_size() * extra,
+                          info.format.pixel_shift_by_row, inverse, shape[0], shape[1]);
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------
+// XYZ lookup tables (xyzlut.cpp:11-124)
+// ---------------------------------------------------------------------------------------
+namespace impl {
+
+DeviceLut::~DeviceLut() {
+    if (handle) ouster_hip_lut_destroy(handle);
+}
+
+std::shared_ptr<DeviceLut> device_lut_from_arrays(const void* direction, const void* offset,
+                                                  size_t h, size_t w, bool f64) {
+    auto d = std::make_shared<DeviceLut>();
+    hip::check(ouster_hip_lut_create_from_arrays(hip::default_ctx(), direction, offset,
+                                                 static_cast<uint32_t>(h), static_cast<uint32_t>(w),
+                                                 f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32, &d->handle));
+    return d;
+}
+
+std::shared_ptr<DeviceLut> device_lut_from_calib(size_t w, size_t h, double range_unit,
+                                                 const mat4d& b2l, const mat4d& transform,
+                                                 const std::vector<double>& az,
+                                                 const std::vector<double>& alt,
+                                                 ArrayX3R<double>* direction,
+                                                 ArrayX3R<double>* offset) {
+    if (w <= 0 || h <= 0) throw std::invalid_argument("lut dimensions must be greater than zero");
+    if ((az.size() != h || alt.size() != h) && (az.size() != w * h || alt.size() != w * h))
+        throw std::invalid_argument("unexpected frame dimensions");
+    ouster_hip_calib c{};
+    c.w = static_cast<uint32_t>(w);
+    c.h = static_cast<uint32_t>(h);
+    c.range_unit = range_unit;
+    std::memcpy(c.beam_to_lidar_transform, b2l.data(), sizeof c.beam_to_lidar_transform);
+    std::memcpy(c.transform, transform.data(), sizeof c.transform);
+    c.azimuth_angles_deg = az.data();
+    c.altitude_angles_deg = alt.data();
+    c.n_angles = az.size();
+    auto d = std::make_shared<DeviceLut>();
+    hip::check(ouster_hip_lut_create(hip::default_ctx(), &c, &d->handle));
+    if (direction && offset) {
+        *direction = ArrayX3R<double>(w * h);
+        *offset = ArrayX3R<double>(w * h);
+        hip::check(ouster_hip_lut_export(d->handle, direction->data(), offset->data()));
+    }
+    return d;
+}
+
+XYZLut make_xyz_lut(size_t w, size_t h, double range_unit, const mat4d& beam_to_lidar_transform,
+                    const mat4d& transform, const std::vector<double>& azimuth_angles_deg,
+                    const std::vector<double>& altitude_angles_deg) {
+    ArrayX3R<double> direction, offset;
+    auto dev = device_lut_from_calib(w, h, range_unit, beam_to_lidar_transform, transform,
+                                     azimuth_angles_deg, altitude_angles_deg, &direction, &offset);
+    XYZLut lut(std::move(direction), std::move(offset), h, w);
+    lut.attach_device(std::move(dev));
+    return lut;
+}
+
+XYZLut make_xyz_lut(const SensorInfo& sensor, bool use_extrinsics) {
+    mat4d transform = sensor.lidar_to_sensor_transform;
+    if (use_extrinsics) {
+        // extrinsics are in metres, the LUT works in range units (mm)
+        mat4d ext = sensor.sensor_to_body;
+        for (int r = 0; r < 3; ++r) ext(r, 3) /= RANGE_UNIT;
+        transform = ext * sensor.lidar_to_sensor_transform;
+    }
+    return make_xyz_lut(sensor.format.columns_per_frame, sensor.format.pixels_per_column, RANGE_UNIT,
+                        sensor.beam_to_lidar_transform, transform, sensor.beam_azimuth_angles,
+                        sensor.beam_altitude_angles);
+}
+
+void cartesian_device(const DeviceLut& dev, const uint32_t* range, size_t n, void* points,
+                      bool points_f64) {
+    if (n == 0) return;
+    const size_t pbytes = n * 3 * (points_f64 ? 8 : 4);
+    hip::DeviceBuffer d_range(n * 4), d_xyz(pbytes);
+    d_range.upload(range, n * 4);
+    hip::check(ouster_hip_cartesian(hip::default_ctx(), dev.handle,
+                                    static_cast<const uint32_t*>(d_range.data()), d_xyz.data(),
+                                    points_f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32, 1));
+    d_xyz.download(points, pbytes);
+}
+
+}  // namespace impl
+
+PointCloudXYZd cartesian(const ImgRef<const uint32_t>& range, const XYZLut& lut) {
+    if (range.cols() * range.rows() != lut.direction.rows())
+        throw std::invalid_argument("unexpected image dimensions");
+    return lut(range);
+}
+
+PointCloudXYZd cartesian(const LidarFrame& frame, const XYZLut& lut) {
+    return cartesian(frame.field<uint32_t>(ChanField::RANGE), lut);
+}
+
+// ---------------------------------------------------------------------------------------
+// PacketFormat::col_field / block_field: one-packet decodes through the decode kernel
+// ---------------------------------------------------------------------------------------
+namespace {
+// Decode `name` of the packet in `lidar_buf` into a device plane of H x cols elements of
+// `elem` bytes, then copy back only the columns the packet actually covers.
+void decode_one_packet(const PacketFormat& pf, const std::string& name, size_t elem,
+                       const uint8_t* lidar_buf, int cols, uint8_t* data) {
+    const FieldDecodeInfo& info = pf.field_decode_info(name);
+    if (elem < field_type_size(info.ty_tag) * static_cast<size_t>(info.num_elements))
+        throw std::invalid_argument("Dest type too small for specified field");
+    ouster_hip_format_desc d;
+    pf.fill_hip_desc(static_cast<uint32_t>(cols), {{name, static_cast<uint32_t>(elem)}}, {false}, d);
+    ouster_hip_ctx* ctx = hip::default_ctx();
+    ouster_hip_format* fmt = nullptr;
+    hip::check(ouster_hip_format_create(ctx, &d, &fmt));
+    const size_t H = pf.pixels_per_column, plane_bytes = H * static_cast<size_t>(cols) * elem;
+    try {
+        hip::DeviceBuffer d_pkt((pf.lidar_packet_size + 15) & ~size_t{15}), d_plane(plane_bytes);
+        d_pkt.upload(lidar_buf, pf.lidar_packet_size);
+        ouster_hip_frame_out out{};
+        out.planes[0] = d_plane.data();
+        out.xyz_field[0] = out.xyz_field[1] = -1;
+        hip::check(ouster_hip_decode(ctx, fmt, static_cast<const uint8_t*>(d_pkt.data()),
+                                     d_pkt.size(), 1, nullptr, 1, nullptr, &out, nullptr, nullptr, 0));
+        std::vector<uint8_t> host(plane_bytes);
+        d_plane.download(host.data(), plane_bytes);
+        for (uint32_t icol = 0; icol < pf.columns_per_packet; ++icol) {
+            const uint8_t* col = pf.nth_col(icol, lidar_buf);
+            const uint16_t m_id = pf.col_measurement_id(col);
+            if (!(pf.col_status(col) & 0x01) || m_id >= cols) continue;
+            for (size_t px = 0; px < H; ++px)
+                std::memcpy(data + (px * cols + m_id) * elem, host.data() + (px * cols + m_id) * elem,
+                            elem);
+        }
+    } catch (...) {
+        ouster_hip_format_destroy(fmt);
+        throw;
+    }
+    ouster_hip_format_destroy(fmt);
+}
+}  // namespace
+
+template <typename T, int BlockDim>
+void PacketFormat::block_field(T* data, int cols, const std::string& f,
+                               const uint8_t* lidar_buf) const {
+    static_assert(BlockDim == 4 || BlockDim == 8 || BlockDim == 16, "BlockDim must be 4, 8 or 16");
+    // block_field trusts its caller: every column is written, at the measurement id of its
+    // block's first column plus its position in the block (parsing.cpp:641-655).  Make a copy of
+    // the packet that says exactly that, so the decode kernel reproduces it.
+    std::vector<uint8_t> pkt(lidar_buf, lidar_buf + lidar_packet_size);
+    pkt.resize(lidar_packet_size + 8, 0);
+    for (uint32_t icol = 0; icol < columns_per_packet; icol += BlockDim) {
+        const uint16_t head = col_measurement_id(nth_col(icol, lidar_buf));
+        for (uint32_t x = 0; x < static_cast<uint32_t>(BlockDim) && icol + x < columns_per_packet; ++x) {
+            uint8_t* col = nth_col(icol + x, pkt.data());
+            set_col_measurement_id(col, static_cast<uint16_t>(head + x));
+            set_col_status(col, col_status(col) | 0x01);
+        }
+    }
+    decode_one_packet(*this, f, sizeof(T), pkt.data(), cols, reinterpret_cast<uint8_t*>(data));
+}
+
+template <typename T>
+void PacketFormat::col_field(const uint8_t* col_buf, const std::string& f, T* dst,
+                             int dst_stride) const {
+    // wrap the column into a one-column packet image: [packet header][column][...]
+    const FieldDecodeInfo& info = field_decode_info(f);
+    if (sizeof(T) < field_type_size(info.ty_tag) * static_cast<size_t>(info.num_elements))
+        throw std::invalid_argument("Dest type too small for specified field");
+    std::vector<uint8_t> pkt(lidar_packet_size + 8, 0);
+    std::memcpy(pkt.data() + packet_header_size, col_buf, col_size);
+    uint8_t* col0 = nth_col(0, pkt.data());
+    set_col_measurement_id(col0, 0);
+    // force the staged copy valid; only column 0 is read back
+    uint32_t st = col_status(col0);
+    set_col_status(col0, st | 0x01);
+    std::vector<T> plane(static_cast<size_t>(pixels_per_column) * columns_per_packet);
+    decode_one_packet(*this, f, sizeof(T), pkt.data(), static_cast<int>(columns_per_packet),
+                      reinterpret_cast<uint8_t*>(plane.data()));
+    for (uint32_t px = 0; px < pixels_per_column; ++px)
+        dst[static_cast<size_t>(px) * dst_stride] = plane[static_cast<size_t>(px) * columns_per_packet];
+}
+
+#define OUSTER_INST_FIELD(T)                                                                      \
+    template void PacketFormat::col_field<T>(const uint8_t*, const std::string&, T*, int) const;  \
+    template void PacketFormat::block_field<T, 4>(T*, int, const std::string&, const uint8_t*) const;  \
+    template void PacketFormat::block_field<T, 8>(T*, int, const std::string&, const uint8_t*) const;  \
+    template void PacketFormat::block_field<T, 16>(T*, int, const std::string&, const uint8_t*) const;
+OUSTER_INST_FIELD(uint8_t)
+OUSTER_INST_FIELD(uint16_t)
+OUSTER_INST_FIELD(uint32_t)
+OUSTER_INST_FIELD(uint64_t)
+OUSTER_INST_FIELD(int8_t)
+OUSTER_INST_FIELD(int16_t)
+OUSTER_INST_FIELD(int32_t)
+OUSTER_INST_FIELD(int64_t)
+OUSTER_INST_FIELD(float)
+OUSTER_INST_FIELD(double)
+OUSTER_INST_FIELD(impl::float3x16_t)
+#undef OUSTER_INST_FIELD
+
+}  // namespace core
+}  // namespace sdk
+}  // namespace ouster

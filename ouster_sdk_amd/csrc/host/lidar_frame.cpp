@@ -1,0 +1,616 @@
+// lidar_frame.cpp -- Field, LidarFrame, FrameBatcher, frame_to_packets (host side).
+//
+// Reference behaviour (paths relative to the reference checkout):
+//   Field                      ouster_core/src/field.cpp:247-296
+//   LidarFrame ctor / fields   ouster_core/src/lidar_frame.cpp:309-359, 1038-1117
+//   FrameBatcher               ouster_core/src/lidar_frame.cpp:1248-1959 (lidar packets)
+//   frame_to_packets           ouster_core/include/ouster/core/impl/lidar_frame_impl.h:435-531
+// FrameBatcher keeps the reference's host state machine (frame boundaries, reorder cache,
+// init-id changes, completeness) but defers ALL per-pixel work: the packets of the frame
+// being assembled are collected in a staging buffer and decoded by one GPU launch when the
+// frame is released.
+#include <cstdio>
+#include <cstring>
+#include <deque>
+
+#include "host_internal.h"
+#include "ouster/core/lidar_frame.h"
+#include "ouster/hip/device_buffer.h"
+
+namespace ouster {
+namespace sdk {
+namespace core {
+
+// ---------------------------------------------------------------------------------------
+// Field
+// ---------------------------------------------------------------------------------------
+Field::Field(ChanFieldType tag, std::vector<size_t> shape, FieldClass c)
+    : tag_(tag), shape_(std::move(shape)), class_(c) {
+    count_ = 1;
+    for (size_t d : shape_) count_ *= d;
+    if (shape_.empty()) count_ = 1;
+    const size_t b = count_ * field_type_size(tag_);
+    ptr_ = b ? std::calloc(b, 1) : nullptr;
+    if (b && !ptr_) throw std::runtime_error("Field: host memory allocation failed");
+}
+Field::Field(const Field& o) : tag_(o.tag_), shape_(o.shape_), class_(o.class_), count_(o.count_) {
+    const size_t b = o.bytes();
+    if (b) {
+        ptr_ = std::malloc(b);
+        if (!ptr_) throw std::runtime_error("Field: host memory allocation failed");
+        std::memcpy(ptr_, o.ptr_, b);
+    }
+}
+Field::Field(Field&& o) noexcept
+    : tag_(o.tag_), shape_(std::move(o.shape_)), class_(o.class_), count_(o.count_), ptr_(o.ptr_) {
+    o.ptr_ = nullptr;
+    o.count_ = 0;
+    o.tag_ = ChanFieldType::VOID;
+}
+Field& Field::operator=(Field o) noexcept {
+    std::swap(tag_, o.tag_);
+    std::swap(shape_, o.shape_);
+    std::swap(class_, o.class_);
+    std::swap(count_, o.count_);
+    std::swap(ptr_, o.ptr_);
+    return *this;
+}
+Field::~Field() { std::free(ptr_); }
+void Field::set_zero() {
+    if (ptr_) std::memset(ptr_, 0, bytes());
+}
+bool Field::operator==(const Field& o) const {
+    return tag_ == o.tag_ && shape_ == o.shape_ &&
+           (bytes() == 0 || std::memcmp(ptr_, o.ptr_, bytes()) == 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// default planes
+// ---------------------------------------------------------------------------------------
+LidarFrameFieldTypes get_field_types(UDPProfileLidar profile) {
+    LidarFrameFieldTypes out;
+    for (const auto& p : impl::default_planes(profile)) {
+        FieldType ft(p.first, p.second, {}, FieldClass::PIXEL_FIELD);
+        if (p.first == ChanField::RGB) ft.extra_dims.push_back(3);  // H x W x 3 float16
+        out.push_back(std::move(ft));
+    }
+    return out;
+}
+
+LidarFrameFieldTypes get_field_types(const DataFormat& format, const Version& fw_version) {
+    LidarFrameFieldTypes out = get_field_types(format.udp_profile_lidar);
+    // WINDOW only exists from fw 3.2 (zone profiles: 3.2.1)
+    const bool zone = format.udp_profile_lidar == UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_ZONE16 ||
+                      format.udp_profile_lidar == UDPProfileLidar::RNG15_RFL8_NIR8_ZONE16;
+    if (fw_version < Version(3, 2, 0) || (zone && fw_version < Version(3, 2, 1)))
+        for (size_t i = 0; i < out.size(); ++i)
+            if (out[i].name == ChanField::WINDOW) {
+                out.erase(out.begin() + static_cast<std::ptrdiff_t>(i));
+                break;
+            }
+    return out;
+}
+
+LidarFrameFieldTypes get_field_types(const SensorInfo& info) {
+    return get_field_types(info.format, info.get_version());
+}
+
+// ---------------------------------------------------------------------------------------
+// LidarFrame
+// ---------------------------------------------------------------------------------------
+LidarFrame::LidarFrame() = default;
+LidarFrame::LidarFrame(const LidarFrame&) = default;
+LidarFrame::LidarFrame(LidarFrame&&) noexcept = default;
+LidarFrame& LidarFrame::operator=(const LidarFrame&) = default;
+LidarFrame& LidarFrame::operator=(LidarFrame&&) noexcept = default;
+LidarFrame::~LidarFrame() = default;
+
+LidarFrame::LidarFrame(size_t h_, size_t w_, const LidarFrameFieldTypes& field_types,
+                       size_t columns_per_packet)
+    : w(w_), h(h_) {
+    if (w * h == 0)
+        throw std::invalid_argument("Cannot construct LidarFrame with zero width or height");
+    if (columns_per_packet == 0)
+        throw std::invalid_argument("columns_per_packet must be greater than 0");
+    packet_count_ = (w + columns_per_packet - 1) / columns_per_packet;
+    for (const auto& ft : field_types) add_field(ft);
+    timestamp_ = Field(ChanFieldType::UINT64, {w}, FieldClass::COLUMN_FIELD);
+    measurement_id_ = Field(ChanFieldType::UINT16, {w}, FieldClass::COLUMN_FIELD);
+    status_ = Field(ChanFieldType::UINT32, {w}, FieldClass::COLUMN_FIELD);
+    packet_timestamp_ = Field(ChanFieldType::UINT64, {packet_count_}, FieldClass::PACKET_FIELD);
+    alert_flags_ = Field(ChanFieldType::UINT8, {packet_count_}, FieldClass::PACKET_FIELD);
+    body_to_world_ = Field(ChanFieldType::FLOAT64, {w, 4, 4}, FieldClass::NONE);
+    double* poses = body_to_world_.get<double>();
+    for (size_t i = 0; i < w; ++i)
+        for (int d = 0; d < 4; ++d) poses[i * 16 + d * 5] = 1.0;
+}
+
+LidarFrame::LidarFrame(size_t h_, size_t w_, UDPProfileLidar profile, size_t columns_per_packet)
+    : LidarFrame(h_, w_, get_field_types(profile), columns_per_packet) {}
+
+LidarFrame::LidarFrame(const DataFormat& format)
+    : LidarFrame(format.pixels_per_column, format.columns_per_frame,
+                 get_field_types(format, Version(0, 0, 0)), format.columns_per_packet) {}
+
+LidarFrame::LidarFrame(const SensorInfo& info) : LidarFrame(std::make_shared<SensorInfo>(info)) {}
+
+LidarFrame::LidarFrame(std::shared_ptr<SensorInfo> info)
+    : LidarFrame(info->format.pixels_per_column, info->format.columns_per_frame,
+                 get_field_types(*info), info->format.columns_per_packet) {
+    sensor_info = std::move(info);
+}
+
+LidarFrame::LidarFrame(std::shared_ptr<SensorInfo> info, const LidarFrameFieldTypes& field_types)
+    : LidarFrame(info->format.pixels_per_column, info->format.columns_per_frame, field_types,
+                 info->format.columns_per_packet) {
+    sensor_info = std::move(info);
+}
+
+Field& LidarFrame::field(const std::string& name) {
+    auto it = fields_.find(name);
+    if (it == fields_.end()) throw std::out_of_range("Field '" + name + "' not found in LidarFrame");
+    return it->second;
+}
+const Field& LidarFrame::field(const std::string& name) const {
+    auto it = fields_.find(name);
+    if (it == fields_.end()) throw std::out_of_range("Field '" + name + "' not found in LidarFrame");
+    return it->second;
+}
+bool LidarFrame::has_field(const std::string& name) const { return fields_.count(name) > 0; }
+
+Field& LidarFrame::add_field(const FieldType& type) {
+    if (has_field(type.name))
+        throw std::invalid_argument("Duplicated field '" + type.name + "'");
+    std::vector<size_t> dims;
+    switch (type.field_class) {
+        case FieldClass::PIXEL_FIELD: dims = {h, w}; break;
+        case FieldClass::COLUMN_FIELD: dims = {w}; break;
+        case FieldClass::PACKET_FIELD: dims = {packet_count_}; break;
+        default: break;
+    }
+    dims.insert(dims.end(), type.extra_dims.begin(), type.extra_dims.end());
+    return fields_.emplace(type.name, Field(type.element_type, dims, type.field_class)).first->second;
+}
+Field& LidarFrame::add_field(const std::string& name, ChanFieldType type,
+                             std::vector<size_t> extra_dims, FieldClass c) {
+    return add_field(FieldType(name, type, std::move(extra_dims), c));
+}
+Field LidarFrame::del_field(const std::string& name) {
+    auto it = fields_.find(name);
+    if (it == fields_.end())
+        throw std::invalid_argument("Attempted deleting non existing field '" + name + "'");
+    Field f = std::move(it->second);
+    fields_.erase(it);
+    return f;
+}
+
+LidarFrameFieldTypes LidarFrame::field_types() const {
+    LidarFrameFieldTypes out;
+    for (const auto& kv : fields_) {
+        const auto& shape = kv.second.shape();
+        size_t skip = 0;
+        switch (kv.second.field_class()) {
+            case FieldClass::PIXEL_FIELD: skip = 2; break;
+            case FieldClass::COLUMN_FIELD:
+            case FieldClass::PACKET_FIELD: skip = 1; break;
+            default: break;
+        }
+        out.emplace_back(kv.first, kv.second.tag(),
+                         std::vector<size_t>(shape.begin() + std::min(skip, shape.size()), shape.end()),
+                         kv.second.field_class());
+    }
+    return out;
+}
+
+bool LidarFrame::complete(ColumnWindow window) const {
+    const uint32_t* st = status_.get<uint32_t>();
+    auto valid = [&](int a, int b) {
+        for (int i = a; i <= b; ++i)
+            if (!(st[i] & 0x01)) return false;
+        return true;
+    };
+    if (window.first <= window.second) return valid(window.first, window.second);
+    return valid(0, window.second) && valid(window.first, static_cast<int>(w) - 1);
+}
+
+bool LidarFrame::equals(const LidarFrame& o) const {
+    return w == o.w && h == o.h && frame_id == o.frame_id && frame_status == o.frame_status &&
+           shutdown_countdown == o.shutdown_countdown &&
+           shot_limiting_countdown == o.shot_limiting_countdown && fields_ == o.fields_ &&
+           timestamp_ == o.timestamp_ && measurement_id_ == o.measurement_id_ &&
+           status_ == o.status_ && packet_timestamp_ == o.packet_timestamp_ &&
+           alert_flags_ == o.alert_flags_ && body_to_world_ == o.body_to_world_;
+}
+bool operator==(const LidarFrame& a, const LidarFrame& b) { return a.equals(b); }
+
+uint64_t column_timestamp_at_destaggered_pixel(const LidarFrame& frame, const SensorInfo& info,
+                                               size_t row, size_t col) {
+    const int wi = static_cast<int>(frame.w);
+    const int shift = info.format.pixel_shift_by_row.at(row);
+    const int src = ((static_cast<int>(col) - shift) % wi + wi) % wi;
+    return frame.timestamp()[static_cast<size_t>(src)];
+}
+
+// ---------------------------------------------------------------------------------------
+// FrameBatcher
+// ---------------------------------------------------------------------------------------
+namespace {
+struct CachedPacket {
+    std::vector<uint8_t> buf;
+    uint64_t host_timestamp;
+    uint64_t seq;
+};
+}  // namespace
+
+struct FrameBatcher::State {
+    std::shared_ptr<SensorInfo> info;
+    size_t max_cache_size = 4;
+    std::deque<CachedPacket> cache;  // small (<= max_cache_size); searched linearly
+    uint64_t seq = 0;
+    int64_t finished_frame_id = -1;
+    int64_t last_frame_id = -1;
+    int64_t last_init_id = 0;
+    bool reset_frame = true;
+    size_t expected_lidar_packets = 0;
+    size_t batched_lidar_packets = 0;
+    size_t dropped_packets = 0;
+
+    // packets of the frame being assembled, in arrival order
+    std::vector<uint8_t> staged;
+    size_t staged_count = 0;
+    size_t stride = 0;
+
+    // device side, created lazily for the frame layout in use
+    ouster_hip_format* fmt = nullptr;
+    std::vector<std::string> fmt_fields;
+    std::vector<uint32_t> fmt_elems;
+    hip::DeviceBuffer d_packets, d_out;
+
+    ~State() {
+        if (fmt) ouster_hip_format_destroy(fmt);
+    }
+};
+
+FrameBatcher::FrameBatcher(const std::shared_ptr<SensorInfo>& info)
+    : pf(get_format(*info)), s_(new State()) {
+    if (info->format.columns_per_packet == 0)
+        throw std::invalid_argument("unexpected columns_per_packet: 0");
+    if (info->format.pixels_per_column == 0)
+        throw std::invalid_argument("unexpected pixels_per_column: 0");
+    s_->info = info;
+    s_->last_init_id = info->init_id;
+    s_->expected_lidar_packets = static_cast<size_t>(info->format.lidar_packets_per_frame());
+    s_->stride = (pf.lidar_packet_size + 15) & ~size_t{15};
+}
+FrameBatcher::FrameBatcher(const SensorInfo& info) : FrameBatcher(std::make_shared<SensorInfo>(info)) {}
+FrameBatcher::FrameBatcher(FrameBatcher&&) noexcept = default;
+FrameBatcher::~FrameBatcher() = default;
+
+void FrameBatcher::reset() {
+    s_->reset_frame = true;
+    s_->finished_frame_id = -1;
+    s_->batched_lidar_packets = 0;
+    s_->staged_count = 0;
+    s_->cache.clear();
+}
+size_t FrameBatcher::batched_packets() const { return s_->batched_lidar_packets; }
+size_t FrameBatcher::dropped_packets() const { return s_->dropped_packets; }
+void FrameBatcher::set_max_cache_size(size_t n) {
+    if (n == 0) throw std::invalid_argument("max_cache_size must be > 0");
+    s_->max_cache_size = n;
+}
+size_t FrameBatcher::get_max_cache_size() const { return s_->max_cache_size; }
+
+// start_frame :1709-1741, batch_lidar_packet :1530-1576, finalize_frame :1905-1927
+struct BatcherOps {
+    static void start_frame(FrameBatcher::State& s, const PacketFormat& pf, int64_t f_id,
+                            const uint8_t* packet_buf, LidarFrame& frame) {
+        s.finished_frame_id = -1;
+        s.batched_lidar_packets = 0;
+        s.staged_count = 0;
+        frame.frame_id = f_id;
+        frame.timestamp().setZero();
+        frame.measurement_id().setZero();
+        frame.status().setZero();
+        frame.packet_timestamp().setZero();
+        const auto th = static_cast<uint8_t>(pf.thermal_shutdown(packet_buf));
+        const auto sl = static_cast<uint8_t>(pf.shot_limiting(packet_buf));
+        frame.frame_status = static_cast<uint64_t>(th & 0x0f) | (static_cast<uint64_t>(sl & 0x0f) << 4);
+        frame.shutdown_countdown = pf.countdown_thermal_shutdown(packet_buf);
+        frame.shot_limiting_countdown = pf.countdown_shot_limiting(packet_buf);
+        frame.sensor_info = s.info;
+    }
+
+    // batch_lidar_packet (lidar_frame.cpp:1530-1576): packet-level values now, pixels later
+    static void stage_packet(FrameBatcher::State& s, const PacketFormat& pf, const uint8_t* buf,
+                             size_t len, uint64_t host_ts, LidarFrame& frame) {
+        const uint16_t packet_id = static_cast<uint16_t>(
+            pf.col_measurement_id(pf.nth_col(0, buf)) / pf.columns_per_packet);
+        if (packet_id < frame.packet_timestamp().rows()) {
+            frame.packet_timestamp()[packet_id] = host_ts;
+            frame.alert_flags()[packet_id] = pf.alert_flags(buf);
+        }
+        if ((s.staged_count + 1) * s.stride > s.staged.size())
+            s.staged.resize(std::max<size_t>(s.staged.size() * 2, (s.staged_count + 8) * s.stride));
+        uint8_t* dst = s.staged.data() + s.staged_count * s.stride;
+        std::memcpy(dst, buf, std::min(len, pf.lidar_packet_size));
+        if (len < pf.lidar_packet_size) std::memset(dst + len, 0, pf.lidar_packet_size - len);
+        s.staged_count++;
+        s.batched_lidar_packets++;
+    }
+
+    static bool frame_complete(const FrameBatcher::State& s, const PacketFormat& pf,
+                               const LidarFrame& frame) {
+        if (pf.udp_profile_lidar == UDPProfileLidar::OFF) return true;
+        return s.batched_lidar_packets >= s.expected_lidar_packets &&
+               frame.packet_timestamp().count() == s.expected_lidar_packets;
+    }
+
+    // finalize_frame (lidar_frame.cpp:1905-1927) + the deferred decode of the whole frame
+    static void finalize_frame(FrameBatcher::State& s, const PacketFormat& pf, LidarFrame& frame) {
+        decode_staged(s, pf, frame);
+        if (frame.sensor_info && frame.sensor_info->init_id == s.last_init_id &&
+            frame.frame_id <= s.last_frame_id && pf.header_type == HeaderType::FUSA)
+            throw std::runtime_error("32-bit frame id did not increase since the last frame");
+        s.finished_frame_id = frame.frame_id;
+        s.last_frame_id = frame.frame_id;
+        s.batched_lidar_packets = 0;
+        s.staged_count = 0;
+    }
+
+    // one GPU launch: every plane the frame shares with the packet format + column headers
+    static void decode_staged(FrameBatcher::State& s, const PacketFormat& pf, LidarFrame& frame) {
+        std::vector<std::pair<std::string, uint32_t>> fields;
+        std::vector<bool> nan;
+        std::vector<Field*> dst;
+        for (auto it = pf.begin(); it != pf.end(); ++it) {  // foreach_channel_field order
+            if (!frame.has_field(it->first)) continue;
+            Field& f = frame.field(it->first);
+            size_t extra = 1;
+            for (size_t i = 2; i < f.shape().size(); ++i) extra *= f.shape()[i];
+            fields.emplace_back(it->first, static_cast<uint32_t>(f.element_size() * extra));
+            nan.push_back(f.tag() == ChanFieldType::FLOAT16);
+            dst.push_back(&f);
+        }
+        std::vector<std::string> names;
+        std::vector<uint32_t> elems;
+        for (const auto& p : fields) {
+            names.push_back(p.first);
+            elems.push_back(p.second);
+        }
+        ouster_hip_ctx* ctx = hip::default_ctx();
+        if (!s.fmt || names != s.fmt_fields || elems != s.fmt_elems) {
+            if (s.fmt) ouster_hip_format_destroy(s.fmt);
+            s.fmt = nullptr;
+            ouster_hip_format_desc d;
+            pf.fill_hip_desc(static_cast<uint32_t>(frame.w), fields, nan, d);
+            hip::check(ouster_hip_format_create(ctx, &d, &s.fmt));
+            s.fmt_fields = names;
+            s.fmt_elems = elems;
+        }
+        const size_t W = frame.w, H = frame.h;
+        // device output block: planes, then timestamp / status / measurement_id (16 B aligned)
+        auto al = [](size_t x) { return (x + 255) & ~size_t{255}; };
+        std::vector<size_t> off(dst.size());
+        size_t total = 0;
+        for (size_t i = 0; i < dst.size(); ++i) {
+            off[i] = total;
+            total += al(H * W * elems[i]);
+        }
+        const size_t off_ts = total;
+        total += al(W * 8);
+        const size_t off_st = total;
+        total += al(W * 4);
+        const size_t off_mid = total;
+        total += al(W * 2);
+        s.d_out.resize(total);
+        const size_t slots = std::max<size_t>(s.staged_count, 1);
+        s.d_packets.resize(slots * s.stride);
+        if (s.staged_count) s.d_packets.upload(s.staged.data(), s.staged_count * s.stride);
+        ouster_hip_frame_out out{};
+        uint8_t* base = static_cast<uint8_t*>(s.d_out.data());
+        for (size_t i = 0; i < dst.size(); ++i) out.planes[i] = base + off[i];
+        out.timestamp = reinterpret_cast<uint64_t*>(base + off_ts);
+        out.status = reinterpret_cast<uint32_t*>(base + off_st);
+        out.measurement_id = reinterpret_cast<uint16_t*>(base + off_mid);
+        out.xyz_field[0] = out.xyz_field[1] = -1;
+        const uint32_t count = static_cast<uint32_t>(s.staged_count);
+        hip::check(ouster_hip_decode(ctx, s.fmt, static_cast<const uint8_t*>(s.d_packets.data()),
+                                     s.stride, static_cast<uint32_t>(slots), &count, 1, nullptr, &out,
+                                     nullptr, nullptr, 0));
+        for (size_t i = 0; i < dst.size(); ++i)
+            s.d_out.download(dst[i]->get(), H * W * elems[i], off[i]);
+        s.d_out.download(frame.timestamp().data(), W * 8, off_ts);
+        s.d_out.download(frame.status().data(), W * 4, off_st);
+        s.d_out.download(frame.measurement_id().data(), W * 2, off_mid);
+    }
+
+    static int top_of_cache(const FrameBatcher::State& s, const PacketFormat& pf) {
+        int best = 0;  // lowest frame id first, ties in arrival order (lidar_frame.h:970-993)
+        for (size_t i = 1; i < s.cache.size(); ++i) {
+            const int d = pf.frame_id_difference(pf.frame_id(s.cache[best].buf.data()),
+                                                 pf.frame_id(s.cache[i].buf.data()));
+            if (d < 0 || (d == 0 && s.cache[i].seq < s.cache[best].seq)) best = static_cast<int>(i);
+        }
+        return best;
+    }
+};
+
+bool FrameBatcher::batch(const Packet& packet, LidarFrame& frame) {
+    State& s = *s_;
+    if (s.reset_frame) {
+        frame.frame_id = -1;
+        s.reset_frame = false;
+    }
+    if (packet.type() == PacketType::Imu || packet.type() == PacketType::Zone) return false;
+    if (frame.w != s.info->format.columns_per_frame || frame.h != s.info->format.pixels_per_column)
+        throw std::invalid_argument("unexpected frame dimensions");
+    if (frame.packet_timestamp().rows() != frame.w / pf.columns_per_packet)
+        throw std::invalid_argument("unexpected frame columns_per_packet: " +
+                                    std::to_string(pf.columns_per_packet));
+    const uint8_t* buf = packet.buf.data();
+    const size_t len = packet.buf.size();
+    auto push_cache = [&] { s.cache.push_back({packet.buf, packet.host_timestamp, s.seq++}); };
+    auto maybe_release = [&]() {
+        if (BatcherOps::frame_complete(s, pf, frame)) {
+            BatcherOps::finalize_frame(s, pf, frame);
+            return true;
+        }
+        return false;
+    };
+
+    // sensor re-initialisation (lidar_frame.cpp:1795-1822)
+    if (pf.udp_profile_lidar != UDPProfileLidar::LEGACY &&
+        static_cast<int64_t>(pf.init_id(buf)) != s.last_init_id) {
+        s.last_init_id = pf.init_id(buf);
+        if (frame.frame_id == -1 || s.finished_frame_id >= 0) {
+            reset();
+            s.reset_frame = false;
+            BatcherOps::start_frame(s, pf, pf.frame_id(buf), buf, frame);
+            BatcherOps::stage_packet(s, pf, buf, len, packet.host_timestamp, frame);
+            return maybe_release();
+        }
+        BatcherOps::finalize_frame(s, pf, frame);
+        reset();
+        push_cache();
+        return true;
+    }
+
+    const int64_t f_id = pf.frame_id(buf);
+    if (s.cache.empty()) {
+        if (s.finished_frame_id >= 0 &&
+            pf.frame_id_difference(static_cast<uint32_t>(s.finished_frame_id),
+                                   static_cast<uint32_t>(f_id)) <= 0) {
+            s.dropped_packets++;  // late packet of a frame already released
+            return false;
+        }
+        if (frame.frame_id == -1 || s.finished_frame_id >= 0) {
+            BatcherOps::start_frame(s, pf, f_id, buf, frame);
+            BatcherOps::stage_packet(s, pf, buf, len, packet.host_timestamp, frame);
+            return maybe_release();
+        }
+    }
+    if (frame.frame_id == f_id && s.finished_frame_id < 0) {
+        BatcherOps::stage_packet(s, pf, buf, len, packet.host_timestamp, frame);
+        return maybe_release();
+    }
+
+    // batch_with_caching (lidar_frame.cpp:1743-1793)
+    push_cache();
+    while (!s.cache.empty()) {
+        const int t = BatcherOps::top_of_cache(s, pf);
+        const uint8_t* tb = s.cache[t].buf.data();
+        const int64_t tf = pf.frame_id(tb);
+        if (s.finished_frame_id >= 0 &&
+            pf.frame_id_difference(static_cast<uint32_t>(s.finished_frame_id),
+                                   static_cast<uint32_t>(tf)) <= 0) {
+            s.dropped_packets++;
+            s.cache.erase(s.cache.begin() + t);
+            continue;
+        }
+        if (frame.frame_id == -1 || s.finished_frame_id >= 0)
+            BatcherOps::start_frame(s, pf, tf, tb, frame);
+        const int diff = pf.frame_id_difference(static_cast<uint32_t>(frame.frame_id),
+                                                static_cast<uint32_t>(tf));
+        if (diff < 0) {
+            s.dropped_packets++;
+            s.cache.erase(s.cache.begin() + t);
+        } else if (diff > 0) {
+            if (s.cache.size() >= s.max_cache_size) {  // give up waiting for the current frame
+                BatcherOps::finalize_frame(s, pf, frame);
+                return true;
+            }
+            return false;
+        } else {
+            BatcherOps::stage_packet(s, pf, tb, s.cache[t].buf.size(), s.cache[t].host_timestamp,
+                                     frame);
+            s.cache.erase(s.cache.begin() + t);
+            if (maybe_release()) return true;
+        }
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------
+// frame_to_packets (host; test-side packet synthesis)
+// ---------------------------------------------------------------------------------------
+namespace impl {
+
+namespace {
+template <typename T>
+void pack_plane(const PacketFormat& pf, const Field& f, const std::string& name, int cols,
+                uint8_t* buf) {
+    pf.set_block<T>(static_cast<const T*>(f.get()), cols, name, buf);
+}
+}  // namespace
+
+std::vector<LidarPacket> frame_to_packets(const LidarFrame& frame,
+                                          std::shared_ptr<PacketFormat> pf, uint32_t init_id,
+                                          uint64_t prod_sn) {
+    if (!pf) throw std::invalid_argument("Null PacketFormat pointer");
+    const size_t total = frame.packet_timestamp().size();
+    if (frame.w / pf->columns_per_packet != total)
+        throw std::invalid_argument(
+            "Mismatch between expected number of packets and PacketFormat.columns_per_packet");
+    std::vector<LidarPacket> out;
+    const uint32_t cpp = pf->columns_per_packet;
+    for (size_t p = 0; p < total; ++p) {
+        LidarPacket pkt(pf);
+        uint8_t* buf = pkt.buf.data();
+        pkt.host_timestamp = frame.packet_timestamp()[p];
+        pf->set_shutdown(buf, static_cast<uint8_t>(frame.thermal_shutdown()));
+        pf->set_shot_limiting(buf, static_cast<uint8_t>(frame.shot_limiting()));
+        pf->set_shutdown_countdown(buf, static_cast<uint8_t>(frame.shutdown_countdown));
+        pf->set_shot_limiting_countdown(buf, static_cast<uint8_t>(frame.shot_limiting_countdown));
+        pf->set_frame_id(buf, static_cast<uint32_t>(frame.frame_id));
+        pf->set_init_id(buf, init_id);
+        pf->set_prod_sn(buf, prod_sn);
+        pf->set_packet_type(buf, 0x1);
+        pf->set_alert_flags(buf, frame.alert_flags()[p]);
+        bool any_valid = false;
+        for (uint32_t icol = 0; icol < cpp; ++icol) {
+            uint8_t* col = pf->nth_col(icol, buf);
+            const size_t id = p * cpp + icol;
+            pf->set_col_status(col, frame.status()[id]);
+            pf->set_col_measurement_id(col, static_cast<uint16_t>(id));
+            pf->set_col_timestamp(col, frame.timestamp()[id]);
+            any_valid |= (frame.status()[id] & 0x01) != 0;
+        }
+        if (!any_valid && !pkt.host_timestamp) continue;  // nothing to say: not emitted
+        for (auto it = pf->begin(); it != pf->end(); ++it) {
+            if (!frame.has_field(it->first)) continue;
+            const Field& f = frame.field(it->first);
+            const int cols = static_cast<int>(frame.w);
+            if (f.shape().size() == 3) {
+                pack_plane<float3x16_t>(*pf, f, it->first, cols, buf);
+                continue;
+            }
+            switch (f.tag()) {
+                case ChanFieldType::UINT8: pack_plane<uint8_t>(*pf, f, it->first, cols, buf); break;
+                case ChanFieldType::UINT16: pack_plane<uint16_t>(*pf, f, it->first, cols, buf); break;
+                case ChanFieldType::UINT32: pack_plane<uint32_t>(*pf, f, it->first, cols, buf); break;
+                case ChanFieldType::UINT64: pack_plane<uint64_t>(*pf, f, it->first, cols, buf); break;
+                case ChanFieldType::INT8: pack_plane<int8_t>(*pf, f, it->first, cols, buf); break;
+                case ChanFieldType::INT16: pack_plane<int16_t>(*pf, f, it->first, cols, buf); break;
+                case ChanFieldType::INT32: pack_plane<int32_t>(*pf, f, it->first, cols, buf); break;
+                case ChanFieldType::INT64: pack_plane<int64_t>(*pf, f, it->first, cols, buf); break;
+                case ChanFieldType::FLOAT32: pack_plane<float>(*pf, f, it->first, cols, buf); break;
+                case ChanFieldType::FLOAT64: pack_plane<double>(*pf, f, it->first, cols, buf); break;
+                default: break;
+            }
+        }
+        if (pf->udp_profile_lidar != UDPProfileLidar::LEGACY &&
+            pf->header_type == HeaderType::STANDARD) {
+            const uint64_t crc = pf->calculate_crc(buf, pkt.buf.size());
+            std::memcpy(buf + pkt.buf.size() - sizeof crc, &crc, sizeof crc);
+        }
+        out.push_back(std::move(pkt));
+    }
+    return out;
+}
+
+}  // namespace impl
+
+}  // namespace core
+}  // namespace sdk
+}  // namespace ouster

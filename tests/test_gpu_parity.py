@@ -126,7 +126,16 @@ def test_captures_match_oracle(oracle, base):
     pf = cal.packet_format()
     pk = O.lidar_packets_from_pcap(os.path.join(PCAPS, base + ".pcap"), pf)
     assert len(pk) > 0
-    err = _check_decode(O, cal, [pk], with_window=False, slots=cal.w // cal.cpp)
+    # split the capture into frames by frame id, as the host-side batcher does
+    import ctypes as C
+    fids = [O.lib().ora_frame_id(C.byref(pf), p.ctypes.data) for p in pk]
+    frames, cur = [], [0]
+    for i in range(1, len(pk)):
+        if fids[i] != fids[i - 1]:
+            frames.append(pk[cur]); cur = []
+        cur.append(i)
+    frames.append(pk[cur])
+    err = _check_decode(O, cal, frames, with_window=False, slots=cal.w // cal.cpp)
     assert err <= 4e-5
 
 
