@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--outputs", default="full", choices=["full", "xyz", "planes", "planes+dst"],
+                    help="ablation of the output set (the metric is 'full')")
     ap.add_argument("--exchange", action="store_true",
                     help="also time RCCL scatter of packets / gather of XYZ (reported separately)")
     args = ap.parse_args()
@@ -161,7 +163,14 @@ def main():
     F = args.frames
     d_pool = torch.from_numpy(pool).cuda()
     packets = d_pool.repeat((F + args.pool - 1) // args.pool, 1, 1)[:F].contiguous()
-    out = hp.alloc_outputs(F, destagger=DESTAGGERED, xyz=["RANGE", "RANGE2"])
+    if args.outputs == "full":
+        out = hp.alloc_outputs(F, destagger=DESTAGGERED, xyz=["RANGE", "RANGE2"])
+    elif args.outputs == "xyz":
+        out = hp.alloc_outputs(F, planes=[], xyz=["RANGE", "RANGE2"], headers=False)
+    elif args.outputs == "planes":
+        out = hp.alloc_outputs(F)
+    else:
+        out = hp.alloc_outputs(F, destagger=DESTAGGERED)
 
     def barrier():
         if world > 1:
@@ -204,6 +213,10 @@ def main():
     points_per_step = F * H * W * 2 * world
     value = points_per_step * args.steps / elapsed / 1e6
     bytes_per_launch = algorithmic_bytes_per_frame() * F
+    if args.outputs != "full":  # ablation runs: count only what is actually moved
+        per = (W // CPP) * (32 + CPP * (12 + H * 8) + 32)
+        per += {"xyz": 2 * H * W * 12, "planes": H * W * 15, "planes+dst": H * W * 25}[args.outputs]
+        bytes_per_launch = per * F
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
     if rank == 0:
@@ -215,7 +228,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[2]: OS-2-128 2048x128 RNG15_RFL8_NIR8_DUAL dual return",
                        "frames_per_step_per_gpu": F, "points_per_frame": H * W * 2,
-                       "outputs": "8 planes + 4 destaggered planes + 2x XYZ f32 + column headers",
+                       "outputs": "8 planes + 4 destaggered planes + 2x XYZ f32 + column headers"
+                       if args.outputs == "full" else "ABLATION:" + args.outputs,
                        "sharding": f"frames x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "k_decode<SpecDualLB,64,sep-f32>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

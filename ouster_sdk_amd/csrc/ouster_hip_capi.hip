@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -621,8 +622,14 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         for (int t : {64, 32, 16})
             if (decode_lds_bytes(g, t) <= 160 * 1024) { tile = t; break; }
     if (!tile) return fail(OUSTER_HIP_ERR_UNSUPPORTED, "column of %u bytes does not fit in LDS", g.col_size);
+    // tuning knobs for experiments (not part of the API contract)
+    if (const char* e = getenv("OUSTER_HIP_TILE")) {
+        const int t = atoi(e);
+        if ((t == 64 || t == 32 || t == 16) && decode_lds_bytes(g, t) <= 160 * 1024) tile = t;
+    }
     da.tiles_per_frame = (W + tile - 1) / tile;
     da.xcd_map = n_frames >= 8 ? 1u : 0u;
+    if (const char* e = getenv("OUSTER_HIP_XCD")) da.xcd_map = (atoi(e) != 0 && n_frames >= 8) ? 1u : 0u;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {

@@ -156,7 +156,8 @@ def test_synthetic_roundtrip(oracle, profile, h, w, hdr):
     cal = O.synthetic_calib(h=h, w=w, profile=profile, header_type=hdr)
     packets, src = O.synth_packets(cal, 9, with_window=True)
     err = _check_decode(O, cal, [packets[f] for f in range(9)], with_window=True)
-    assert err <= 4e-5
+    # one f32 rounding: half an ulp of the largest coordinate (20-bit LEGACY ranges reach 1048 m)
+    assert err <= (6.2e-5 if profile == "LEGACY" else 4e-5)
 
 
 def test_dropped_invalid_shuffled(oracle):
@@ -282,7 +283,7 @@ def test_cartesian_standalone(oracle):
     got64 = _np(hp.cartesian(dr, lut=lut64, dtype=torch.float64))
     assert np.array_equal(got64, want)
     with pytest.raises(ValueError):
-        hp.cartesian(dr[:, :64])
+        hp.cartesian(dr[:, :64].contiguous())
 
 
 def test_lut_dimension_errors(oracle):
