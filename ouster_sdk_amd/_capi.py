@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-HIP_SO = os.path.join(LIB_DIR, "libouster_hip.so")
+HIP_SO = os.environ.get("OUSTER_HIP_SO") or os.path.join(LIB_DIR, "libouster_hip.so")  # env: A/B builds
 CORE_SO = os.path.join(LIB_DIR, "libouster_core_amd.so")
 
 MAX_FIELDS = 32

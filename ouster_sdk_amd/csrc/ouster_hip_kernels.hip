@@ -326,6 +326,32 @@ __device__ __forceinline__ void store_xyz4<double>(double* dst, const double (&p
     d[5] = make_double2(p[3][1], p[3][2]);
 }
 
+// f32 xyz of 4 consecutive pixels per lane = 48 contiguous bytes per lane.  Stored directly,
+// each of the three 16 B store instructions would touch every third 16 B chunk of the row
+// segment.  Instead the wave transposes through a private LDS scratch so that instruction k
+// writes chunks [k*LPR, (k+1)*LPR) of the row segment: LPR x 16 B contiguous per row.
+//   row_base: xyz address of the first pixel of this lane's row segment (tile column 0)
+template <int LPR>
+__device__ __forceinline__ void store_xyz4_coalesced(float4* s_xyz, uint32_t tid, float* row_base,
+                                                     uint32_t q, const double (&p)[4][3]) {
+    const uint32_t wave = tid >> 6, lane = tid & 63u, rho = lane / LPR;
+    float4* sc = s_xyz + wave * 192 + rho * (3 * LPR);
+    sc[3 * q + 0] = make_float4((float)p[0][0], (float)p[0][1], (float)p[0][2], (float)p[1][0]);
+    sc[3 * q + 1] = make_float4((float)p[1][1], (float)p[1][2], (float)p[2][0], (float)p[2][1]);
+    sc[3 * q + 2] = make_float4((float)p[2][2], (float)p[3][0], (float)p[3][1], (float)p[3][2]);
+    // same-wave LDS write -> read: DS ops of a wave execute in order; keep the compiler from
+    // reordering and wait for the writes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float4* d = (float4*)row_base;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 v = sc[k * LPR + q];
+        d[k * LPR + q] = v;
+    }
+    // the next use of the scratch (second return / next row) must not overtake these reads
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <class T>
 __device__ __forceinline__ void store_xyz1(T* dst, const double (&p)[3]) {
     dst[0] = (T)p[0]; dst[1] = (T)p[1]; dst[2] = (T)p[2];
@@ -382,7 +408,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
     int32_t* s_src = (int32_t*)(smem + (tile_bytes >> 2));      // [TILE]
     uint64_t* s_masks = (uint64_t*)(s_src + TILE);              // [0] valid, [1] group-ok
     int32_t* s_off = (int32_t*)(s_masks + 2);                   // [H] destagger offsets
-    double* s_beam = (double*)(s_off + ((H + 3) & ~3u));        // [H][9] per-beam table
+    float4* s_xyz = (float4*)(s_off + ((H + 3) & ~3u));         // [4 waves][192] xyz transpose
 
     // ---- phase 0: source map of this tile
     if (tid < TILE) {
@@ -401,14 +427,46 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
     if (a.any_destagger)
         for (uint32_t r = tid; r < H; r += NT) s_off[r] = a.dst_offsets[r];
     const LutDev lut = (XYZM != 0) ? a.luts[f % a.n_luts] : LutDev{};
-    if (XYZM == 1 || XYZM == 2)
-        for (uint32_t i = tid; i < H * 9; i += NT) s_beam[i] = lut.beam_tab[i];
     __syncthreads();
 
     // ---- phase 1: stage the tile's columns in LDS, column j at byte j*col_size
     const uint64_t validmask = s_masks[0], groupmask = s_masks[1];
     const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
-    if (TILE % cpp == 0) {
+    const uint64_t fullmask = (TILE >= 64) ? ~0ull : ((1ull << TILE) - 1);
+    const uint32_t gbytes_all = cpp * col_size;
+    const bool flat = (TILE % cpp == 0) && (TILE / cpp <= 4) && (groupmask == fullmask) &&
+                      (((gbytes_all | a.packet_stride | a.g.packet_header_size |
+                         (uint32_t)(uintptr_t)fbase) & 15u) == 0);
+    if (flat) {
+        // the common case: the tile is G whole packets, all present and in order.  One flat
+        // copy with every load of the thread in flight before the first LDS write.
+        const uint32_t G = TILE / cpp, n16 = gbytes_all >> 4, total = G * n16;
+        const u32x4* src[4];
+#pragma unroll
+        for (uint32_t g = 0; g < 4; ++g) {
+            const uint32_t p = (g < G) ? (uint32_t)s_src[g * cpp] / cpp : 0u;
+            src[g] = (const u32x4*)(fbase + (size_t)p * a.packet_stride + a.g.packet_header_size);
+        }
+        u32x4* dst = (u32x4*)s_tile;
+        constexpr int DEPTH = 17;  // 17 x 256 x 16 B = 68 KB: a 64-column dual-LB tile in one pass
+        for (uint32_t base = 0; base < total; base += NT * DEPTH) {
+            u32x4 t[DEPTH];
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                const uint32_t idx = base + k * NT + tid;
+                if (idx < total) {
+                    const uint32_t g = (idx >= n16) + (idx >= 2 * n16) + (idx >= 3 * n16);
+                    const u32x4* sp = g == 0 ? src[0] : g == 1 ? src[1] : g == 2 ? src[2] : src[3];
+                    t[k] = __builtin_nontemporal_load(sp + (idx - g * n16));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                const uint32_t idx = base + k * NT + tid;
+                if (idx < total) dst[idx] = t[k];
+            }
+        }
+    } else if (TILE % cpp == 0) {
         const uint32_t gbytes = cpp * col_size;
         for (uint32_t j0 = 0; j0 < TILE; j0 += cpp) {
             const uint64_t gm = (cpp >= 64 ? ~0ull : ((1ull << cpp) - 1)) << j0;
@@ -569,7 +627,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
 
         if constexpr (XYZM == 1 || XYZM == 2) {
             using XT = typename std::conditional<XYZM == 1, float, double>::type;
-            const double* b = s_beam + r * 9;
+            const double* b = lut.beam_tab + (size_t)r * 9;  // 9 KB table, L1/L2 resident
             const double u0 = b[0], u1 = b[1], u2 = b[2], v0 = b[3], v1 = b[4], v2 = b[5],
                          w0 = b[6], w1 = b[7], w2 = b[8];
             double d[4][3];
@@ -592,6 +650,12 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
                     for (int k = 0; k < 3; ++k) p[c][k] = rr ? fma(rm, d[c][k], kc[c][k]) : 0.0;
                 }
                 XT* dst = out + ((size_t)f * plane_px + rowpix) * 3;
+                if constexpr (XYZM == 1) {
+                    if (a.vec_ok && c0 + TILE <= W) {  // full tile: every lane of the row is here
+                        store_xyz4_coalesced<LPR>(s_xyz, tid, dst - (size_t)jq * 3, q, p);
+                        continue;
+                    }
+                }
                 if (vec) store_xyz4<XT>(dst, p);
                 else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<XT>(dst + c * 3, p[c]);
             }
@@ -741,7 +805,7 @@ __global__ __launch_bounds__(256) void k_cartesian(CartesianArgs a) {
 size_t decode_lds_bytes(const Geometry& g, int tile) {
     size_t tile_bytes = ((size_t)tile * g.col_size + 16 + 15) & ~(size_t)15;
     size_t h4 = (g.pixels_per_column + 3) & ~3u;
-    return tile_bytes + (size_t)tile * 4 + 16 + h4 * 4 + (size_t)g.pixels_per_column * 9 * 8;
+    return tile_bytes + (size_t)tile * 4 + 16 + h4 * 4 + 4 * 192 * 16;
 }
 
 template <class S, int TILE>

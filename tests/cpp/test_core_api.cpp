@@ -1,0 +1,459 @@
+// test_core_api.cpp -- exercises the C++ host API (include/ouster/core/*.h) the way the
+// reference's gtest suites exercise ouster_core (gtest is not available here, so a tiny
+// CHECK harness is used).  Needs a GPU: every per-pixel result below comes from the HIP
+// kernels.  Modelled on, and citing, the reference tests:
+//   tests/packet_format_test.cpp:63-151, 184-216, 218-406, 776-820
+//   tests/frame_batcher_test.cpp:73-303, 644-747
+//   tests/destagger_test.cpp:135-210, 321-355;  tests/lidar_frame_test.cpp:492-510
+//   tests/cartesian_test.cpp:53-99;  python/tests/test_xyzlut.py:15-136
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <map>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "ouster/core/lidar_scan.h"  // pulls in everything + the legacy aliases
+
+using namespace ouster::sdk::core;
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        ++g_checks;                                                              \
+        if (!(cond)) {                                                           \
+            ++g_fail;                                                            \
+            std::printf("  CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+        }                                                                        \
+    } while (0)
+
+template <typename E>
+static bool throws_with(const std::function<void()>& f, const std::string& needle) {
+    try {
+        f();
+    } catch (const E& e) {
+        return std::string(e.what()).find(needle) != std::string::npos;
+    } catch (...) {
+        return false;
+    }
+    return false;
+}
+
+static SensorInfo make_info(UDPProfileLidar profile, HeaderType ht, uint32_t h, uint32_t w,
+                            uint32_t cpp = 16) {
+    SensorInfo info;
+    info.format.pixels_per_column = h;
+    info.format.columns_per_packet = cpp;
+    info.format.columns_per_frame = w;
+    info.format.column_window = {0, static_cast<int>(w) - 1};
+    info.format.udp_profile_lidar = profile;
+    info.format.header_type = ht;
+    info.format.fps = 10;
+    for (uint32_t i = 0; i < h; ++i) {
+        static const int pat[4] = {12, 4, -4, -12};
+        info.format.pixel_shift_by_row.push_back(pat[i % 4] * static_cast<int>(w / 1024 ? w / 1024 : 1));
+        info.beam_altitude_angles.push_back(21.0 - 42.0 * i / (h > 1 ? h - 1 : 1));
+        info.beam_azimuth_angles.push_back(4.2 - 2.8 * (i % 4));
+    }
+    info.prod_line = "OS-1-128";
+    info.beam_to_lidar_transform = default_beam_to_lidar_transform(info.prod_line);
+    info.lidar_to_sensor_transform = DEFAULT_LIDAR_TO_SENSOR;
+    info.sensor_to_body = mat4d::Identity();
+    info.fw_rev = "v3.2.0";
+    info.init_id = 0x123456;
+    info.sn = 0x1122334455ull;
+    return info;
+}
+
+// randomize every plane under its value mask (tests/util.h:84-96)
+static void randomize(LidarFrame& frame, const PacketFormat& pf, uint64_t seed) {
+    std::mt19937 g(seed);
+    for (auto it = pf.begin(); it != pf.end(); ++it) {
+        if (!frame.has_field(it->first)) continue;
+        Field& f = frame.field(it->first);
+        const uint64_t mask = pf.field_value_mask(it->first);
+        std::uniform_int_distribution<uint64_t> d(0, mask);
+        const size_t es = f.element_size();
+        uint8_t* p = static_cast<uint8_t*>(f.get());
+        for (size_t i = 0; i < f.size(); ++i) {
+            uint64_t v = (f.shape().size() == 3 ? d(g) & 0xffff : d(g) & mask);
+            std::memcpy(p + i * es, &v, es);
+        }
+    }
+    for (size_t i = 0; i < frame.w; ++i) {
+        frame.timestamp()[i] = 1000 + i;
+        frame.measurement_id()[i] = static_cast<uint16_t>(i);
+        frame.status()[i] = pf.udp_profile_lidar == UDPProfileLidar::LEGACY ? 0xffffffffu : 0x01;
+    }
+    for (size_t i = 0; i < frame.packet_count(); ++i) frame.packet_timestamp()[i] = 10 + i;
+    frame.frame_id = 700;
+}
+
+static bool planes_equal(const LidarFrame& a, const LidarFrame& b, const PacketFormat& pf) {
+    bool ok = true;
+    for (auto it = pf.begin(); it != pf.end(); ++it)
+        if (a.has_field(it->first)) ok &= a.field(it->first) == b.field(it->first);
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------
+static void test_packet_format_tables() {
+    std::printf("packet format tables / geometry\n");
+    struct Case { UDPProfileLidar p; uint32_t h; size_t size; };
+    for (auto c : {Case{UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, 128, 24832},
+                   Case{UDPProfileLidar::RNG15_RFL8_NIR8, 128, 8448},
+                   Case{UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_DUAL, 32, 8448},
+                   Case{UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, 128, 16640},
+                   Case{UDPProfileLidar::LEGACY, 32, 6464}}) {
+        auto info = make_info(c.p, HeaderType::STANDARD, c.h, 1024);
+        PacketFormat pf(info);
+        CHECK(pf.lidar_packet_size == c.size);
+    }
+    // bit widths (packet_format_test.cpp:71-121)
+    auto info = make_info(UDPProfileLidar::FUSA_RNG15_RFL8_NIR8_DUAL, HeaderType::FUSA, 128, 1024);
+    PacketFormat pf(info);
+    std::map<std::string, int> bits = {{"RANGE", 15}, {"FLAGS", 1}, {"REFLECTIVITY", 8},
+                                       {"RANGE2", 15}, {"FLAGS2", 1}, {"REFLECTIVITY2", 8},
+                                       {"NEAR_IR", 8}, {"WINDOW", 8}, {"RAW32_WORD1", 32},
+                                       {"RAW32_WORD2", 32}};
+    size_t n = 0;
+    for (auto it = pf.begin(); it != pf.end(); ++it, ++n) CHECK(pf.field_bitness(it->first) == bits[it->first]);
+    CHECK(n == bits.size());
+    CHECK(pf.max_frame_id == 0xffffffffu);
+    CHECK(pf.frame_id_difference(pf.max_frame_id, 1) == 2);
+    CHECK(pf.frame_id_difference(1, pf.max_frame_id) == -2);
+    CHECK(pf.block_parsable() == 16);
+    // header set/get round trip (packet_format_test.cpp:184-216)
+    auto sinfo = make_info(UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, HeaderType::STANDARD, 64, 1024);
+    PacketFormat spf(sinfo);
+    std::vector<uint8_t> buf(spf.lidar_packet_size + 8, 0);
+    spf.set_frame_id(buf.data(), 0xbeef);
+    spf.set_init_id(buf.data(), 0xabcdef);
+    spf.set_prod_sn(buf.data(), 0x1234567890ull);
+    spf.set_alert_flags(buf.data(), 0x5a);
+    spf.set_shot_limiting(buf.data(), 0x3);
+    CHECK(spf.frame_id(buf.data()) == 0xbeef);
+    CHECK(spf.init_id(buf.data()) == 0xabcdef);
+    CHECK(spf.prod_sn(buf.data()) == 0x1234567890ull);
+    CHECK(spf.alert_flags(buf.data()) == 0x5a);
+    CHECK(static_cast<int>(spf.shot_limiting(buf.data())) == 0x3);
+    CHECK(throws_with<std::invalid_argument>(
+        [] {
+            auto i = make_info(static_cast<UDPProfileLidar>(77), HeaderType::STANDARD, 64, 1024);
+            PacketFormat p(i);
+        },
+        "Unknown lidar udp profile"));
+}
+
+static void test_lidar_frame_container() {
+    std::printf("LidarFrame container\n");
+    CHECK(throws_with<std::invalid_argument>([] { LidarFrame f(0, 10, LidarFrameFieldTypes{}); },
+                                             "zero width or height"));
+    CHECK(throws_with<std::invalid_argument>([] { LidarFrame f(4, 16, LidarFrameFieldTypes{}, 0); },
+                                             "columns_per_packet"));
+    auto info = make_info(UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, HeaderType::STANDARD, 128, 1024);
+    LidarFrame f(info);
+    CHECK(f.w == 1024 && f.h == 128 && f.packet_count() == 64);
+    CHECK(f.has_field("RANGE") && f.has_field("WINDOW") && f.fields().size() == 8);
+    CHECK(f.field("RANGE").tag() == ChanFieldType::UINT32);
+    CHECK(f.field<uint8_t>("REFLECTIVITY").rows() == 128);
+    CHECK(throws_with<std::out_of_range>([&] { f.field("NOPE"); }, "NOPE"));
+    CHECK(throws_with<std::invalid_argument>([&] { f.field<uint16_t>("RANGE"); }, "ineligible"));
+    info.fw_rev = "v2.4.0";  // WINDOW dropped below fw 3.2 (lidar_frame.cpp:1097-1110)
+    CHECK(!LidarFrame(info).has_field("WINDOW"));
+    const double* pose = f.body_to_world().get<double>();
+    CHECK(pose[0] == 1.0 && pose[5] == 1.0 && pose[1] == 0.0 && pose[16 * 5 + 15] == 1.0);
+    LidarFrame g = f;  // deep copy
+    g.field<uint32_t>("RANGE")(3, 4) = 7;
+    CHECK(f.field<uint32_t>("RANGE")(3, 4) == 0 && !(f == g));
+}
+
+// frame -> packets -> FrameBatcher -> frame identity (packet_format_test.cpp:218-326)
+static void test_batcher_roundtrip() {
+    std::printf("FrameBatcher round trip (GPU decode)\n");
+    struct Case { UDPProfileLidar p; HeaderType ht; uint32_t h, w; };
+    for (auto c : {Case{UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, HeaderType::STANDARD, 128, 1024},
+                   Case{UDPProfileLidar::FUSA_RNG15_RFL8_NIR8_DUAL, HeaderType::FUSA, 128, 1024},
+                   Case{UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, HeaderType::STANDARD, 128, 1024},
+                   Case{UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_DUAL, HeaderType::STANDARD, 64, 512},
+                   Case{UDPProfileLidar::RNG15_RFL8_NIR8, HeaderType::STANDARD, 32, 512},
+                   Case{UDPProfileLidar::LEGACY, HeaderType::STANDARD, 64, 1024},
+                   Case{UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_RGB16, HeaderType::STANDARD, 32, 512}}) {
+        auto info = std::make_shared<SensorInfo>(make_info(c.p, c.ht, c.h, c.w));
+        auto pf = std::make_shared<PacketFormat>(*info);
+        LidarFrame src(info);
+        randomize(src, *pf, 0xdeadbeef);
+        auto packets = impl::frame_to_packets(src, pf, info->init_id, info->sn);
+        CHECK(packets.size() == c.w / 16);
+        if (c.p != UDPProfileLidar::LEGACY && c.ht == HeaderType::STANDARD) {
+            uint64_t stored = 0;
+            CHECK(pf->crc(packets[0].buf.data(), packets[0].buf.size(), stored));
+            CHECK(stored == pf->calculate_crc(packets[0].buf.data(), packets[0].buf.size()));
+        }
+        LidarFrame dst(info);
+        dst.add_field("CUSTOM0", ChanFieldType::UINT8);  // user plane must stay untouched
+        for (auto& kv : dst.fields()) std::memset(kv.second.get(), 1, kv.second.bytes());
+        FrameBatcher batcher(info);
+        bool done = false;
+        for (size_t i = 0; i < packets.size(); ++i) {
+            done = batcher(packets[i], dst);
+            CHECK(done == (i + 1 == packets.size()));
+        }
+        CHECK(done);
+        CHECK(planes_equal(src, dst, *pf));
+        CHECK(dst.frame_id == src.frame_id);
+        bool hdr = true;
+        for (size_t i = 0; i < dst.w; ++i)
+            hdr &= dst.timestamp()[i] == src.timestamp()[i] && dst.measurement_id()[i] == i &&
+                   dst.status()[i] == src.status()[i];
+        CHECK(hdr);
+        for (size_t i = 0; i < dst.packet_count(); ++i) hdr &= dst.packet_timestamp()[i] == 10 + i;
+        CHECK(hdr);
+        const uint8_t* custom = dst.field("CUSTOM0").get<uint8_t>();
+        bool untouched = true;
+        for (size_t i = 0; i < dst.field("CUSTOM0").size(); ++i) untouched &= custom[i] == 1;
+        CHECK(untouched);
+
+        // dropped packets -> zero-filled columns; second frame releases the first
+        // (packet_format_test.cpp:328-406, frame_batcher_test.cpp:73-303)
+        LidarFrame dst2(info);
+        for (auto& kv : dst2.fields()) std::memset(kv.second.get(), 1, kv.second.bytes());
+        FrameBatcher b2(info);
+        for (size_t i = 0; i < packets.size(); ++i)
+            if (i != 3 && i != 4) CHECK(!b2(packets[i], dst2));
+        LidarFrame next_src(src);
+        next_src.frame_id = 701;
+        auto next = impl::frame_to_packets(next_src, pf, info->init_id, info->sn);
+        bool released = false;
+        for (size_t i = 0; i < 4 && !released; ++i) released = b2(next[i], dst2);
+        CHECK(released && dst2.frame_id == 700);
+        bool zeros = true, kept = true;
+        auto got = dst2.field("RANGE").get<uint32_t>();
+        auto want = src.field("RANGE").get<uint32_t>();
+        for (size_t r = 0; r < dst2.h; ++r)
+            for (size_t col = 0; col < dst2.w; ++col) {
+                const bool dropped = col >= 48 && col < 80;
+                if (dropped) zeros &= got[r * dst2.w + col] == 0;
+                else kept &= got[r * dst2.w + col] == want[r * dst2.w + col];
+            }
+        CHECK(zeros && kept);
+        CHECK(dst2.status()[50] == 0 && dst2.timestamp()[50] == 0 && dst2.packet_timestamp()[3] == 0);
+    }
+    // dimension checks of batch() (lidar_frame.cpp:1836-1844)
+    auto info = std::make_shared<SensorInfo>(
+        make_info(UDPProfileLidar::RNG15_RFL8_NIR8, HeaderType::STANDARD, 32, 512));
+    FrameBatcher b(info);
+    LidarFrame wrong(32, 1024, UDPProfileLidar::RNG15_RFL8_NIR8);
+    LidarPacket p(std::make_shared<PacketFormat>(*info));
+    CHECK(throws_with<std::invalid_argument>([&] { b.batch(p, wrong); }, "unexpected frame dimensions"));
+}
+
+// alternative encodings registered at run time decode identically (frame_batcher_test.cpp:644-747)
+static void test_custom_profile() {
+    std::printf("add_custom_profile\n");
+    std::vector<std::pair<std::string, FieldDecodeInfo>> alt = {
+        {"RANGE", {ChanFieldType::UINT32, 0, 0x7fff, -3}},
+        {"FLAGS", {ChanFieldType::UINT8, 1, 0x80, 7}},
+        {"REFLECTIVITY", {ChanFieldType::UINT8, 1, 0xff00, 8}},
+        {"NEAR_IR", {ChanFieldType::UINT16, 2, 0xff00, 4}}};
+    UDPProfileLidar custom = add_custom_profile("PROFILE_LOWBAND_ALT", alt, 4);
+    CHECK(to_string(custom) == "PROFILE_LOWBAND_ALT");
+    CHECK(throws_with<std::invalid_argument>(
+        [&] { add_custom_profile("PROFILE_LOWBAND_ALT", alt, 4); }, "name already exists"));
+    auto info = std::make_shared<SensorInfo>(
+        make_info(UDPProfileLidar::RNG15_RFL8_NIR8, HeaderType::STANDARD, 64, 512));
+    auto pf = std::make_shared<PacketFormat>(*info);
+    LidarFrame src(info);
+    randomize(src, *pf, 42);
+    auto packets = impl::frame_to_packets(src, pf, info->init_id, info->sn);
+    auto cinfo = std::make_shared<SensorInfo>(*info);
+    cinfo->format.udp_profile_lidar = custom;
+    LidarFrame a(info), c(cinfo);
+    FrameBatcher ba(info), bc(cinfo);
+    for (auto& p : packets) {
+        ba(p, a);
+        bc(p, c);
+    }
+    for (const char* n : {"RANGE", "FLAGS", "REFLECTIVITY", "NEAR_IR"}) CHECK(a.field(n) == c.field(n));
+    CHECK(a.field("RANGE") == src.field("RANGE"));
+}
+
+static void test_col_and_block_field() {
+    std::printf("PacketFormat::col_field / block_field\n");
+    auto info = std::make_shared<SensorInfo>(
+        make_info(UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, HeaderType::STANDARD, 64, 512));
+    auto pf = std::make_shared<PacketFormat>(*info);
+    LidarFrame src(info);
+    randomize(src, *pf, 7);
+    auto packets = impl::frame_to_packets(src, pf, info->init_id, info->sn);
+    const auto& pkt = packets[5];
+    img_t<uint32_t> plane(64, 512);
+    pf->block_field<uint32_t, 16>(plane.data(), 512, "RANGE", pkt.buf.data());
+    bool ok = true;
+    for (size_t r = 0; r < 64; ++r)
+        for (size_t c = 0; c < 512; ++c)
+            ok &= plane(r, c) == ((c >= 80 && c < 96) ? src.field<uint32_t>("RANGE")(r, c) : 0u);
+    CHECK(ok);
+    std::vector<uint16_t> col(64 * 3, 0xffff);
+    pf->col_field<uint16_t>(pf->nth_col(2, pkt.buf.data()), "SIGNAL", col.data(), 3);
+    ok = true;
+    for (size_t r = 0; r < 64; ++r)
+        ok &= col[r * 3] == src.field<uint16_t>("SIGNAL")(r, 82) && col[r * 3 + 1] == 0xffff;
+    CHECK(ok);
+    CHECK(throws_with<std::invalid_argument>(
+        [&] {
+            std::vector<uint8_t> small(64);
+            pf->col_field<uint8_t>(pf->nth_col(0, pkt.buf.data()), "RANGE", small.data(), 1);
+        },
+        "Dest type too small"));
+}
+
+static void test_destagger() {
+    std::printf("destagger\n");
+    std::mt19937 g(3);
+    const size_t h = 128, w = 1024;
+    std::vector<int> shifts(h);
+    for (auto& s : shifts) s = static_cast<int>(g() % 61) - 30;  // destagger_test.cpp:123-133
+    img_t<uint32_t> img(h, w);
+    for (size_t i = 0; i < img.size(); ++i) img.data()[i] = g();
+    auto d = destagger<uint32_t>(img, shifts);
+    bool roll = true;
+    for (size_t r = 0; r < h; ++r)
+        for (size_t c = 0; c < w; ++c)
+            roll &= d(r, (c + w + shifts[r]) % w) == img(r, c);  // np.roll(row, shift)
+    CHECK(roll);
+    CHECK(destagger<uint32_t>(d, shifts, true) == img);  // stagger . destagger == id
+    img_t<uint8_t> b(h, w);
+    for (size_t i = 0; i < b.size(); ++i) b.data()[i] = static_cast<uint8_t>(g());
+    CHECK(destagger<uint8_t>(destagger<uint8_t>(b, shifts), shifts, true) == b);
+    img_t<double> dd(h, w);
+    for (size_t i = 0; i < dd.size(); ++i) dd.data()[i] = static_cast<double>(g()) * 0.5;
+    CHECK(destagger<double>(destagger<double>(dd, shifts), shifts, true) == dd);
+    // exact messages asserted by destagger_test.cpp:332,351 / lidar_frame_test.cpp:504
+    std::vector<int> bad(shifts.begin(), shifts.end() - 1);
+    CHECK(throws_with<std::invalid_argument>([&] { destagger<uint32_t>(img, bad); },
+                                             "image height does not match shifts size"));
+    img_t<uint32_t> small(h, w / 2);
+    CHECK(throws_with<std::invalid_argument>(
+        [&] { destagger_into<uint32_t>(ImgRef<const uint32_t>(img), shifts, false, ImgRef<uint32_t>(small)); },
+        "image and destaggered must have the same shape"));
+    auto info = make_info(UDPProfileLidar::RNG15_RFL8_NIR8, HeaderType::STANDARD, 128, 1024);
+    LidarFrame f(info);
+    auto r = f.field<uint32_t>("RANGE");
+    for (size_t i = 0; i < r.size(); ++i) r.data()[i] = g();
+    Field df = destagger(info, f.field("RANGE"));
+    img_t<uint32_t> ref(h, w);
+    std::memcpy(ref.data(), r.data(), ref.size() * 4);
+    auto dref = destagger<uint32_t>(info, ref);
+    CHECK(std::memcmp(df.get(), dref.data(), df.bytes()) == 0);
+    for (size_t i = 0; i < f.w; ++i) f.timestamp()[i] = 5000 + i;
+    CHECK(column_timestamp_at_destaggered_pixel(f, info, 1, 10) ==
+          5000 + (10 - info.format.pixel_shift_by_row[1] + 1024) % 1024);
+}
+
+static void test_xyzlut() {
+    std::printf("XYZLut / cartesian\n");
+    auto info = make_info(UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, HeaderType::STANDARD, 128, 1024);
+    info.sensor_to_body(0, 3) = 1.5;   // metres
+    info.sensor_to_body(1, 3) = -0.5;
+    XYZLut lut(info, true);
+    CHECK(lut.h == 128 && lut.w == 1024 && lut.direction.rows() == 128 * 1024);
+    std::mt19937 g(11);
+    img_t<uint32_t> range(128, 1024);
+    for (size_t i = 0; i < range.size(); ++i) range.data()[i] = (g() % 3 == 0) ? 0 : g() % (1u << 19);
+    PointCloudXYZd pts = lut(range);
+    // (1) matches the table definition r*direction + offset (cartesian.h:53-65)
+    double worst = 0;
+    bool zeros = true;
+    for (size_t i = 0; i < range.size(); ++i) {
+        const double r = range.data()[i];
+        for (int k = 0; k < 3; ++k) {
+            const double want = r == 0 ? 0.0 : r * lut.direction(i, k) + lut.offset(i, k);
+            worst = std::max(worst, std::abs(pts(i, k) - want));
+            if (r == 0) zeros &= pts(i, k) == 0.0;
+        }
+    }
+    CHECK(worst < 1e-9 && zeros);
+    // (2) matches the closed-form formula of the user manual (reference.py:19-70) incl. extrinsics
+    const double n = info.beam_to_lidar_transform(0, 3);
+    double worst_formula = 0;
+    for (size_t u = 0; u < 128; u += 7)
+        for (size_t v = 0; v < 1024; v += 13) {
+            const double r = range(u, v);
+            if (r == 0) continue;
+            const double te = 2.0 * M_PI * (1.0 - static_cast<double>(v) / 1024);
+            const double ta = -2.0 * M_PI * info.beam_azimuth_angles[u] / 360.0;
+            const double ph = 2.0 * M_PI * info.beam_altitude_angles[u] / 360.0;
+            const double x = (r - n) * std::cos(te + ta) * std::cos(ph) + n * std::cos(te);
+            const double y = (r - n) * std::sin(te + ta) * std::cos(ph) + n * std::sin(te);
+            const double z = (r - n) * std::sin(ph);
+            const mat4d& m = info.lidar_to_sensor_transform;
+            const double sx = (m(0, 0) * x + m(0, 1) * y + m(0, 2) * z + m(0, 3)) * 0.001 + 1.5;
+            const double sy = (m(1, 0) * x + m(1, 1) * y + m(1, 2) * z + m(1, 3)) * 0.001 - 0.5;
+            const double sz = (m(2, 0) * x + m(2, 1) * y + m(2, 2) * z + m(2, 3)) * 0.001;
+            const size_t i = u * 1024 + v;
+            worst_formula = std::max({worst_formula, std::abs(pts(i, 0) - sx), std::abs(pts(i, 1) - sy),
+                                      std::abs(pts(i, 2) - sz)});
+        }
+    CHECK(worst_formula < 1e-9);
+    // (3) float LUT vs double LUT (cartesian_test.cpp:53-99), deprecated cartesian()
+    XYZLutT<float> lutf(lut);
+    PointCloudXYZf ptsf = lutf(range);
+    double worst_f = 0;
+    for (size_t i = 0; i < pts.size(); ++i)
+        worst_f = std::max(worst_f, std::abs(static_cast<double>(ptsf.data()[i]) - pts.data()[i]));
+    CHECK(worst_f < 1e-4);
+    PointCloudXYZd c = cartesian(range, lut);
+    CHECK(c == pts);
+    PointCloudXYZd ct = impl::cartesianT<double>(ImgRef<const uint32_t>(range), lut.direction, lut.offset);
+    double worst_ct = 0;
+    for (size_t i = 0; i < pts.size(); ++i) worst_ct = std::max(worst_ct, std::abs(ct.data()[i] - pts.data()[i]));
+    CHECK(worst_ct < 1e-9);
+    // dimension errors (test_xyzlut.py:15-116, xyzlut.cpp:14-21)
+    CHECK(throws_with<std::invalid_argument>(
+        [&] { impl::make_xyz_lut(0, 128, 0.001, mat4d::Identity(), mat4d::Identity(), {}, {}); },
+        "lut dimensions must be greater than zero"));
+    CHECK(throws_with<std::invalid_argument>(
+        [&] {
+            std::vector<double> a(127, 0.0);
+            impl::make_xyz_lut(1024, 128, 0.001, mat4d::Identity(), mat4d::Identity(), a, a);
+        },
+        "unexpected frame dimensions"));
+    img_t<uint32_t> wrong(64, 1024);
+    CHECK(throws_with<std::invalid_argument>([&] { lut(wrong); }, "unexpected image dimensions"));
+    // per-pixel angle ("DF") calibration: full LUT fallback
+    std::vector<double> az(16 * 64), alt(16 * 64);
+    for (size_t i = 0; i < az.size(); ++i) { az[i] = 0.1 * (i % 64) - 3; alt[i] = 0.2 * (i / 64) - 1; }
+    XYZLut df = impl::make_xyz_lut(64, 16, 0.001, mat4d::Identity(), mat4d::Identity(), az, alt);
+    img_t<uint32_t> rr(16, 64);
+    rr.setConstant(1000);
+    PointCloudXYZd dp = df(rr);
+    CHECK(std::abs(dp(5, 0) - std::cos(az[5] * M_PI / 180) * std::cos(alt[5] * M_PI / 180)) < 1e-12);
+}
+
+static void test_legacy_aliases() {
+    std::printf("legacy aliases\n");
+    ouster::sensor::sensor_info info =
+        make_info(UDPProfileLidar::RNG15_RFL8_NIR8, HeaderType::STANDARD, 32, 512);
+    const ouster::sensor::packet_format& pf = ouster::sensor::get_format(info);
+    ouster::LidarScan scan(info);
+    ouster::XYZLut lut = ouster::make_xyz_lut(info, false);
+    auto pts = ouster::cartesian(scan, lut);
+    auto img = ouster::destagger<uint32_t>(info, ouster::img_t<uint32_t>(32, 512));
+    CHECK(pf.pixels_per_column == 32 && pts.rows() == 32 * 512 && img.cols() == 512);
+    CHECK(ouster::sensor::range_unit == 0.001);
+}
+
+int main() {
+    test_packet_format_tables();
+    test_lidar_frame_container();
+    test_batcher_roundtrip();
+    test_custom_profile();
+    test_col_and_block_field();
+    test_destagger();
+    test_xyzlut();
+    test_legacy_aliases();
+    std::printf("%d checks, %d failed\n", g_checks, g_fail);
+    return g_fail ? 1 : 0;
+}
