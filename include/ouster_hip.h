@@ -149,7 +149,9 @@ typedef struct ouster_hip_frame_out {
 
 /* ---- context ------------------------------------------------------------ */
 /* stream: an existing hipStream_t to order on (e.g. torch's current stream),
+ * OUSTER_HIP_STREAM_NULL to order on the device's null (legacy default) stream,
  * or NULL to let the context create and own a non-blocking stream. */
+#define OUSTER_HIP_STREAM_NULL ((void*)(intptr_t)-1)
 int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out);
 void ouster_hip_ctx_destroy(ouster_hip_ctx* ctx);
 void* ouster_hip_ctx_stream(ouster_hip_ctx* ctx);

@@ -175,13 +175,21 @@ def format_desc(profile: str, h: int, cpp: int, w: int, fields: Sequence[Tuple[s
 
 
 class Context:
-    """Owns an ouster_hip_ctx.  stream: raw hipStream_t value (int) or None."""
+    """Owns an ouster_hip_ctx.  stream: raw hipStream_t value (int; 0 = the null stream) or
+    None to let the context create its own non-blocking stream."""
+
+    STREAM_NULL = C.c_void_p(-1)  # OUSTER_HIP_STREAM_NULL
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         self.L = load_hip()
         h = C.c_void_p()
-        check(self.L.ouster_hip_ctx_create(device, C.c_void_p(stream) if stream else None,
-                                           C.byref(h)))
+        if stream is None:
+            sp = None
+        elif stream == 0:
+            sp = self.STREAM_NULL
+        else:
+            sp = C.c_void_p(stream)
+        check(self.L.ouster_hip_ctx_create(device, sp, C.byref(h)))
         self.h = h
         self.device = device
 

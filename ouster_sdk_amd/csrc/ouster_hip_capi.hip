@@ -222,7 +222,9 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
     ouster_hip_ctx* c = new (std::nothrow) ouster_hip_ctx();
     if (!c) return fail(OUSTER_HIP_ERR_RUNTIME, "out of memory");
     c->device = device;
-    if (stream) {
+    if (stream == OUSTER_HIP_STREAM_NULL) {
+        c->stream = nullptr;  // the null stream
+    } else if (stream) {
         c->stream = (hipStream_t)stream;
     } else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
