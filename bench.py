@@ -191,6 +191,19 @@ def main():
     kern_ms, n_launch = hp.ctx.timing_read()
     hp.ctx.timing(False)
 
+    # context for the roofline: what a plain device-to-device copy reaches on THIS box right now
+    # (boxes of the pool differ by up to ~35 % in sustained HBM bandwidth)
+    cp_src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    cp_dst = torch.empty_like(cp_src)
+    cp_dst.copy_(cp_src)
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    for _ in range(5):
+        cp_dst.copy_(cp_src)
+    torch.cuda.synchronize()
+    box_copy_gbps = 5 * 2 * (1 << 30) / (time.perf_counter() - c0) / 1e9
+    del cp_src, cp_dst
+
     elapsed = t1 - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -235,7 +248,8 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel_ms_avg": round(kern_ms, 4), "launches_timed": n_launch},
+                         "kernel_ms_avg": round(kern_ms, 4), "launches_timed": n_launch,
+                         "box_d2d_copy_GBps": round(box_copy_gbps, 1)},
             "cpu_baseline": None,
         }
         if exchange:

@@ -13,6 +13,7 @@ stream the kernels are ordered on.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -35,6 +36,8 @@ class HotPath:
             raise capi.OusterHipError("no MI355X visible: the hot path has no CPU fallback")
         self.device = torch.cuda.current_device() if device is None else device
         torch.cuda.set_device(self.device)
+        if os.environ.get("OUSTER_HIP_OWN_STREAM"):  # experiment knob
+            use_torch_stream = False
         stream = torch.cuda.current_stream().cuda_stream if use_torch_stream else None
         self.ctx = capi.Context(self.device, stream)
         self.profile, self.h, self.w, self.cpp = profile, h, w, cpp

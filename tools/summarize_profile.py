@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_bench.sh output directory into the summary committed under profiles/."""
+import csv
+import json
+import os
+import sys
+
+d = sys.argv[1]
+
+
+def rows(path):
+    return list(csv.DictReader(open(path))) if os.path.exists(path) else []
+
+
+print(f"# rocprofv3 summary ({os.path.basename(d)})\n")
+print("Command: `python bench.py --steps 20 --warmup 3 --no-cpu` (kernel trace); PMC passes use "
+      "`--steps 3 --warmup 1`.\n")
+print("## kernel stats (rocprofv3 --kernel-trace --stats)\n")
+print("| kernel | calls | avg us | min us | max us | % |")
+print("|---|---|---|---|---|---|")
+for r in rows(os.path.join(d, "trace", "bench_kernel_stats.csv"))[:6]:
+    name = r["Name"].split("(")[0][-70:]
+    print(f"| `{name}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
+          f"{float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
+print("\n## HBM traffic per launch (separate --pmc passes)\n")
+agg = {}
+for c in ("pmc_fetch", "pmc_write"):
+    for r in rows(os.path.join(d, c, "bench_counter_collection.csv")):
+        k = (r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])
+        agg.setdefault(k, []).append(float(r["Counter_Value"]))
+print("| kernel | counter | launches | avg KB (raw) | MB corrected |")
+print("|---|---|---|---|---|")
+tot = {}
+for (k, c), v in sorted(agg.items()):
+    if "ouster_hip" not in k:
+        continue
+    avg = sum(v) / len(v)
+    corr = avg * 1024 / 1e6 * (2.0 if c == "FETCH_SIZE" else 1.0)
+    tot.setdefault(k, 0.0)
+    tot[k] += corr
+    print(f"| `{k}` | {c} | {len(v)} | {avg:.1f} | {corr:.1f} |")
+print("\nFETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read stream, "
+      "MI355X_MICROARCH.md; re-checked here on a torch 545 MB copy). Units: counters in KB.\n")
+for name in ("bench_under_rocprof.json", "bench_plain.json"):
+    p = os.path.join(d, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        try:
+            j = json.loads(open(p).read().strip().splitlines()[-1])
+            rf = j["roofline"]
+            print(f"## {name}\n\nvalue {j['value']} Mpoints/s, ms/step {j['ms_per_step']}, k_decode avg "
+                  f"{rf['kernel_ms_avg']} ms (HIP events), achieved {rf['achieved']} GB/s = {rf['frac']*100:.1f} % "
+                  f"of 8 TB/s; algorithmic {rf['algorithmic_bytes_per_launch']/1e6:.1f} MB/launch; "
+                  f"box d2d copy {rf.get('box_d2d_copy_GBps')} GB/s\n")
+            for k, t in tot.items():
+                if "k_decode" in k:
+                    print(f"k_decode HBM traffic (PMC) {t:.1f} MB/launch = "
+                          f"{t*1e6/rf['algorithmic_bytes_per_launch']:.3f} x algorithmic\n")
+            if j.get("cpu_baseline"):
+                print(f"cpu_baseline: {json.dumps(j['cpu_baseline'])}\n")
+        except Exception as e:
+            print(f"({name}: {e})")
