@@ -69,6 +69,7 @@ struct ouster_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevBuf map, offsets, luts, counts;
+    bool map_clean = false;              // map is all -1 (k_decode resets what it consumes)
     std::vector<int32_t> offsets_host;   // cache key of `offsets`
     std::vector<LutDev> luts_host;       // cache key of `luts`
     bool timing = false;
@@ -515,8 +516,13 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
 
     // ---- scratch: column map, destagger offsets, LUT descriptors, packet counts
     const size_t map_bytes = (size_t)n_frames * W * 4;
-    if (ctx->map.ensure(map_bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(map) failed");
-    HIP_TRY(hipMemsetAsync(ctx->map.p, 0xFF, map_bytes, st));
+    {
+        const void* before = ctx->map.p;
+        if (ctx->map.ensure(map_bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(map) failed");
+        if (ctx->map.p != before) ctx->map_clean = false;
+    }
+    if (!ctx->map_clean) HIP_TRY(hipMemsetAsync(ctx->map.p, 0xFF, ctx->map.cap, st));
+    ctx->map_clean = false;  // dirty until k_decode has consumed it
     const uint32_t n_packets_out = W / g.columns_per_packet;
     if (out->packet_timestamp && host_timestamps)  // start_frame zeroes it (lidar_frame.cpp:1719)
         HIP_TRY(hipMemsetAsync(out->packet_timestamp, 0, (size_t)n_frames * n_packets_out * 8, st));
@@ -575,7 +581,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     da.packet_stride = packet_stride;
     da.slots_per_frame = slots_per_frame;
     da.n_frames = n_frames;
-    da.map = (const int32_t*)ctx->map.p;
+    da.map = (int32_t*)ctx->map.p;
     da.dst_offsets = (const int32_t*)ctx->offsets.p;
     da.luts = (const LutDev*)ctx->luts.p;
     da.n_luts = n_luts ? n_luts : 1;
@@ -648,6 +654,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     }
     HIP_TRY(launch_decode(da, spec, tile, xyzm, st));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
+    ctx->map_clean = true;  // every entry k_colmap wrote has been read back and reset
     return OUSTER_HIP_OK;
 }
 

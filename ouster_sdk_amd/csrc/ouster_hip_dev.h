@@ -56,7 +56,7 @@ struct DecodeArgs {
     uint32_t xcd_map;        // 1: blockIdx -> (frame, tile) keeps a frame on one XCD
     uint32_t vec_ok;         // W % 4 == 0 and all output bases/strides 16 B aligned
     uint32_t any_destagger;
-    const int32_t* map;          // [n_frames][W]
+    int32_t* map;                // [n_frames][W]; every entry is consumed and reset to -1
     const int32_t* dst_offsets;  // [H] destination column offset per row (device)
     const LutDev* luts;          // [n_luts] (device)
     uint32_t n_luts;

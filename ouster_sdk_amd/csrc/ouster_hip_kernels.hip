@@ -54,6 +54,22 @@ __device__ __forceinline__ uint64_t window_global(const uint8_t* p) {
     return funnel3(d0, d1, d2, sh);
 }
 
+// like window_global, but only the dwords that `mask` (applied to the window) can see are
+// loaded; header fields are 1-4 bytes wide, so this is usually a single dword
+__device__ __forceinline__ uint64_t window_global_masked(const uint8_t* p, uint64_t mask) {
+    if (mask == 0) return 0;
+    const uint32_t lo = (uint32_t)__builtin_ctzll(mask) >> 3, hi = (63u - (uint32_t)__builtin_clzll(mask)) >> 3;
+    const uintptr_t a = (uintptr_t)p;
+    const uintptr_t first = (a + lo) & ~(uintptr_t)3, last = (a + hi) & ~(uintptr_t)3;
+    uint64_t v = 0;
+    for (uintptr_t q = first; q <= last; q += 4) {
+        const uint64_t d = *(const uint32_t*)q;
+        const long sh = (long)(q - a) * 8;  // bit position of this dword inside the window
+        v |= sh >= 0 ? (sh < 64 ? d << sh : 0) : d >> (-sh);
+    }
+    return v;
+}
+
 // same, from the LDS tile (byte offset into the tile)
 __device__ __forceinline__ uint64_t window_lds(const uint32_t* tile, uint32_t byte_off) {
     const uint32_t* q = tile + (byte_off >> 2);
@@ -173,11 +189,12 @@ __global__ __launch_bounds__(256) void k_colmap(ColmapArgs a) {
     if (p >= count) return;
     const uint8_t* pkt = a.packets + ((size_t)f * a.slots_per_frame + p) * a.packet_stride;
     const uint8_t* col = pkt + a.g.packet_header_size + (size_t)icol * a.g.col_size;
-    const uint32_t m_id = (uint16_t)apply_bits(window_global(col + a.g.col_measurement_id.offset),
-                                               a.g.col_measurement_id.mask,
-                                               a.g.col_measurement_id.shift);
-    const uint32_t status = (uint32_t)apply_bits(window_global(col + a.g.col_status.offset),
-                                                 a.g.col_status.mask, a.g.col_status.shift);
+    const uint32_t m_id = (uint16_t)apply_bits(
+        window_global_masked(col + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask),
+        a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
+    const uint32_t status = (uint32_t)apply_bits(
+        window_global_masked(col + a.g.col_status.offset, a.g.col_status.mask), a.g.col_status.mask,
+        a.g.col_status.shift);
     if (icol == 0) {
         const uint32_t packet_id = m_id / cpp;
         if (packet_id < a.n_packets_out) {
@@ -413,7 +430,11 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
     // ---- phase 0: source map of this tile
     if (tid < TILE) {
         const uint32_t c = c0 + tid;
-        int32_t src = (c < W) ? a.map[(size_t)f * W + c] : -1;
+        int32_t src = -1;
+        if (c < W) {  // read-and-reset: the map is left at -1 for the next call
+            src = a.map[(size_t)f * W + c];
+            a.map[(size_t)f * W + c] = -1;
+        }
         s_src[tid] = src;
         const uint32_t j0 = tid - tid % cpp;  // first column of my packet group in the tile
         // "group ok": my packet's cpp columns sit in order, packet-aligned, all present
