@@ -35,6 +35,18 @@ DUAL_LB_BITS = {"RANGE": (0, 15, 3), "FLAGS": (15, 1, 0), "REFLECTIVITY": (16, 8
                 "NEAR_IR": (24, 8, 4), "RANGE2": (32, 15, 3), "FLAGS2": (47, 1, 0),
                 "REFLECTIVITY2": (48, 8, 0), "WINDOW": (56, 8, 0)}
 DESTAGGERED = ["RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"]
+# configs[1]: RNG19_RFL8_SIG16_NIR16 single return, 12 B/px -- parsing.cpp:251-261
+SINGLE_BITS = {"RANGE": (0, 19, 0), "FLAGS": (19, 5, 0), "REFLECTIVITY": (32, 8, 0),
+               "SIGNAL": (48, 16, 0), "NEAR_IR": (64, 16, 0), "WINDOW": (88, 8, 0)}
+WORKLOADS = {
+    # name: (profile, bits, chan bytes, destaggered planes, xyz planes, plane B/px, dst B/px, config label)
+    "dual": ("RNG15_RFL8_NIR8_DUAL", DUAL_LB_BITS, 8, DESTAGGERED, ["RANGE", "RANGE2"], 15, 10,
+             "configs[2]: OS-2-128 2048x128 RNG15_RFL8_NIR8_DUAL dual return"),
+    "single": ("RNG19_RFL8_SIG16_NIR16", SINGLE_BITS, 12, ["RANGE", "REFLECTIVITY"], ["RANGE"], 11, 5,
+               "configs[1]: OS-1-128 2048x128 RNG19_RFL8_SIG16_NIR16 single return"),
+    "fused4": ("RNG15_RFL8_NIR8_DUAL", DUAL_LB_BITS, 8, DESTAGGERED, ["RANGE", "RANGE2"], 15, 10,
+               "configs[4] per-GPU share: 4 sensors x dual return per tick, per-sensor extrinsics in-kernel"),
+}
 
 
 def synth_calibration():
@@ -48,29 +60,37 @@ def synth_calibration():
     return alt, az, shifts, b2l, l2s
 
 
-def synth_packets(n_frames: int, seed: int = 0xDEADBEEF, zero_frac: float = 0.3) -> np.ndarray:
+def synth_packets(n_frames: int, seed: int = 0xDEADBEEF, zero_frac: float = 0.3,
+                  bits=None, chan: int = 8) -> np.ndarray:
     """Wire packets of n_frames random dual-return frames, [n, 128, 16640] uint8.
     Numpy bit packing of the RNG15_RFL8_NIR8_DUAL layout with STANDARD headers
     (packet header: type u16 | frame_id u16 | init_id u24 | prod_sn u40; column header:
     timestamp u64 | measurement_id u16 | status u16) -- independent of oracle/ and of the
     library under test."""
-    col_size = 12 + H * 8
+    bits = bits or DUAL_LB_BITS
+    col_size = 12 + H * chan
     pkt_size = 32 + CPP * col_size + 32
     ppf = W // CPP
     out = np.zeros((n_frames, ppf, pkt_size), dtype=np.uint8)
     for f in range(n_frames):
         rng = np.random.default_rng(seed + f)
-        px = np.zeros((W, H), dtype=np.uint64)  # column major like the wire
-        for name, (start, size, up) in DUAL_LB_BITS.items():
+        lo = np.zeros((W, H), dtype=np.uint64)  # pixel bits 0..63, column major like the wire
+        hi = np.zeros((W, H), dtype=np.uint64)  # pixel bits 64..127
+        for name, (start, size, up) in bits.items():
             v = rng.integers(0, 1 << size, size=(W, H), dtype=np.uint64)
             if name in ("RANGE", "RANGE2"):
                 v[rng.random((W, H)) < zero_frac] = 0
-            px |= v << np.uint64(start)
+            if start < 64:
+                lo |= v << np.uint64(start)
+            else:
+                hi |= v << np.uint64(start - 64)
+        raw = np.concatenate([lo.view(np.uint8).reshape(W, H, 8), hi.view(np.uint8).reshape(W, H, 8)],
+                             axis=2)[:, :, :chan]
         cols = np.zeros((W, col_size), dtype=np.uint8)
         cols[:, 0:8] = (1000 + np.arange(W, dtype=np.uint64)).view(np.uint8).reshape(W, 8)
         cols[:, 8:10] = np.arange(W, dtype=np.uint16).view(np.uint8).reshape(W, 2)
         cols[:, 10] = 1
-        cols[:, 12:] = px.view(np.uint8).reshape(W, H * 8)
+        cols[:, 12:] = raw.reshape(W, H * chan)
         out[f, :, 32:32 + CPP * col_size] = cols.reshape(ppf, CPP * col_size)
         hdr = np.zeros(32, dtype=np.uint8)
         hdr[0] = 1
@@ -81,13 +101,12 @@ def synth_packets(n_frames: int, seed: int = 0xDEADBEEF, zero_frac: float = 0.3)
     return out
 
 
-def algorithmic_bytes_per_frame() -> int:
-    """SURVEY.md 8(d), config 3, f32 XYZ, separable LUT tables (no LUT bytes)."""
-    pkts = (W // CPP) * (32 + CPP * (12 + H * 8) + 32)          # 2 129 920
-    planes = H * W * 15                                           # 8 planes, 15 B/px
-    dst = H * W * 10                                              # RANGE,RANGE2,REFL,REFL2
-    xyz = 2 * H * W * 3 * 4                                       # two returns, f32
-    return pkts + planes + dst + xyz                              # 14 974 976
+def algorithmic_bytes_per_frame(workload: str = "dual") -> int:
+    """packets + planes + destaggered planes + XYZ f32 (separable LUT tables:
+    no LUT bytes).  dual (config 3) = 14 974 976 B, single (config 2) = 10 518 528 B."""
+    _, _, chan, _, xyz_names, plane_b, dst_b, _ = WORKLOADS[workload]
+    pkts = (W // CPP) * (32 + CPP * (12 + H * chan) + 32)
+    return pkts + H * W * plane_b + H * W * dst_b + len(xyz_names) * H * W * 3 * 4
 
 
 def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 12.0):
@@ -134,6 +153,8 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--workload", default="dual", choices=sorted(WORKLOADS),
+                    help="'dual' is the metric (configs[2]); the others are extra report rows")
     ap.add_argument("--outputs", default="full", choices=["full", "xyz", "planes", "planes+dst"],
                     help="ablation of the output set (the metric is 'full')")
     ap.add_argument("--exchange", action="store_true",
@@ -154,23 +175,31 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    profile, bits, chan, dst_names, xyz_names, _, _, wl_label = WORKLOADS[args.workload]
     alt, az, shifts, b2l, l2s = synth_calibration()
-    hp = HotPath(PROFILE, H, W, CPP)
+    hp = HotPath(profile, H, W, CPP)
     hp.set_pixel_shift_by_row(shifts)
-    hp.add_lut(b2l, l2s, az, alt)
+    if args.workload == "fused4":  # four sensors, four rigid extrinsics folded into their LUTs
+        for k in range(4):
+            a = 0.5 * np.pi * k
+            ext = np.array([[np.cos(a), -np.sin(a), 0, 1000.0 * k], [np.sin(a), np.cos(a), 0, -500.0 * k],
+                            [0, 0, 1, 250.0], [0, 0, 0, 1]])   # translation already in mm
+            hp.add_lut(b2l, ext @ l2s, az, alt)
+    else:
+        hp.add_lut(b2l, l2s, az, alt)
 
-    pool = synth_packets(args.pool, seed=0xDEADBEEF + 1000 * rank)
+    pool = synth_packets(args.pool, seed=0xDEADBEEF + 1000 * rank, bits=bits, chan=chan)
     F = args.frames
     d_pool = torch.from_numpy(pool).cuda()
     packets = d_pool.repeat((F + args.pool - 1) // args.pool, 1, 1)[:F].contiguous()
     if args.outputs == "full":
-        out = hp.alloc_outputs(F, destagger=DESTAGGERED, xyz=["RANGE", "RANGE2"])
+        out = hp.alloc_outputs(F, destagger=dst_names, xyz=xyz_names)
     elif args.outputs == "xyz":
-        out = hp.alloc_outputs(F, planes=[], xyz=["RANGE", "RANGE2"], headers=False)
+        out = hp.alloc_outputs(F, planes=[], xyz=xyz_names, headers=False)
     elif args.outputs == "planes":
         out = hp.alloc_outputs(F)
     else:
-        out = hp.alloc_outputs(F, destagger=DESTAGGERED)
+        out = hp.alloc_outputs(F, destagger=dst_names)
 
     def barrier():
         if world > 1:
@@ -223,9 +252,10 @@ def main():
         torch.cuda.synchronize(); barrier()
         exchange = {"scatter_packets_gather_xyz_ms": (time.perf_counter() - e0) * 1e3}
 
-    points_per_step = F * H * W * 2 * world
+    n_ret = len(xyz_names)
+    points_per_step = F * H * W * n_ret * world
     value = points_per_step * args.steps / elapsed / 1e6
-    bytes_per_launch = algorithmic_bytes_per_frame() * F
+    bytes_per_launch = algorithmic_bytes_per_frame(args.workload) * F
     if args.outputs != "full":  # ablation runs: count only what is actually moved
         per = (W // CPP) * (32 + CPP * (12 + H * 8) + 32)
         per += {"xyz": 2 * H * W * 12, "planes": H * W * 15, "planes+dst": H * W * 25}[args.outputs]
@@ -239,12 +269,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32+f64",
             "data": "synthetic",
-            "config": {"workload": "configs[2]: OS-2-128 2048x128 RNG15_RFL8_NIR8_DUAL dual return",
-                       "frames_per_step_per_gpu": F, "points_per_frame": H * W * 2,
+            "config": {"workload": wl_label,
+                       "frames_per_step_per_gpu": F, "points_per_frame": H * W * n_ret,
                        "outputs": "8 planes + 4 destaggered planes + 2x XYZ f32 + column headers"
                        if args.outputs == "full" else "ABLATION:" + args.outputs,
                        "sharding": f"frames x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_decode<SpecDualLB,64,sep-f32>",
+            "roofline": {"bound": "hbm",
+                         "kernel": "k_decode<SpecDualLB,64,sep-f32>" if args.workload != "single"
+                         else "k_decode<SpecSingle,32,sep-f32>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -254,7 +286,7 @@ def main():
         }
         if exchange:
             line["exchange"] = exchange
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and args.workload == "dual":
             line["cpu_baseline"] = cpu_baseline(pool, shifts)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -430,11 +430,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
     // ---- phase 0: source map of this tile
     if (tid < TILE) {
         const uint32_t c = c0 + tid;
-        int32_t src = -1;
-        if (c < W) {  // read-and-reset: the map is left at -1 for the next call
-            src = a.map[(size_t)f * W + c];
-            a.map[(size_t)f * W + c] = -1;
-        }
+        const int32_t src = (c < W) ? a.map[(size_t)f * W + c] : -1;
         s_src[tid] = src;
         const uint32_t j0 = tid - tid % cpp;  // first column of my packet group in the tile
         // "group ok": my packet's cpp columns sit in order, packet-aligned, all present
@@ -525,6 +521,9 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
     // ---- phase 2a: column headers (timestamp / measurement_id / status), one lane per column
     if (tid < TILE && c0 + tid < W) {
         const uint32_t c = c0 + tid;
+        // consume-and-reset: the map is left at -1 for the next call.  Done here, after the
+        // last barrier, so no workgroup barrier ever waits for this store to be acknowledged.
+        a.map[(size_t)f * W + c] = -1;
         const bool v = (validmask >> tid) & 1;
         const uint32_t cb = tid * col_size;
         if (a.timestamp)
