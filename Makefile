@@ -18,7 +18,7 @@ $(LIB)/libouster_hip.so: $(HIP_SRC) $(CSRC)/ouster_hip_dev.h include/ouster_hip.
 	mkdir -p $(LIB)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
-$(LIB)/libouster_core_amd.so: $(HOST_SRC) $(wildcard include/ouster/core/*.h include/ouster/hip/*.h) $(CSRC)/host/host_internal.h $(LIB)/libouster_hip.so
+$(LIB)/libouster_core_amd.so: $(HOST_SRC) $(wildcard include/ouster/core/*.h include/ouster/hip/*.h include/ouster/pcap/*.h) $(CSRC)/host/host_internal.h $(LIB)/libouster_hip.so
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -louster_hip -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN'
 
 oracle:

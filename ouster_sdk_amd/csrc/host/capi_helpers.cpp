@@ -8,6 +8,7 @@
 #include "host_internal.h"
 #include "ouster/core/lidar_frame.h"
 #include "ouster/core/types.h"
+#include "ouster/pcap/pcap.h"
 
 using namespace ouster::sdk::core;
 
@@ -77,6 +78,37 @@ int ouster_core_default_planes(const char* profile_name, int with_window, char* 
         std::memcpy(names_out, s.c_str(), s.size() + 1);
         return static_cast<int>(n);
     } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+/** Read every UDP payload with destination port `port` (0 = any) and, if `exact_size` != 0,
+ * exactly that size, from a classic pcap into out (capacity cap bytes, payloads back to back);
+ * sizes[i] receives each payload's length (up to max_n).  Returns the number of payloads, or
+ * -1 on error (msg filled). */
+int ouster_pcap_read_udp(const char* path, int port, size_t exact_size, uint8_t* out, size_t cap,
+                         uint32_t* sizes, int* ports, uint32_t max_n, char* msg, size_t msg_len) {
+    try {
+        ouster::sdk::pcap::PcapReader r(path);
+        size_t used = 0;
+        uint32_t n = 0;
+        while (r.next_packet()) {
+            const auto& info = r.current_info();
+            if (port && info.dst_port != port) continue;
+            if (exact_size && r.current_length() != exact_size) continue;
+            if (n >= max_n || used + r.current_length() > cap) break;
+            std::memcpy(out + used, r.current_data(), r.current_length());
+            used += r.current_length();
+            if (sizes) sizes[n] = static_cast<uint32_t>(r.current_length());
+            if (ports) ports[n] = info.dst_port;
+            ++n;
+        }
+        return static_cast<int>(n);
+    } catch (const std::exception& e) {
+        if (msg && msg_len) {
+            std::strncpy(msg, e.what(), msg_len - 1);
+            msg[msg_len - 1] = 0;
+        }
         return -1;
     }
 }

@@ -23,3 +23,32 @@ def test_cpp_core_api():
     print(p.stderr[-2000:])
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
     assert "0 failed" in p.stdout
+
+
+def test_reference_snapshot_hashes_through_cpp_mirror(oracle):
+    """The reference's FrameBatcherSnapshotTest goldens (tests/frame_batcher_test.cpp:553-595),
+    reproduced by the C++ mirror: PcapReader -> FrameBatcher (GPU decode) -> matrix_hash."""
+    import json
+    from conftest import GOLDEN, PCAPS
+    O = oracle
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "snapshot_tool")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", ROOT, "cpptests"])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "ouster_sdk_amd", "lib") + ":/opt/rocm/lib:" + \
+        env.get("LD_LIBRARY_PATH", "")
+    snaps = json.load(open(os.path.join(GOLDEN, "snapshot_hashes.json")))
+    names = {v: k for k, v in O.PROFILES.items()}
+    assert len(snaps) == 5
+    for base, fields in snaps.items():
+        cal = O.calib_from_json(os.path.join(PCAPS, base + ".json"))
+        args = [exe, os.path.join(PCAPS, base + ".pcap"), names[cal.profile], str(cal.header_type),
+                str(cal.h), str(cal.w), str(cal.cpp), str(cal.init_id), "v2.0.0"]
+        p = subprocess.run(args, capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got = {}
+        for line in p.stdout.splitlines()[1:]:
+            k, v = line.split()
+            got[k] = int(v)
+        for name, want in fields.items():
+            assert got.get(name) == want, (base, name, p.stdout)
