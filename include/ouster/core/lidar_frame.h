@@ -283,6 +283,13 @@ class FrameBatcher {
     bool batch(const Packet& packet, LidarFrame& lidar_frame);
     bool operator()(const Packet& packet, LidarFrame& lidar_frame) { return batch(packet, lidar_frame); }
     void reset();
+    /**
+     * Extension (not in the reference, whose batcher decodes packet by packet): decode the
+     * packets collected so far into `lidar_frame` without releasing the frame, so a caller can
+     * look at a partially assembled frame.  Columns not received yet read as zero.  Batching
+     * continues normally afterwards.
+     */
+    void flush(LidarFrame& lidar_frame);
     size_t batched_packets() const;
     size_t dropped_packets() const;
     void set_max_cache_size(size_t n);

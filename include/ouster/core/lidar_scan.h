@@ -8,6 +8,7 @@
 #pragma once
 
 #include "ouster/core/lidar_frame.h"
+#include "ouster/core/pose_util.h"
 #include "ouster/core/profile_extension.h"
 #include "ouster/core/xyzlut.h"
 

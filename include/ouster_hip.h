@@ -233,6 +233,16 @@ int ouster_hip_cartesian(ouster_hip_ctx* ctx, const ouster_hip_lut* lut,
                          const uint32_t* range, void* xyz, int xyz_dtype,
                          uint32_t n_images);
 
+/* ---- dense dewarp ---------------------------------------------------------- */
+/* Replaces dewarp<T>(dewarped, points, poses) (ouster_core/include/ouster/core/pose_util.h:38-56):
+ * points [n_images][h*w][3] (row-major pixel order, i = row*w + col) are moved by the pose of
+ * their column: p' = R_col * p + t_col.  poses: device array [n_images][w][16] doubles, each a
+ * row-major 4x4 (LidarFrame::body_to_world layout, lidar_frame.cpp:350-358).  dtype F32/F64 is
+ * the element type of points/dewarped; the arithmetic is done in that type like the
+ * reference.  points and dewarped may alias. */
+int ouster_hip_dewarp(ouster_hip_ctx* ctx, const void* points, const double* poses, void* dewarped,
+                      int dtype, uint32_t h, uint32_t w, uint32_t n_images);
+
 /* ---- instrumentation ------------------------------------------------------ */
 /* Average duration in ms of the dominant decode kernel over the launches made
  * since the last reset, measured with HIP events on the context's stream

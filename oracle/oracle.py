@@ -188,6 +188,9 @@ def lib():
               "ora_cartesian_f32_omp"):
         getattr(L, n).argtypes = [C.c_void_p] * 4 + [C.c_size_t]
         getattr(L, n).restype = None
+    for n in ("ora_dewarp_f64", "ora_dewarp_f32"):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        getattr(L, n).restype = None
     L.ora_bench_hot_path.restype = C.c_double
     L.ora_bench_hot_path.argtypes = [C.POINTER(PF), C.c_int, C.c_void_p, C.c_uint32,
                                      C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -435,6 +438,16 @@ def cartesian(range_img: np.ndarray, direction: np.ndarray, offset: np.ndarray) 
         pts = np.empty((n, 3), dtype=np.float64)
         lib().ora_cartesian_f64(_ptr(pts), _ptr(r), _ptr(d), _ptr(o), n)
     return pts
+
+
+def dewarp(points: np.ndarray, poses: np.ndarray, h: int, w: int) -> np.ndarray:
+    """pose_util.h:38-56 -- points [h*w, 3], poses [w, 4, 4] (or [w, 16]) float64."""
+    pts = np.ascontiguousarray(points)
+    po = np.ascontiguousarray(poses, dtype=np.float64).reshape(w, 16)
+    out = np.empty_like(pts)
+    fn = lib().ora_dewarp_f32 if pts.dtype == np.float32 else lib().ora_dewarp_f64
+    fn(_ptr(out), _ptr(pts), _ptr(po), h, w)
+    return out
 
 
 # --------------------------------------------------------------------------- #

@@ -1121,6 +1121,35 @@ void ora_cartesian_f32_omp(float* pts, const uint32_t* range, const float* dir,
     CARTESIAN_BODY(float)
 }
 
+/* dewarp<T>(dewarped, points, poses): include/ouster/core/pose_util.h:38-56.
+ * points [h*w][3] row-major pixel order (ix = i*W + w), poses [W][16] (row-major 4x4 each),
+ * arithmetic in T.  For T = float the poses are cast to float first, as MatrixX16R<float>. */
+void ora_dewarp_f64(double* out, const double* pts, const double* poses, size_t h, size_t w) {
+    for (size_t c = 0; c < w; ++c) {
+        const double* m = poses + c * 16;
+        for (size_t i = 0; i < h; ++i) {
+            const size_t ix = i * w + c;
+            const double x = pts[ix * 3], y = pts[ix * 3 + 1], z = pts[ix * 3 + 2];
+            out[ix * 3 + 0] = m[0] * x + m[1] * y + m[2] * z + m[3];
+            out[ix * 3 + 1] = m[4] * x + m[5] * y + m[6] * z + m[7];
+            out[ix * 3 + 2] = m[8] * x + m[9] * y + m[10] * z + m[11];
+        }
+    }
+}
+void ora_dewarp_f32(float* out, const float* pts, const double* poses, size_t h, size_t w) {
+    for (size_t c = 0; c < w; ++c) {
+        float m[12];
+        for (int k = 0; k < 12; ++k) m[k] = (float)poses[c * 16 + k];
+        for (size_t i = 0; i < h; ++i) {
+            const size_t ix = i * w + c;
+            const float x = pts[ix * 3], y = pts[ix * 3 + 1], z = pts[ix * 3 + 2];
+            out[ix * 3 + 0] = m[0] * x + m[1] * y + m[2] * z + m[3];
+            out[ix * 3 + 1] = m[4] * x + m[5] * y + m[6] * z + m[7];
+            out[ix * 3 + 2] = m[8] * x + m[9] * y + m[10] * z + m[11];
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* CPU baseline driver: the reference's own sequence on a pool of frames      */
 /* (cf. tests/benchmarks/core_benchmark.cpp:29-154)                          */

@@ -210,6 +210,10 @@ void ora_cartesian_f64_omp(double* points, const uint32_t* range,
 void ora_cartesian_f32_omp(float* points, const uint32_t* range,
                            const float* dir, const float* ofs, size_t n);
 
+/* ---- dense dewarp (pose_util.h:38-56) ---- */
+void ora_dewarp_f64(double* out, const double* pts, const double* poses, size_t h, size_t w);
+void ora_dewarp_f32(float* out, const float* pts, const double* poses, size_t h, size_t w);
+
 /* ---- whole hot path for the CPU baseline (decode + destagger + cartesian) ---- */
 /* Runs n_frames frames of `ppf` packets each through batcher -> destagger of
  * the named planes -> cartesian (f64 if xyz_f64 else f32) for RANGE (+RANGE2).

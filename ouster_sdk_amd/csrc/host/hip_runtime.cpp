@@ -13,6 +13,7 @@
 
 #include "host_internal.h"
 #include "ouster/core/lidar_frame.h"
+#include "ouster/core/pose_util.h"
 #include "ouster/core/xyzlut.h"
 #include "ouster/hip/device_buffer.h"
 
@@ -204,6 +205,20 @@ void cartesian_device(const DeviceLut& dev, const uint32_t* range, size_t n, voi
     d_xyz.download(points, pbytes);
 }
 
+}  // namespace impl
+
+namespace impl {
+void dewarp_device(const void* points, const double* poses, void* out, bool f64, size_t h, size_t w) {
+    const size_t pbytes = h * w * 3 * (f64 ? 8 : 4);
+    hip::DeviceBuffer d_pts(pbytes), d_poses(w * 16 * 8);
+    d_pts.upload(points, pbytes);
+    d_poses.upload(poses, w * 16 * 8);
+    hip::check(ouster_hip_dewarp(hip::default_ctx(), d_pts.data(),
+                                 static_cast<const double*>(d_poses.data()), d_pts.data(),
+                                 f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32, static_cast<uint32_t>(h),
+                                 static_cast<uint32_t>(w), 1));
+    d_pts.download(out, pbytes);
+}
 }  // namespace impl
 
 PointCloudXYZd cartesian(const ImgRef<const uint32_t>& range, const XYZLut& lut) {

@@ -436,6 +436,10 @@ struct BatcherOps {
     }
 };
 
+void FrameBatcher::flush(LidarFrame& frame) {
+    if (frame.frame_id != -1 && s_->finished_frame_id < 0) BatcherOps::decode_staged(*s_, pf, frame);
+}
+
 bool FrameBatcher::batch(const Packet& packet, LidarFrame& frame) {
     State& s = *s_;
     if (s.reset_frame) {

@@ -707,6 +707,27 @@ int ouster_hip_cartesian(ouster_hip_ctx* ctx, const ouster_hip_lut* lut, const u
     return OUSTER_HIP_OK;
 }
 
+// ---- dense dewarp -----------------------------------------------------------------------------
+int ouster_hip_dewarp(ouster_hip_ctx* ctx, const void* points, const double* poses, void* dewarped,
+                      int dtype, uint32_t h, uint32_t w, uint32_t n_images) {
+    if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (dtype != OUSTER_HIP_F32 && dtype != OUSTER_HIP_F64)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "dtype must be F32 or F64");
+    if (n_images == 0 || h == 0 || w == 0) return OUSTER_HIP_OK;
+    if (!points || !poses || !dewarped) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DewarpArgs a{};
+    a.points = points;
+    a.out = dewarped;
+    a.poses = poses;
+    a.w = w;
+    a.h = h;
+    a.n_images = n_images;
+    a.dtype = dtype;
+    HIP_TRY(launch_dewarp(a, ctx->stream));
+    return OUSTER_HIP_OK;
+}
+
 // ---- timing ------------------------------------------------------------------------------------
 int ouster_hip_timing_enable(ouster_hip_ctx* ctx, int on) {
     if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");

@@ -91,6 +91,14 @@ struct CartesianArgs {
     uint32_t vec_ok;
 };
 
+struct DewarpArgs {
+    const void* points;
+    void* out;
+    const double* poses;  // [n_images][w][16]
+    uint32_t w, h, n_images;
+    int32_t dtype;
+};
+
 // one compile-time field of a standard profile (see the Spec* tables in the kernels file)
 struct FieldC {
     uint32_t offset;
@@ -105,5 +113,6 @@ hipError_t launch_colmap(const ColmapArgs& a, uint32_t n_frames, hipStream_t st)
 hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, hipStream_t st);
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st);
 hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
+hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);
 
 }  // namespace ouster_hip_dev

@@ -820,6 +820,29 @@ __global__ __launch_bounds__(256) void k_cartesian(CartesianArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_dewarp: p' = R_col * p + t_col for every point (pose_util.h:38-56).  One thread per point;
+// a wave reads 64 consecutive points = 768 contiguous bytes (f32) of one row, the 64 column
+// poses come from the L2-resident pose table.  HBM bound: 2 x 3 x sizeof(T) B/point.
+// ------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_dewarp(DewarpArgs a) {
+    const size_t npix = (size_t)a.w * a.h, total = npix * a.n_images;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t img = i / npix, pix = i - img * npix;
+        const uint32_t col = (uint32_t)(pix % a.w);
+        const double* m = a.poses + (img * a.w + col) * 16;
+        const T* p = (const T*)a.points + i * 3;
+        const T x = p[0], y = p[1], z = p[2];
+        T* o = (T*)a.out + i * 3;
+        // rotation * s + translation in T, row by row, like the reference's Eigen expression
+        o[0] = (T)m[0] * x + (T)m[1] * y + (T)m[2] * z + (T)m[3];
+        o[1] = (T)m[4] * x + (T)m[5] * y + (T)m[6] * z + (T)m[7];
+        o[2] = (T)m[8] * x + (T)m[9] * y + (T)m[10] * z + (T)m[11];
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------
 size_t decode_lds_bytes(const Geometry& g, int tile) {
@@ -896,6 +919,16 @@ hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st) {
         case 2: hipLaunchKernelGGL(k_cartesian<2>, grid, dim3(256), 0, st, a); break;
         default: hipLaunchKernelGGL(k_cartesian<3>, grid, dim3(256), 0, st, a); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st) {
+    const size_t total = (size_t)a.w * a.h * a.n_images;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks == 0) blocks = 1;
+    if (a.dtype == OUSTER_HIP_F32) hipLaunchKernelGGL(k_dewarp<float>, dim3((uint32_t)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_dewarp<double>, dim3((uint32_t)blocks), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

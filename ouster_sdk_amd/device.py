@@ -170,5 +170,16 @@ class HotPath:
                                                    capi.F32 if dtype == torch.float32 else capi.F64, n))
         return xyz
 
+    def dewarp(self, points: torch.Tensor, poses: torch.Tensor) -> torch.Tensor:
+        """points [n, h*w, 3] f32/f64, poses [n, w, 4, 4] f64 (per-column body_to_world)."""
+        assert points.is_cuda and poses.is_cuda and poses.dtype == torch.float64
+        assert points.is_contiguous() and poses.is_contiguous()
+        n = points.shape[0]
+        out = torch.empty_like(points)
+        capi.check(self.ctx.L.ouster_hip_dewarp(
+            self.ctx.h, points.data_ptr(), poses.data_ptr(), out.data_ptr(),
+            capi.F32 if points.dtype == torch.float32 else capi.F64, self.h, self.w, n))
+        return out
+
     def sync(self):
         self.ctx.sync()

@@ -432,6 +432,35 @@ static void test_xyzlut() {
     CHECK(std::abs(dp(5, 0) - std::cos(az[5] * M_PI / 180) * std::cos(alt[5] * M_PI / 180)) < 1e-12);
 }
 
+static void test_dewarp() {
+    std::printf("dense dewarp\n");
+    const size_t h = 32, w = 256;
+    std::mt19937 g(5);
+    PointCloudXYZd pts(h * w);
+    for (size_t i = 0; i < pts.size(); ++i) pts.data()[i] = (static_cast<double>(g() % 20000) - 10000) * 0.01;
+    Poses poses(w, 16);
+    for (size_t c = 0; c < w; ++c) {
+        const double a = 0.001 * c;
+        const double m[16] = {std::cos(a), -std::sin(a), 0, 0.1 * c, std::sin(a), std::cos(a), 0, -0.05 * c,
+                              0, 0, 1, 2.0, 0, 0, 0, 1};
+        for (int k = 0; k < 16; ++k) poses(c, k) = m[k];
+    }
+    PointCloudXYZd out = dewarp<double>(pts, poses);
+    double worst = 0;
+    for (size_t i = 0; i < h; ++i)
+        for (size_t c = 0; c < w; ++c) {
+            const size_t ix = i * w + c;
+            for (int r = 0; r < 3; ++r) {
+                const double want = poses(c, r * 4) * pts(ix, 0) + poses(c, r * 4 + 1) * pts(ix, 1) +
+                                    poses(c, r * 4 + 2) * pts(ix, 2) + poses(c, r * 4 + 3);
+                worst = std::max(worst, std::abs(out(ix, r) - want));
+            }
+        }
+    CHECK(worst < 1e-12);
+    CHECK(throws_with<std::invalid_argument>([&] { Poses bad(w, 12); dewarp<double>(pts, bad); },
+                                             "unexpected dimensions"));
+}
+
 static void test_legacy_aliases() {
     std::printf("legacy aliases\n");
     ouster::sensor::sensor_info info =
@@ -453,6 +482,7 @@ int main() {
     test_col_and_block_field();
     test_destagger();
     test_xyzlut();
+    test_dewarp();
     test_legacy_aliases();
     std::printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail ? 1 : 0;

@@ -361,3 +361,26 @@ def test_multi_sensor_batch_per_sensor_extrinsics(oracle):
             assert np.abs(got - want).max() <= 4e-5, (f, name)
     # different sensors really produce different clouds for the same ranges
     assert not torch.equal(out["xyz:RANGE"][0], out["xyz:RANGE"][1])
+
+
+def test_dense_dewarp_matches_oracle(oracle):
+    """dewarp<T>(points, poses) (pose_util.h:38-56): per-column pose applied to every point."""
+    O = oracle
+    h, w, n = 64, 512, 3
+    rng = np.random.default_rng(21)
+    hp = HotPath("RNG15_RFL8_NIR8", h, w, 16)
+    poses = np.tile(np.eye(4), (n, w, 1, 1))
+    ang = rng.uniform(-0.2, 0.2, size=(n, w))
+    poses[..., 0, 0] = np.cos(ang); poses[..., 0, 1] = -np.sin(ang)
+    poses[..., 1, 0] = np.sin(ang); poses[..., 1, 1] = np.cos(ang)
+    poses[..., :3, 3] = rng.uniform(-5, 5, size=(n, w, 3))
+    for dt, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
+        pts = rng.uniform(-100, 100, size=(n, h * w, 3)).astype(dt)
+        got = _np(hp.dewarp(torch.from_numpy(pts).cuda(), torch.from_numpy(poses).cuda()))
+        want = np.stack([O.dewarp(pts[k], poses[k], h, w) for k in range(n)])
+        tol = 1e-12 if dt == np.float64 else 2e-5   # f32: fma contraction vs separate mul/add
+        assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= tol
+    # identity poses leave the cloud unchanged
+    ident = torch.from_numpy(np.tile(np.eye(4), (n, w, 1, 1))).cuda()
+    p32 = torch.from_numpy(pts).cuda()
+    assert torch.equal(hp.dewarp(p32, ident), p32)
