@@ -12,7 +12,10 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result
 ROCM ?= /opt/rocm
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -I$(CSRC)/host -I$(ROCM)/include -D__HIP_PLATFORM_AMD__
 
-all: $(LIB)/libouster_hip.so $(LIB)/libouster_core_amd.so oracle
+PYEXT := ouster_sdk_amd/core$(shell python3-config --extension-suffix)
+PYINC := $(shell python3 -m pybind11 --includes)
+
+all: $(LIB)/libouster_hip.so $(LIB)/libouster_core_amd.so $(PYEXT) oracle
 
 $(LIB)/libouster_hip.so: $(HIP_SRC) $(CSRC)/ouster_hip_dev.h include/ouster_hip.h
 	mkdir -p $(LIB)
@@ -20,6 +23,9 @@ $(LIB)/libouster_hip.so: $(HIP_SRC) $(CSRC)/ouster_hip_dev.h include/ouster_hip.
 
 $(LIB)/libouster_core_amd.so: $(HOST_SRC) $(wildcard include/ouster/core/*.h include/ouster/hip/*.h include/ouster/pcap/*.h) $(CSRC)/host/host_internal.h $(LIB)/libouster_hip.so
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -louster_hip -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN'
+
+$(PYEXT): $(CSRC)/python/bindings.cpp $(LIB)/libouster_core_amd.so $(wildcard include/ouster/core/*.h)
+	$(CXX) -O2 -std=c++17 -fPIC -shared -fvisibility=hidden -Iinclude $(PYINC) -o $@ $(CSRC)/python/bindings.cpp -L$(LIB) -louster_core_amd -louster_hip -Wl,-rpath,'$$ORIGIN/lib'
 
 oracle:
 	$(MAKE) -C oracle -s

@@ -170,10 +170,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
+    # test knobs: BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and BENCH_BACKEND=gloo swaps RCCL
+    # for gloo, so the N>1 launch path can be smoke-tested on a 1-GPU box
+    one_device = os.environ.get("BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(0 if one_device else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    red_device = "cuda" if backend == "nccl" else "cpu"
 
     profile, bits, chan, dst_names, xyz_names, _, _, wl_label = WORKLOADS[args.workload]
     alt, az, shifts, b2l, l2s = synth_calibration()
@@ -235,12 +243,12 @@ def main():
 
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     exchange = None
-    if args.exchange and world > 1:
+    if args.exchange and world > 1 and backend == "nccl":
         # the only real exchange step of the path: rank 0 scatters raw packets, gathers XYZ
         xyz = out["xyz:RANGE"]
         torch.cuda.synchronize(); barrier()

@@ -2,9 +2,18 @@
 
 The product is native: `lib/libouster_hip.so` (HIP kernels behind the C ABI of
 include/ouster_hip.h) and `lib/libouster_core_amd.so` (C++ host API with the reference's
-names, include/ouster/core/*.h).  The Python modules here are plumbing for tests and the
-benchmark: `_capi` (ctypes) and `device` (torch-owned HBM buffers + streams).
+names, include/ouster/core/*.h).  Python pieces:
+  core      pybind11 module over the C++ mirror (XYZLut, destagger, FrameBatcher, LidarFrame,
+            PacketFormat ...) -- the `ouster.sdk.core` call shapes for this path
+  _capi     ctypes binding of the C ABI
+  device    torch-owned HBM buffers + streams around the C ABI (batched, device resident)
+  parallel  frame sharding across GPUs (torch.distributed)
 """
-from . import _capi  # noqa: F401
+try:  # torch first: its bundled HIP runtime must be the one libouster_hip.so binds to
+    import torch as _torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for the pure C++/ctypes users
+    _torch = None
+
+from . import _capi  # noqa: F401,E402
 
 __all__ = ["_capi"]

@@ -1,0 +1,325 @@
+// bindings.cpp -- pybind11 module `ouster_sdk_amd.core`: the Python face of the C++ mirror
+// (SURVEY.md section 8 f-3).  Names and call shapes follow the reference's nanobind module for
+// this path (python/src/cpp/client/processing.cpp:340-357 XYZLut, :527-638 destagger,
+// :640-790 FrameBatcher; python/src/cpp/client/lidar_frame.cpp LidarFrame; packet.cpp
+// PacketFormat) so tests written against `ouster.sdk.core` read the same:
+//     lut = core.XYZLut(info); xyz = lut(frame)            # (h, w, 3) float64
+//     img = core.destagger(info, frame.field("RANGE"))
+//     batch = core.FrameBatcher(info); done = batch(packet, frame)
+// std::invalid_argument surfaces as ValueError like in the reference bindings.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <cstring>
+
+#include "ouster/core/lidar_scan.h"
+
+namespace py = pybind11;
+using namespace ouster::sdk::core;
+
+namespace {
+
+py::dtype dtype_of(ChanFieldType t) {
+    switch (t) {
+        case ChanFieldType::UINT8: return py::dtype::of<uint8_t>();
+        case ChanFieldType::UINT16: return py::dtype::of<uint16_t>();
+        case ChanFieldType::UINT32: return py::dtype::of<uint32_t>();
+        case ChanFieldType::UINT64: return py::dtype::of<uint64_t>();
+        case ChanFieldType::INT8: return py::dtype::of<int8_t>();
+        case ChanFieldType::INT16: return py::dtype::of<int16_t>();
+        case ChanFieldType::INT32: return py::dtype::of<int32_t>();
+        case ChanFieldType::INT64: return py::dtype::of<int64_t>();
+        case ChanFieldType::FLOAT32: return py::dtype::of<float>();
+        case ChanFieldType::FLOAT64: return py::dtype::of<double>();
+        case ChanFieldType::FLOAT16: return py::dtype("float16");
+        default: throw std::invalid_argument("Invalid field for LidarFrame");
+    }
+}
+
+ChanFieldType tag_of(const py::dtype& d) {
+    for (auto t : {ChanFieldType::UINT8, ChanFieldType::UINT16, ChanFieldType::UINT32,
+                   ChanFieldType::UINT64, ChanFieldType::INT8, ChanFieldType::INT16,
+                   ChanFieldType::INT32, ChanFieldType::INT64, ChanFieldType::FLOAT32,
+                   ChanFieldType::FLOAT64, ChanFieldType::FLOAT16})
+        if (dtype_of(t).is(d) || dtype_of(t).equal(d)) return t;
+    throw std::invalid_argument("unsupported numpy dtype");
+}
+
+// numpy view over a Field's memory; `owner` keeps the frame alive
+py::array field_view(Field& f, py::handle owner) {
+    std::vector<py::ssize_t> shape(f.shape().begin(), f.shape().end());
+    return py::array(dtype_of(f.tag()), shape, f.get(), owner);
+}
+
+mat4d mat_from(const py::array_t<double, py::array::c_style | py::array::forcecast>& a) {
+    if (a.size() != 16) throw std::invalid_argument("expected a 4x4 matrix");
+    return mat4d::FromRowMajor(a.data());
+}
+py::array_t<double> mat_to(const mat4d& m) {
+    py::array_t<double> a({4, 4});
+    std::memcpy(a.mutable_data(), m.data(), sizeof(double) * 16);
+    return a;
+}
+
+const uint8_t* buf_ptr(const py::buffer& b, size_t min_size) {
+    py::buffer_info info = b.request();
+    if (static_cast<size_t>(info.size * info.itemsize) < min_size)
+        throw std::invalid_argument("Incompatible argument: expected a bytearray of size >= " +
+                                    std::to_string(min_size));
+    return static_cast<const uint8_t*>(info.ptr);
+}
+
+template <typename T>
+py::array lut_call(const XYZLutT<T>& lut, const py::object& arg) {
+    PointCloudXYZ<T> pts;
+    if (py::isinstance<LidarFrame>(arg)) {
+        const LidarFrame& fr = arg.cast<const LidarFrame&>();
+        if (fr.w != lut.w || fr.h != lut.h) throw std::invalid_argument("unexpected image dimensions");
+        pts = lut(fr);
+    } else {
+        auto r = py::array_t<uint32_t, py::array::c_style | py::array::forcecast>::ensure(arg);
+        if (!r || r.ndim() != 2) throw std::invalid_argument("Incompatible argument: expected a 2d range image");
+        if (static_cast<size_t>(r.shape(0)) != lut.h || static_cast<size_t>(r.shape(1)) != lut.w)
+            throw std::invalid_argument("unexpected image dimensions");
+        pts = lut(ImgRef<const uint32_t>(r.data(), r.shape(0), r.shape(1)));
+    }
+    py::array_t<T> out({static_cast<py::ssize_t>(lut.h), static_cast<py::ssize_t>(lut.w), py::ssize_t{3}});
+    std::memcpy(out.mutable_data(), pts.data(), pts.size() * sizeof(T));
+    return std::move(out);
+}
+
+template <typename T>
+void bind_lut(py::module_& m, const char* name) {
+    py::class_<XYZLutT<T>>(m, name)
+        .def(py::init([](const SensorInfo& info, bool use_extrinsics) {
+                 return XYZLutT<T>(XYZLutT<double>(info, use_extrinsics));
+             }),
+             py::arg("info"), py::arg("use_extrinsics") = true)
+        .def("__call__", &lut_call<T>)
+        .def_property_readonly("direction",
+                               [](const XYZLutT<T>& l) {
+                                   py::array_t<T> a({static_cast<py::ssize_t>(l.direction.rows()), py::ssize_t{3}});
+                                   std::memcpy(a.mutable_data(), l.direction.data(), l.direction.size() * sizeof(T));
+                                   return a;
+                               })
+        .def_property_readonly("offset", [](const XYZLutT<T>& l) {
+            py::array_t<T> a({static_cast<py::ssize_t>(l.offset.rows()), py::ssize_t{3}});
+            std::memcpy(a.mutable_data(), l.offset.data(), l.offset.size() * sizeof(T));
+            return a;
+        });
+}
+
+}  // namespace
+
+PYBIND11_MODULE(core, m) {
+    m.doc() = "MI355X implementation of the ouster.sdk.core hot path (decode, destagger, XYZLut)";
+
+    py::enum_<UDPProfileLidar>(m, "UDPProfileLidar")
+        .value("LEGACY", UDPProfileLidar::LEGACY)
+        .value("RNG19_RFL8_SIG16_NIR16_DUAL", UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_DUAL)
+        .value("RNG19_RFL8_SIG16_NIR16", UDPProfileLidar::RNG19_RFL8_SIG16_NIR16)
+        .value("RNG15_RFL8_NIR8", UDPProfileLidar::RNG15_RFL8_NIR8)
+        .value("FIVE_WORD_PIXEL", UDPProfileLidar::FIVE_WORD_PIXEL)
+        .value("FUSA_RNG15_RFL8_NIR8_DUAL", UDPProfileLidar::FUSA_RNG15_RFL8_NIR8_DUAL)
+        .value("RNG15_RFL8_NIR8_DUAL", UDPProfileLidar::RNG15_RFL8_NIR8_DUAL)
+        .value("RNG15_RFL8_NIR8_ZONE16", UDPProfileLidar::RNG15_RFL8_NIR8_ZONE16)
+        .value("RNG19_RFL8_SIG16_NIR16_ZONE16", UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_ZONE16)
+        .value("RNG15_RFL8_WIN8", UDPProfileLidar::RNG15_RFL8_WIN8)
+        .value("RNG19_RFL8_SIG16_ZONE16_DUAL", UDPProfileLidar::RNG19_RFL8_SIG16_ZONE16_DUAL)
+        .value("RNG19_RFL8_SIG16_NIR16_RGB16", UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_RGB16)
+        .value("RNG19_RFL8_SIG16_NIR16_RGB16_DUAL", UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_RGB16_DUAL)
+        .value("OFF", UDPProfileLidar::OFF)
+        .def_static("from_string", &udp_profile_lidar_of_string);
+    py::enum_<HeaderType>(m, "HeaderType").value("STANDARD", HeaderType::STANDARD).value("FUSA", HeaderType::FUSA);
+
+    py::class_<DataFormat>(m, "DataFormat")
+        .def(py::init<>())
+        .def_readwrite("pixels_per_column", &DataFormat::pixels_per_column)
+        .def_readwrite("columns_per_packet", &DataFormat::columns_per_packet)
+        .def_readwrite("columns_per_frame", &DataFormat::columns_per_frame)
+        .def_readwrite("pixel_shift_by_row", &DataFormat::pixel_shift_by_row)
+        .def_readwrite("column_window", &DataFormat::column_window)
+        .def_readwrite("udp_profile_lidar", &DataFormat::udp_profile_lidar)
+        .def_readwrite("header_type", &DataFormat::header_type)
+        .def_readwrite("fps", &DataFormat::fps)
+        .def("lidar_packets_per_frame", &DataFormat::lidar_packets_per_frame);
+
+    py::class_<SensorInfo>(m, "SensorInfo")
+        .def(py::init<>())
+        .def("__copy__", [](const SensorInfo& s) { return SensorInfo(s); })
+        .def_readwrite("sn", &SensorInfo::sn)
+        .def_readwrite("fw_rev", &SensorInfo::fw_rev)
+        .def_readwrite("prod_line", &SensorInfo::prod_line)
+        .def_readwrite("format", &SensorInfo::format)
+        .def_readwrite("beam_azimuth_angles", &SensorInfo::beam_azimuth_angles)
+        .def_readwrite("beam_altitude_angles", &SensorInfo::beam_altitude_angles)
+        .def_readwrite("init_id", &SensorInfo::init_id)
+        .def_property("beam_to_lidar_transform", [](const SensorInfo& s) { return mat_to(s.beam_to_lidar_transform); },
+                      [](SensorInfo& s, const py::array_t<double, py::array::c_style | py::array::forcecast>& a) {
+                          s.beam_to_lidar_transform = mat_from(a);
+                      })
+        .def_property("lidar_to_sensor_transform", [](const SensorInfo& s) { return mat_to(s.lidar_to_sensor_transform); },
+                      [](SensorInfo& s, const py::array_t<double, py::array::c_style | py::array::forcecast>& a) {
+                          s.lidar_to_sensor_transform = mat_from(a);
+                      })
+        .def_property("sensor_to_body", [](const SensorInfo& s) { return mat_to(s.sensor_to_body); },
+                      [](SensorInfo& s, const py::array_t<double, py::array::c_style | py::array::forcecast>& a) {
+                          s.sensor_to_body = mat_from(a);
+                      })
+        .def_property_readonly("w", &SensorInfo::w)
+        .def_property_readonly("h", &SensorInfo::h);
+
+    py::class_<PacketFormat, std::shared_ptr<PacketFormat>>(m, "PacketFormat")
+        .def(py::init<const SensorInfo&>())
+        .def_readonly("lidar_packet_size", &PacketFormat::lidar_packet_size)
+        .def_readonly("columns_per_packet", &PacketFormat::columns_per_packet)
+        .def_readonly("pixels_per_column", &PacketFormat::pixels_per_column)
+        .def_readonly("packet_header_size", &PacketFormat::packet_header_size)
+        .def_readonly("col_header_size", &PacketFormat::col_header_size)
+        .def_readonly("col_size", &PacketFormat::col_size)
+        .def_readonly("packet_footer_size", &PacketFormat::packet_footer_size)
+        .def_readonly("udp_profile_lidar", &PacketFormat::udp_profile_lidar)
+        .def_property_readonly("fields",
+                               [](const PacketFormat& pf) {
+                                   std::vector<std::string> names;
+                                   for (auto it = pf.begin(); it != pf.end(); ++it) names.push_back(it->first);
+                                   return names;
+                               })
+        .def("frame_id", [](const PacketFormat& pf, const py::buffer& b) { return pf.frame_id(buf_ptr(b, 32)); })
+        .def("init_id", [](const PacketFormat& pf, const py::buffer& b) { return pf.init_id(buf_ptr(b, 32)); })
+        .def("prod_sn", [](const PacketFormat& pf, const py::buffer& b) { return pf.prod_sn(buf_ptr(b, 32)); })
+        .def("field_value_mask", &PacketFormat::field_value_mask)
+        .def("field_bitness", &PacketFormat::field_bitness)
+        // python/src/cpp/client/packet.cpp:173-210 -- (H, columns_per_packet) array, GPU decode
+        .def("packet_field", [](const PacketFormat& pf, const std::string& name, const py::buffer& b) {
+            const uint8_t* p = buf_ptr(b, pf.lidar_packet_size);
+            const FieldDecodeInfo& info = pf.field_decode_info(name);
+            std::vector<uint8_t> pkt(p, p + pf.lidar_packet_size);
+            pkt.resize(pkt.size() + 8, 0);
+            // relabel the columns 0..cpp-1 so the packet lands in an H x cpp plane
+            for (uint32_t i = 0; i < pf.columns_per_packet; ++i) {
+                uint8_t* col = pf.nth_col(i, pkt.data());
+                pf.set_col_measurement_id(col, static_cast<uint16_t>(i));
+                pf.set_col_status(col, pf.col_status(col) | 0x01);
+            }
+            const int cols = static_cast<int>(pf.columns_per_packet);
+            py::array out(dtype_of(info.ty_tag), std::vector<py::ssize_t>{pf.pixels_per_column, cols});
+            std::memset(out.mutable_data(), 0, static_cast<size_t>(out.nbytes()));
+            switch (field_type_size(info.ty_tag)) {
+                case 1: pf.block_field<uint8_t, 4>(static_cast<uint8_t*>(out.mutable_data()), cols, name, pkt.data()); break;
+                case 2: pf.block_field<uint16_t, 4>(static_cast<uint16_t*>(out.mutable_data()), cols, name, pkt.data()); break;
+                case 4: pf.block_field<uint32_t, 4>(static_cast<uint32_t*>(out.mutable_data()), cols, name, pkt.data()); break;
+                default: pf.block_field<uint64_t, 4>(static_cast<uint64_t*>(out.mutable_data()), cols, name, pkt.data());
+            }
+            return out;
+        });
+
+    py::class_<LidarPacket>(m, "LidarPacket")
+        .def(py::init<int>(), py::arg("size") = 65536)
+        .def_readwrite("host_timestamp", &LidarPacket::host_timestamp)
+        .def_property("buf",
+                      [](py::object self) {
+                          LidarPacket& p = self.cast<LidarPacket&>();
+                          return py::array(py::dtype::of<uint8_t>(), {static_cast<py::ssize_t>(p.buf.size())},
+                                           p.buf.data(), self);
+                      },
+                      [](LidarPacket& p, const py::buffer& b) {
+                          py::buffer_info i = b.request();
+                          const uint8_t* src = static_cast<const uint8_t*>(i.ptr);
+                          p.buf.assign(src, src + i.size * i.itemsize);
+                      });
+
+    py::class_<LidarFrame>(m, "LidarFrame")
+        .def(py::init<const SensorInfo&>())
+        .def(py::init<size_t, size_t, UDPProfileLidar, size_t>(), py::arg("h"), py::arg("w"),
+             py::arg("profile"), py::arg("columns_per_packet") = DEFAULT_COLUMNS_PER_PACKET)
+        .def_readonly("w", &LidarFrame::w)
+        .def_readonly("h", &LidarFrame::h)
+        .def_readwrite("frame_id", &LidarFrame::frame_id)
+        .def_readwrite("frame_status", &LidarFrame::frame_status)
+        .def("has_field", &LidarFrame::has_field)
+        .def("field", [](py::object self, const std::string& name) {
+            return field_view(self.cast<LidarFrame&>().field(name), self);
+        })
+        .def("add_field",
+             [](py::object self, const std::string& name, const py::object& dt, std::vector<size_t> extra) {
+                 LidarFrame& f = self.cast<LidarFrame&>();
+                 return field_view(f.add_field(name, tag_of(py::dtype::from_args(dt)), std::move(extra)), self);
+             },
+             py::arg("name"), py::arg("dtype"), py::arg("extra_dims") = std::vector<size_t>{})
+        .def("del_field", [](LidarFrame& f, const std::string& n) { f.del_field(n); })
+        .def_property_readonly("fields",
+                               [](const LidarFrame& f) {
+                                   std::vector<std::string> names;
+                                   for (const auto& kv : f.fields()) names.push_back(kv.first);
+                                   return names;
+                               })
+        .def_property_readonly("timestamp", [](py::object self) {
+            LidarFrame& f = self.cast<LidarFrame&>();
+            return py::array(py::dtype::of<uint64_t>(), {static_cast<py::ssize_t>(f.w)}, f.timestamp().data(), self);
+        })
+        .def_property_readonly("measurement_id", [](py::object self) {
+            LidarFrame& f = self.cast<LidarFrame&>();
+            return py::array(py::dtype::of<uint16_t>(), {static_cast<py::ssize_t>(f.w)}, f.measurement_id().data(), self);
+        })
+        .def_property_readonly("status", [](py::object self) {
+            LidarFrame& f = self.cast<LidarFrame&>();
+            return py::array(py::dtype::of<uint32_t>(), {static_cast<py::ssize_t>(f.w)}, f.status().data(), self);
+        })
+        .def_property_readonly("packet_timestamp", [](py::object self) {
+            LidarFrame& f = self.cast<LidarFrame&>();
+            return py::array(py::dtype::of<uint64_t>(), {static_cast<py::ssize_t>(f.packet_count())},
+                             f.packet_timestamp().data(), self);
+        })
+        .def_property_readonly("alert_flags", [](py::object self) {
+            LidarFrame& f = self.cast<LidarFrame&>();
+            return py::array(py::dtype::of<uint8_t>(), {static_cast<py::ssize_t>(f.packet_count())},
+                             f.alert_flags().data(), self);
+        })
+        .def("__eq__", [](const LidarFrame& a, const LidarFrame& b) { return a == b; });
+
+    py::class_<FrameBatcher>(m, "FrameBatcher")
+        .def(py::init<const SensorInfo&>())
+        .def("__call__", [](FrameBatcher& b, const LidarPacket& p, LidarFrame& f) { return b.batch(p, f); })
+        .def("batch", [](FrameBatcher& b, const LidarPacket& p, LidarFrame& f) { return b.batch(p, f); })
+        .def("flush", &FrameBatcher::flush)
+        .def("reset", &FrameBatcher::reset)
+        .def("batched_packets", &FrameBatcher::batched_packets)
+        .def("dropped_packets", &FrameBatcher::dropped_packets);
+    m.attr("ScanBatcher") = m.attr("FrameBatcher");
+    m.attr("LidarScan") = m.attr("LidarFrame");
+
+    bind_lut<double>(m, "XYZLut");
+    bind_lut<float>(m, "XYZLutFloat");
+
+    // python/src/cpp/client/processing.cpp:527-608: any dtype, (h, w) or (h, w, n)
+    m.def(
+        "destagger",
+        [](const SensorInfo& info, const py::array& field, bool inverse) {
+            if (field.ndim() < 2) throw std::invalid_argument("Expected at least two dimensions for destagger");
+            py::array src = py::array::ensure(field, py::array::c_style);
+            const size_t h = static_cast<size_t>(src.shape(0)), w = static_cast<size_t>(src.shape(1));
+            if (h != info.format.pixels_per_column || w != info.format.columns_per_frame ||
+                h != info.format.pixel_shift_by_row.size() || src.size() == 0)
+                throw std::invalid_argument("Image resolution must match SensorInfo.");
+            size_t extra = 1;
+            for (py::ssize_t i = 2; i < src.ndim(); ++i) extra *= static_cast<size_t>(src.shape(i));
+            py::array out(src.dtype(), std::vector<py::ssize_t>(src.shape(), src.shape() + src.ndim()));
+            impl::destagger_bytes(src.data(), out.mutable_data(), h, w,
+                                  static_cast<size_t>(src.itemsize()) * extra,
+                                  info.format.pixel_shift_by_row, inverse, h, w);
+            return out;
+        },
+        py::arg("info"), py::arg("field"), py::arg("inverse") = false);
+
+    m.def(
+        "frame_to_packets",
+        [](const LidarFrame& f, std::shared_ptr<PacketFormat> pf, uint32_t init_id, uint64_t prod_sn) {
+            return impl::frame_to_packets(f, std::move(pf), init_id, prod_sn);
+        },
+        py::arg("frame"), py::arg("packet_format"), py::arg("init_id") = 0, py::arg("prod_sn") = 0);
+
+    m.def("default_lidar_to_sensor", [] { return mat_to(DEFAULT_LIDAR_TO_SENSOR); });
+    m.def("default_beam_to_lidar_transform", [](const std::string& p) { return mat_to(default_beam_to_lidar_transform(p)); });
+}

@@ -1,0 +1,169 @@
+"""GPU tests of the pybind11 module `ouster_sdk_amd.core`, written like the reference's pytest
+suites for this path (python/tests/test_xyzlut.py:15-136, test_destagger.py:13-114,
+test_core.py / _digest.py:55-82) so they read the same against `ouster.sdk.core`."""
+import hashlib
+import json
+import os
+from copy import copy
+from math import cos, pi, sin
+
+import numpy as np
+import pytest
+
+from conftest import PCAPS, has_gpu
+
+pytestmark = pytest.mark.gpu
+
+if has_gpu():
+    from ouster_sdk_amd import core
+
+
+def _meta(O, base):
+    cal = O.calib_from_json(os.path.join(PCAPS, base + ".json"))
+    names = {v: k for k, v in O.PROFILES.items()}
+    info = core.SensorInfo()
+    f = info.format
+    f.pixels_per_column, f.columns_per_frame, f.columns_per_packet = cal.h, cal.w, cal.cpp
+    f.column_window = (0, cal.w - 1)
+    f.udp_profile_lidar = core.UDPProfileLidar.from_string(names[cal.profile])
+    f.header_type = core.HeaderType.FUSA if cal.header_type else core.HeaderType.STANDARD
+    f.pixel_shift_by_row = [int(x) for x in cal.pixel_shift_by_row]
+    info.format = f
+    info.beam_azimuth_angles = list(cal.beam_azimuth_angles)
+    info.beam_altitude_angles = list(cal.beam_altitude_angles)
+    info.beam_to_lidar_transform = cal.beam_to_lidar
+    info.lidar_to_sensor_transform = cal.lidar_to_sensor
+    info.sensor_to_body = np.eye(4)
+    info.init_id = cal.init_id
+    info.fw_rev = "v2.0.0"
+    info.prod_line = cal.prod_line
+    return info, cal
+
+
+@pytest.fixture
+def meta(oracle):
+    return _meta(oracle, "OS-2-32-U0_v2.0.0_1024x10")[0]   # the reference's 'legacy-2.0' key
+
+
+def test_xyz_lut_dims(meta):
+    w, h = meta.format.columns_per_frame, meta.format.pixels_per_column
+    core.XYZLut(meta)
+    for bad_h in (0, h + 1, h - 1):
+        m = copy(meta)
+        fmt = m.format
+        fmt.pixels_per_column = bad_h
+        m.format = fmt
+        with pytest.raises(ValueError):
+            core.XYZLut(m)
+    for ok_w in (w + 1, w - 1):
+        m = copy(meta)
+        fmt = m.format
+        fmt.columns_per_frame = ok_w
+        m.format = fmt
+        core.XYZLut(m)
+    m = copy(meta)
+    fmt = m.format
+    fmt.columns_per_frame = 0
+    m.format = fmt
+    with pytest.raises(ValueError):
+        core.XYZLut(m)
+
+
+def test_xyz_lut_angles(meta):
+    for angles in (list(meta.beam_azimuth_angles) + [0.0], list(meta.beam_azimuth_angles)[:-2], []):
+        m = copy(meta)
+        m.beam_azimuth_angles = angles
+        with pytest.raises(ValueError):
+            core.XYZLut(m)
+
+
+def test_xyz_lut_frame_dims(meta):
+    w, h = meta.format.columns_per_frame, meta.format.pixels_per_column
+    lut = core.XYZLut(meta)
+    assert lut(core.LidarFrame(meta)).shape == (h, w, 3)
+    for dh, dw in ((1, 0), (0, -1)):
+        m = copy(meta)
+        fmt = m.format
+        fmt.pixels_per_column, fmt.columns_per_frame = h + dh, w + dw
+        fmt.pixel_shift_by_row = [0] * (h + dh)
+        m.format = fmt
+        m.beam_azimuth_angles = [0.0] * (h + dh)
+        m.beam_altitude_angles = [0.0] * (h + dh)
+        with pytest.raises(ValueError):
+            lut(core.LidarFrame(m))
+        with pytest.raises(ValueError):
+            lut(core.LidarFrame(m).field("RANGE"))
+
+
+@pytest.mark.parametrize("base", ["OS-2-32-U0_v2.0.0_1024x10", "OS-2-128-U1_v2.3.0_1024x10",
+                                  "OS-0-32-U1_v2.2.0_1024x10", "OS-0-128-U1_v2.3.0_1024x10"])
+def test_batch_digest_and_xyz_formula(oracle, base):
+    """pcap -> FrameBatcher -> frame: md5s of the reference digest (_digest.py:69-82), then
+    XYZLut(meta)(frame) vs the user-manual formula (reference.py:19-70, np.allclose)."""
+    O = oracle
+    info, cal = _meta(O, base)
+    pf = core.PacketFormat(info)
+    pk = O.lidar_packets_from_pcap(os.path.join(PCAPS, base + ".pcap"), cal.packet_format())
+    frame = core.LidarFrame(info)
+    batch = core.FrameBatcher(info)
+    done = []
+    for p in pk:
+        lp = core.LidarPacket(pf.lidar_packet_size)
+        lp.buf = p.tobytes()
+        lp.host_timestamp = 1234
+        done.append(batch(lp, frame))
+    assert done.index(True) == 63
+    dig = json.load(open(os.path.join(PCAPS, base + "_digest.json")))["scans"][0]
+    md5 = lambda a: hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+    got = {"FRAME_ID": str(frame.frame_id), "TIMESTAMP": md5(frame.timestamp.astype(np.uint64)),
+           "STATUS": md5(frame.status.astype(np.uint64)),
+           "MEASUREMENT_ID": md5(frame.measurement_id.astype(np.uint16))}
+    got.update({n: md5(frame.field(n)) for n in frame.fields})
+    for k, v in dig.items():
+        if k != "ENCODER_COUNT":
+            assert got[k] == v, k
+    # per-packet field digest through the GPU-backed packet_field (first 4 packets)
+    for name in ("RANGE", "REFLECTIVITY"):
+        for p in pk[:4]:
+            assert np.array_equal(pf.packet_field(name, p.tobytes()), O.packet_field(cal.packet_format(), name, p))
+
+    lut = core.XYZLut(info, False)
+    xyz = lut(frame)
+    rng = frame.field("RANGE")
+    h, w = rng.shape
+    n = cal.beam_to_lidar[0, 3]
+    want = np.zeros((h, w, 3))
+    for u in range(0, h, 3):
+        for v in range(0, w, 29):
+            r = float(rng[u, v])
+            if r == 0:
+                continue
+            te = 2.0 * pi * (1.0 - v / w)
+            ta = -2.0 * pi * (cal.beam_azimuth_angles[u] / 360.0)
+            ph = 2.0 * pi * (cal.beam_altitude_angles[u] / 360.0)
+            p = np.array([(r - n) * cos(te + ta) * cos(ph) + n * cos(te),
+                          (r - n) * sin(te + ta) * cos(ph) + n * sin(te), (r - n) * sin(ph), 1.0])
+            want[u, v] = (cal.lidar_to_sensor @ p)[:3] * 0.001
+            assert np.allclose(xyz[u, v], want[u, v])
+    assert np.all(xyz[rng == 0] == 0)
+    xyzf = core.XYZLutFloat(info, False)(frame)
+    assert xyzf.dtype == np.float32 and np.abs(xyzf - xyz).max() < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.uint32, np.uint64, np.int8, np.int16,
+                                   np.int32, np.int64, np.float32, np.float64])
+def test_destagger_type_shape_and_roll(meta, dtype):
+    h, w = meta.format.pixels_per_column, meta.format.columns_per_frame
+    fmt = meta.format
+    fmt.pixel_shift_by_row = [int(x) for x in np.random.default_rng(1).integers(-30, 31, h)]
+    meta.format = fmt
+    assert core.destagger(meta, np.zeros((h, w), dtype)).dtype == dtype
+    assert core.destagger(meta, np.zeros((h, w, 2), dtype)).shape == (h, w, 2)
+    img = np.random.default_rng(2).integers(0, 100, size=(h, w)).astype(dtype)
+    d = core.destagger(meta, img)
+    ref = np.stack([np.roll(img[u], fmt.pixel_shift_by_row[u]) for u in range(h)])  # reference.py:131-158
+    assert np.array_equal(d, ref)
+    assert np.array_equal(core.destagger(meta, d, inverse=True), img)
+    for bad in ((0, w), (h, w + 1), (h - 1, w), (h, w - 1, 1), (h + 1, w, 2)):
+        with pytest.raises(ValueError):
+            core.destagger(meta, np.zeros(bad, dtype))
