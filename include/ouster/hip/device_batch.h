@@ -1,0 +1,85 @@
+// device_batch.h -- device-resident, batched form of the hot path for C++ callers.
+//
+// The reference API works one host LidarFrame at a time; on a GPU that costs a PCIe round
+// trip per frame.  DeviceFrameBatch keeps a batch of frames in HBM end to end:
+//     raw packets (device) --decode+destagger+cartesian--> planes / destaggered planes / XYZ (device)
+// It is a thin owner of device buffers around ouster_hip_decode (include/ouster_hip.h); results
+// can be read back selectively or handed to other device code through the raw pointers.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ouster/core/lidar_frame.h"
+#include "ouster/core/xyzlut.h"
+#include "ouster/hip/device_buffer.h"
+
+struct ouster_hip_format;
+
+namespace ouster {
+namespace sdk {
+namespace hip {
+
+struct BatchOptions {
+    std::vector<std::string> planes;      ///< staggered planes to produce (empty: the profile's defaults)
+    std::vector<std::string> destagger;   ///< planes to also produce destaggered
+    bool xyz = false;                     ///< project RANGE (and RANGE2 when present)
+    bool xyz_f64 = false;                 ///< XYZ element type (default float)
+    bool use_extrinsics = true;           ///< fold SensorInfo::sensor_to_body into the LUT
+};
+
+class DeviceFrameBatch {
+   public:
+    /** One LUT per sensor; frame f of the batch uses sensor f % sensors.size(). */
+    DeviceFrameBatch(const std::vector<core::SensorInfo>& sensors, uint32_t n_frames,
+                     const BatchOptions& options);
+    DeviceFrameBatch(const core::SensorInfo& sensor, uint32_t n_frames, const BatchOptions& options)
+        : DeviceFrameBatch(std::vector<core::SensorInfo>{sensor}, n_frames, options) {}
+    ~DeviceFrameBatch();
+    DeviceFrameBatch(const DeviceFrameBatch&) = delete;
+    DeviceFrameBatch& operator=(const DeviceFrameBatch&) = delete;
+
+    uint32_t n_frames() const { return n_frames_; }
+    size_t packet_stride() const { return stride_; }
+    uint32_t slots_per_frame() const { return slots_; }
+
+    /** Device buffer for the raw packets, laid out [n_frames][slots_per_frame][packet_stride]. */
+    uint8_t* packets_device() { return static_cast<uint8_t*>(d_packets_.data()); }
+    /** Copy one frame's packets (host, each lidar_packet_size bytes) into its slots. */
+    void upload_frame_packets(uint32_t frame, const std::vector<const uint8_t*>& packets);
+
+    /** Run the fused kernels on everything uploaded so far (asynchronous; sync() to wait). */
+    void decode();
+    void sync();
+
+    /** Device pointers of the results ([n_frames][H][W] elements; xyz [n_frames][H*W][3]). */
+    void* plane_device(const std::string& name);
+    void* destaggered_device(const std::string& name);
+    void* xyz_device(int return_index);
+    /** Read one frame's result back (synchronous). */
+    void download_plane(const std::string& name, uint32_t frame, void* host, bool destaggered = false);
+    void download_xyz(int return_index, uint32_t frame, void* host);
+    void download_headers(uint32_t frame, uint64_t* timestamp, uint16_t* measurement_id, uint32_t* status);
+
+   private:
+    core::PacketFormat pf_;
+    uint32_t n_frames_, h_, w_, slots_;
+    size_t stride_;
+    BatchOptions opt_;
+    std::vector<std::pair<std::string, uint32_t>> fields_;
+    ::ouster_hip_format* fmt_ = nullptr;
+    std::vector<core::XYZLut> luts_;
+    std::vector<int32_t> shifts_;
+    std::vector<uint32_t> counts_;
+    DeviceBuffer d_packets_, d_ts_, d_mid_, d_status_;
+    std::map<std::string, DeviceBuffer> d_planes_, d_dst_;
+    DeviceBuffer d_xyz_[2];
+    int xyz_field_[2] = {-1, -1};
+};
+
+}  // namespace hip
+}  // namespace sdk
+}  // namespace ouster

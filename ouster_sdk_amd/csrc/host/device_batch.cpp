@@ -1,0 +1,153 @@
+// device_batch.cpp -- see include/ouster/hip/device_batch.h
+#include "ouster/hip/device_batch.h"
+
+#include <cstring>
+#include <stdexcept>
+
+#include "host_internal.h"
+
+namespace ouster {
+namespace sdk {
+namespace hip {
+
+using namespace core;
+
+DeviceFrameBatch::DeviceFrameBatch(const std::vector<SensorInfo>& sensors, uint32_t n_frames,
+                                   const BatchOptions& options)
+    : pf_(sensors.at(0)), n_frames_(n_frames), opt_(options) {
+    if (n_frames == 0) throw std::invalid_argument("DeviceFrameBatch: n_frames must be > 0");
+    const SensorInfo& s0 = sensors[0];
+    h_ = s0.format.pixels_per_column;
+    w_ = s0.format.columns_per_frame;
+    for (const auto& s : sensors)
+        if (s.format.pixels_per_column != h_ || s.format.columns_per_frame != w_ ||
+            s.format.udp_profile_lidar != s0.format.udp_profile_lidar ||
+            s.format.header_type != s0.format.header_type)
+            throw std::invalid_argument("DeviceFrameBatch: sensors of one batch must share a data format");
+    slots_ = w_ / pf_.columns_per_packet;
+    stride_ = (pf_.lidar_packet_size + 15) & ~size_t{15};
+
+    // which planes: requested ones (must exist in the profile) or the frame defaults
+    LidarFrameFieldTypes defaults = get_field_types(s0);
+    std::vector<std::string> names = opt_.planes;
+    if (names.empty())
+        for (const auto& ft : defaults) names.push_back(ft.name);
+    auto want = [&](const std::string& n) {
+        for (const auto& x : names)
+            if (x == n) return true;
+        for (const auto& x : opt_.destagger)
+            if (x == n) return true;
+        return opt_.xyz && (n == ChanField::RANGE || n == ChanField::RANGE2);
+    };
+    std::vector<bool> nan;
+    for (auto it = pf_.begin(); it != pf_.end(); ++it) {  // format order, like the batcher
+        if (!want(it->first)) continue;
+        uint32_t es = 0;
+        bool f16 = false;
+        for (const auto& ft : defaults)
+            if (ft.name == it->first) {
+                f16 = ft.element_type == ChanFieldType::FLOAT16;
+                es = static_cast<uint32_t>(field_type_size(ft.element_type)) * (f16 ? 3 : 1);
+            }
+        if (!es) es = static_cast<uint32_t>(field_type_size(it->second.first)) * it->second.second;
+        fields_.emplace_back(it->first, es);
+        nan.push_back(f16);
+    }
+    ouster_hip_format_desc d;
+    pf_.fill_hip_desc(w_, fields_, nan, d);
+    check(ouster_hip_format_create(default_ctx(), &d, &fmt_));
+
+    const size_t npx = static_cast<size_t>(h_) * w_;
+    for (size_t i = 0; i < fields_.size(); ++i) {
+        const auto& f = fields_[i];
+        bool is_plane = opt_.planes.empty();
+        for (const auto& x : opt_.planes) is_plane |= x == f.first;
+        if (is_plane) d_planes_[f.first].resize(npx * f.second * n_frames_);
+        for (const auto& x : opt_.destagger)
+            if (x == f.first) d_dst_[f.first].resize(npx * f.second * n_frames_);
+        if (opt_.xyz && f.first == ChanField::RANGE) xyz_field_[0] = static_cast<int>(i);
+        if (opt_.xyz && f.first == ChanField::RANGE2) xyz_field_[1] = static_cast<int>(i);
+    }
+    for (const auto& x : opt_.destagger)
+        if (!d_dst_.count(x)) throw std::invalid_argument("DeviceFrameBatch: unknown plane '" + x + "'");
+    const size_t xes = opt_.xyz_f64 ? 8 : 4;
+    for (int k = 0; k < 2; ++k)
+        if (xyz_field_[k] >= 0) d_xyz_[k].resize(npx * 3 * xes * n_frames_);
+    if (opt_.xyz)
+        for (const auto& s : sensors) luts_.emplace_back(s, opt_.use_extrinsics);
+    shifts_.assign(s0.format.pixel_shift_by_row.begin(), s0.format.pixel_shift_by_row.end());
+    if (!opt_.destagger.empty() && shifts_.size() != h_)
+        throw std::invalid_argument("image height does not match shifts size");
+    d_packets_.resize(static_cast<size_t>(n_frames_) * slots_ * stride_);
+    d_ts_.resize(static_cast<size_t>(n_frames_) * w_ * 8);
+    d_mid_.resize(static_cast<size_t>(n_frames_) * w_ * 2);
+    d_status_.resize(static_cast<size_t>(n_frames_) * w_ * 4);
+    counts_.assign(n_frames_, 0);
+}
+
+DeviceFrameBatch::~DeviceFrameBatch() {
+    if (fmt_) ouster_hip_format_destroy(fmt_);
+}
+
+void DeviceFrameBatch::upload_frame_packets(uint32_t frame, const std::vector<const uint8_t*>& packets) {
+    if (frame >= n_frames_) throw std::out_of_range("DeviceFrameBatch: frame index");
+    if (packets.size() > slots_) throw std::invalid_argument("DeviceFrameBatch: too many packets for a frame");
+    std::vector<uint8_t> staging(packets.size() * stride_, 0);
+    for (size_t i = 0; i < packets.size(); ++i)
+        std::memcpy(staging.data() + i * stride_, packets[i], pf_.lidar_packet_size);
+    if (!staging.empty())
+        d_packets_.upload(staging.data(), staging.size(), static_cast<size_t>(frame) * slots_ * stride_);
+    counts_[frame] = static_cast<uint32_t>(packets.size());
+}
+
+void DeviceFrameBatch::decode() {
+    ouster_hip_frame_out out{};
+    for (size_t i = 0; i < fields_.size(); ++i) {
+        auto p = d_planes_.find(fields_[i].first);
+        if (p != d_planes_.end()) out.planes[i] = p->second.data();
+        auto q = d_dst_.find(fields_[i].first);
+        if (q != d_dst_.end()) out.destaggered[i] = q->second.data();
+    }
+    out.timestamp = static_cast<uint64_t*>(d_ts_.data());
+    out.measurement_id = static_cast<uint16_t*>(d_mid_.data());
+    out.status = static_cast<uint32_t*>(d_status_.data());
+    out.xyz_dtype = opt_.xyz_f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32;
+    std::vector<const ouster_hip_lut*> luts;
+    for (int k = 0; k < 2; ++k) {
+        out.xyz_field[k] = xyz_field_[k];
+        out.xyz[k] = xyz_field_[k] >= 0 ? d_xyz_[k].data() : nullptr;
+    }
+    for (const auto& l : luts_) luts.push_back(l.device().handle);
+    check(ouster_hip_decode(default_ctx(), fmt_, static_cast<const uint8_t*>(d_packets_.data()), stride_,
+                            slots_, counts_.data(), n_frames_, nullptr, &out,
+                            d_dst_.empty() ? nullptr : shifts_.data(), luts.empty() ? nullptr : luts.data(),
+                            static_cast<uint32_t>(luts.size())));
+}
+
+void DeviceFrameBatch::sync() { check(ouster_hip_sync(default_ctx())); }
+
+void* DeviceFrameBatch::plane_device(const std::string& name) { return d_planes_.at(name).data(); }
+void* DeviceFrameBatch::destaggered_device(const std::string& name) { return d_dst_.at(name).data(); }
+void* DeviceFrameBatch::xyz_device(int k) { return d_xyz_[k].data(); }
+
+void DeviceFrameBatch::download_plane(const std::string& name, uint32_t frame, void* host, bool destaggered) {
+    DeviceBuffer& b = destaggered ? d_dst_.at(name) : d_planes_.at(name);
+    const size_t bytes = b.size() / n_frames_;
+    sync();
+    b.download(host, bytes, bytes * frame);
+}
+void DeviceFrameBatch::download_xyz(int k, uint32_t frame, void* host) {
+    const size_t bytes = d_xyz_[k].size() / n_frames_;
+    sync();
+    d_xyz_[k].download(host, bytes, bytes * frame);
+}
+void DeviceFrameBatch::download_headers(uint32_t frame, uint64_t* ts, uint16_t* mid, uint32_t* st) {
+    sync();
+    if (ts) d_ts_.download(ts, static_cast<size_t>(w_) * 8, static_cast<size_t>(frame) * w_ * 8);
+    if (mid) d_mid_.download(mid, static_cast<size_t>(w_) * 2, static_cast<size_t>(frame) * w_ * 2);
+    if (st) d_status_.download(st, static_cast<size_t>(w_) * 4, static_cast<size_t>(frame) * w_ * 4);
+}
+
+}  // namespace hip
+}  // namespace sdk
+}  // namespace ouster

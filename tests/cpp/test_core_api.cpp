@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "ouster/core/lidar_scan.h"  // pulls in everything + the legacy aliases
+#include "ouster/hip/device_batch.h"
 
 using namespace ouster::sdk::core;
 
@@ -461,6 +462,62 @@ static void test_dewarp() {
                                              "unexpected dimensions"));
 }
 
+// device-resident batch: same results as the frame-at-a-time host API
+static void test_device_batch() {
+    std::printf("DeviceFrameBatch (device resident, multi-sensor)\n");
+    auto a = make_info(UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, HeaderType::STANDARD, 128, 1024);
+    auto b = a;
+    b.sensor_to_body(0, 3) = 2.0;
+    b.sensor_to_body(0, 0) = 0; b.sensor_to_body(0, 1) = -1; b.sensor_to_body(1, 0) = 1; b.sensor_to_body(1, 1) = 0;
+    std::vector<SensorInfo> sensors = {a, b};
+    const uint32_t n = 6;
+    ouster::sdk::hip::BatchOptions opt;
+    opt.destagger = {"RANGE", "REFLECTIVITY"};
+    opt.xyz = true;
+    ouster::sdk::hip::DeviceFrameBatch batch(sensors, n, opt);
+    auto pf = std::make_shared<PacketFormat>(a);
+    std::vector<LidarFrame> src;
+    for (uint32_t f = 0; f < n; ++f) {
+        src.emplace_back(a);
+        randomize(src.back(), *pf, 100 + f);
+        auto packets = impl::frame_to_packets(src.back(), pf, a.init_id, a.sn);
+        std::vector<const uint8_t*> ptrs;
+        for (size_t i = 0; i < packets.size(); ++i)
+            if (!(f == 2 && i == 5)) ptrs.push_back(packets[i].buf.data());  // frame 2 loses a packet
+        batch.upload_frame_packets(f, ptrs);
+    }
+    batch.decode();
+    XYZLut luts[2] = {XYZLut(a, true), XYZLut(b, true)};
+    bool planes_ok = true, dst_ok = true;
+    double worst = 0;
+    for (uint32_t f = 0; f < n; ++f) {
+        img_t<uint32_t> rng(128, 1024), drng(128, 1024);
+        img_t<uint8_t> refl(128, 1024);
+        batch.download_plane("RANGE", f, rng.data());
+        batch.download_plane("REFLECTIVITY", f, refl.data());
+        batch.download_plane("RANGE", f, drng.data(), true);
+        img_t<uint32_t> want(128, 1024);
+        std::memcpy(want.data(), src[f].field("RANGE").get(), want.size() * 4);
+        if (f == 2)
+            for (size_t r = 0; r < 128; ++r)
+                for (size_t c = 80; c < 96; ++c) want(r, c) = 0;
+        planes_ok &= rng == want;
+        if (f != 2) planes_ok &= std::memcmp(refl.data(), src[f].field("REFLECTIVITY").get(), refl.size()) == 0;
+        dst_ok &= drng == destagger<uint32_t>(a, want);
+        PointCloudXYZf xyz(128 * 1024);
+        batch.download_xyz(0, f, xyz.data());
+        PointCloudXYZd ref = luts[f % 2](want);
+        for (size_t i = 0; i < xyz.size(); ++i)
+            worst = std::max(worst, std::abs(static_cast<double>(xyz.data()[i]) - ref.data()[i]));
+    }
+    CHECK(planes_ok);
+    CHECK(dst_ok);
+    CHECK(worst <= 4e-5);
+    std::vector<uint32_t> st(1024);
+    batch.download_headers(2, nullptr, nullptr, st.data());
+    CHECK(st[79] == 1 && st[80] == 0 && st[95] == 0 && st[96] == 1);
+}
+
 static void test_legacy_aliases() {
     std::printf("legacy aliases\n");
     ouster::sensor::sensor_info info =
@@ -483,6 +540,7 @@ int main() {
     test_destagger();
     test_xyzlut();
     test_dewarp();
+    test_device_batch();
     test_legacy_aliases();
     std::printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail ? 1 : 0;
