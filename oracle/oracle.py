@@ -192,7 +192,7 @@ def lib():
         getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         getattr(L, n).restype = None
     L.ora_bench_hot_path.restype = C.c_double
-    L.ora_bench_hot_path.argtypes = [C.POINTER(PF), C.c_int, C.c_void_p, C.c_uint32,
+    L.ora_bench_hot_path.argtypes = [C.POINTER(PF), C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     _lib = L

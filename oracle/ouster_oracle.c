@@ -1161,7 +1161,7 @@ static double now_s(void) {
 }
 
 double ora_bench_hot_path(const ora_pf* pf, int with_window, const uint8_t* packets,
-                          uint32_t n_frames, uint32_t ppf, const int32_t* shifts,
+                          uint32_t pool_frames, uint32_t n_frames, uint32_t ppf, const int32_t* shifts,
                           const double* lut_dir, const double* lut_ofs, int xyz_f64,
                           int reps, int threads, uint64_t* checksum_out) {
     const uint32_t h = pf->pixels_per_column, w = pf->columns_per_frame;
@@ -1199,10 +1199,11 @@ double ora_bench_hot_path(const ora_pf* pf, int with_window, const uint8_t* pack
 #pragma omp for schedule(dynamic, 1)
             for (uint32_t f = 0; f < n_frames; ++f) {
                 ora_batcher_reset(b);
-                b->last_init_id = ora_init_id(pf, packets + (size_t)f * ppf * psz);
+                const uint8_t* fpk = packets + (size_t)(f % pool_frames) * ppf * psz;
+                b->last_init_id = ora_init_id(pf, fpk);
                 b->last_frame_id = -1;
                 for (uint32_t p = 0; p < ppf; ++p)
-                    ora_batcher_batch(b, packets + ((size_t)f * ppf + p) * psz, psz, 1 + p, fr);
+                    ora_batcher_batch(b, fpk + (size_t)p * psz, psz, 1 + p, fr);
                 for (int k = 0; k < 4; ++k)
                     if (dst[k])
                         ora_destagger(ora_frame_plane(fr, dst_names[k]), dst[k], h, w,

@@ -215,12 +215,12 @@ void ora_dewarp_f64(double* out, const double* pts, const double* poses, size_t 
 void ora_dewarp_f32(float* out, const float* pts, const double* poses, size_t h, size_t w);
 
 /* ---- whole hot path for the CPU baseline (decode + destagger + cartesian) ---- */
-/* Runs n_frames frames of `ppf` packets each through batcher -> destagger of
- * the named planes -> cartesian (f64 if xyz_f64 else f32) for RANGE (+RANGE2).
- * Frames are independent; `threads` > 1 distributes frames with OpenMP.
+/* Runs n_frames frames (frame f = pool frame f % pool_frames) of `ppf` packets each through
+ * batcher -> destagger of the named planes -> cartesian (f64 if xyz_f64 else f32) for RANGE
+ * (+RANGE2).  Frames are independent; `threads` > 1 distributes frames with OpenMP.
  * Returns seconds elapsed for the timed loop (reps passes over the pool). */
 double ora_bench_hot_path(const ora_pf* pf, int with_window,
-                          const uint8_t* packets, uint32_t n_frames,
+                          const uint8_t* packets, uint32_t pool_frames, uint32_t n_frames,
                           uint32_t ppf, const int32_t* pixel_shift_by_row,
                           const double* lut_dir, const double* lut_ofs,
                           int xyz_f64, int reps, int threads,

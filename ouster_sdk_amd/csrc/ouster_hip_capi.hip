@@ -630,6 +630,9 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         for (int t : {64, 32, 16})
             if (decode_lds_bytes(g, t) <= 160 * 1024) { tile = t; break; }
     if (!tile) return fail(OUSTER_HIP_ERR_UNSUPPORTED, "column of %u bytes does not fit in LDS", g.col_size);
+    // small batches: prefer narrower tiles so that at least ~2 workgroups per CU exist
+    // (one 128x2048 frame is only 32 tiles of 64 columns -- latency, not bandwidth, bound)
+    while (tile > 16 && (size_t)n_frames * ((W + tile - 1) / tile) < 512) tile /= 2;
     // tuning knobs for experiments (not part of the API contract)
     if (const char* e = getenv("OUSTER_HIP_TILE")) {
         const int t = atoi(e);

@@ -384,3 +384,18 @@ def test_dense_dewarp_matches_oracle(oracle):
     ident = torch.from_numpy(np.tile(np.eye(4), (n, w, 1, 1))).cuda()
     p32 = torch.from_numpy(pts).cuda()
     assert torch.equal(hp.dewarp(p32, ident), p32)
+
+
+@pytest.mark.parametrize("profile,h,w,cpp", [
+    ("RNG15_RFL8_NIR8", 30, 1002, 6),             # W % 4 != 0, cpp does not divide the tile, ragged tile
+    ("RNG19_RFL8_SIG16_NIR16_DUAL", 17, 136, 8),  # tiny odd frame, 16 B/px
+    ("RNG15_RFL8_NIR8_DUAL", 128, 4096, 32),      # widest mode, 32-column packets
+    ("LEGACY", 16, 512, 16),
+])
+def test_odd_geometries(oracle, profile, h, w, cpp):
+    """Frame shapes no sensor ships: element-wise store path, per-column staging, ragged tiles."""
+    O = oracle
+    cal = O.synthetic_calib(h=h, w=w, cpp=cpp, profile=profile)
+    packets, _ = O.synth_packets(cal, 3, with_window=True)
+    frames = [packets[0], packets[1][::-1].copy(), packets[2][: packets.shape[1] - 2]]
+    _check_decode(O, cal, frames, with_window=True, slots=packets.shape[1])
