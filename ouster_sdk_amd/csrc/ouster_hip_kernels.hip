@@ -394,8 +394,11 @@ __device__ __forceinline__ void project_full(const LT* dir, const LT* ofs, size_
 // ------------------------------------------------------------------------------------
 // XYZM: 0 no xyz, 1 separable tables -> f32, 2 separable -> f64, 3 full LUT (runtime dtypes)
 template <class S, int TILE, int XYZM>
-__global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
-    constexpr int NT = 256;
+#ifndef OUSTER_DECODE_NT
+#define OUSTER_DECODE_NT 256
+#endif
+__global__ __launch_bounds__(OUSTER_DECODE_NT) void k_decode(DecodeArgs a) {
+    constexpr int NT = OUSTER_DECODE_NT;
     constexpr int LPR = TILE / 4;    // lanes per row segment
     constexpr int RPP = NT / LPR;    // rows per pass of the workgroup
     extern __shared__ __align__(16) uint32_t smem[];
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(256) void k_dewarp(DewarpArgs a) {
 size_t decode_lds_bytes(const Geometry& g, int tile) {
     size_t tile_bytes = ((size_t)tile * g.col_size + 16 + 15) & ~(size_t)15;
     size_t h4 = (g.pixels_per_column + 3) & ~3u;
-    return tile_bytes + (size_t)tile * 4 + 16 + h4 * 4 + 4 * 192 * 16;
+    return tile_bytes + (size_t)tile * 4 + 16 + h4 * 4 + (OUSTER_DECODE_NT / 64) * 192 * 16;
 }
 
 template <class S, int TILE>
@@ -866,7 +869,7 @@ static hipError_t launch_decode_t(const DecodeArgs& a, int xyzm, dim3 grid, size
                                            (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k, grid, dim3(OUSTER_DECODE_NT), lds, st, a);
     return hipGetLastError();
 }
 
