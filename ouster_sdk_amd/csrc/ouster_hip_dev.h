@@ -89,6 +89,7 @@ struct CartesianArgs {
     uint32_t w, h, n_images;
     int32_t xyz_dtype;
     uint32_t vec_ok;
+    uint32_t rows_per_block;  // tiled kernels: rows of a 64-column tile handled by one workgroup
 };
 
 struct DewarpArgs {
@@ -97,6 +98,7 @@ struct DewarpArgs {
     const double* poses;  // [n_images][w][16]
     uint32_t w, h, n_images;
     int32_t dtype;
+    uint32_t rows_per_block;
 };
 
 // one compile-time field of a standard profile (see the Spec* tables in the kernels file)

@@ -369,6 +369,30 @@ __device__ __forceinline__ void store_xyz4_coalesced(float4* s_xyz, uint32_t tid
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// Generic forms of the same transpose for a "lane owns 4 consecutive pixels x NV 16 B chunks"
+// register block (NV = 3: 4 x f32 xyz, NV = 6: 4 x f64 xyz).  sc = this lane-row's private
+// scratch of NV*LPR float4; row_base = address of tile column 0 of the lane's row.
+template <int NV, int LPR>
+__device__ __forceinline__ void store_quad_coalesced(float4* sc, float4* row_base, uint32_t q,
+                                                     const float4 (&v)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sc[NV * q + k] = v[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NV; ++k) row_base[k * LPR + q] = sc[k * LPR + q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <int NV, int LPR>
+__device__ __forceinline__ void load_quad_coalesced(float4* sc, const float4* row_base, uint32_t q,
+                                                    float4 (&v)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sc[k * LPR + q] = row_base[k * LPR + q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = sc[NV * q + k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <class T>
 __device__ __forceinline__ void store_xyz1(T* dst, const double (&p)[3]) {
     dst[0] = (T)p[0]; dst[1] = (T)p[1]; dst[2] = (T)p[2];
@@ -452,7 +476,7 @@ __global__ __launch_bounds__(OUSTER_DECODE_NT) void k_decode(DecodeArgs a) {
     // ---- phase 1: stage the tile's columns in LDS, column j at byte j*col_size
     const uint64_t validmask = s_masks[0], groupmask = s_masks[1];
     const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
-    const uint64_t fullmask = (TILE >= 64) ? ~0ull : ((1ull << TILE) - 1);
+    const uint64_t fullmask = ~0ull >> (64 - TILE);
     const uint32_t gbytes_all = cpp * col_size;
     const bool flat = (TILE % cpp == 0) && (TILE / cpp <= 4) && (groupmask == fullmask) &&
                       (((gbytes_all | a.packet_stride | a.g.packet_header_size |
@@ -846,6 +870,196 @@ __global__ __launch_bounds__(256) void k_dewarp(DewarpArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_cartesian_tiled: the fast standalone form for W % 4 == 0 and 16 B aligned buffers.
+// Same lane mapping as k_decode's compute phase: a workgroup owns 64 columns x RC rows of one
+// image, lane = (row within pass, quad of 4 consecutive columns).  Per-column constants live in
+// registers for the whole row loop, the row's 9 beam constants come from the L1-resident table,
+// the range quad is one 16 B load and f32 XYZ goes out through the wave-private LDS transpose
+// (256 contiguous bytes per row per store instruction).
+//   MODE 1: separable tables -> f32, 2: separable -> f64, 3: full LUT (runtime dtypes)
+// ------------------------------------------------------------------------------------
+// full-LUT projection of a lane's 4 pixels from registers; LT = LUT element type
+template <class LT>
+__device__ __forceinline__ void project_full4(const LT (&dir)[12], const LT (&ofs)[12],
+                                              const uint32_t (&rng)[4], double (&p)[4][3]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const LT rr = (LT)rng[c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            LT m = rr * dir[3 * c + k];
+            asm volatile("" : "+v"(m));  // no fma contraction (cartesianT host build)
+            p[c][k] = rng[c] ? (double)(LT)(m + ofs[3 * c + k]) : 0.0;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cartesian_tiled(CartesianArgs a) {
+    constexpr int TILE = 64, LPR = 16, RPP = 16;
+    __shared__ float4 s_xyz[16 * 6 * LPR];  // one 6-chunk scratch per lane-row
+    const uint32_t W = a.w, H = a.h;
+    const uint32_t tiles = (W + TILE - 1) / TILE;
+    const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const uint32_t img = blockIdx.y, tid = threadIdx.x;
+    const uint32_t q = tid % LPR, ty = tid / LPR;
+    const uint32_t c0 = tile * TILE, col = c0 + 4 * q;
+    const uint32_t r_begin = chunk * a.rows_per_block;
+    const uint32_t r_end = min(H, r_begin + a.rows_per_block);
+    const bool full_tile = c0 + TILE <= W;
+    const bool live = col < W;  // W % 4 == 0: a quad is entirely inside or outside
+    const LutDev lut = a.lut;
+    const size_t npix = (size_t)W * H;
+    float4* sc = s_xyz + ty * (6 * LPR);
+
+    double cx[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0}, kc[4][3] = {};
+    if constexpr (MODE == 1 || MODE == 2) {
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double* t = lut.col_tab + (size_t)(col + c) * 5;
+                cx[c] = t[0]; sx[c] = t[1]; kc[c][0] = t[2]; kc[c][1] = t[3]; kc[c][2] = t[4];
+            }
+        }
+    }
+    for (uint32_t r = r_begin + ty; r < r_end; r += RPP) {
+        const size_t rowpix = (size_t)r * W + col;
+        const size_t rowpix0 = (size_t)r * W + c0;
+        uint32_t rng[4] = {0, 0, 0, 0};
+        if (live) {
+            const uint4 t = *(const uint4*)(a.range + (size_t)img * npix + rowpix);
+            rng[0] = t.x; rng[1] = t.y; rng[2] = t.z; rng[3] = t.w;
+        }
+        double p[4][3];
+        if constexpr (MODE == 1 || MODE == 2) {
+            const double* b = lut.beam_tab + (size_t)r * 9;
+            const double u0 = b[0], u1 = b[1], u2 = b[2], v0 = b[3], v1 = b[4], v2 = b[5],
+                         w0 = b[6], w1 = b[7], w2 = b[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double d0 = fma(cx[c], u0, fma(sx[c], v0, w0));
+                const double d1 = fma(cx[c], u1, fma(sx[c], v1, w1));
+                const double d2 = fma(cx[c], u2, fma(sx[c], v2, w2));
+                const double rm = (double)rng[c] - lut.n;
+                p[c][0] = rng[c] ? fma(rm, d0, kc[c][0]) : 0.0;
+                p[c][1] = rng[c] ? fma(rm, d1, kc[c][1]) : 0.0;
+                p[c][2] = rng[c] ? fma(rm, d2, kc[c][2]) : 0.0;
+            }
+        } else {
+            // the LUT rows are streamed like the output: coalesced row segments, transposed
+            // to "lane owns 4 pixels" through the scratch
+            if (lut.full_dtype == OUSTER_HIP_F32) {
+                union { float4 f4[3]; float t[12]; } d, o;
+                if (full_tile) {
+                    load_quad_coalesced<3, LPR>(sc, (const float4*)((const float*)lut.full_dir + rowpix0 * 3), q, d.f4);
+                    load_quad_coalesced<3, LPR>(sc, (const float4*)((const float*)lut.full_ofs + rowpix0 * 3), q, o.f4);
+                } else if (live) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        d.f4[k] = ((const float4*)((const float*)lut.full_dir + rowpix * 3))[k];
+                        o.f4[k] = ((const float4*)((const float*)lut.full_ofs + rowpix * 3))[k];
+                    }
+                }
+                project_full4<float>(d.t, o.t, rng, p);
+            } else {
+                union { float4 f4[6]; double t[12]; } d, o;
+                if (full_tile) {
+                    load_quad_coalesced<6, LPR>(sc, (const float4*)((const double*)lut.full_dir + rowpix0 * 3), q, d.f4);
+                    load_quad_coalesced<6, LPR>(sc, (const float4*)((const double*)lut.full_ofs + rowpix0 * 3), q, o.f4);
+                } else if (live) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        d.f4[k] = ((const float4*)((const double*)lut.full_dir + rowpix * 3))[k];
+                        o.f4[k] = ((const float4*)((const double*)lut.full_ofs + rowpix * 3))[k];
+                    }
+                }
+                project_full4<double>(d.t, o.t, rng, p);
+            }
+        }
+        if (a.xyz_dtype == OUSTER_HIP_F32) {
+            float* dst = (float*)a.xyz + ((size_t)img * npix + rowpix) * 3;
+            if (full_tile) {
+                union { float4 f4[3]; float t[12]; } o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) o.t[3 * c + k] = (float)p[c][k];
+                store_quad_coalesced<3, LPR>(sc, (float4*)(dst - (size_t)(4 * q) * 3), q, o.f4);
+            } else if (live) store_xyz4<float>(dst, p);
+        } else {
+            double* dst = (double*)a.xyz + ((size_t)img * npix + rowpix) * 3;
+            if (full_tile) {
+                union { float4 f4[6]; double t[12]; } o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) o.t[3 * c + k] = p[c][k];
+                store_quad_coalesced<6, LPR>(sc, (float4*)(dst - (size_t)(4 * q) * 3), q, o.f4);
+            } else if (live) store_xyz4<double>(dst, p);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_dewarp_tiled: p' = R_col * p + t_col (pose_util.h:38-56) with the k_decode lane mapping:
+// each lane keeps the 3x4 poses of its 4 columns in registers for the whole row loop.
+// ------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_dewarp_tiled(DewarpArgs a) {
+    constexpr int TILE = 64, LPR = 16, RPP = 16;
+    constexpr int NV = 3 * sizeof(T) / 4;  // 16 B chunks per lane quad: 3 (f32) or 6 (f64)
+    __shared__ float4 s_xyz[16 * NV * LPR];
+    const uint32_t W = a.w, H = a.h;
+    const uint32_t tiles = (W + TILE - 1) / TILE;
+    const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const uint32_t img = blockIdx.y, tid = threadIdx.x;
+    const uint32_t q = tid % LPR, ty = tid / LPR;
+    const uint32_t c0 = tile * TILE, col = c0 + 4 * q;
+    const bool full_tile = c0 + TILE <= W;
+    const bool live = col < W;
+    const uint32_t r_begin = chunk * a.rows_per_block;
+    const uint32_t r_end = min(H, r_begin + a.rows_per_block);
+    const size_t npix = (size_t)W * H;
+    float4* sc = s_xyz + ty * (NV * LPR);
+    T m[4][12];
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double* pm = a.poses + ((size_t)img * W + col + c) * 16;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) m[c][k] = (T)pm[k];
+        }
+    }
+    for (uint32_t r = r_begin + ty; r < r_end; r += RPP) {
+        const size_t i = ((size_t)img * npix + (size_t)r * W + col) * 3;
+        union { float4 f4[NV]; T t[12]; } v, o;
+        if (full_tile) {
+            // coalesced row-segment read (LPR x 16 B contiguous per instruction), transposed
+            // to "lane owns 4 points" through the lane-row's private scratch
+            load_quad_coalesced<NV, LPR>(sc, (const float4*)((const T*)a.points + i - (size_t)(4 * q) * 3), q, v.f4);
+        } else if (live) {
+            const float4* src = (const float4*)((const T*)a.points + i);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v.f4[k] = src[k];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const T x = v.t[3 * c], y = v.t[3 * c + 1], z = v.t[3 * c + 2];
+            o.t[3 * c + 0] = m[c][0] * x + m[c][1] * y + m[c][2] * z + m[c][3];
+            o.t[3 * c + 1] = m[c][4] * x + m[c][5] * y + m[c][6] * z + m[c][7];
+            o.t[3 * c + 2] = m[c][8] * x + m[c][9] * y + m[c][10] * z + m[c][11];
+        }
+        if (full_tile) {
+            store_quad_coalesced<NV, LPR>(sc, (float4*)((T*)a.out + i - (size_t)(4 * q) * 3), q, o.f4);
+        } else if (live) {
+            float4* dst = (float4*)((T*)a.out + i);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) dst[k] = o.f4[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------
 size_t decode_lds_bytes(const Geometry& g, int tile) {
@@ -911,7 +1125,23 @@ hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st) {
+hipError_t launch_cartesian(const CartesianArgs& a_in, int mode, hipStream_t st) {
+    CartesianArgs a = a_in;
+    if (a.vec_ok && a.w % 4 == 0) {
+        // enough workgroups to fill the chip: split the rows when the batch is small
+        const uint32_t tiles = (a.w + 63) / 64;
+        uint32_t rpb = a.h;
+        while (rpb > 16 && (size_t)tiles * a.n_images * ((a.h + rpb - 1) / rpb) < 1024) rpb = (rpb + 1) / 2;
+        rpb = (rpb + 15) / 16 * 16;
+        a.rows_per_block = rpb;
+        dim3 grid(tiles * ((a.h + rpb - 1) / rpb), a.n_images);
+        switch (mode) {
+            case 1: hipLaunchKernelGGL(k_cartesian_tiled<1>, grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL(k_cartesian_tiled<2>, grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL(k_cartesian_tiled<3>, grid, dim3(256), 0, st, a); break;
+        }
+        return hipGetLastError();
+    }
     const size_t quads = ((size_t)a.w * a.h + 3) / 4 * a.n_images;
     size_t blocks = (quads + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
@@ -925,7 +1155,19 @@ hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st) {
+hipError_t launch_dewarp(const DewarpArgs& a_in, hipStream_t st) {
+    DewarpArgs a = a_in;
+    if (a.w % 4 == 0 && (((uintptr_t)a.points | (uintptr_t)a.out) & 15) == 0) {
+        const uint32_t tiles = (a.w + 63) / 64;
+        uint32_t rpb = a.h;
+        while (rpb > 16 && (size_t)tiles * a.n_images * ((a.h + rpb - 1) / rpb) < 1024) rpb = (rpb + 1) / 2;
+        rpb = (rpb + 15) / 16 * 16;
+        a.rows_per_block = rpb;
+        dim3 grid(tiles * ((a.h + rpb - 1) / rpb), a.n_images);
+        if (a.dtype == OUSTER_HIP_F32) hipLaunchKernelGGL(k_dewarp_tiled<float>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_dewarp_tiled<double>, grid, dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)a.w * a.h * a.n_images;
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;

@@ -386,6 +386,40 @@ def test_dense_dewarp_matches_oracle(oracle):
     assert torch.equal(hp.dewarp(p32, ident), p32)
 
 
+@pytest.mark.parametrize("h,w", [(16, 100), (33, 1001), (7, 36), (128, 2048), (40, 1088)])
+def test_standalone_kernels_shapes(oracle, h, w):
+    """k_cartesian_tiled / k_dewarp_tiled (W % 4 == 0: full + ragged 64-column tiles, row chunks that
+    are not multiples of 16) and the generic fallbacks (W % 4 != 0) against the oracle."""
+    O = oracle
+    rng = np.random.default_rng(h * 10007 + w)
+    cal = O.synthetic_calib(h=h, w=w, b2l_x=27.67)
+    ldir, lofs = cal.xyz_lut(True)
+    hp = HotPath("RNG15_RFL8_NIR8", h, w, 4 if w % 4 == 0 else 1)
+    lut = hp.add_lut(cal.beam_to_lidar, cal.lut_transform(True), cal.beam_azimuth_angles,
+                     cal.beam_altitude_angles)
+    n = 2
+    r = rng.integers(0, 2 ** 19, size=(n, h, w)).astype(np.uint32)
+    r[rng.random(r.shape) < 0.2] = 0
+    dr = torch.from_numpy(r).cuda()
+    want = np.stack([O.cartesian(r[k], ldir, lofs) for k in range(n)])
+    assert np.abs(_np(hp.cartesian(dr, dtype=torch.float64)) - want).max() < 1e-9
+    assert np.abs(_np(hp.cartesian(dr, dtype=torch.float32)).astype(np.float64) - want).max() <= 4e-5
+    for ldt, tdt in ((np.float32, torch.float32), (np.float64, torch.float64)):
+        l = hp.add_lut_arrays(ldir.astype(ldt), lofs.astype(ldt))
+        w_l = np.stack([O.cartesian(r[k], ldir.astype(ldt), lofs.astype(ldt)) for k in range(n)])
+        assert np.array_equal(_np(hp.cartesian(dr, lut=l, dtype=tdt)), w_l), ldt
+    poses = np.tile(np.eye(4), (n, w, 1, 1))
+    ang = rng.uniform(-0.3, 0.3, size=(n, w))
+    poses[..., 0, 0] = np.cos(ang); poses[..., 0, 2] = np.sin(ang)
+    poses[..., 2, 0] = -np.sin(ang); poses[..., 2, 2] = np.cos(ang)
+    poses[..., :3, 3] = rng.uniform(-5, 5, size=(n, w, 3))
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+        pts = rng.uniform(-100, 100, size=(n, h * w, 3)).astype(dt)
+        got = _np(hp.dewarp(torch.from_numpy(pts).cuda(), torch.from_numpy(poses).cuda()))
+        want_d = np.stack([O.dewarp(pts[k], poses[k], h, w) for k in range(n)])
+        assert np.abs(got.astype(np.float64) - want_d.astype(np.float64)).max() <= tol
+
+
 @pytest.mark.parametrize("profile,h,w,cpp", [
     ("RNG15_RFL8_NIR8", 30, 1002, 6),             # W % 4 != 0, cpp does not divide the tile, ragged tile
     ("RNG19_RFL8_SIG16_NIR16_DUAL", 17, 136, 8),  # tiny odd frame, 16 B/px

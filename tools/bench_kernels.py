@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Standalone-kernel rooflines (k_destagger, k_cartesian, k_dewarp) on resident data.
+Prints one JSON object; algorithmic bytes per the definitions in DESIGN.md section 3."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from ouster_sdk_amd.device import HotPath
+
+H, W, N = 128, 2048, 256
+
+
+def timeit(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3
+
+
+def main():
+    alt, az, shifts, b2l, l2s = bench.synth_calibration()
+    hp = HotPath("RNG15_RFL8_NIR8_DUAL", H, W, 16)
+    hp.set_pixel_shift_by_row(shifts)
+    lut = hp.add_lut(b2l, l2s, az, alt)
+    d, o = lut.export(W, H)
+    lut32 = hp.add_lut_arrays(d.astype(np.float32), o.astype(np.float32))
+    rng = torch.randint(0, 2 ** 19, (N, H, W), dtype=torch.int64, device="cuda").to(torch.uint32)
+    res = {}
+    for name, t in (("u32", rng), ("u8", rng.to(torch.uint8)), ("u16", rng.to(torch.uint16))):
+        s = timeit(lambda: hp.destagger(t))
+        res[f"destagger_{name}"] = {"GBps": round(2 * t.numel() * t.element_size() / s / 1e9, 1),
+                                    "ms": round(s * 1e3, 3)}
+    npx = N * H * W
+    for name, l, dt, bpp in (("sep_f32", lut, torch.float32, 4 + 12), ("sep_f64", lut, torch.float64, 4 + 24),
+                             ("fullLUT_f32", lut32, torch.float32, 4 + 12 + 24 / N)):  # the LUT is shared by the N images
+        s = timeit(lambda: hp.cartesian(rng, lut=l, dtype=dt))
+        res[f"cartesian_{name}"] = {"GBps": round(npx * bpp / s / 1e9, 1), "Mpoints_per_s": round(npx / s / 1e6, 1),
+                                    "ms": round(s * 1e3, 3)}
+    pts = hp.cartesian(rng[:64].contiguous())
+    poses = torch.eye(4, dtype=torch.float64, device="cuda").repeat(64, W, 1, 1).contiguous()
+    s = timeit(lambda: hp.dewarp(pts, poses))
+    res["dewarp_f32"] = {"GBps": round(2 * pts.numel() * 4 / s / 1e9, 1),
+                         "Mpoints_per_s": round(pts.numel() / 3 / s / 1e6, 1), "ms": round(s * 1e3, 3)}
+    pts64 = pts.double()
+    s = timeit(lambda: hp.dewarp(pts64, poses))
+    res["dewarp_f64"] = {"GBps": round(2 * pts64.numel() * 8 / s / 1e9, 1),
+                         "Mpoints_per_s": round(pts64.numel() / 3 / s / 1e6, 1), "ms": round(s * 1e3, 3)}
+    res["note"] = f"{N} images of {H}x{W}; includes torch.empty_like of the output per call"
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
