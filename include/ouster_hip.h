@@ -243,6 +243,31 @@ int ouster_hip_cartesian(ouster_hip_ctx* ctx, const ouster_hip_lut* lut,
 int ouster_hip_dewarp(ouster_hip_ctx* ctx, const void* points, const double* poses, void* dewarped,
                       int dtype, uint32_t h, uint32_t w, uint32_t n_images);
 
+/* ---- range-gated, compacting frame dewarp ---------------------------------- */
+/* Replaces dewarp<T>(const LidarFrame&, const XYZLutT<T>&, min_range, max_range) and its FrameSet
+ * form with provenance (ouster_core/include/ouster/core/pose_util.h:456-493,
+ * impl/dewarp_impl.h:23-115) for a batch of frames resident in HBM.
+ *   range     [n_frames][h][w] u32   staggered RANGE planes (h, w taken from the LUTs)
+ *   status    [n_frames][w]    u32   column status; timestamp [n_frames][w] u64 (nullable unless
+ *                                    timestamps_ns is requested); poses [n_frames][w][16] f64
+ *   luts      host array, frame f uses luts[f % n_luts] (one XYZLut per sensor of a FrameSet)
+ * Per frame: columns first_valid..last_valid (status & 1, lidar_frame.cpp:907-925), skipping
+ * status == 0; rows top to bottom; a point is kept when ceil(min_range*1e3) <= r <=
+ * floor(max_range*1e3); xyz = lut(r) (f64 tables, or r*dir+ofs in a user LUT's precision), then
+ * p' = R_col*p + t_col evaluated in `dtype` with the pose cast to it.  Frames are concatenated in
+ * index order.
+ * Outputs (device): points [capacity][3] of dtype; optional frame_idxs / col_idxs [capacity] u32,
+ * timestamps_ns [capacity] u64; frame_offsets [n_frames + 1] u64 = exclusive prefix of the kept
+ * points per frame (frame_offsets[n_frames] = total).  Points beyond `capacity` are dropped, the
+ * offsets still report the full counts: h*w*n_frames is always enough
+ * (impl::max_number_of_valid_points, pose_util.cpp:15-29). */
+int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* luts, uint32_t n_luts,
+                             const uint32_t* range, const uint32_t* status,
+                             const uint64_t* timestamp, const double* poses, uint32_t n_frames,
+                             double min_range, double max_range, int dtype, void* points,
+                             uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
+                             uint64_t capacity, uint64_t* frame_offsets);
+
 /* ---- instrumentation ------------------------------------------------------ */
 /* Average duration in ms of the dominant decode kernel over the launches made
  * since the last reset, measured with HIP events on the context's stream

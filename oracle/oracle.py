@@ -191,6 +191,9 @@ def lib():
     for n in ("ora_dewarp_f64", "ora_dewarp_f32"):
         getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         getattr(L, n).restype = None
+    for n in ("ora_dewarp_frame_f64", "ora_dewarp_frame_f32"):
+        getattr(L, n).argtypes = [C.c_void_p] * 9 + [C.c_size_t, C.c_size_t, C.c_double, C.c_double]
+        getattr(L, n).restype = C.c_size_t
     L.ora_bench_hot_path.restype = C.c_double
     L.ora_bench_hot_path.argtypes = [C.POINTER(PF), C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -448,6 +451,27 @@ def dewarp(points: np.ndarray, poses: np.ndarray, h: int, w: int) -> np.ndarray:
     fn = lib().ora_dewarp_f32 if pts.dtype == np.float32 else lib().ora_dewarp_f64
     fn(_ptr(out), _ptr(pts), _ptr(po), h, w)
     return out
+
+
+def dewarp_frame(range_img: np.ndarray, status: np.ndarray, timestamp: np.ndarray, poses: np.ndarray,
+                 lut_dir: np.ndarray, lut_ofs: np.ndarray, min_range: float, max_range: float):
+    """impl/dewarp_impl.h:23-81 -- range-gated, compacting dewarp of one frame.  The LUT dtype
+    (float32 / float64) selects T.  Returns (points [n,3] T, col_idxs [n] u32, timestamps [n] u64)."""
+    h, w = range_img.shape
+    T = np.float32 if lut_dir.dtype == np.float32 else np.float64
+    r = np.ascontiguousarray(range_img, dtype=np.uint32)
+    st = np.ascontiguousarray(status, dtype=np.uint32)
+    tsn = np.ascontiguousarray(timestamp, dtype=np.uint64)
+    po = np.ascontiguousarray(poses, dtype=np.float64).reshape(w, 16)
+    d = np.ascontiguousarray(lut_dir, dtype=T).reshape(h * w, 3)
+    o = np.ascontiguousarray(lut_ofs, dtype=T).reshape(h * w, 3)
+    out = np.empty((h * w, 3), dtype=T)
+    col = np.empty(h * w, dtype=np.uint32)
+    ts = np.empty(h * w, dtype=np.uint64)
+    fn = lib().ora_dewarp_frame_f32 if T == np.float32 else lib().ora_dewarp_frame_f64
+    n = fn(_ptr(out), _ptr(col), _ptr(ts), _ptr(r), _ptr(st), _ptr(tsn), _ptr(po), _ptr(d), _ptr(o),
+           h, w, float(min_range), float(max_range))
+    return out[:n].copy(), col[:n].copy(), ts[:n].copy()
 
 
 # --------------------------------------------------------------------------- #

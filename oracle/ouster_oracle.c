@@ -1150,6 +1150,53 @@ void ora_dewarp_f32(float* out, const float* pts, const double* poses, size_t h,
     }
 }
 
+/* dewarp(LidarFrame, XYZLutT<T>, min_range, max_range) with provenance:
+ * include/ouster/core/impl/dewarp_impl.h:23-81.  pts = xyzlut(range) (cartesianT<T> with the T LUT),
+ * columns first_valid..last_valid (status & 1, lidar_frame.cpp:907-925), skipping status == 0,
+ * rows top to bottom, keeping ceil(min*1e3) <= r <= floor(max*1e3); pt = R*pt + t in T with the
+ * pose cast to T.  Returns the number of points written; col_idx / ts may be NULL. */
+#define DEWARP_FRAME_BODY(T)                                                                     \
+    int start = -1, stop = -1;                                                                   \
+    for (size_t i = 0; i < w; ++i) if (status[i] & 1u) { start = (int)i; break; }                \
+    for (int i = (int)w - 1; i >= 0; --i) if (status[i] & 1u) { stop = i; break; }               \
+    if (start < 0 || stop < start) return 0;                                                     \
+    const uint32_t min_r = (uint32_t)ceil(min_range * 1e3);                                      \
+    const uint32_t max_r = (uint32_t)floor(max_range * 1e3);                                     \
+    size_t n = 0;                                                                                \
+    for (int x = start; x <= stop; ++x) {                                                        \
+        if (status[x] == 0) continue;                                                            \
+        T m[12];                                                                                 \
+        for (int k = 0; k < 12; ++k) m[k] = (T)poses[(size_t)x * 16 + k];                        \
+        for (size_t y = 0; y < h; ++y) {                                                         \
+            const size_t ix = y * w + (size_t)x;                                                 \
+            const uint32_t r = range[ix];                                                        \
+            if (r < min_r || r > max_r) continue;                                                \
+            T p[3];                                                                              \
+            if (r == 0) { p[0] = p[1] = p[2] = (T)0; }                                           \
+            else for (int k = 0; k < 3; ++k) p[k] = (T)r * dir[ix * 3 + k] + ofs[ix * 3 + k];    \
+            out[n * 3 + 0] = m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3];                     \
+            out[n * 3 + 1] = m[4] * p[0] + m[5] * p[1] + m[6] * p[2] + m[7];                     \
+            out[n * 3 + 2] = m[8] * p[0] + m[9] * p[1] + m[10] * p[2] + m[11];                   \
+            if (col_idx) col_idx[n] = (uint32_t)x;                                               \
+            if (ts) ts[n] = timestamp[x];                                                        \
+            ++n;                                                                                 \
+        }                                                                                        \
+    }                                                                                            \
+    return n;
+
+size_t ora_dewarp_frame_f64(double* out, uint32_t* col_idx, uint64_t* ts, const uint32_t* range,
+                            const uint32_t* status, const uint64_t* timestamp, const double* poses,
+                            const double* dir, const double* ofs, size_t h, size_t w,
+                            double min_range, double max_range) {
+    DEWARP_FRAME_BODY(double)
+}
+size_t ora_dewarp_frame_f32(float* out, uint32_t* col_idx, uint64_t* ts, const uint32_t* range,
+                            const uint32_t* status, const uint64_t* timestamp, const double* poses,
+                            const float* dir, const float* ofs, size_t h, size_t w,
+                            double min_range, double max_range) {
+    DEWARP_FRAME_BODY(float)
+}
+
 /* ------------------------------------------------------------------------- */
 /* CPU baseline driver: the reference's own sequence on a pool of frames      */
 /* (cf. tests/benchmarks/core_benchmark.cpp:29-154)                          */

@@ -213,6 +213,15 @@ void ora_cartesian_f32_omp(float* points, const uint32_t* range,
 /* ---- dense dewarp (pose_util.h:38-56) ---- */
 void ora_dewarp_f64(double* out, const double* pts, const double* poses, size_t h, size_t w);
 void ora_dewarp_f32(float* out, const float* pts, const double* poses, size_t h, size_t w);
+/* ---- range-gated, compacting frame dewarp (impl/dewarp_impl.h:23-81) ---- */
+size_t ora_dewarp_frame_f64(double* out, uint32_t* col_idx, uint64_t* ts, const uint32_t* range,
+                            const uint32_t* status, const uint64_t* timestamp, const double* poses,
+                            const double* dir, const double* ofs, size_t h, size_t w,
+                            double min_range, double max_range);
+size_t ora_dewarp_frame_f32(float* out, uint32_t* col_idx, uint64_t* ts, const uint32_t* range,
+                            const uint32_t* status, const uint64_t* timestamp, const double* poses,
+                            const float* dir, const float* ofs, size_t h, size_t w,
+                            double min_range, double max_range);
 
 /* ---- whole hot path for the CPU baseline (decode + destagger + cartesian) ---- */
 /* Runs n_frames frames (frame f = pool frame f % pool_frames) of `ppf` packets each through

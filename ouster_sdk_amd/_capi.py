@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "ouster_hip_last_error", "ouster_hip_version", "ouster_hip_format_create",
     "ouster_hip_format_destroy", "ouster_hip_lut_create", "ouster_hip_lut_create_from_arrays",
     "ouster_hip_lut_export", "ouster_hip_lut_destroy", "ouster_hip_decode", "ouster_hip_destagger",
-    "ouster_hip_cartesian", "ouster_hip_dewarp", "ouster_hip_timing_enable", "ouster_hip_timing_read",
+    "ouster_hip_cartesian", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_timing_enable", "ouster_hip_timing_read",
 ]
 
 _hip = None
@@ -118,6 +118,8 @@ def load_hip():
                                        C.c_uint32, C.c_int, C.c_uint32]
     L.ouster_hip_cartesian.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint32]
     L.ouster_hip_dewarp.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.ouster_hip_dewarp_frames.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, C.c_double,
+                                           C.c_double, C.c_int, vp, vp, vp, vp, C.c_uint64, vp]
     L.ouster_hip_timing_enable.argtypes = [vp, C.c_int]
     L.ouster_hip_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     _hip = L

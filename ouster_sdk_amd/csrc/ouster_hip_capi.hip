@@ -68,7 +68,7 @@ struct ouster_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf map, offsets, luts, counts;
+    DevBuf map, offsets, luts, counts, scratch;
     bool map_clean = false;              // map is all -1 (k_decode resets what it consumes)
     std::vector<int32_t> offsets_host;   // cache key of `offsets`
     std::vector<LutDev> luts_host;       // cache key of `luts`
@@ -247,6 +247,7 @@ void ouster_hip_ctx_destroy(ouster_hip_ctx* c) {
     c->offsets.release();
     c->luts.release();
     c->counts.release();
+    c->scratch.release();
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -728,6 +729,70 @@ int ouster_hip_dewarp(ouster_hip_ctx* ctx, const void* points, const double* pos
     a.n_images = n_images;
     a.dtype = dtype;
     HIP_TRY(launch_dewarp(a, ctx->stream));
+    return OUSTER_HIP_OK;
+}
+
+// ---- range-gated, compacting frame dewarp ------------------------------------------------------
+int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* luts, uint32_t n_luts,
+                             const uint32_t* range, const uint32_t* status,
+                             const uint64_t* timestamp, const double* poses, uint32_t n_frames,
+                             double min_range, double max_range, int dtype, void* points,
+                             uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
+                             uint64_t capacity, uint64_t* frame_offsets) {
+    if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (dtype != OUSTER_HIP_F32 && dtype != OUSTER_HIP_F64)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "dtype must be F32 or F64");
+    if (!luts || n_luts == 0) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "at least one LUT is required");
+    for (uint32_t i = 0; i < n_luts; ++i) {
+        if (!luts[i]) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL LUT handle");
+        if (luts[i]->w != luts[0]->w || luts[i]->h != luts[0]->h)
+            return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "all LUTs of a batch must have the same dimensions");
+        if (luts[i]->separable != luts[0]->separable)
+            return fail(OUSTER_HIP_ERR_UNSUPPORTED, "cannot mix separable and full LUTs in one batch");
+    }
+    if (!frame_offsets) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "frame_offsets is NULL");
+    if (timestamps_ns && !timestamp)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "timestamps_ns requested without column timestamps");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n_frames == 0) {
+        HIP_TRY(hipMemsetAsync(frame_offsets, 0, sizeof(uint64_t), ctx->stream));
+        return OUSTER_HIP_OK;
+    }
+    if (!range || !status || !poses || (!points && capacity))
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL pointer");
+    const uint32_t w = luts[0]->w, h = luts[0]->h;
+    // uint32_t min_r = ceil(min_range * 1e3), max_r = floor(max_range * 1e3): dewarp_impl.h:33-34
+    const double lo = std::ceil(min_range * 1e3), hi = std::floor(max_range * 1e3);
+    if (!(hi >= 0) || !(lo <= 4294967295.0) || hi < lo) {  // nothing can pass the gate
+        HIP_TRY(hipMemsetAsync(frame_offsets, 0, sizeof(uint64_t) * ((size_t)n_frames + 1), ctx->stream));
+        return OUSTER_HIP_OK;
+    }
+    std::vector<LutDev> l(n_luts);
+    for (uint32_t i = 0; i < n_luts; ++i) l[i] = luts[i]->dev;
+    if (ensure_luts(ctx, l)) return fail(OUSTER_HIP_ERR_RUNTIME, "LUT descriptor upload failed");
+    if (ctx->scratch.ensure((size_t)n_frames * (w + 1) * sizeof(uint32_t)))
+        return fail(OUSTER_HIP_ERR_RUNTIME, "scratch allocation failed");
+    DewarpFramesArgs a{};
+    a.range = range;
+    a.status = status;
+    a.timestamp = timestamp;
+    a.poses = poses;
+    a.luts = (const LutDev*)ctx->luts.p;
+    a.n_luts = n_luts;
+    a.w = w;
+    a.h = h;
+    a.n_frames = n_frames;
+    a.min_r = lo <= 0 ? 0u : (uint32_t)lo;
+    a.max_r = hi >= 4294967295.0 ? 0xffffffffu : (uint32_t)hi;
+    a.dtype = dtype;
+    a.col_off = (uint32_t*)ctx->scratch.p;
+    a.frame_off = frame_offsets;
+    a.points = points;
+    a.frame_idxs = frame_idxs;
+    a.col_idxs = col_idxs;
+    a.timestamps_ns = timestamps_ns;
+    a.capacity = capacity;
+    HIP_TRY(launch_dewarp_frames(a, luts[0]->separable, ctx->stream));
     return OUSTER_HIP_OK;
 }
 

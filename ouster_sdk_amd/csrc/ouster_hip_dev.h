@@ -101,6 +101,26 @@ struct DewarpArgs {
     uint32_t rows_per_block;
 };
 
+// range-gated, compacting frame dewarp (impl/dewarp_impl.h:23-115)
+struct DewarpFramesArgs {
+    const uint32_t* range;      // [n_frames][h][w] staggered RANGE planes
+    const uint32_t* status;     // [n_frames][w]
+    const uint64_t* timestamp;  // [n_frames][w], nullable unless timestamps_ns is set
+    const double* poses;        // [n_frames][w][16]
+    const LutDev* luts;         // device array, luts[f % n_luts]
+    uint32_t n_luts;
+    uint32_t w, h, n_frames;
+    uint32_t min_r, max_r;      // raw range units (mm), inclusive
+    int32_t dtype;              // element type of points
+    uint32_t* col_off;          // scratch [n_frames][w + 1]
+    uint64_t* frame_off;        // out [n_frames + 1]: exclusive prefix of points per frame
+    void* points;               // [capacity][3]
+    uint32_t* frame_idxs;       // nullable provenance outputs, [capacity]
+    uint32_t* col_idxs;
+    uint64_t* timestamps_ns;
+    uint64_t capacity;
+};
+
 // one compile-time field of a standard profile (see the Spec* tables in the kernels file)
 struct FieldC {
     uint32_t offset;
@@ -116,5 +136,6 @@ hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, h
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st);
 hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
 hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);
+hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st);
 
 }  // namespace ouster_hip_dev

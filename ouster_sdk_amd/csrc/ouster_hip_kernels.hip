@@ -1060,6 +1060,221 @@ __global__ __launch_bounds__(256) void k_dewarp_tiled(DewarpArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// Range-gated, compacting frame dewarp: dewarp(LidarFrame|FrameSet, XYZLut, min_range, max_range)
+// (impl/dewarp_impl.h:23-115).  Output order is the reference's: frame, then column
+// first_valid..last_valid with status != 0, then row; a point is kept when min_r <= r <= max_r.
+//   k_dwf_count       kept points per (frame, column) from the range plane (ignores status)
+//   k_dwf_scan        per frame: first/last valid column (status & 1, lidar_frame.cpp:907-925),
+//                     mask, exclusive scan over the columns; frame total
+//   k_dwf_frame_scan  exclusive scan of the frame totals
+//   k_dwf_emit        stage a 64-row x 64-column range tile in LDS, wave = column, lane = row:
+//                     ballot-rank the kept rows, project (f64 tables or the full LUT), apply the
+//                     column pose in T, and write the compacted run through a wave-private LDS
+//                     buffer so the global stores are contiguous dwords.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dwf_count(DewarpFramesArgs a) {
+    constexpr int TILE = 64, LPR = 16, RPP = 16;
+    __shared__ uint32_t s_cnt[TILE];
+    const uint32_t W = a.w, H = a.h, f = blockIdx.y, tid = threadIdx.x;
+    const uint32_t q = tid % LPR, ty = tid / LPR;
+    const uint32_t c0 = blockIdx.x * TILE, col = c0 + 4 * q;
+    if (tid < TILE) s_cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t* rp = a.range + (size_t)f * W * H;
+    const bool vec = (W % 4 == 0) && ((((uintptr_t)a.range) & 15) == 0);
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    if (col < W) {
+        for (uint32_t r = ty; r < H; r += RPP) {
+            uint32_t v[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (vec) {
+                const uint4 t = *(const uint4*)(rp + (size_t)r * W + col);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                for (uint32_t c = 0; c < 4 && col + c < W; ++c) v[c] = rp[(size_t)r * W + col + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                cnt[c] += (col + c < W && v[c] >= a.min_r && v[c] <= a.max_r) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (cnt[c]) atomicAdd(&s_cnt[4 * q + c], cnt[c]);
+    }
+    __syncthreads();
+    if (tid < TILE && c0 + tid < W) a.col_off[(size_t)f * (W + 1) + c0 + tid] = s_cnt[tid];
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix,
+// *total = block sum
+__device__ __forceinline__ uint32_t block_exscan_256(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wave; ++k) base += s_wave[k];
+    *total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_dwf_scan(DewarpFramesArgs a) {
+    __shared__ int s_lo, s_hi;
+    __shared__ uint32_t s_wave[4];
+    const uint32_t W = a.w, f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* st = a.status + (size_t)f * W;
+    uint32_t* off = a.col_off + (size_t)f * (W + 1);
+    if (tid == 0) { s_lo = 0x7fffffff; s_hi = -1; }
+    __syncthreads();
+    int lo = 0x7fffffff, hi = -1;
+    for (uint32_t x = tid; x < W; x += 256)
+        if (st[x] & 1u) { lo = min(lo, (int)x); hi = max(hi, (int)x); }
+    if (hi >= 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    __syncthreads();
+    lo = s_lo; hi = s_hi;
+    // contiguous segment per thread
+    const uint32_t seg = (W + 255) / 256;
+    const uint32_t x0 = tid * seg, x1 = min(W, x0 + seg);
+    uint32_t sum = 0;
+    for (uint32_t x = x0; x < x1; ++x) {
+        const bool keep = (int)x >= lo && (int)x <= hi && st[x] != 0;
+        sum += keep ? off[x] : 0u;
+    }
+    uint32_t total;
+    uint32_t run = block_exscan_256(sum, s_wave, &total);
+    for (uint32_t x = x0; x < x1; ++x) {
+        const bool keep = (int)x >= lo && (int)x <= hi && st[x] != 0;
+        const uint32_t c = keep ? off[x] : 0u;
+        off[x] = run;
+        run += c;
+    }
+    if (tid == 0) {
+        off[W] = total;
+        a.frame_off[f + 1] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dwf_frame_scan(DewarpFramesArgs a) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t tid = threadIdx.x;
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < a.n_frames; base += 256) {
+        const uint32_t f = base + tid;
+        const uint32_t v = f < a.n_frames ? (uint32_t)a.frame_off[f + 1] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exscan_256(v, s_wave, &total);
+        if (f < a.n_frames) a.frame_off[f + 1] = carry + ex + v;
+        carry += total;
+    }
+    if (tid == 0) a.frame_off[0] = 0;
+}
+
+template <class T, bool SEP>
+__global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
+    constexpr int TILE = 64, LPR = 16, ROWS = 64, PITCH = TILE + 1;
+    __shared__ uint32_t s_rng[ROWS * PITCH];
+    __shared__ uint32_t s_run[TILE];
+    __shared__ T s_out[4][64 * 3];
+    const uint32_t W = a.w, H = a.h, f = blockIdx.y, tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t q = tid % LPR, ty = tid / LPR;
+    const uint32_t c0 = blockIdx.x * TILE;
+    const uint32_t* rp = a.range + (size_t)f * W * H;
+    const uint32_t* off = a.col_off + (size_t)f * (W + 1);
+    const uint64_t fbase = a.frame_off[f];
+    const LutDev lut = a.luts[f % a.n_luts];
+    const bool vec = (W % 4 == 0) && ((((uintptr_t)a.range) & 15) == 0);
+    if (tid < TILE) s_run[tid] = 0;
+    // nothing kept in this tile: leave before touching the range plane
+    {
+        const uint32_t cl = min(W, c0 + TILE);
+        if (off[cl] == off[c0]) return;  // uniform over the workgroup
+    }
+    T* sc = s_out[wave];
+    for (uint32_t r0 = 0; r0 < H; r0 += ROWS) {
+        __syncthreads();  // previous chunk consumed (and s_run initialised)
+        for (uint32_t rr = ty; rr < ROWS; rr += 16) {
+            const uint32_t r = r0 + rr, col = c0 + 4 * q;
+            uint32_t v[4] = {0, 0, 0, 0};
+            if (r < H && col < W) {
+                if (vec) {
+                    const uint4 t = *(const uint4*)(rp + (size_t)r * W + col);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+                    for (uint32_t c = 0; c < 4 && col + c < W; ++c) v[c] = rp[(size_t)r * W + col + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_rng[rr * PITCH + 4 * q + c] = v[c];
+        }
+        __syncthreads();
+        const uint32_t row = r0 + lane;
+        double bt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (SEP) {
+            if (row < H) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) bt[k] = lut.beam_tab[(size_t)row * 9 + k];
+            }
+        }
+        for (uint32_t jj = 0; jj < 16; ++jj) {
+            const uint32_t j = wave * 16 + jj, x = c0 + j;  // wave-uniform
+            if (x >= W) break;
+            const uint32_t cbase = off[x];
+            if (off[x + 1] == cbase) continue;  // masked out or empty column
+            const uint32_t r = s_rng[lane * PITCH + j];
+            const bool keep = row < H && r >= a.min_r && r <= a.max_r;
+            const uint64_t mask = __ballot(keep);
+            if (mask == 0) continue;
+            const uint32_t n_keep = __popcll(mask);
+            const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+            const uint32_t run = s_run[j];
+            if (keep) {
+                double p[3];
+                if constexpr (SEP) {
+                    const double* ct = lut.col_tab + (size_t)x * 5;
+                    const double cx = ct[0], sx = ct[1];
+                    const double rm = (double)r - lut.n;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double d = fma(cx, bt[k], fma(sx, bt[3 + k], bt[6 + k]));
+                        p[k] = r ? fma(rm, d, ct[2 + k]) : 0.0;
+                    }
+                } else {
+                    const size_t pix = (size_t)row * W + x;
+                    if (lut.full_dtype == OUSTER_HIP_F32)
+                        project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs, pix, r, p);
+                    else
+                        project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs, pix, r, p);
+                }
+                const double* pm = a.poses + ((size_t)f * W + x) * 16;
+                const T px = (T)p[0], py = (T)p[1], pz = (T)p[2];
+                sc[rank * 3 + 0] = (T)pm[0] * px + (T)pm[1] * py + (T)pm[2] * pz + (T)pm[3];
+                sc[rank * 3 + 1] = (T)pm[4] * px + (T)pm[5] * py + (T)pm[6] * pz + (T)pm[7];
+                sc[rank * 3 + 2] = (T)pm[8] * px + (T)pm[9] * py + (T)pm[10] * pz + (T)pm[11];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const uint64_t g0 = fbase + cbase + run;  // first output point of this run
+            T* dst = (T*)a.points + g0 * 3;
+            const uint64_t room = g0 < a.capacity ? a.capacity - g0 : 0;
+            const uint32_t n_ok = (uint32_t)min((uint64_t)n_keep, room);
+            for (uint32_t i = lane; i < n_ok * 3; i += 64) dst[i] = sc[i];
+            if (lane < n_ok) {
+                if (a.col_idxs) a.col_idxs[g0 + lane] = x;
+                if (a.frame_idxs) a.frame_idxs[g0 + lane] = f;
+                if (a.timestamps_ns) a.timestamps_ns[g0 + lane] = a.timestamp[(size_t)f * W + x];
+            }
+            if (lane == 0) s_run[j] = run + n_keep;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------
 size_t decode_lds_bytes(const Geometry& g, int tile) {
@@ -1174,6 +1389,22 @@ hipError_t launch_dewarp(const DewarpArgs& a_in, hipStream_t st) {
     if (blocks == 0) blocks = 1;
     if (a.dtype == OUSTER_HIP_F32) hipLaunchKernelGGL(k_dewarp<float>, dim3((uint32_t)blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_dewarp<double>, dim3((uint32_t)blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st) {
+    const uint32_t tiles = (a.w + 63) / 64;
+    hipLaunchKernelGGL(k_dwf_count, dim3(tiles, a.n_frames), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dwf_scan, dim3(a.n_frames), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dwf_frame_scan, dim3(1), dim3(256), 0, st, a);
+    const dim3 grid(tiles, a.n_frames);
+    if (a.dtype == OUSTER_HIP_F32) {
+        if (separable) hipLaunchKernelGGL((k_dwf_emit<float, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_dwf_emit<float, false>), grid, dim3(256), 0, st, a);
+    } else {
+        if (separable) hipLaunchKernelGGL((k_dwf_emit<double, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_dwf_emit<double, false>), grid, dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 

@@ -181,5 +181,41 @@ class HotPath:
             capi.F32 if points.dtype == torch.float32 else capi.F64, self.h, self.w, n))
         return out
 
+    def dewarp_frames(self, rng: torch.Tensor, status: torch.Tensor, poses: torch.Tensor,
+                      min_range: float, max_range: float, timestamp: Optional[torch.Tensor] = None,
+                      luts=None, dtype=torch.float32, provenance: bool = True,
+                      capacity: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """Range-gated, compacting dewarp of a batch of frames (impl/dewarp_impl.h:23-115).
+        rng [n, h, w] u32, status [n, w] u32, poses [n, w, 4, 4] f64, timestamp [n, w] u64.
+        Returns {"points" [cap, 3], "frame_offsets" [n + 1] u64, and with provenance
+        "frame_idxs", "col_idxs" (u32) and, when timestamp is given, "timestamps_ns" (u64)};
+        the first frame_offsets[n] rows are valid."""
+        assert rng.is_cuda and rng.is_contiguous() and rng.dtype == torch.uint32
+        assert status.is_cuda and status.is_contiguous() and status.dtype == torch.uint32
+        assert poses.is_cuda and poses.is_contiguous() and poses.dtype == torch.float64
+        n = rng.shape[0]
+        if rng.numel() != n * self.h * self.w or status.numel() != n * self.w or \
+                poses.numel() != n * self.w * 16:
+            raise ValueError("unexpected image dimensions")
+        luts = list(luts) if luts is not None else self.luts
+        cap = n * self.h * self.w if capacity is None else int(capacity)
+        out = {"points": torch.empty((cap, 3), dtype=dtype, device="cuda"),
+               "frame_offsets": torch.empty(n + 1, dtype=torch.uint64, device="cuda")}
+        if provenance:
+            out["frame_idxs"] = torch.empty(cap, dtype=torch.uint32, device="cuda")
+            out["col_idxs"] = torch.empty(cap, dtype=torch.uint32, device="cuda")
+            if timestamp is not None:
+                assert timestamp.is_cuda and timestamp.is_contiguous() and timestamp.dtype == torch.uint64
+                out["timestamps_ns"] = torch.empty(cap, dtype=torch.uint64, device="cuda")
+        luts_arr = (C.c_void_p * max(len(luts), 1))(*[l.h for l in luts])
+        ptr = lambda k: out[k].data_ptr() if k in out else None
+        capi.check(self.ctx.L.ouster_hip_dewarp_frames(
+            self.ctx.h, luts_arr, len(luts), rng.data_ptr(), status.data_ptr(),
+            timestamp.data_ptr() if timestamp is not None else None, poses.data_ptr(), n,
+            float(min_range), float(max_range), capi.F32 if dtype == torch.float32 else capi.F64,
+            out["points"].data_ptr(), ptr("frame_idxs"), ptr("col_idxs"), ptr("timestamps_ns"),
+            cap, out["frame_offsets"].data_ptr()))
+        return out
+
     def sync(self):
         self.ctx.sync()

@@ -386,6 +386,69 @@ def test_dense_dewarp_matches_oracle(oracle):
     assert torch.equal(hp.dewarp(p32, ident), p32)
 
 
+@pytest.mark.parametrize("h,w,n", [(128, 1024, 3), (32, 512, 2), (9, 100, 2), (70, 130, 2), (130, 64, 1)])
+def test_dewarp_frames_matches_oracle(oracle, h, w, n):
+    """dewarp(LidarFrame / FrameSet, XYZLut, min_range, max_range) with provenance
+    (impl/dewarp_impl.h:23-115): order, counts, col/frame indices and timestamps bit-exact;
+    points within the XYZ bar."""
+    O = oracle
+    rng = np.random.default_rng(h * 31 + w)
+    cal = O.synthetic_calib(h=h, w=w, b2l_x=15.806)
+    ldir, lofs = cal.xyz_lut(True)
+    hp = HotPath("RNG15_RFL8_NIR8", h, w, 4 if w % 4 == 0 else 1)
+    hp.add_lut(cal.beam_to_lidar, cal.lut_transform(True), cal.beam_azimuth_angles,
+               cal.beam_altitude_angles)
+    r = rng.integers(0, 2 ** 17, size=(n, h, w)).astype(np.uint32)
+    r[rng.random(r.shape) < 0.3] = 0
+    status = np.ones((n, w), dtype=np.uint32)
+    status[0, :5] = 0                       # leading invalid columns
+    status[0, w - 3:] = 0                   # trailing invalid columns
+    status[0, w // 2] = 0                   # a hole
+    status[0, w // 2 + 1] = 2               # non-zero but not "valid": still emitted (status == 0 test)
+    if n > 1:
+        status[1, :] = 0                    # a frame without valid columns contributes nothing
+        status[1, 7] = 2
+    ts = (rng.integers(1, 2 ** 62, size=(n, w))).astype(np.uint64)
+    poses = np.tile(np.eye(4), (n, w, 1, 1))
+    ang = rng.uniform(-0.3, 0.3, size=(n, w))
+    poses[..., 0, 0] = np.cos(ang); poses[..., 0, 1] = -np.sin(ang)
+    poses[..., 1, 0] = np.sin(ang); poses[..., 1, 1] = np.cos(ang)
+    poses[..., :3, 3] = rng.uniform(-20, 20, size=(n, w, 3))
+    d_r, d_st = torch.from_numpy(r).cuda(), torch.from_numpy(status).cuda()
+    d_ts, d_po = torch.from_numpy(ts).cuda(), torch.from_numpy(poses).cuda()
+    for (lo, hi) in ((0.0, 1000.0), (1.0, 60.0), (0.0005, 0.0009), (50.0, 10.0)):
+        for ldt, tdt, tol in ((np.float64, torch.float64, 1e-9), (np.float32, torch.float32, 1e-4)):
+            want = [O.dewarp_frame(r[k], status[k], ts[k], poses[k], ldir.astype(ldt), lofs.astype(ldt), lo, hi)
+                    for k in range(n)]
+            offs = np.concatenate([[0], np.cumsum([len(x[0]) for x in want])]).astype(np.uint64)
+            got = hp.dewarp_frames(d_r, d_st, d_po, lo, hi, timestamp=d_ts, dtype=tdt)
+            g_off = _np(got["frame_offsets"])
+            assert np.array_equal(g_off, offs), (lo, hi)
+            tot = int(offs[-1])
+            assert np.array_equal(_np(got["col_idxs"])[:tot], np.concatenate([x[1] for x in want]))
+            assert np.array_equal(_np(got["timestamps_ns"])[:tot], np.concatenate([x[2] for x in want]))
+            assert np.array_equal(_np(got["frame_idxs"])[:tot],
+                                  np.concatenate([np.full(len(x[0]), k, np.uint32) for k, x in enumerate(want)]))
+            if tot:
+                wp = np.concatenate([x[0] for x in want]).astype(np.float64)
+                assert np.abs(_np(got["points"])[:tot].astype(np.float64) - wp).max() <= tol
+    # user-supplied f32 LUT: the reference's own XYZLutT<float> arithmetic, then the pose in f32
+    l32 = hp.add_lut_arrays(ldir.astype(np.float32), lofs.astype(np.float32))
+    got = hp.dewarp_frames(d_r, d_st, d_po, 1.0, 60.0, luts=[l32], dtype=torch.float32, provenance=False)
+    want = [O.dewarp_frame(r[k], status[k], ts[k], poses[k], ldir.astype(np.float32), lofs.astype(np.float32), 1.0, 60.0)
+            for k in range(n)]
+    tot = sum(len(x[0]) for x in want)
+    assert int(_np(got["frame_offsets"])[-1]) == tot and set(got) == {"points", "frame_offsets"}
+    wp = np.concatenate([x[0] for x in want])
+    assert np.abs(_np(got["points"])[:tot].astype(np.float64) - wp.astype(np.float64)).max() <= 3e-5  # fma vs mul+add
+    # capacity smaller than the result: offsets still complete, the prefix is intact
+    cap = max(tot // 2, 1)
+    got2 = hp.dewarp_frames(d_r, d_st, d_po, 1.0, 60.0, luts=[l32], dtype=torch.float32, provenance=False,
+                            capacity=cap)
+    assert int(_np(got2["frame_offsets"])[-1]) == tot
+    assert torch.equal(got2["points"][:cap], got["points"][:cap])
+
+
 @pytest.mark.parametrize("h,w", [(16, 100), (33, 1001), (7, 36), (128, 2048), (40, 1088)])
 def test_standalone_kernels_shapes(oracle, h, w):
     """k_cartesian_tiled / k_dewarp_tiled (W % 4 == 0: full + ragged 64-column tiles, row chunks that
