@@ -193,6 +193,10 @@ class LidarFrame {
     }
     /** true when every column in `window` has status bit 0 set */
     bool complete(ColumnWindow window) const;
+    /** first / last column with status bit 0 set (lidar_frame.cpp:907-925).
+     *  @throw std::runtime_error("No valid columns in LidarFrame") */
+    int get_first_valid_column() const;
+    int get_last_valid_column() const;
 
     bool equals(const LidarFrame& other) const;
 

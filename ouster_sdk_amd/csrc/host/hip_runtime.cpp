@@ -6,6 +6,7 @@
 // (no GPU), every entry point throws std::runtime_error.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -218,6 +219,74 @@ void dewarp_device(const void* points, const double* poses, void* out, bool f64,
                                  f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32, static_cast<uint32_t>(h),
                                  static_cast<uint32_t>(w), 1));
     d_pts.download(out, pbytes);
+}
+}  // namespace impl
+
+namespace impl {
+// dewarp(LidarFrame | FrameSet, ...) (impl/dewarp_impl.h:23-115): stage RANGE / status /
+// timestamp / body_to_world of the frames, one ouster_hip_dewarp_frames per run of frames with
+// equal dimensions, append the compacted results.
+void dewarp_frames_device(const std::vector<const LidarFrame*>& frames,
+                          const std::vector<const DeviceLut*>& luts,
+                          const std::vector<uint32_t>& frame_index, double min_range,
+                          double max_range, bool f64, std::vector<unsigned char>& points,
+                          std::vector<uint32_t>* frame_idxs, std::vector<uint32_t>* col_idxs,
+                          std::vector<uint64_t>* timestamps_ns) {
+    const size_t esz = f64 ? 24 : 12;
+    size_t i = 0;
+    while (i < frames.size()) {
+        const size_t h = frames[i]->h, w = frames[i]->w;
+        size_t j = i;
+        while (j < frames.size() && frames[j]->h == h && frames[j]->w == w) ++j;
+        const size_t n = j - i, npx = h * w;
+        hip::DeviceBuffer d_rng(n * npx * 4), d_st(n * w * 4), d_ts(n * w * 8), d_po(n * w * 128),
+            d_off((n + 1) * 8), d_pts(n * npx * esz), d_ci, d_tn;
+        if (col_idxs) d_ci.resize(n * npx * 4);
+        if (timestamps_ns) d_tn.resize(n * npx * 8);
+        std::vector<const ouster_hip_lut*> handles(n);
+        for (size_t k = 0; k < n; ++k) {
+            const LidarFrame& fr = *frames[i + k];
+            const auto range = fr.field<uint32_t>(ChanField::RANGE);
+            d_rng.upload(range.data(), npx * 4, k * npx * 4);
+            d_st.upload(fr.status().data(), w * 4, k * w * 4);
+            d_ts.upload(fr.timestamp().data(), w * 8, k * w * 8);
+            d_po.upload(fr.body_to_world().get<double>(), w * 128, k * w * 128);
+            handles[k] = luts[i + k]->handle;
+        }
+        hip::check(ouster_hip_dewarp_frames(
+            hip::default_ctx(), handles.data(), static_cast<uint32_t>(n),
+            static_cast<const uint32_t*>(d_rng.data()), static_cast<const uint32_t*>(d_st.data()),
+            static_cast<const uint64_t*>(d_ts.data()), static_cast<const double*>(d_po.data()),
+            static_cast<uint32_t>(n), min_range, max_range, f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32,
+            d_pts.data(), nullptr, static_cast<uint32_t*>(d_ci.data()),
+            static_cast<uint64_t*>(d_tn.data()), n * npx, static_cast<uint64_t*>(d_off.data())));
+        std::vector<uint64_t> off(n + 1);
+        d_off.download(off.data(), (n + 1) * 8);
+        const size_t total = off[n];
+        if (total) {
+            const size_t p0 = points.size();
+            points.resize(p0 + total * esz);
+            d_pts.download(points.data() + p0, total * esz);
+            if (col_idxs) {
+                const size_t c0 = col_idxs->size();
+                col_idxs->resize(c0 + total);
+                d_ci.download(col_idxs->data() + c0, total * 4);
+            }
+            if (timestamps_ns) {
+                const size_t t0 = timestamps_ns->size();
+                timestamps_ns->resize(t0 + total);
+                d_tn.download(timestamps_ns->data() + t0, total * 8);
+            }
+            if (frame_idxs) {  // batch-local index -> caller's FrameSet index
+                const size_t f0 = frame_idxs->size();
+                frame_idxs->resize(f0 + total);
+                for (size_t k = 0; k < n; ++k)
+                    std::fill(frame_idxs->begin() + f0 + off[k], frame_idxs->begin() + f0 + off[k + 1],
+                              frame_index[i + k]);
+            }
+        }
+        i = j;
+    }
 }
 }  // namespace impl
 

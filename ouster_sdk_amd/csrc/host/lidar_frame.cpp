@@ -213,6 +213,20 @@ bool LidarFrame::complete(ColumnWindow window) const {
     return valid(0, window.second) && valid(window.first, static_cast<int>(w) - 1);
 }
 
+int LidarFrame::get_first_valid_column() const {
+    const auto st = status();
+    for (size_t i = 0; i < w; ++i)
+        if (st[i] & 1u) return static_cast<int>(i);
+    throw std::runtime_error("No valid columns in LidarFrame");
+}
+
+int LidarFrame::get_last_valid_column() const {
+    const auto st = status();
+    for (size_t i = w; i-- > 0;)
+        if (st[i] & 1u) return static_cast<int>(i);
+    throw std::runtime_error("No valid columns in LidarFrame");
+}
+
 bool LidarFrame::equals(const LidarFrame& o) const {
     return w == o.w && h == o.h && frame_id == o.frame_id && frame_status == o.frame_status &&
            shutdown_countdown == o.shutdown_countdown &&

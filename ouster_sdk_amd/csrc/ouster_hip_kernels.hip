@@ -22,6 +22,7 @@
 // planes) vector store of a contiguous row segment.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ouster_hip_dev.h"
 
@@ -1174,30 +1175,67 @@ __global__ __launch_bounds__(256) void k_dwf_frame_scan(DewarpFramesArgs a) {
     if (tid == 0) a.frame_off[0] = 0;
 }
 
+// wave-uniform broadcast of a register of lane `src` (v_readlane_b32 with an SGPR lane select)
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src);
+}
+__device__ __forceinline__ float bcast(float v, uint32_t src) {
+    return __uint_as_float(bcast_u32(__float_as_uint(v), src));
+}
+__device__ __forceinline__ double bcast(double v, uint32_t src) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint64_t r = (uint64_t)bcast_u32((uint32_t)u, src) | ((uint64_t)bcast_u32((uint32_t)(u >> 32), src) << 32);
+    return __longlong_as_double((long long)r);
+}
+template <class T> struct __attribute__((packed, aligned(4))) Pt3 { T x, y, z; };
+
 template <class T, bool SEP>
 __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
-    constexpr int TILE = 64, LPR = 16, ROWS = 64, PITCH = TILE + 1;
+    // tile = 64 columns, rows in chunks of 64.  A wave owns 16 columns; lane l < 16 keeps the
+    // metadata of column l (output base, pose cast to T, table row, timestamp) in registers and
+    // each column iteration broadcasts it with v_readlane -- no dependent global loads and no
+    // LDS traffic in the column loop apart from the transposed range read.  Lane = row: the
+    // kept rows are ranked with a ballot and every lane stores its own 12 / 24 B point, so one
+    // store instruction writes one dense run.
+    constexpr int TILE = 64, LPR = 16, ROWS = 64, PITCH = TILE + 1, CPW = 16;
     __shared__ uint32_t s_rng[ROWS * PITCH];
-    __shared__ uint32_t s_run[TILE];
-    __shared__ T s_out[4][64 * 3];
     const uint32_t W = a.w, H = a.h, f = blockIdx.y, tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t q = tid % LPR, ty = tid / LPR;
     const uint32_t c0 = blockIdx.x * TILE;
+    const uint32_t ncol = min((uint32_t)TILE, W - c0);
     const uint32_t* rp = a.range + (size_t)f * W * H;
     const uint32_t* off = a.col_off + (size_t)f * (W + 1);
+    // nothing kept in this tile: leave before touching the range plane (uniform over the workgroup)
+    if (off[c0 + ncol] == off[c0]) return;
     const uint64_t fbase = a.frame_off[f];
     const LutDev lut = a.luts[f % a.n_luts];
     const bool vec = (W % 4 == 0) && ((((uintptr_t)a.range) & 15) == 0);
-    if (tid < TILE) s_run[tid] = 0;
-    // nothing kept in this tile: leave before touching the range plane
-    {
-        const uint32_t cl = min(W, c0 + TILE);
-        if (off[cl] == off[c0]) return;  // uniform over the workgroup
+    // column metadata: lane l of the wave holds column wave*16 + l
+    const uint32_t mj = wave * CPW + (lane & 15u), mx = c0 + mj;
+    uint32_t m_base = 0, m_cnt = 0;
+    uint64_t m_ts = 0;
+    T m_pose[12];
+    double m_col[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m_pose[k] = (T)0;
+    if (mj < ncol) {
+        m_base = off[mx];
+        m_cnt = off[mx + 1] - m_base;
+        if (m_cnt) {
+            const double* pm = a.poses + ((size_t)f * W + mx) * 16;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) m_pose[k] = (T)pm[k];
+            if constexpr (SEP) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) m_col[k] = lut.col_tab[(size_t)mx * 5 + k];
+            }
+            if (a.timestamps_ns) m_ts = a.timestamp[(size_t)f * W + mx];
+        }
     }
-    T* sc = s_out[wave];
+    uint32_t m_run = 0;  // points of column l already written (previous row chunks)
     for (uint32_t r0 = 0; r0 < H; r0 += ROWS) {
-        __syncthreads();  // previous chunk consumed (and s_run initialised)
+        __syncthreads();  // previous chunk consumed
         for (uint32_t rr = ty; rr < ROWS; rr += 16) {
             const uint32_t r = r0 + rr, col = c0 + 4 * q;
             uint32_t v[4] = {0, 0, 0, 0};
@@ -1221,28 +1259,27 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
                 for (int k = 0; k < 9; ++k) bt[k] = lut.beam_tab[(size_t)row * 9 + k];
             }
         }
-        for (uint32_t jj = 0; jj < 16; ++jj) {
-            const uint32_t j = wave * 16 + jj, x = c0 + j;  // wave-uniform
-            if (x >= W) break;
-            const uint32_t cbase = off[x];
-            if (off[x + 1] == cbase) continue;  // masked out or empty column
+        for (uint32_t jj = 0; jj < CPW; ++jj) {
+            const uint32_t j = wave * CPW + jj, x = c0 + j;  // wave-uniform
+            if (j >= ncol) break;
+            if (bcast_u32(m_cnt, jj) == 0) continue;  // masked out or empty column
             const uint32_t r = s_rng[lane * PITCH + j];
             const bool keep = row < H && r >= a.min_r && r <= a.max_r;
             const uint64_t mask = __ballot(keep);
             if (mask == 0) continue;
             const uint32_t n_keep = __popcll(mask);
             const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-            const uint32_t run = s_run[j];
-            if (keep) {
+            const uint64_t g0 = fbase + bcast_u32(m_base, jj) + bcast_u32(m_run, jj);  // first point of this run
+            const uint64_t room = g0 < a.capacity ? a.capacity - g0 : 0;
+            if (keep && rank < room) {
                 double p[3];
                 if constexpr (SEP) {
-                    const double* ct = lut.col_tab + (size_t)x * 5;
-                    const double cx = ct[0], sx = ct[1];
+                    const double cx = bcast(m_col[0], jj), sx = bcast(m_col[1], jj);
                     const double rm = (double)r - lut.n;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const double d = fma(cx, bt[k], fma(sx, bt[3 + k], bt[6 + k]));
-                        p[k] = r ? fma(rm, d, ct[2 + k]) : 0.0;
+                        p[k] = r ? fma(rm, d, bcast(m_col[2 + k], jj)) : 0.0;
                     }
                 } else {
                     const size_t pix = (size_t)row * W + x;
@@ -1251,25 +1288,24 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
                     else
                         project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs, pix, r, p);
                 }
-                const double* pm = a.poses + ((size_t)f * W + x) * 16;
                 const T px = (T)p[0], py = (T)p[1], pz = (T)p[2];
-                sc[rank * 3 + 0] = (T)pm[0] * px + (T)pm[1] * py + (T)pm[2] * pz + (T)pm[3];
-                sc[rank * 3 + 1] = (T)pm[4] * px + (T)pm[5] * py + (T)pm[6] * pz + (T)pm[7];
-                sc[rank * 3 + 2] = (T)pm[8] * px + (T)pm[9] * py + (T)pm[10] * pz + (T)pm[11];
+                Pt3<T> o;
+                o.x = bcast(m_pose[0], jj) * px + bcast(m_pose[1], jj) * py + bcast(m_pose[2], jj) * pz + bcast(m_pose[3], jj);
+                o.y = bcast(m_pose[4], jj) * px + bcast(m_pose[5], jj) * py + bcast(m_pose[6], jj) * pz + bcast(m_pose[7], jj);
+                o.z = bcast(m_pose[8], jj) * px + bcast(m_pose[9], jj) * py + bcast(m_pose[10], jj) * pz + bcast(m_pose[11], jj);
+                ((Pt3<T>*)a.points)[g0 + rank] = o;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const uint64_t g0 = fbase + cbase + run;  // first output point of this run
-            T* dst = (T*)a.points + g0 * 3;
-            const uint64_t room = g0 < a.capacity ? a.capacity - g0 : 0;
-            const uint32_t n_ok = (uint32_t)min((uint64_t)n_keep, room);
-            for (uint32_t i = lane; i < n_ok * 3; i += 64) dst[i] = sc[i];
-            if (lane < n_ok) {
+            // every point of the run carries the same provenance: dense lanes 0..n_keep-1
+            if (lane < n_keep && lane < room) {
                 if (a.col_idxs) a.col_idxs[g0 + lane] = x;
                 if (a.frame_idxs) a.frame_idxs[g0 + lane] = f;
-                if (a.timestamps_ns) a.timestamps_ns[g0 + lane] = a.timestamp[(size_t)f * W + x];
+                if (a.timestamps_ns) {
+                    const uint64_t ts = (uint64_t)bcast_u32((uint32_t)m_ts, jj) |
+                                        ((uint64_t)bcast_u32((uint32_t)(m_ts >> 32), jj) << 32);
+                    a.timestamps_ns[g0 + lane] = ts;
+                }
             }
-            if (lane == 0) s_run[j] = run + n_keep;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if ((lane & 15u) == jj) m_run += n_keep;
         }
     }
 }

@@ -462,6 +462,78 @@ static void test_dewarp() {
                                              "unexpected dimensions"));
 }
 
+// dewarp(LidarFrame | FrameSet, XYZLut, min_range, max_range): same selection, order and points
+// as "project everything, dewarp everything, then walk valid columns" (impl/dewarp_impl.h:23-115)
+static void test_frame_dewarp() {
+    std::printf("range-gated frame dewarp\n");
+    auto info = make_info(UDPProfileLidar::RNG15_RFL8_NIR8, HeaderType::STANDARD, 64, 512);
+    auto pf = std::make_shared<PacketFormat>(info);
+    FrameSet set;
+    std::vector<XYZLutT<double>> luts;
+    for (int f = 0; f < 3; ++f) {
+        auto fr = std::make_shared<LidarFrame>(info);
+        randomize(*fr, *pf, 900 + f);
+        for (size_t c = 0; c < fr->w; ++c) {
+            fr->status()[c] = (c < 7 || c > 500 || c == 100) ? 0u : 1u;
+            fr->timestamp()[c] = 1000 * (f + 1) + c;
+            double* m = fr->body_to_world().get<double>() + c * 16;
+            const double a = 0.002 * c + 0.1 * f;
+            const double mm[16] = {std::cos(a), -std::sin(a), 0, 0.01 * c, std::sin(a), std::cos(a), 0, 1.0 * f,
+                                   0, 0, 1, -0.5, 0, 0, 0, 1};
+            for (int k = 0; k < 16; ++k) m[k] = mm[k];
+        }
+        set.push_back(f == 1 ? nullptr : fr);  // index 1 is an invalid slot of the set
+        luts.emplace_back(info, true);
+    }
+    const double lo = 2.0, hi = 120.0;
+    std::vector<uint32_t> fidx, cidx;
+    std::vector<uint64_t> ts;
+    auto got = impl::dewarp_impl<double>(set, luts, lo, hi, &fidx, &cidx, &ts);
+    // expectation from the dense building blocks
+    std::vector<Vector3<double>> want;
+    std::vector<uint32_t> wf, wc;
+    std::vector<uint64_t> wt;
+    for (size_t f = 0; f < set.size(); ++f) {
+        if (!set[f]) continue;
+        const LidarFrame& fr = *set[f];
+        auto range = fr.field<uint32_t>(ChanField::RANGE);
+        PointCloudXYZd pts = luts[f](range);
+        Poses poses(fr.w, 16);
+        std::memcpy(poses.data(), fr.body_to_world().get<double>(), fr.w * 128);
+        PointCloudXYZd dw = dewarp<double>(pts, poses);
+        for (size_t c = fr.get_first_valid_column(); c <= (size_t)fr.get_last_valid_column(); ++c) {
+            if (fr.status()[c] == 0) continue;
+            for (size_t r = 0; r < fr.h; ++r) {
+                const uint32_t v = range(r, c);
+                if (v < 2000 || v > 120000) continue;
+                want.push_back({dw(r * fr.w + c, 0), dw(r * fr.w + c, 1), dw(r * fr.w + c, 2)});
+                wf.push_back(f); wc.push_back(c); wt.push_back(fr.timestamp()[c]);
+            }
+        }
+    }
+    CHECK(got.size() == want.size() && !got.empty());
+    CHECK(fidx == wf && cidx == wc && ts == wt);
+    double worst = 0;
+    for (size_t i = 0; i < std::min(got.size(), want.size()); ++i)
+        for (int k = 0; k < 3; ++k) worst = std::max(worst, std::abs(got[i][k] - want[i][k]));
+    CHECK(worst < 1e-9);
+    // single-frame overloads, float
+    XYZLutT<float> lf(luts[0]);
+    auto g32 = dewarp<float>(*set[0], lf, lo, hi);
+    auto g64 = dewarp<double>(*set[0], luts[0], lo, hi);
+    CHECK(g32.size() == g64.size() && !g32.empty());
+    float w32 = 0;
+    for (size_t i = 0; i < std::min(g32.size(), g64.size()); ++i)
+        for (int k = 0; k < 3; ++k) w32 = std::max(w32, std::abs(g32[i][k] - (float)g64[i][k]));
+    CHECK(w32 < 1e-4f);
+    // a frame without valid columns yields nothing; mismatched set/LUT sizes throw
+    LidarFrame empty(info);
+    CHECK(dewarp<double>(empty, luts[0], 0.0, 1000.0).empty());
+    luts.pop_back();
+    CHECK(throws_with<std::invalid_argument>([&] { dewarp<double>(set, luts, lo, hi); },
+                                             "Number of frames and number of XYZLuts"));
+}
+
 // device-resident batch: same results as the frame-at-a-time host API
 static void test_device_batch() {
     std::printf("DeviceFrameBatch (device resident, multi-sensor)\n");
@@ -540,6 +612,7 @@ int main() {
     test_destagger();
     test_xyzlut();
     test_dewarp();
+    test_frame_dewarp();
     test_device_batch();
     test_legacy_aliases();
     std::printf("%d checks, %d failed\n", g_checks, g_fail);

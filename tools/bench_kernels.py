@@ -53,6 +53,19 @@ def main():
     s = timeit(lambda: hp.dewarp(pts64, poses))
     res["dewarp_f64"] = {"GBps": round(2 * pts64.numel() * 8 / s / 1e9, 1),
                          "Mpoints_per_s": round(pts64.numel() / 3 / s / 1e6, 1), "ms": round(s * 1e3, 3)}
+    # range-gated compacting dewarp of whole frames (dewarp_impl.h:23-115): ~30 % zeros in the ranges
+    rz = (rng.to(torch.int64) * (torch.rand(rng.shape, device="cuda") >= 0.3)).to(torch.uint32)
+    status = torch.ones((N, W), dtype=torch.int32, device="cuda").to(torch.uint32)
+    ts = torch.arange(N * W, dtype=torch.int64, device="cuda").reshape(N, W).to(torch.uint64)
+    posesN = torch.eye(4, dtype=torch.float64, device="cuda").repeat(N, W, 1, 1).contiguous()
+    for name, prov in (("dewarp_frames_f32", False), ("dewarp_frames_f32_provenance", True)):
+        out = hp.dewarp_frames(rz, status, posesN, 0.5, 400.0, timestamp=ts if prov else None, provenance=prov, luts=[lut])
+        kept = int(out["frame_offsets"][-1].item())
+        s = timeit(lambda: hp.dewarp_frames(rz, status, posesN, 0.5, 400.0, timestamp=ts if prov else None, luts=[lut],
+                                            provenance=prov))
+        byts = npx * 4 + kept * (12 + (16 if prov else 0)) + N * W * (128 + 4)
+        res[name] = {"GBps": round(byts / s / 1e9, 1), "Mpixels_per_s": round(npx / s / 1e6, 1),
+                     "kept_fraction": round(kept / npx, 3), "ms": round(s * 1e3, 3)}
     res["note"] = f"{N} images of {H}x{W}; includes torch.empty_like of the output per call"
     print(json.dumps(res))
 
