@@ -303,6 +303,23 @@ def main():
         per += {"xyz": 2 * H * W * 12, "planes": H * W * 15, "planes+dst": H * W * 25}[args.outputs]
         bytes_per_launch = per * F
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot wrap a run from inside):
+    # only quoted when the committed profile is of exactly this workload and output set.
+    traffic, traffic_src = None, None
+    if args.workload == "dual" and args.outputs == "full":
+        import glob
+        for pj in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                "profiles", "*", "pmc_traffic.json")), reverse=True):
+            try:
+                t = json.load(open(pj))
+                if t.get("workload") == "dual" and t.get("frames_per_launch"):
+                    traffic = int(round(t["total_bytes"] * F / t["frames_per_launch"]))
+                    traffic_src = (os.path.relpath(pj, os.path.dirname(os.path.abspath(__file__))) +
+                                   f": {t['total_bytes']} B per {t['frames_per_launch']}-frame launch; " +
+                                   t.get("method", ""))
+                    break
+            except Exception:
+                pass
 
     if rank == 0:
         line = {
@@ -320,7 +337,8 @@ def main():
                          "kernel": "k_decode<SpecDualLB,64,sep-f32>" if args.workload != "single"
                          else "k_decode<SpecSingle,32,sep-f32>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel_ms_avg": round(kern_ms, 4), "launches_timed": n_launch,
                          "box_d2d_copy_GBps": round(box_copy_gbps, 1)},

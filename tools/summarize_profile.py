@@ -41,6 +41,18 @@ for (k, c), v in sorted(agg.items()):
     print(f"| `{k}` | {c} | {len(v)} | {avg:.1f} | {corr:.1f} |")
 print("\nFETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read stream, "
       "MI355X_MICROARCH.md; re-checked here on a torch 545 MB copy). Units: counters in KB.\n")
+# machine-readable per-launch traffic of the dominant kernel, read back by bench.py (roofline.traffic)
+parts = {}
+for (k, c), v in agg.items():
+    if "k_decode" in k:
+        parts[c] = sum(v) / len(v) * 1024 * (2.0 if c == "FETCH_SIZE" else 1.0)
+if len(parts) == 2:
+    json.dump({"kernel": "k_decode", "workload": "dual", "frames_per_launch": 256,
+               "fetch_bytes": round(parts["FETCH_SIZE"]), "write_bytes": round(parts["WRITE_SIZE"]),
+               "total_bytes": round(parts["FETCH_SIZE"] + parts["WRITE_SIZE"]),
+               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of "
+                         "bench.py --steps 3 --warmup 1; counters in KB; FETCH_SIZE x2 (gfx950)"},
+              open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
 for name in ("bench_under_rocprof.json", "bench_plain.json"):
     p = os.path.join(d, name)
     if os.path.exists(p) and os.path.getsize(p):
