@@ -277,6 +277,19 @@ PYBIND11_MODULE(core, m) {
             return py::array(py::dtype::of<uint8_t>(), {static_cast<py::ssize_t>(f.packet_count())},
                              f.alert_flags().data(), self);
         })
+        // per-column 4x4 poses, (w, 4, 4) float64 view (python/src/cpp/client/lidar_frame.cpp:536-559)
+        .def_property_readonly("body_to_world", [](py::object self) {
+            LidarFrame& f = self.cast<LidarFrame&>();
+            return py::array(py::dtype::of<double>(), {static_cast<py::ssize_t>(f.w), py::ssize_t(4), py::ssize_t(4)},
+                             f.body_to_world().get<double>(), self);
+        })
+        .def_property_readonly("pose", [](py::object self) {  // deprecated alias of body_to_world
+            LidarFrame& f = self.cast<LidarFrame&>();
+            return py::array(py::dtype::of<double>(), {static_cast<py::ssize_t>(f.w), py::ssize_t(4), py::ssize_t(4)},
+                             f.body_to_world().get<double>(), self);
+        })
+        .def("get_first_valid_column", &LidarFrame::get_first_valid_column)
+        .def("get_last_valid_column", &LidarFrame::get_last_valid_column)
         .def("__eq__", [](const LidarFrame& a, const LidarFrame& b) { return a == b; });
 
     py::class_<FrameBatcher>(m, "FrameBatcher")
@@ -319,6 +332,52 @@ PYBIND11_MODULE(core, m) {
             return impl::frame_to_packets(f, std::move(pf), init_id, prod_sn);
         },
         py::arg("frame"), py::arg("packet_format"), py::arg("init_id") = 0, py::arg("prod_sn") = 0);
+
+    // dewarp(points (H, W, 3), poses (W, 4, 4)) -> (H, W, 3): python/src/cpp/client/processing.cpp:132-164,
+    // dtype dispatch :300-309 (float32 stays float32, everything else is computed in float64)
+    m.def(
+        "dewarp",
+        [](const py::array& points, const py::array& poses) -> py::array {
+            if (points.ndim() != 3 || points.shape(2) != 3 || poses.ndim() != 3 || poses.shape(1) != 4 ||
+                poses.shape(2) != 4)
+                throw std::invalid_argument("dewarp: expected points (H, W, 3) and poses (W, 4, 4)");
+            if (points.shape(1) != poses.shape(0))
+                throw std::runtime_error("Number of points per set must match number of poses");
+            const size_t h = static_cast<size_t>(points.shape(0)), w = static_cast<size_t>(points.shape(1));
+            auto po = py::array_t<double, py::array::c_style | py::array::forcecast>::ensure(poses);
+            Poses pm(w, 16);
+            if (w) std::memcpy(pm.data(), po.data(), w * 16 * sizeof(double));
+            const std::vector<py::ssize_t> shape = {points.shape(0), points.shape(1), 3};
+            if (points.dtype().is(py::dtype::of<float>())) {
+                auto pt = py::array_t<float, py::array::c_style | py::array::forcecast>::ensure(points);
+                py::array_t<float> out(shape);
+                if (h * w) impl::dewarp_device(pt.data(), pm.data(), out.mutable_data(), false, h, w);
+                return std::move(out);
+            }
+            auto pt = py::array_t<double, py::array::c_style | py::array::forcecast>::ensure(points);
+            py::array_t<double> out(shape);
+            if (h * w) impl::dewarp_device(pt.data(), pm.data(), out.mutable_data(), true, h, w);
+            return std::move(out);
+        },
+        py::arg("points"), py::arg("poses"));
+
+    // extension over the reference's Python surface: the C++ dewarp(LidarFrame, XYZLut, min_range,
+    // max_range) with provenance (pose_util.h:456-485, impl/dewarp_impl.h:23-81)
+    m.def(
+        "dewarp_frame",
+        [](const LidarFrame& frame, const XYZLutT<double>& lut, double min_range, double max_range) {
+            std::vector<uint32_t> cols;
+            std::vector<uint64_t> ts;
+            auto pts = impl::dewarp_impl<double>(frame, lut, min_range, max_range, &cols, &ts);
+            py::array_t<double> p({static_cast<py::ssize_t>(pts.size()), py::ssize_t(3)});
+            if (!pts.empty()) std::memcpy(p.mutable_data(), pts.data(), pts.size() * 24);
+            py::array_t<uint32_t> c(static_cast<py::ssize_t>(cols.size()));
+            if (!cols.empty()) std::memcpy(c.mutable_data(), cols.data(), cols.size() * 4);
+            py::array_t<uint64_t> t(static_cast<py::ssize_t>(ts.size()));
+            if (!ts.empty()) std::memcpy(t.mutable_data(), ts.data(), ts.size() * 8);
+            return py::make_tuple(p, c, t);
+        },
+        py::arg("frame"), py::arg("xyzlut"), py::arg("min_range"), py::arg("max_range"));
 
     m.def("default_lidar_to_sensor", [] { return mat_to(DEFAULT_LIDAR_TO_SENSOR); });
     m.def("default_beam_to_lidar_transform", [](const std::string& p) { return mat_to(default_beam_to_lidar_transform(p)); });

@@ -167,3 +167,66 @@ def test_destagger_type_shape_and_roll(meta, dtype):
     for bad in ((0, w), (h, w + 1), (h - 1, w), (h, w - 1, 1), (h + 1, w, 2)):
         with pytest.raises(ValueError):
             core.destagger(meta, np.zeros(bad, dtype))
+
+
+def test_dewarp():
+    """python/tests/test_pose_util.py:334-359 (values and layout from the reference test)."""
+    poses = np.array([[1, 0, 0, 1, 0, 1, 0, -2, 0, 0, 1, 3, 0, 0, 0, 1] for _ in range(4)], dtype=np.float64)
+    points = np.array([[i - 3, i + 1, i + 2] for i in range(2 * 4)], dtype=np.float64)
+    poses_c = np.ascontiguousarray(poses.reshape(4, 4, 4))
+    points_c = np.ascontiguousarray(points.reshape(2, 4, 3))
+    expected = np.array([[[-2, -1, 5], [-1, 0, 6], [0, 1, 7], [1, 2, 8]],
+                         [[2, 3, 9], [3, 4, 10], [4, 5, 11], [5, 6, 12]]], dtype=np.float64)
+    out = core.dewarp(points_c, poses_c)
+    assert out.shape == (2, 4, 3) and out.dtype == np.float64
+    np.testing.assert_allclose(out, expected, rtol=1e-5, atol=1e-8)
+    out32 = core.dewarp(points_c.astype(np.float32), poses_c)
+    assert out32.dtype == np.float32
+    np.testing.assert_allclose(out32, expected, rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError, match="Number of points per set must match number of poses"):
+        core.dewarp(points_c, poses_c[:3])
+
+
+def test_frame_dewarp_against_dense_path(oracle):
+    """dewarp(frame, lut, min, max) (pose_util.h:456-485) == gate(dewarp(lut(frame), body_to_world)),
+    the composition python/src/ouster/sdk/core/frame_ops.py:102-110 uses, and == the oracle."""
+    O = oracle
+    base = "OS-0-128-U1_v2.3.0_1024x10"
+    info, cal = _meta(O, base)
+    pf = core.PacketFormat(info)
+    pk = O.lidar_packets_from_pcap(os.path.join(PCAPS, base + ".pcap"), cal.packet_format())
+    frame = core.LidarFrame(info)
+    batch = core.FrameBatcher(info)
+    for p in pk[:64]:
+        lp = core.LidarPacket(pf.lidar_packet_size)
+        lp.buf = p.tobytes()
+        lp.host_timestamp = 77
+        if batch(lp, frame):
+            break
+    else:
+        raise AssertionError("frame not completed")
+    w = frame.w
+    ang = np.linspace(0, 0.2, w)
+    b2w = frame.body_to_world
+    assert b2w.shape == (w, 4, 4) and np.array_equal(b2w[7], np.eye(4))
+    b2w[:, 0, 0] = np.cos(ang); b2w[:, 0, 1] = -np.sin(ang)
+    b2w[:, 1, 0] = np.sin(ang); b2w[:, 1, 1] = np.cos(ang)
+    b2w[:, 0, 3] = np.linspace(0, 3, w)
+    assert np.array_equal(frame.pose, b2w)
+    lut = core.XYZLut(info, False)
+    pts, cols, ts = core.dewarp_frame(frame, lut, 1.0, 80.0)
+    rng = frame.field("RANGE")
+    dense = core.dewarp(lut(frame), frame.body_to_world)
+    first, last = frame.get_first_valid_column(), frame.get_last_valid_column()
+    keep = (rng >= 1000) & (rng <= 80000) & (frame.status != 0)[None, :]
+    keep[:, :first] = False
+    keep[:, last + 1:] = False
+    vv, uu = np.nonzero(keep.T)            # column-major order: column, then row
+    assert len(pts) == len(vv) > 0
+    assert np.array_equal(cols, vv.astype(np.uint32))
+    assert np.array_equal(ts, frame.timestamp[vv])
+    assert np.abs(pts - dense[uu, vv]).max() < 1e-9
+    ldir, lofs = cal.xyz_lut(False)
+    op, oc, ot = O.dewarp_frame(rng, frame.status, frame.timestamp, frame.body_to_world.reshape(w, 16),
+                                ldir, lofs, 1.0, 80.0)
+    assert np.array_equal(oc, cols) and np.array_equal(ot, ts) and np.abs(op - pts).max() < 1e-9
