@@ -156,3 +156,42 @@ def test_float_lut_vs_double_and_extrinsics(oracle):
         O.make_xyz_lut(512, 64, 0.001, np.eye(4), np.eye(4), np.zeros(63), np.zeros(63))
     with pytest.raises(ValueError, match="lut dimensions must be greater than zero"):
         O.make_xyz_lut(0, 64, 0.001, np.eye(4), np.eye(4), np.zeros(64), np.zeros(64))
+
+
+def test_dewarp_frame_matches_dense_composition(oracle):
+    """impl/dewarp_impl.h:23-81 restated == gate(dewarp(cartesian(range))) walked column-major over
+    first_valid..last_valid (status & 1), skipping status == 0; empty for frames without valid columns."""
+    O = oracle
+    h, w = 16, 64
+    cal = O.synthetic_calib(h=h, w=w, cpp=16)
+    d, o = cal.xyz_lut(True)
+    g = np.random.default_rng(3)
+    r = g.integers(0, 60000, (h, w)).astype(np.uint32)
+    r[g.random(r.shape) < 0.25] = 0
+    st = np.ones(w, np.uint32)
+    st[:3] = 0; st[10] = 0; st[11] = 2; st[60:] = 0
+    ts = (np.arange(w) + 1000).astype(np.uint64)
+    poses = np.tile(np.eye(4), (w, 1, 1))
+    ang = g.uniform(-0.2, 0.2, w)
+    poses[:, 0, 0] = np.cos(ang); poses[:, 0, 1] = -np.sin(ang)
+    poses[:, 1, 0] = np.sin(ang); poses[:, 1, 1] = np.cos(ang)
+    poses[:, :3, 3] = g.uniform(-4, 4, (w, 3))
+    for ldt, tol in ((np.float64, 1e-12), (np.float32, 5e-5)):
+        p, c, t = O.dewarp_frame(r, st, ts, poses, d.astype(ldt), o.astype(ldt), 1.0, 30.0)
+        dense = O.dewarp(O.cartesian(r, d.astype(ldt), o.astype(ldt)), poses, h, w).reshape(h, w, 3)
+        exp, ec = [], []
+        for x in range(3, 60):
+            if st[x] == 0:
+                continue
+            for y in range(h):
+                if 1000 <= r[y, x] <= 30000:
+                    exp.append(dense[y, x]); ec.append(x)
+        assert np.array_equal(c, np.array(ec, np.uint32)) and np.array_equal(t, ts[c])
+        assert p.dtype == ldt and np.abs(p.astype(np.float64) - np.array(exp, np.float64)).max() <= tol
+    # column 11 (status 2) is inside the valid span and emitted; no valid column at all -> nothing
+    assert 11 in c
+    p, c, t = O.dewarp_frame(r, np.zeros(w, np.uint32), ts, poses, d, o, 0.0, 1000.0)
+    assert len(p) == 0 and len(c) == 0
+    # min > max and sub-millimetre windows keep nothing but zero-range... (ceil/floor of the bounds)
+    p, _, _ = O.dewarp_frame(r, st, ts, poses, d, o, 0.0005, 0.0009)
+    assert len(p) == 0
