@@ -64,6 +64,21 @@ class DeviceFrameBatch {
     void download_xyz(int return_index, uint32_t frame, void* host);
     void download_headers(uint32_t frame, uint64_t* timestamp, uint16_t* measurement_id, uint32_t* status);
 
+    /** Per-column body_to_world poses of one frame (w x 16 doubles, row-major 4x4 each; identity
+     *  until set), the input of dewarp(). */
+    void upload_poses(uint32_t frame, const double* poses_w_by_16);
+    /** Range-gated, compacting dewarp of the whole decoded batch, on the device
+     *  (core::dewarp(FrameSet, luts, min_range, max_range) with provenance, pose_util.h:475-493 /
+     *  impl/dewarp_impl.h:86-115): RANGE planes + status + poses -> world-frame points of type
+     *  float (or double with xyz_f64), frames concatenated in index order.  Needs the RANGE plane
+     *  and options.xyz (for the LUTs).  Synchronous; returns the number of points. */
+    uint64_t dewarp(double min_range, double max_range, bool provenance = false);
+    /** Results of the last dewarp(): device pointers and per-frame exclusive offsets [n_frames+1]. */
+    void* dewarped_points_device() { return d_dw_pts_.data(); }
+    const std::vector<uint64_t>& dewarped_frame_offsets() const { return dw_offsets_; }
+    /** Copy the compacted results to the host (null pointers are skipped). */
+    void download_dewarped(void* points, uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns);
+
    private:
     core::PacketFormat pf_;
     uint32_t n_frames_, h_, w_, slots_;
@@ -78,6 +93,9 @@ class DeviceFrameBatch {
     std::map<std::string, DeviceBuffer> d_planes_, d_dst_;
     DeviceBuffer d_xyz_[2];
     int xyz_field_[2] = {-1, -1};
+    DeviceBuffer d_poses_, d_dw_pts_, d_dw_fi_, d_dw_ci_, d_dw_ts_, d_dw_off_;
+    std::vector<uint64_t> dw_offsets_;
+    bool dw_prov_ = false;
 };
 
 }  // namespace hip

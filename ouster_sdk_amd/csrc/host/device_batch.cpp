@@ -148,6 +148,59 @@ void DeviceFrameBatch::download_headers(uint32_t frame, uint64_t* ts, uint16_t* 
     if (st) d_status_.download(st, static_cast<size_t>(w_) * 4, static_cast<size_t>(frame) * w_ * 4);
 }
 
+void DeviceFrameBatch::upload_poses(uint32_t frame, const double* poses) {
+    if (frame >= n_frames_) throw std::out_of_range("DeviceFrameBatch: frame index");
+    const size_t per = static_cast<size_t>(w_) * 128;
+    if (d_poses_.size() == 0) {  // identity for every column, like a fresh LidarFrame
+        std::vector<double> ident(static_cast<size_t>(n_frames_) * w_ * 16, 0.0);
+        for (size_t i = 0; i < ident.size(); i += 16) ident[i] = ident[i + 5] = ident[i + 10] = ident[i + 15] = 1.0;
+        d_poses_.resize(ident.size() * 8);
+        d_poses_.upload(ident.data(), ident.size() * 8);
+    }
+    if (poses) d_poses_.upload(poses, per, per * frame);
+}
+
+uint64_t DeviceFrameBatch::dewarp(double min_range, double max_range, bool provenance) {
+    auto rp = d_planes_.find(ChanField::RANGE);
+    if (rp == d_planes_.end() || luts_.empty())
+        throw std::invalid_argument("DeviceFrameBatch::dewarp needs the RANGE plane and options.xyz");
+    if (d_poses_.size() == 0) upload_poses(0, nullptr);
+    const size_t cap = static_cast<size_t>(n_frames_) * h_ * w_;
+    d_dw_pts_.resize(cap * (opt_.xyz_f64 ? 24 : 12));
+    d_dw_off_.resize((static_cast<size_t>(n_frames_) + 1) * 8);
+    dw_prov_ = provenance;
+    if (provenance) {
+        d_dw_fi_.resize(cap * 4);
+        d_dw_ci_.resize(cap * 4);
+        d_dw_ts_.resize(cap * 8);
+    }
+    std::vector<const ouster_hip_lut*> luts;
+    for (const auto& l : luts_) luts.push_back(l.device().handle);
+    check(ouster_hip_dewarp_frames(
+        default_ctx(), luts.data(), static_cast<uint32_t>(luts.size()),
+        static_cast<const uint32_t*>(rp->second.data()), static_cast<const uint32_t*>(d_status_.data()),
+        static_cast<const uint64_t*>(d_ts_.data()), static_cast<const double*>(d_poses_.data()), n_frames_,
+        min_range, max_range, opt_.xyz_f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32, d_dw_pts_.data(),
+        provenance ? static_cast<uint32_t*>(d_dw_fi_.data()) : nullptr,
+        provenance ? static_cast<uint32_t*>(d_dw_ci_.data()) : nullptr,
+        provenance ? static_cast<uint64_t*>(d_dw_ts_.data()) : nullptr, cap,
+        static_cast<uint64_t*>(d_dw_off_.data())));
+    dw_offsets_.resize(static_cast<size_t>(n_frames_) + 1);
+    d_dw_off_.download(dw_offsets_.data(), dw_offsets_.size() * 8);  // synchronous
+    return dw_offsets_.back();
+}
+
+void DeviceFrameBatch::download_dewarped(void* points, uint32_t* fi, uint32_t* ci, uint64_t* ts) {
+    if (dw_offsets_.empty()) throw std::logic_error("DeviceFrameBatch: dewarp() has not run");
+    const size_t n = dw_offsets_.back();
+    if (!n) return;
+    if (points) d_dw_pts_.download(points, n * (opt_.xyz_f64 ? 24 : 12));
+    if ((fi || ci || ts) && !dw_prov_) throw std::logic_error("DeviceFrameBatch: dewarp() ran without provenance");
+    if (fi) d_dw_fi_.download(fi, n * 4);
+    if (ci) d_dw_ci_.download(ci, n * 4);
+    if (ts) d_dw_ts_.download(ts, n * 8);
+}
+
 }  // namespace hip
 }  // namespace sdk
 }  // namespace ouster

@@ -588,6 +588,42 @@ static void test_device_batch() {
     std::vector<uint32_t> st(1024);
     batch.download_headers(2, nullptr, nullptr, st.data());
     CHECK(st[79] == 1 && st[80] == 0 && st[95] == 0 && st[96] == 1);
+
+    // packets -> world-frame points without leaving the device; same result as the host API on
+    // the frames the batch decoded (frame 2 lost columns 80..95)
+    std::vector<double> poses(1024 * 16, 0.0);
+    for (size_t c = 0; c < 1024; ++c) {
+        const double ang = 0.0005 * c;
+        const double m[16] = {std::cos(ang), -std::sin(ang), 0, 0.02 * c, std::sin(ang), std::cos(ang), 0, 0.5,
+                              0, 0, 1, 0, 0, 0, 0, 1};
+        std::memcpy(&poses[c * 16], m, sizeof m);
+    }
+    for (uint32_t f = 0; f < n; ++f) batch.upload_poses(f, poses.data());
+    const uint64_t total = batch.dewarp(1.0, 150.0, true);
+    CHECK(total > 0 && batch.dewarped_frame_offsets().size() == n + 1 &&
+          batch.dewarped_frame_offsets().back() == total);
+    std::vector<Vector3<float>> got(total);
+    std::vector<uint32_t> fi(total), ci(total);
+    std::vector<uint64_t> tsn(total);
+    batch.download_dewarped(got.data(), fi.data(), ci.data(), tsn.data());
+    FrameSet set;
+    std::vector<XYZLutT<float>> lf;
+    for (uint32_t f = 0; f < n; ++f) {
+        auto fr = std::make_shared<LidarFrame>(a);
+        batch.download_plane("RANGE", f, fr->field("RANGE").get());
+        batch.download_headers(f, fr->timestamp().data(), fr->measurement_id().data(), fr->status().data());
+        std::memcpy(fr->body_to_world().get<double>(), poses.data(), poses.size() * 8);
+        set.push_back(fr);
+        lf.emplace_back(luts[f % 2]);
+    }
+    std::vector<uint32_t> wfi, wci;
+    std::vector<uint64_t> wts;
+    auto want_pts = impl::dewarp_impl<float>(set, lf, 1.0, 150.0, &wfi, &wci, &wts);
+    CHECK(want_pts.size() == total && wfi == fi && wci == ci && wts == tsn);
+    float wd = 0;
+    for (size_t i = 0; i < std::min<size_t>(total, want_pts.size()); ++i)
+        for (int k = 0; k < 3; ++k) wd = std::max(wd, std::abs(got[i][k] - want_pts[i][k]));
+    CHECK(wd <= 1e-4f);  // batch: f64 tables -> f32; XYZLutT<float>: the reference's f32 LUT arithmetic
 }
 
 static void test_legacy_aliases() {
