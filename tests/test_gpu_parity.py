@@ -496,3 +496,40 @@ def test_odd_geometries(oracle, profile, h, w, cpp):
     packets, _ = O.synth_packets(cal, 3, with_window=True)
     frames = [packets[0], packets[1][::-1].copy(), packets[2][: packets.shape[1] - 2]]
     _check_decode(O, cal, frames, with_window=True, slots=packets.shape[1])
+
+
+def test_decode_is_graph_capturable(oracle):
+    """The launch sequence of ouster_hip_decode (k_colmap, k_decode, the packet_timestamp memset) is
+    stream-capturable once the LUT / offset caches are warm and packet_counts is NULL: capture it in
+    a HIP graph, replay it on new packet contents in the same buffers, compare with the oracle."""
+    O = oracle
+    cal = O.synthetic_calib(h=64, w=512, profile="RNG15_RFL8_NIR8_DUAL")
+    pk_a, _ = O.synth_packets(cal, 2, seed=5, with_window=True)
+    pk_b, src_b = O.synth_packets(cal, 2, seed=6, with_window=True)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        hp = HotPath("RNG15_RFL8_NIR8_DUAL", 64, 512, 16)
+        hp.set_pixel_shift_by_row(cal.pixel_shift_by_row)
+        hp.add_lut(cal.beam_to_lidar, cal.lut_transform(True), cal.beam_azimuth_angles,
+                   cal.beam_altitude_angles)
+        d_pk = torch.from_numpy(pk_a).cuda()
+        out = hp.alloc_outputs(2, destagger=["RANGE"], xyz=["RANGE", "RANGE2"])
+        hp.decode(d_pk, out)          # warm: uploads the offsets / LUT descriptors, cleans the map
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            hp.decode(d_pk, out)
+        d_pk.copy_(torch.from_numpy(pk_b))
+        g.replay()
+        g.replay()                     # replays leave the column map clean for the next one
+        s.synchronize()
+    torch.cuda.synchronize()
+    ldir, lofs = cal.xyz_lut(True)
+    for f in range(2):
+        want = src_b[f]                # encode -> decode identity (test_synthetic_roundtrip)
+        for name in ("RANGE", "RANGE2", "REFLECTIVITY", "NEAR_IR"):
+            assert np.array_equal(_np(out[name][f]), want.plane(name)), name
+        assert np.array_equal(_np(out["destaggered:RANGE"][f]),
+                              O.destagger(want.plane("RANGE"), cal.pixel_shift_by_row))
+        x = O.cartesian(want.plane("RANGE2"), ldir, lofs)
+        assert np.abs(_np(out["xyz:RANGE2"][f]).astype(np.float64) - x).max() <= 4e-5
