@@ -639,7 +639,37 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         const int t = atoi(e);
         if ((t == 64 || t == 32 || t == 16) && decode_lds_bytes(g, t) <= 160 * 1024) tile = t;
     }
-    da.tiles_per_frame = (W + tile - 1) / tile;
+    // wide, short tiles (k_decode_wide): TW columns x TR rows with TW*TR*chan ~ 64 KB.  Needs the
+    // 4 B granular wire layout every standard profile has and a batch large enough to fill the chip.
+    int wide = 0;
+    {
+        const uint32_t chan = g.channel_data_size;
+        int want = 256;
+        if (const char* e = getenv("OUSTER_HIP_WIDE")) want = atoi(e);
+        if ((want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 && g.col_size % 4 == 0 &&
+            packet_stride % 4 == 0 && g.packet_header_size % 4 == 0 && g.col_header_size % 4 == 0 &&
+            ((uintptr_t)packets & 3) == 0 && W >= (uint32_t)want) {
+            const uint32_t rpp = 1024u / (uint32_t)want;  // rows per pass of the 256-thread workgroup
+            uint32_t budget_kb = 64;  // LDS for the tile image
+            if (const char* e = getenv("OUSTER_HIP_WIDE_KB")) budget_kb = (uint32_t)atoi(e);
+            uint32_t tr = (budget_kb * 1024u) / ((uint32_t)want * chan);
+            tr = tr / rpp * rpp;
+            if (tr > H) tr = (H + rpp - 1) / rpp * rpp;
+            if (tr >= rpp) {
+                const uint32_t nch = (H + tr - 1) / tr, tiles = (W + want - 1) / want;
+                size_t min_blocks = 512;  // below that the narrow tiles' small-batch heuristic does better
+                if (const char* e = getenv("OUSTER_HIP_WIDE_MIN_BLOCKS")) min_blocks = (size_t)atol(e);
+                if ((size_t)n_frames * tiles * nch >= min_blocks) {
+                    wide = want;
+                    da.rows_per_tile = tr;
+                    da.row_chunks = nch;
+                    da.lds_col_slot = (tr * chan / 4 + 1) * 4;  // +1 dword: bank spread
+                    da.tiles_per_frame = tiles;
+                }
+            }
+        }
+    }
+    if (!wide) da.tiles_per_frame = (W + tile - 1) / tile;
     da.xcd_map = n_frames >= 8 ? 1u : 0u;
     if (const char* e = getenv("OUSTER_HIP_XCD")) da.xcd_map = (atoi(e) != 0 && n_frames >= 8) ? 1u : 0u;
 
@@ -655,6 +685,13 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         e1 = ctx->ev_pool[ctx->ev_used].second;
         ctx->ev_used++;
         HIP_TRY(hipEventRecord(e0, st));
+    }
+    if (wide) {
+        if (const char* e = getenv("OUSTER_HIP_DBG")) da.dbg = (uint32_t)atoi(e);
+        HIP_TRY(launch_decode_wide(da, spec, wide, xyzm, st));
+        if (e1) HIP_TRY(hipEventRecord(e1, st));
+        ctx->map_clean = false;  // several row chunks read an entry: cleared by the next call's memset
+        return OUSTER_HIP_OK;
     }
     HIP_TRY(launch_decode(da, spec, tile, xyzm, st));
     if (e1) HIP_TRY(hipEventRecord(e1, st));

@@ -56,6 +56,10 @@ struct DecodeArgs {
     uint32_t xcd_map;        // 1: blockIdx -> (frame, tile) keeps a frame on one XCD
     uint32_t vec_ok;         // W % 4 == 0 and all output bases/strides 16 B aligned
     uint32_t any_destagger;
+    uint32_t rows_per_tile;   // k_decode_wide: rows of a tile, row chunks per column tile,
+    uint32_t row_chunks;      //   bytes of one column's LDS slot (tiles_per_frame = column tiles)
+    uint32_t lds_col_slot;
+    uint32_t dbg;             // experiments: 1 = stop after staging, 2 = skip the staging loads
     int32_t* map;                // [n_frames][W]; every entry is consumed and reset to -1
     const int32_t* dst_offsets;  // [H] destination column offset per row (device)
     const LutDev* luts;          // [n_luts] (device)
@@ -133,6 +137,8 @@ const FieldC* spec_fields(int spec_id, int* nf, uint32_t* chan, int* r1, int* r2
 size_t decode_lds_bytes(const Geometry& g, int tile);
 hipError_t launch_colmap(const ColmapArgs& a, uint32_t n_frames, hipStream_t st);
 hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, hipStream_t st);
+size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_slot);
+hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, hipStream_t st);
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st);
 hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
 hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);

@@ -157,13 +157,14 @@ __device__ __forceinline__ uint64_t zero_value(uint32_t f16_nan) {
 //   batch_lidar_packet :1534-1539 (packet_timestamp / alert_flags per packet),
 //   start_frame :1709-1741 (frame meta from the first packet).
 // ------------------------------------------------------------------------------------
+template <int COLMAP_U>
 __global__ __launch_bounds__(256) void k_colmap(ColmapArgs a) {
     const uint32_t cpp = a.g.columns_per_packet;
     const uint32_t slots = a.slots_per_frame * cpp;
     const uint32_t f = blockIdx.y;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s0 = blockIdx.x * (256u * COLMAP_U) + threadIdx.x;
     const uint32_t count = a.packet_counts ? a.packet_counts[f] : a.slots_per_frame;
-    if (s == 0 && a.frame_meta) {
+    if (s0 == 0 && a.frame_meta) {
         ouster_hip_frame_meta m;
         m.frame_id = -1; m.frame_status = 0; m.shutdown_countdown = 0;
         m.shot_limiting_countdown = 0; m.n_valid_columns = 0;
@@ -185,31 +186,46 @@ __global__ __launch_bounds__(256) void k_colmap(ColmapArgs a) {
         }
         a.frame_meta[f] = m;
     }
-    if (s >= slots) return;
-    const uint32_t p = s / cpp, icol = s - p * cpp;
-    if (p >= count) return;
-    const uint8_t* pkt = a.packets + ((size_t)f * a.slots_per_frame + p) * a.packet_stride;
-    const uint8_t* col = pkt + a.g.packet_header_size + (size_t)icol * a.g.col_size;
-    const uint32_t m_id = (uint16_t)apply_bits(
-        window_global_masked(col + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask),
-        a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
-    const uint32_t status = (uint32_t)apply_bits(
-        window_global_masked(col + a.g.col_status.offset, a.g.col_status.mask), a.g.col_status.mask,
-        a.g.col_status.shift);
-    if (icol == 0) {
-        const uint32_t packet_id = m_id / cpp;
-        if (packet_id < a.n_packets_out) {
-            if (a.packet_timestamp && a.host_timestamps)
-                a.packet_timestamp[(size_t)f * a.n_packets_out + packet_id] =
-                    a.host_timestamps[(size_t)f * a.slots_per_frame + p];
-            if (a.alert_flags)
-                a.alert_flags[(size_t)f * a.n_packets_out + packet_id] = (uint8_t)apply_bits(
-                    window_global(pkt + a.g.alert_flags.offset), a.g.alert_flags.mask,
-                    a.g.alert_flags.shift);
+    // COLMAP_U column headers per thread, all loads issued before the first use: the reads are
+    // scattered 2-4 B accesses (one cache line each), so memory-level parallelism is what counts
+    const uint8_t* fpk = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
+    uint64_t w_mid[COLMAP_U], w_st[COLMAP_U];
+    uint32_t sl[COLMAP_U];
+#pragma unroll
+    for (int u = 0; u < COLMAP_U; ++u) {
+        sl[u] = s0 + (uint32_t)u * 256u;
+        const uint32_t p = sl[u] / cpp, icol = sl[u] - p * cpp;
+        w_mid[u] = w_st[u] = 0;
+        if (sl[u] < slots && p < count) {
+            const uint8_t* col = fpk + (size_t)p * a.packet_stride + a.g.packet_header_size +
+                                 (size_t)icol * a.g.col_size;
+            w_mid[u] = window_global_masked(col + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask);
+            w_st[u] = window_global_masked(col + a.g.col_status.offset, a.g.col_status.mask);
         }
     }
-    if ((status & 1u) && m_id < a.g.columns_per_frame)
-        atomicMax(&a.map[(size_t)f * a.g.columns_per_frame + m_id], (int32_t)s);
+#pragma unroll
+    for (int u = 0; u < COLMAP_U; ++u) {
+        const uint32_t p = sl[u] / cpp, icol = sl[u] - p * cpp;
+        if (sl[u] >= slots || p >= count) continue;
+        const uint32_t m_id = (uint16_t)apply_bits(w_mid[u], a.g.col_measurement_id.mask,
+                                                   a.g.col_measurement_id.shift);
+        const uint32_t status = (uint32_t)apply_bits(w_st[u], a.g.col_status.mask, a.g.col_status.shift);
+        if (icol == 0) {
+            const uint8_t* pkt = fpk + (size_t)p * a.packet_stride;
+            const uint32_t packet_id = m_id / cpp;
+            if (packet_id < a.n_packets_out) {
+                if (a.packet_timestamp && a.host_timestamps)
+                    a.packet_timestamp[(size_t)f * a.n_packets_out + packet_id] =
+                        a.host_timestamps[(size_t)f * a.slots_per_frame + p];
+                if (a.alert_flags)
+                    a.alert_flags[(size_t)f * a.n_packets_out + packet_id] = (uint8_t)apply_bits(
+                        window_global(pkt + a.g.alert_flags.offset), a.g.alert_flags.mask,
+                        a.g.alert_flags.shift);
+            }
+        }
+        if ((status & 1u) && m_id < a.g.columns_per_frame)
+            atomicMax(&a.map[(size_t)f * a.g.columns_per_frame + m_id], (int32_t)sl[u]);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -701,6 +717,321 @@ __global__ __launch_bounds__(OUSTER_DECODE_NT) void k_decode(DecodeArgs a) {
                 if constexpr (XYZM == 1) {
                     if (a.vec_ok && c0 + TILE <= W) {  // full tile: every lane of the row is here
                         store_xyz4_coalesced<LPR>(s_xyz, tid, dst - (size_t)jq * 3, q, p);
+                        continue;
+                    }
+                }
+                if (vec) store_xyz4<XT>(dst, p);
+                else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<XT>(dst + c * 3, p[c]);
+            }
+        } else if constexpr (XYZM == 3) {
+#pragma unroll
+            for (int ret = 0; ret < 2; ++ret) {
+                if (!a.xyz[ret]) continue;
+                double p[4][3];
+                for (uint32_t c = 0; c < ncol; ++c) {
+                    if (lut.full_dtype == OUSTER_HIP_F32)
+                        project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs,
+                                            rowpix + c, rng[ret][c], p[c]);
+                    else
+                        project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs,
+                                             rowpix + c, rng[ret][c], p[c]);
+                }
+                if (a.xyz_dtype == OUSTER_HIP_F32) {
+                    float* dst = (float*)a.xyz[ret] + ((size_t)f * plane_px + rowpix) * 3;
+                    if (vec) store_xyz4<float>(dst, p);
+                    else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<float>(dst + c * 3, p[c]);
+                } else {
+                    double* dst = (double*)a.xyz[ret] + ((size_t)f * plane_px + rowpix) * 3;
+                    if (vec) store_xyz4<double>(dst, p);
+                    else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<double>(dst + c * 3, p[c]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_decode_wide: the same fused decode + destagger + cartesian with WIDE, SHORT tiles:
+// a workgroup owns TW columns x TR rows (TW = 128/256/512, TW*TR*chan ~ 64 KB of LDS) instead of
+// 64 columns x all rows.  Every output row segment is then TW/64 times longer (1 KB of a u32 plane,
+// 256 B of a u8 plane, 3 KB of xyz for TW = 256), which is what HBM wants: with 64-column tiles the
+// achieved write rate swings between 3.4 and 4.9 TB/s with the physical placement of the output
+// planes (tools/storebench.hip), with 256-column tiles it stays at 5.1-6.1 TB/s.
+// The price is on the (8x smaller) input side: a column is no longer read whole but in TR-row pieces
+// (TR*chan bytes, 256 B for dual-LB at TW = 256), staged with dword loads -- one wave per column
+// piece -- into per-column LDS slots padded by one dword (bank spread for the 4-columns-per-lane
+// reads).  The row chunks of a column tile are consecutive blocks of one XCD so the shared cache
+// lines of their pieces meet in that L2.  Column headers are read directly by the first row chunk.
+// Used when W % TW == 0 and the batch is large enough; everything else runs k_decode.
+// ------------------------------------------------------------------------------------
+template <class S, int TW, int XYZM>
+__global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
+    constexpr int NT = 256;
+    constexpr int QPR = TW / 4;                    // quads (lanes) per tile row
+    constexpr int LPR = QPR < 64 ? QPR : 64;       // lanes of one wave in a row segment
+    constexpr int RPP = NT / QPR > 0 ? NT / QPR : 1;  // rows per pass (TW <= 1024)
+    static_assert(TW % 64 == 0 && QPR <= NT, "tile width");
+    extern __shared__ __align__(16) uint32_t smem[];
+
+    const uint32_t TR = a.rows_per_tile, nch = a.row_chunks;
+    const uint32_t tpf = a.tiles_per_frame * nch;  // blocks per frame
+    uint32_t f, sub;
+    if (a.xcd_map) {
+        const uint32_t xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        f = (i / tpf) * 8u + xcd;
+        sub = i % tpf;
+        if (f >= a.n_frames) return;
+    } else {
+        f = blockIdx.x / tpf;
+        sub = blockIdx.x - f * tpf;
+    }
+    const uint32_t tile = sub / nch, rc = sub - tile * nch;  // row chunks of a tile are neighbours
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = a.g.columns_per_frame, H = a.g.pixels_per_column;
+    const uint32_t cpp = a.g.columns_per_packet, col_size = a.g.col_size;
+    const uint32_t chan = S::is_static ? S::chan : a.g.channel_data_size;
+    const uint32_t hdr = a.g.col_header_size;
+    const uint32_t c0 = tile * TW, r0 = rc * TR;
+    const uint32_t nrows = min(TR, H - r0);
+    const uint32_t PD = (TR * chan) >> 2;          // dwords of one column piece
+    const uint32_t slot = a.lds_col_slot >> 2;     // LDS dwords per column (PD + pad)
+
+    uint32_t* s_tile = smem;                                  // [TW][slot]
+    uint32_t* s_colofs = smem + TW * slot + 4;                // [TW] byte offset of the column in the frame buffer
+    int32_t* s_off = (int32_t*)(s_colofs + TW);               // [TR] destagger offsets of my rows
+    float4* s_xyz = (float4*)(s_off + ((TR + 3) & ~3u));      // [4 waves][192]
+
+    // ---- phase 0: where do my columns live?
+    const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
+    for (uint32_t j = tid; j < (uint32_t)TW; j += NT) {
+        const uint32_t c = c0 + j;
+        const int32_t src = (c < W) ? a.map[(size_t)f * W + c] : -1;
+        uint32_t ofs = 0xffffffffu;
+        if (src >= 0) {
+            const uint32_t p = (uint32_t)src / cpp, ic = (uint32_t)src - p * cpp;
+            ofs = p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
+        }
+        s_colofs[j] = ofs;
+    }
+    if (a.any_destagger)
+        for (uint32_t r = tid; r < nrows; r += NT) s_off[r] = a.dst_offsets[r0 + r];
+    const LutDev lut = (XYZM != 0) ? a.luts[f % a.n_luts] : LutDev{};
+    __syncthreads();
+
+    // ---- phase 1: stage my TR-row piece of every column, dword granular (packets are 4 B granular)
+    {
+        // 16 B aligned loads that keep each column piece's own 16 B phase: chunk ch of column j is
+        // the aligned 16 B at (piece start - delta) + 16*ch; its dwords land at piece-relative
+        // positions 4*ch - delta/4 + {0..3}, those outside [0, piece) are dropped.  Thread t owns
+        // chunks t, t + NT, ...; a wave reads 1 KB of (almost) consecutive bytes per instruction.
+        const uint32_t rowofs = hdr + r0 * chan;
+        const uint32_t piece = (nrows * chan) >> 2;        // dwords of a column piece in this chunk
+        const uint32_t NCH = (piece * 4u + 15u + 15u) >> 4;  // aligned 16 B chunks that can touch it
+        const uint32_t total = TW * NCH;
+        const uint8_t* fend = fbase + (size_t)a.slots_per_frame * a.packet_stride;
+        uint32_t j = tid / NCH, ch = tid - j * NCH;
+        const uint32_t dj = NT / NCH, dc = NT - dj * NCH;
+        constexpr int DEPTH = 18;  // 256 columns x 17 chunks = 17 per thread for 256 B pieces
+        for (uint32_t base = 0; base < total; base += NT * DEPTH) {
+            u32x4 t[DEPTH];
+            int32_t p0[DEPTH];   // piece-relative dword index of t[k].x, or a value that drops all four
+            uint32_t sj[DEPTH];
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                p0[k] = -1000000;
+                sj[k] = 0;
+                t[k] = u32x4{0, 0, 0, 0};
+                if (base + k * NT + tid < total) {
+                    const uint32_t ofs = s_colofs[j];
+                    if (ofs != 0xffffffffu && a.dbg != 2) {
+                        const uint8_t* src = fbase + ofs + rowofs;
+                        const uint32_t delta = (uint32_t)((uintptr_t)src & 15u);
+                        const u32x4* q = (const u32x4*)(src - delta) + ch;
+                        if (ch * 16u < delta + piece * 4u) {
+                            if ((const uint8_t*)(q + 1) <= fend) t[k] = *q;
+                            else {  // last chunk of the frame buffer: stay inside it
+                                const uint32_t* qd = (const uint32_t*)q;
+                                for (int w = 0; w < 4; ++w)
+                                    if ((const uint8_t*)(qd + w + 1) <= fend) t[k][w] = qd[w];
+                            }
+                            p0[k] = (int32_t)(ch * 4u) - (int32_t)(delta >> 2);
+                            sj[k] = j * slot;
+                        }
+                    }
+                }
+                j += dj; ch += dc;
+                if (ch >= NCH) { ch -= NCH; ++j; }
+            }
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int32_t pp = p0[k] + w;
+                    if (pp >= 0 && pp < (int32_t)piece) s_tile[sj[k] + (uint32_t)pp] = t[k][w];
+                }
+            }
+        }
+        // missing columns and the rows past H keep whatever the LDS held: nothing reads them (vq / nrows)
+        if (tid < 4) s_tile[TW * slot + tid] = 0;  // slack read by 64-bit windows
+    }
+    __syncthreads();
+
+    if (a.dbg == 1) { if (s_tile[tid] == 0x12345678u) a.map[0] = 0; return; }
+    // ---- phase 2a: column headers, by the first row chunk, straight from the packets
+    if (rc == 0) {
+        for (uint32_t j = tid; j < (uint32_t)TW && c0 + j < W; j += NT) {
+            const uint32_t c = c0 + j, ofs = s_colofs[j];
+            const bool v = ofs != 0xffffffffu;
+            uint64_t w_ts = 0, w_st = 0;
+            if (v) {
+                const uint8_t* colp = fbase + ofs;
+                if (a.timestamp) w_ts = window_global_masked(colp + a.g.col_timestamp.offset, a.g.col_timestamp.mask);
+                if (a.status) w_st = window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask);
+            }
+            if (a.timestamp)
+                a.timestamp[(size_t)f * W + c] = v ? apply_bits(w_ts, a.g.col_timestamp.mask, a.g.col_timestamp.shift) : 0ull;
+            if (a.measurement_id) a.measurement_id[(size_t)f * W + c] = v ? (uint16_t)c : (uint16_t)0;
+            if (a.status)
+                a.status[(size_t)f * W + c] = v ? (uint32_t)apply_bits(w_st, a.g.col_status.mask, a.g.col_status.shift) : 0u;
+        }
+    }
+
+    // ---- phase 2b: pixels.  lane = (row within pass, quad of 4 consecutive columns)
+    const uint32_t q = tid % QPR, ty = tid / QPR;
+    const uint32_t jq = q * 4, col = c0 + jq;
+    if (col >= W) return;
+    uint32_t vq = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_colofs[jq + c] != 0xffffffffu) ? (1u << c) : 0u;
+    const bool vec = a.vec_ok && (col + 3 < W);
+    const uint32_t ncol = (W - col) < 4 ? (W - col) : 4;
+    const size_t plane_px = (size_t)H * W;
+    const uint32_t ql = q % LPR;                       // lane position inside its wave's row segment
+    const uint32_t seg0 = c0 + (q - ql) * 4;           // first column of that segment
+
+    double cx[4], sx[4], kc[4][3];
+    if (XYZM == 1 || XYZM == 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t cc = (col + c < W) ? col + c : W - 1;
+            const double* t = lut.col_tab + (size_t)cc * 5;
+            cx[c] = t[0]; sx[c] = t[1]; kc[c][0] = t[2]; kc[c][1] = t[3]; kc[c][2] = t[4];
+        }
+    }
+
+    for (uint32_t rrel = ty; rrel < nrows; rrel += RPP) {
+        const uint32_t r = r0 + rrel;
+        const size_t rowpix = (size_t)r * W + col;
+        uint32_t doff = 0;
+        bool dvec = false;
+        if (a.any_destagger) {
+            doff = col + (uint32_t)s_off[rrel];
+            if (doff >= W) doff -= W;
+            dvec = vec && (doff + 3 < W);
+        }
+        uint32_t rng[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+
+        if constexpr (S::is_static) {
+            constexpr int CW = S::chan / 4;
+            uint32_t w[4][CW];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t* px = s_tile + (jq + c) * slot + rrel * CW;
+#pragma unroll
+                for (int k = 0; k < CW; ++k) w[c][k] = px[k];
+            }
+            auto do_field = [&](auto kc_) {
+                constexpr int K = decltype(kc_)::value;
+                const int di = a.desc_of_spec[K];
+                if (di < 0) return;
+                uint64_t v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    v[c] = ((vq >> c) & 1) ? extract_static<S, K, CW>(w[c])
+                                           : trunc_elem(zero_value(a.f16_nan[di]), S::f[K].elem);
+                if (K == S::range_idx) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
+                if (K == S::range2_idx) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
+                constexpr uint32_t e = S::f[K].elem;
+                uint8_t* pl = (uint8_t*)a.planes[di];
+                if (pl) {
+                    uint8_t* d = pl + ((size_t)f * plane_px + rowpix) * e;
+                    if (vec) store4(d, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) store1(d + c * e, v[c], e);
+                }
+                uint8_t* dp = (uint8_t*)a.destaggered[di];
+                if (dp) {
+                    uint8_t* drow = dp + ((size_t)f * plane_px + (size_t)r * W) * e;
+                    if (dvec) store4(drow + (size_t)doff * e, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) {
+                        uint32_t dc = doff + c; if (dc >= W) dc -= W;
+                        store1(drow + (size_t)dc * e, v[c], e);
+                    }
+                }
+            };
+            [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+                (do_field(std::integral_constant<int, Ks>{}), ...);
+            }(std::make_integer_sequence<int, S::nf>{});
+        } else {
+            for (uint32_t i = 0; i < a.n_fields; ++i) {
+                const bool want_xyz = (XYZM != 0) && ((int)i == a.xyz_field[0] || (int)i == a.xyz_field[1]);
+                uint8_t* pl = (uint8_t*)a.planes[i];
+                uint8_t* dp = (uint8_t*)a.destaggered[i];
+                if (!pl && !dp && !want_xyz) continue;
+                const uint32_t e = a.elem[i];
+                uint64_t v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t bo = ((jq + c) * slot << 2) + rrel * chan + a.bits[i].offset;
+                    v[c] = ((vq >> c) & 1)
+                               ? trunc_elem(apply_bits(window_lds(s_tile, bo), a.bits[i].mask, a.bits[i].shift), e)
+                               : trunc_elem(zero_value(a.f16_nan[i]), e);
+                }
+                if ((int)i == a.xyz_field[0]) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
+                if ((int)i == a.xyz_field[1]) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
+                if (pl) {
+                    uint8_t* d = pl + ((size_t)f * plane_px + rowpix) * e;
+                    if (vec) store4(d, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) store1(d + c * e, v[c], e);
+                }
+                if (dp) {
+                    uint8_t* drow = dp + ((size_t)f * plane_px + (size_t)r * W) * e;
+                    if (dvec) store4(drow + (size_t)doff * e, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) {
+                        uint32_t dc = doff + c; if (dc >= W) dc -= W;
+                        store1(drow + (size_t)dc * e, v[c], e);
+                    }
+                }
+            }
+        }
+
+        if constexpr (XYZM == 1 || XYZM == 2) {
+            using XT = typename std::conditional<XYZM == 1, float, double>::type;
+            const double* b = lut.beam_tab + (size_t)r * 9;
+            const double u0 = b[0], u1 = b[1], u2 = b[2], v0 = b[3], v1 = b[4], v2 = b[5],
+                         w0 = b[6], w1 = b[7], w2 = b[8];
+            double d[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                d[c][0] = fma(cx[c], u0, fma(sx[c], v0, w0));
+                d[c][1] = fma(cx[c], u1, fma(sx[c], v1, w1));
+                d[c][2] = fma(cx[c], u2, fma(sx[c], v2, w2));
+            }
+#pragma unroll
+            for (int ret = 0; ret < 2; ++ret) {
+                XT* out = (XT*)a.xyz[ret];
+                if (!out) continue;
+                double p[4][3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t rr = rng[ret][c];
+                    const double rm = (double)rr - lut.n;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) p[c][k] = rr ? fma(rm, d[c][k], kc[c][k]) : 0.0;
+                }
+                XT* dst = out + ((size_t)f * plane_px + rowpix) * 3;
+                if constexpr (XYZM == 1) {
+                    if (a.vec_ok && seg0 + 4 * LPR <= W) {  // my wave's whole row segment exists
+                        store_xyz4_coalesced<LPR>(s_xyz, tid, dst - (size_t)(4 * ql) * 3, ql, p);
                         continue;
                     }
                 }
@@ -1375,10 +1706,56 @@ hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, h
     }
 }
 
+template <class S, int TW>
+static hipError_t launch_decode_wide_t(const DecodeArgs& a, int xyzm, dim3 grid, size_t lds, hipStream_t st) {
+    void (*k)(DecodeArgs) = nullptr;
+    switch (xyzm) {
+        case 0: k = k_decode_wide<S, TW, 0>; break;
+        case 1: k = k_decode_wide<S, TW, 1>; break;
+        case 2: k = k_decode_wide<S, TW, 2>; break;
+        default: k = k_decode_wide<S, TW, 3>; break;
+    }
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <class S>
+static hipError_t launch_decode_wide_s(const DecodeArgs& a, int tw, int xyzm, dim3 grid, size_t lds, hipStream_t st) {
+    switch (tw) {
+        case 128: return launch_decode_wide_t<S, 128>(a, xyzm, grid, lds, st);
+        case 512: return launch_decode_wide_t<S, 512>(a, xyzm, grid, lds, st);
+        default: return launch_decode_wide_t<S, 256>(a, xyzm, grid, lds, st);
+    }
+}
+
+size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_slot) {
+    return ((size_t)tw * (lds_col_slot >> 2) + 4 + tw + ((rows_per_tile + 3) & ~3u)) * 4 + 4 * 192 * 16;
+}
+
+hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, hipStream_t st) {
+    const uint32_t bpf = a.tiles_per_frame * a.row_chunks;
+    const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * bpf : a.n_frames * bpf;
+    const dim3 grid(nblocks);
+    const size_t lds = decode_wide_lds_bytes(tw, a.rows_per_tile, a.lds_col_slot);
+    switch (spec_id) {
+        case SPEC_DUAL_LB: return launch_decode_wide_s<SpecDualLB>(a, tw, xyzm, grid, lds, st);
+        case SPEC_LB: return launch_decode_wide_s<SpecLB>(a, tw, xyzm, grid, lds, st);
+        case SPEC_SINGLE: return launch_decode_wide_s<SpecSingle>(a, tw, xyzm, grid, lds, st);
+        case SPEC_DUAL: return launch_decode_wide_s<SpecDual>(a, tw, xyzm, grid, lds, st);
+        case SPEC_LEGACY: return launch_decode_wide_s<SpecLegacy>(a, tw, xyzm, grid, lds, st);
+        default: return launch_decode_wide_s<SpecGeneric>(a, tw, xyzm, grid, lds, st);
+    }
+}
+
 hipError_t launch_colmap(const ColmapArgs& a, uint32_t n_frames, hipStream_t st) {
     const uint32_t slots = a.slots_per_frame * a.g.columns_per_packet;
-    dim3 grid((slots + 255) / 256, n_frames);
-    hipLaunchKernelGGL(k_colmap, grid, dim3(256), 0, st, a);
+    constexpr int U = 4;  // column headers per thread (1/2/4/8 measured within 1 us of each other)
+    dim3 grid((slots + 256 * U - 1) / (256 * U), n_frames);
+    hipLaunchKernelGGL(k_colmap<U>, grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

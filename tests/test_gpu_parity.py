@@ -533,3 +533,34 @@ def test_decode_is_graph_capturable(oracle):
                               O.destagger(want.plane("RANGE"), cal.pixel_shift_by_row))
         x = O.cartesian(want.plane("RANGE2"), ldir, lofs)
         assert np.abs(_np(out["xyz:RANGE2"][f]).astype(np.float64) - x).max() <= 4e-5
+
+
+@pytest.mark.parametrize("tw", [128, 256, 512])
+@pytest.mark.parametrize("profile,h,w,hdr", [
+    ("RNG15_RFL8_NIR8_DUAL", 128, 2048, 0),        # the metric profile: 2 or 4 row chunks per tile
+    ("RNG19_RFL8_SIG16_NIR16", 128, 1024, 0),      # 12 B/px: rows per tile not a power of two
+    ("RNG19_RFL8_SIG16_NIR16_DUAL", 64, 1024, 0),
+    ("LEGACY", 64, 1024, 0),
+    ("FIVE_WORD_PIXEL", 32, 512, 0),               # generic descriptors, 20 B/px
+    ("RNG15_RFL8_NIR8", 30, 1000, 0),              # ragged last tile, W % 64 != 0, short last row chunk
+])
+def test_wide_tiles_match_oracle(oracle, monkeypatch, tw, profile, h, w, hdr):
+    """k_decode_wide (TW columns x TR rows tiles, row-chunked staging) forced for small batches:
+    same results as the oracle, incl. dropped packets / invalid columns."""
+    O = oracle
+    monkeypatch.setenv("OUSTER_HIP_WIDE", str(tw))
+    monkeypatch.setenv("OUSTER_HIP_WIDE_MIN_BLOCKS", "0")
+    cpp = 8 if w == 1000 else 16
+    cal = O.synthetic_calib(h=h, w=w, cpp=cpp, profile=profile, header_type=hdr)
+    packets, src = O.synth_packets(cal, 9, with_window=True)
+    by_frame = [packets[f] for f in range(9)]
+    by_frame[3] = np.delete(by_frame[3], [2, 7], axis=0)          # two dropped packets
+    pf = cal.packet_format()
+    if hdr == 0 and profile != "LEGACY":   # invalid columns: clear status bit 0 (packet_format_test.cpp:374-382)
+        bad = by_frame[5].copy()
+        for c in (0, 3, cpp - 1):
+            bad[1, pf.packet_header_size + c * pf.col_size + 10] &= 0xFE
+        by_frame[5] = bad
+    by_frame[6] = by_frame[6][::-1].copy()                         # reversed order
+    err = _check_decode(O, cal, by_frame, with_window=True)
+    assert err <= (6.2e-5 if profile == "LEGACY" else 4e-5)
