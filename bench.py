@@ -233,6 +233,10 @@ def main():
     barrier()
     t1 = time.perf_counter()
     kern_ms, n_launch = hp.ctx.timing_read()
+    tc, tr = hp.ctx.last_decode_tile()
+    spec_name = "SpecSingle" if args.workload == "single" else "SpecDualLB"
+    kernel_name = (f"k_decode_wide<{spec_name},{tc},sep-f32> ({tc}x{tr} tiles)" if tr < H
+                   else f"k_decode<{spec_name},{tc},sep-f32> ({tc}x{tr} tiles)")
     hp.ctx.timing(False)
 
     # context for the roofline: what a plain device-to-device copy reaches on THIS box right now
@@ -334,8 +338,7 @@ def main():
                        if args.outputs == "full" else "ABLATION:" + args.outputs,
                        "sharding": f"frames x{world}, no data-path collective"},
             "roofline": {"bound": "hbm",
-                         "kernel": "k_decode<SpecDualLB,64,sep-f32>" if args.workload != "single"
-                         else "k_decode<SpecSingle,32,sep-f32>",
+                         "kernel": kernel_name,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,

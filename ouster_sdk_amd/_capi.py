@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "ouster_hip_last_error", "ouster_hip_version", "ouster_hip_format_create",
     "ouster_hip_format_destroy", "ouster_hip_lut_create", "ouster_hip_lut_create_from_arrays",
     "ouster_hip_lut_export", "ouster_hip_lut_destroy", "ouster_hip_decode", "ouster_hip_destagger",
-    "ouster_hip_cartesian", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_timing_enable", "ouster_hip_timing_read",
+    "ouster_hip_cartesian", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_timing_enable", "ouster_hip_timing_read", "ouster_hip_last_decode_tile",
 ]
 
 _hip = None
@@ -122,6 +122,7 @@ def load_hip():
                                            C.c_double, C.c_int, vp, vp, vp, vp, C.c_uint64, vp]
     L.ouster_hip_timing_enable.argtypes = [vp, C.c_int]
     L.ouster_hip_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.ouster_hip_last_decode_tile.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _hip = L
     return L
 
@@ -215,6 +216,11 @@ class Context:
 
     def timing(self, on: bool):
         check(self.L.ouster_hip_timing_enable(self.h, int(on)))
+
+    def last_decode_tile(self) -> Tuple[int, int]:
+        c, r = C.c_int(), C.c_int()
+        check(self.L.ouster_hip_last_decode_tile(self.h, C.byref(c), C.byref(r)))
+        return c.value, r.value
 
     def timing_read(self) -> Tuple[float, int]:
         ms = C.c_double()

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -75,6 +76,16 @@ struct ouster_hip_ctx {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
+    // k_decode variant (64-column tiles / wide tiles of 128 or 256 columns) per workload, picked by
+    // timing each candidate once on the first calls: which one is faster depends on how the output
+    // planes happen to be placed in HBM
+    struct Tune {
+        int best = -2;  // -2: still measuring; 0: narrow; 128 / 256: wide
+        int calls = 0;
+        hipEvent_t ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    };
+    std::map<uint64_t, Tune> tune;
+    int last_tile_cols = 0, last_tile_rows = 0;  // tile of the last k_decode launch
 };
 
 struct ouster_hip_format {
@@ -252,6 +263,10 @@ void ouster_hip_ctx_destroy(ouster_hip_ctx* c) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
     }
+    for (auto& kv : c->tune)
+        for (auto& pr : kv.second.ev)
+            for (hipEvent_t e : pr)
+                if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -641,35 +656,79 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     }
     // wide, short tiles (k_decode_wide): TW columns x TR rows with TW*TR*chan ~ 64 KB.  Needs the
     // 4 B granular wire layout every standard profile has and a batch large enough to fill the chip.
-    int wide = 0;
-    {
+    const uint32_t narrow_tiles = (W + tile - 1) / tile;
+    auto setup_wide = [&](int want) -> bool {
         const uint32_t chan = g.channel_data_size;
-        int want = 256;
-        if (const char* e = getenv("OUSTER_HIP_WIDE")) want = atoi(e);
-        if ((want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 && g.col_size % 4 == 0 &&
-            packet_stride % 4 == 0 && g.packet_header_size % 4 == 0 && g.col_header_size % 4 == 0 &&
-            ((uintptr_t)packets & 3) == 0 && W >= (uint32_t)want) {
-            const uint32_t rpp = 1024u / (uint32_t)want;  // rows per pass of the 256-thread workgroup
-            uint32_t budget_kb = 64;  // LDS for the tile image
-            if (const char* e = getenv("OUSTER_HIP_WIDE_KB")) budget_kb = (uint32_t)atoi(e);
-            uint32_t tr = (budget_kb * 1024u) / ((uint32_t)want * chan);
-            tr = tr / rpp * rpp;
-            if (tr > H) tr = (H + rpp - 1) / rpp * rpp;
-            if (tr >= rpp) {
-                const uint32_t nch = (H + tr - 1) / tr, tiles = (W + want - 1) / want;
-                size_t min_blocks = 512;  // below that the narrow tiles' small-batch heuristic does better
-                if (const char* e = getenv("OUSTER_HIP_WIDE_MIN_BLOCKS")) min_blocks = (size_t)atol(e);
-                if ((size_t)n_frames * tiles * nch >= min_blocks) {
-                    wide = want;
-                    da.rows_per_tile = tr;
-                    da.row_chunks = nch;
-                    da.lds_col_slot = (tr * chan / 4 + 1) * 4;  // +1 dword: bank spread
-                    da.tiles_per_frame = tiles;
-                }
+        if (!((want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 && g.col_size % 4 == 0 &&
+              packet_stride % 4 == 0 && g.packet_header_size % 4 == 0 && g.col_header_size % 4 == 0 &&
+              ((uintptr_t)packets & 3) == 0 && W >= (uint32_t)want))
+            return false;
+        const uint32_t rpp = 1024u / (uint32_t)want;  // rows per pass of the 256-thread workgroup
+        uint32_t budget_kb = 64;                       // LDS for the tile image
+        if (const char* e = getenv("OUSTER_HIP_WIDE_KB")) budget_kb = (uint32_t)atoi(e);
+        uint32_t tr = (budget_kb * 1024u) / ((uint32_t)want * chan);
+        tr = tr / rpp * rpp;
+        if (tr > H) tr = (H + rpp - 1) / rpp * rpp;
+        if (tr < rpp) return false;
+        const uint32_t nch = (H + tr - 1) / tr, tiles = (W + want - 1) / want;
+        size_t min_blocks = 512;  // below that the narrow tiles' small-batch heuristic does better
+        if (const char* e = getenv("OUSTER_HIP_WIDE_MIN_BLOCKS")) min_blocks = (size_t)atol(e);
+        if ((size_t)n_frames * tiles * nch < min_blocks) return false;
+        da.rows_per_tile = tr;
+        da.row_chunks = nch;
+        da.lds_col_slot = (tr * chan / 4 + 1) * 4;  // +1 dword: bank spread
+        da.tiles_per_frame = tiles;
+        return true;
+    };
+    int wide = 0;
+    ouster_hip_ctx::Tune* tuning = nullptr;
+    int tune_slot = -1;
+    if (const char* e = getenv("OUSTER_HIP_WIDE")) {  // forced (experiments, tests)
+        const int want = atoi(e);
+        if (want && setup_wide(want)) wide = want;
+    } else if (setup_wide(256)) {
+        wide = 256;
+        const char* te = getenv("OUSTER_HIP_TUNE");
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (!(te && atoi(te) == 0) && cap == hipStreamCaptureStatusNone) {
+            uint64_t key = 1469598103934665603ull;
+            auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+            mix((uint64_t)spec); mix(W); mix(H); mix(g.channel_data_size); mix(n_frames); mix((uint64_t)xyzm);
+            uint64_t pm = 0, dm = 0;
+            for (uint32_t i = 0; i < nf; ++i) {
+                pm |= da.planes[i] ? (1ull << i) : 0;
+                dm |= da.destaggered[i] ? (1ull << i) : 0;
             }
+            mix(pm); mix(dm); mix((da.xyz[0] ? 1u : 0u) | (da.xyz[1] ? 2u : 0u));
+            ouster_hip_ctx::Tune& t = ctx->tune[key];
+            static const int cand[3] = {256, 128, 0};
+            if (t.best == -2 && t.calls >= 3) {  // every candidate has run once: read the clocks
+                float best_ms = 0;
+                for (int c = 0; c < 3; ++c) {
+                    float ms = 0;
+                    if (hipEventSynchronize(t.ev[c][1]) != hipSuccess ||
+                        hipEventElapsedTime(&ms, t.ev[c][0], t.ev[c][1]) != hipSuccess)
+                        continue;
+                    if (t.best == -2 || ms < best_ms) { t.best = cand[c]; best_ms = ms; }
+                }
+                if (t.best == -2) t.best = 256;
+            }
+            if (t.best != -2) {
+                wide = t.best;
+            } else {
+                tune_slot = t.calls % 3;
+                wide = cand[tune_slot];
+                tuning = &t;
+                ++t.calls;
+            }
+            if (wide && !setup_wide(wide)) wide = (setup_wide(256) ? 256 : 0);
         }
     }
-    if (!wide) da.tiles_per_frame = (W + tile - 1) / tile;
+    if (!wide) {
+        da.rows_per_tile = da.row_chunks = da.lds_col_slot = 0;
+        da.tiles_per_frame = narrow_tiles;
+    }
     da.xcd_map = n_frames >= 8 ? 1u : 0u;
     if (const char* e = getenv("OUSTER_HIP_XCD")) da.xcd_map = (atoi(e) != 0 && n_frames >= 8) ? 1u : 0u;
 
@@ -686,14 +745,25 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         ctx->ev_used++;
         HIP_TRY(hipEventRecord(e0, st));
     }
+    if (tuning) {
+        for (int k = 0; k < 2; ++k)
+            if (!tuning->ev[tune_slot][k]) HIP_TRY(hipEventCreate(&tuning->ev[tune_slot][k]));
+        HIP_TRY(hipEventRecord(tuning->ev[tune_slot][0], st));
+    }
     if (wide) {
         if (const char* e = getenv("OUSTER_HIP_DBG")) da.dbg = (uint32_t)atoi(e);
         HIP_TRY(launch_decode_wide(da, spec, wide, xyzm, st));
+        ctx->last_tile_cols = wide;
+        ctx->last_tile_rows = (int)da.rows_per_tile;
+        if (tuning) HIP_TRY(hipEventRecord(tuning->ev[tune_slot][1], st));
         if (e1) HIP_TRY(hipEventRecord(e1, st));
         ctx->map_clean = false;  // several row chunks read an entry: cleared by the next call's memset
         return OUSTER_HIP_OK;
     }
     HIP_TRY(launch_decode(da, spec, tile, xyzm, st));
+    ctx->last_tile_cols = tile;
+    ctx->last_tile_rows = (int)H;
+    if (tuning) HIP_TRY(hipEventRecord(tuning->ev[tune_slot][1], st));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
     ctx->map_clean = true;  // every entry k_colmap wrote has been read back and reset
     return OUSTER_HIP_OK;
@@ -830,6 +900,13 @@ int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* l
     a.timestamps_ns = timestamps_ns;
     a.capacity = capacity;
     HIP_TRY(launch_dewarp_frames(a, luts[0]->separable, ctx->stream));
+    return OUSTER_HIP_OK;
+}
+
+int ouster_hip_last_decode_tile(ouster_hip_ctx* ctx, int* tile_cols, int* tile_rows) {
+    if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (tile_cols) *tile_cols = ctx->last_tile_cols;
+    if (tile_rows) *tile_rows = ctx->last_tile_rows;
     return OUSTER_HIP_OK;
 }
 
