@@ -317,10 +317,11 @@ def main():
             try:
                 t = json.load(open(pj))
                 if t.get("workload") == "dual" and t.get("frames_per_launch"):
-                    traffic = int(round(t["total_bytes"] * F / t["frames_per_launch"]))
+                    v = t.get("variants_by_tile_columns", {}).get(str(tc), t)  # the variant that ran here
+                    traffic = int(round(v["total_bytes"] * F / t["frames_per_launch"]))
                     traffic_src = (os.path.relpath(pj, os.path.dirname(os.path.abspath(__file__))) +
-                                   f": {t['total_bytes']} B per {t['frames_per_launch']}-frame launch; " +
-                                   t.get("method", ""))
+                                   f": {v['total_bytes']} B per {t['frames_per_launch']}-frame launch of " +
+                                   f"{v.get('kernel', t.get('kernel'))}; " + t.get("method", ""))
                     break
             except Exception:
                 pass

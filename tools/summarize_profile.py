@@ -3,6 +3,7 @@
 import csv
 import json
 import os
+import re
 import sys
 
 d = sys.argv[1]
@@ -18,7 +19,7 @@ print("Command: `python bench.py --steps 20 --warmup 3 --no-cpu` (kernel trace);
 print("## kernel stats (rocprofv3 --kernel-trace --stats)\n")
 print("| kernel | calls | avg us | min us | max us | % |")
 print("|---|---|---|---|---|---|")
-for r in rows(os.path.join(d, "trace", "bench_kernel_stats.csv"))[:6]:
+for r in rows(os.path.join(d, "trace", "bench_kernel_stats.csv"))[:8]:
     name = r["Name"].split("(")[0][-70:]
     print(f"| `{name}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
           f"{float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
@@ -26,7 +27,7 @@ print("\n## HBM traffic per launch (separate --pmc passes)\n")
 agg = {}
 for c in ("pmc_fetch", "pmc_write"):
     for r in rows(os.path.join(d, c, "bench_counter_collection.csv")):
-        k = (r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])
+        k = (r["Kernel_Name"].split("(")[0][-75:], r["Counter_Name"])
         agg.setdefault(k, []).append(float(r["Counter_Value"]))
 print("| kernel | counter | launches | avg KB (raw) | MB corrected |")
 print("|---|---|---|---|---|")
@@ -42,12 +43,26 @@ for (k, c), v in sorted(agg.items()):
 print("\nFETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read stream, "
       "MI355X_MICROARCH.md; re-checked here on a torch 545 MB copy). Units: counters in KB.\n")
 # machine-readable per-launch traffic of the dominant kernel, read back by bench.py (roofline.traffic)
+# (the variant the tuner settled on = the decode kernel with the most launches)
+dom = None
+for (k, c), v in agg.items():
+    if "k_decode" in k and c == "WRITE_SIZE" and (dom is None or len(v) > len(agg[(dom, c)])):
+        dom = k
 parts = {}
 for (k, c), v in agg.items():
-    if "k_decode" in k:
+    if k == dom:
         parts[c] = sum(v) / len(v) * 1024 * (2.0 if c == "FETCH_SIZE" else 1.0)
+variants = {}
+for (k, c), v in agg.items():
+    m = re.search(r"k_decode(?:_wide)?<[^,]+, (\d+),", k)
+    if m:
+        variants.setdefault(m.group(1), {"kernel": k.strip(), "fetch_bytes": 0, "write_bytes": 0})
+        key = "fetch_bytes" if c == "FETCH_SIZE" else "write_bytes"
+        variants[m.group(1)][key] = round(sum(v) / len(v) * 1024 * (2.0 if c == "FETCH_SIZE" else 1.0))
+for v in variants.values():
+    v["total_bytes"] = v["fetch_bytes"] + v["write_bytes"]
 if len(parts) == 2:
-    json.dump({"kernel": "k_decode", "workload": "dual", "frames_per_launch": 256,
+    json.dump({"kernel": dom.strip(), "workload": "dual", "frames_per_launch": 256, "variants_by_tile_columns": variants,
                "fetch_bytes": round(parts["FETCH_SIZE"]), "write_bytes": round(parts["WRITE_SIZE"]),
                "total_bytes": round(parts["FETCH_SIZE"] + parts["WRITE_SIZE"]),
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of "
@@ -65,7 +80,7 @@ for name in ("bench_under_rocprof.json", "bench_plain.json"):
                   f"box d2d copy {rf.get('box_d2d_copy_GBps')} GB/s\n")
             for k, t in tot.items():
                 if "k_decode" in k:
-                    print(f"k_decode HBM traffic (PMC) {t:.1f} MB/launch = "
+                    print(f"`{k.strip()}` HBM traffic (PMC) {t:.1f} MB/launch = "
                           f"{t*1e6/rf['algorithmic_bytes_per_launch']:.3f} x algorithmic\n")
             if j.get("cpu_baseline"):
                 print(f"cpu_baseline: {json.dumps(j['cpu_baseline'])}\n")
