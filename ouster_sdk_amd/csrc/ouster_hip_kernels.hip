@@ -1226,10 +1226,10 @@ __device__ __forceinline__ void project_full4(const LT (&dir)[12], const LT (&of
     }
 }
 
-template <int MODE>
+template <int MODE, int TILE>
 __global__ __launch_bounds__(256) void k_cartesian_tiled(CartesianArgs a) {
-    constexpr int TILE = 64, LPR = 16, RPP = 16;
-    __shared__ float4 s_xyz[16 * 6 * LPR];  // one 6-chunk scratch per lane-row
+    constexpr int LPR = TILE / 4, RPP = 256 / LPR;
+    __shared__ float4 s_xyz[RPP * 6 * LPR];  // one 6-chunk scratch per lane-row
     const uint32_t W = a.w, H = a.h;
     const uint32_t tiles = (W + TILE - 1) / TILE;
     const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
@@ -1336,11 +1336,11 @@ __global__ __launch_bounds__(256) void k_cartesian_tiled(CartesianArgs a) {
 // k_dewarp_tiled: p' = R_col * p + t_col (pose_util.h:38-56) with the k_decode lane mapping:
 // each lane keeps the 3x4 poses of its 4 columns in registers for the whole row loop.
 // ------------------------------------------------------------------------------------
-template <class T>
+template <class T, int TILE>
 __global__ __launch_bounds__(256) void k_dewarp_tiled(DewarpArgs a) {
-    constexpr int TILE = 64, LPR = 16, RPP = 16;
+    constexpr int LPR = TILE / 4, RPP = 256 / LPR;
     constexpr int NV = 3 * sizeof(T) / 4;  // 16 B chunks per lane quad: 3 (f32) or 6 (f64)
-    __shared__ float4 s_xyz[16 * NV * LPR];
+    __shared__ float4 s_xyz[RPP * NV * LPR];
     const uint32_t W = a.w, H = a.h;
     const uint32_t tiles = (W + TILE - 1) / TILE;
     const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
@@ -1765,20 +1765,38 @@ hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream
     return hipGetLastError();
 }
 
+// tile width of the standalone tiled kernels.  Unlike the 14-stream k_decode these one/two-stream
+// kernels gain nothing from 256-column tiles (same-box A/B: equal for f32, 5-10 % slower for f64 and
+// full-LUT), so 64 stays the default; OUSTER_HIP_CT_TILE=256 is kept for experiments.
+static uint32_t standalone_tile_width(uint32_t w) {
+    static const int env = [] { const char* e = getenv("OUSTER_HIP_CT_TILE"); return e ? atoi(e) : 0; }();
+    (void)w;
+    return env == 256 ? 256u : 64u;
+}
+
 hipError_t launch_cartesian(const CartesianArgs& a_in, int mode, hipStream_t st) {
     CartesianArgs a = a_in;
     if (a.vec_ok && a.w % 4 == 0) {
         // enough workgroups to fill the chip: split the rows when the batch is small
-        const uint32_t tiles = (a.w + 63) / 64;
+        const uint32_t tw = standalone_tile_width(a.w);
+        const uint32_t tiles = (a.w + tw - 1) / tw;
         uint32_t rpb = a.h;
         while (rpb > 16 && (size_t)tiles * a.n_images * ((a.h + rpb - 1) / rpb) < 1024) rpb = (rpb + 1) / 2;
         rpb = (rpb + 15) / 16 * 16;
         a.rows_per_block = rpb;
         dim3 grid(tiles * ((a.h + rpb - 1) / rpb), a.n_images);
-        switch (mode) {
-            case 1: hipLaunchKernelGGL(k_cartesian_tiled<1>, grid, dim3(256), 0, st, a); break;
-            case 2: hipLaunchKernelGGL(k_cartesian_tiled<2>, grid, dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL(k_cartesian_tiled<3>, grid, dim3(256), 0, st, a); break;
+        if (tw == 256) {
+            switch (mode) {
+                case 1: hipLaunchKernelGGL((k_cartesian_tiled<1, 256>), grid, dim3(256), 0, st, a); break;
+                case 2: hipLaunchKernelGGL((k_cartesian_tiled<2, 256>), grid, dim3(256), 0, st, a); break;
+                default: hipLaunchKernelGGL((k_cartesian_tiled<3, 256>), grid, dim3(256), 0, st, a); break;
+            }
+        } else {
+            switch (mode) {
+                case 1: hipLaunchKernelGGL((k_cartesian_tiled<1, 64>), grid, dim3(256), 0, st, a); break;
+                case 2: hipLaunchKernelGGL((k_cartesian_tiled<2, 64>), grid, dim3(256), 0, st, a); break;
+                default: hipLaunchKernelGGL((k_cartesian_tiled<3, 64>), grid, dim3(256), 0, st, a); break;
+            }
         }
         return hipGetLastError();
     }
@@ -1798,14 +1816,20 @@ hipError_t launch_cartesian(const CartesianArgs& a_in, int mode, hipStream_t st)
 hipError_t launch_dewarp(const DewarpArgs& a_in, hipStream_t st) {
     DewarpArgs a = a_in;
     if (a.w % 4 == 0 && (((uintptr_t)a.points | (uintptr_t)a.out) & 15) == 0) {
-        const uint32_t tiles = (a.w + 63) / 64;
+        const uint32_t tw = standalone_tile_width(a.w);
+        const uint32_t tiles = (a.w + tw - 1) / tw;
         uint32_t rpb = a.h;
         while (rpb > 16 && (size_t)tiles * a.n_images * ((a.h + rpb - 1) / rpb) < 1024) rpb = (rpb + 1) / 2;
         rpb = (rpb + 15) / 16 * 16;
         a.rows_per_block = rpb;
         dim3 grid(tiles * ((a.h + rpb - 1) / rpb), a.n_images);
-        if (a.dtype == OUSTER_HIP_F32) hipLaunchKernelGGL(k_dewarp_tiled<float>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_dewarp_tiled<double>, grid, dim3(256), 0, st, a);
+        if (tw == 256) {
+            if (a.dtype == OUSTER_HIP_F32) hipLaunchKernelGGL((k_dewarp_tiled<float, 256>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_dewarp_tiled<double, 256>), grid, dim3(256), 0, st, a);
+        } else {
+            if (a.dtype == OUSTER_HIP_F32) hipLaunchKernelGGL((k_dewarp_tiled<float, 64>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_dewarp_tiled<double, 64>), grid, dim3(256), 0, st, a);
+        }
         return hipGetLastError();
     }
     const size_t total = (size_t)a.w * a.h * a.n_images;
