@@ -760,8 +760,8 @@ __global__ __launch_bounds__(OUSTER_DECODE_NT) void k_decode(DecodeArgs a) {
 // The price is on the (8x smaller) input side: a column is no longer read whole but in TR-row pieces
 // (TR*chan bytes, 256 B for dual-LB at TW = 256), staged with dword loads -- one wave per column
 // piece -- into per-column LDS slots padded by one dword (bank spread for the 4-columns-per-lane
-// reads).  The row chunks of a column tile are consecutive blocks of one XCD so the shared cache
-// lines of their pieces meet in that L2.  Column headers are read directly by the first row chunk.
+// reads).  The column tiles of one row chunk are consecutive blocks of one XCD, so neighbouring
+// workgroups write whole rows together.  Column headers are read directly by the first row chunk.
 // Used when W % TW == 0 and the batch is large enough; everything else runs k_decode.
 // ------------------------------------------------------------------------------------
 template <class S, int TW, int XYZM>
@@ -785,7 +785,11 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
         f = blockIdx.x / tpf;
         sub = blockIdx.x - f * tpf;
     }
-    const uint32_t tile = sub / nch, rc = sub - tile * nch;  // row chunks of a tile are neighbours
+    // the column tiles of one row chunk are neighbouring blocks of an XCD: together they write whole
+    // 8 KB rows at the same time (dbg 3, experiment: the row chunks of a column tile are neighbours
+    // instead, which shares input cache lines but measured 6 % slower)
+    const uint32_t tile = a.dbg == 3 ? sub / nch : sub % a.tiles_per_frame;
+    const uint32_t rc = a.dbg == 3 ? sub - tile * nch : sub / a.tiles_per_frame;
     const uint32_t tid = threadIdx.x;
     const uint32_t W = a.g.columns_per_frame, H = a.g.pixels_per_column;
     const uint32_t cpp = a.g.columns_per_packet, col_size = a.g.col_size;
