@@ -276,7 +276,7 @@ int ouster_hip_timing_enable(ouster_hip_ctx* ctx, int on);
 int ouster_hip_timing_read(ouster_hip_ctx* ctx, double* avg_ms, uint32_t* n_launches);
 /* Tile (columns x rows) of the decode kernel variant the last ouster_hip_decode launched: 64/32/16
  * columns x all rows (k_decode) or 128/256 columns x a row chunk (k_decode_wide).  The variant is
- * picked per workload by timing each candidate once on the first calls (OUSTER_HIP_TUNE=0 disables
+ * picked per workload by timing each candidate twice on the first six calls (OUSTER_HIP_TUNE=0 disables
  * that, OUSTER_HIP_WIDE=0|128|256 forces one). */
 int ouster_hip_last_decode_tile(ouster_hip_ctx* ctx, int* tile_cols, int* tile_rows);
 

@@ -83,6 +83,7 @@ struct ouster_hip_ctx {
         int best = -2;  // -2: still measuring; 0: narrow; 128 / 256: wide
         int calls = 0;
         hipEvent_t ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+        float ms[3] = {0, 0, 0};  // fastest sample of each candidate so far
     };
     std::map<uint64_t, Tune> tune;
     int last_tile_cols = 0, last_tile_rows = 0;  // tile of the last k_decode launch
@@ -703,16 +704,23 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             mix(pm); mix(dm); mix((da.xyz[0] ? 1u : 0u) | (da.xyz[1] ? 2u : 0u));
             ouster_hip_ctx::Tune& t = ctx->tune[key];
             static const int cand[3] = {256, 128, 0};
-            if (t.best == -2 && t.calls >= 3) {  // every candidate has run once: read the clocks
-                float best_ms = 0;
+            // two rounds over the candidates (single launches vary by ~10 %, mostly upwards: keep each
+            // candidate's faster sample); the clocks of a round are read when the next one starts
+            constexpr int ROUNDS = 2;
+            if (t.best == -2 && t.calls > 0 && t.calls % 3 == 0) {
                 for (int c = 0; c < 3; ++c) {
                     float ms = 0;
-                    if (hipEventSynchronize(t.ev[c][1]) != hipSuccess ||
-                        hipEventElapsedTime(&ms, t.ev[c][0], t.ev[c][1]) != hipSuccess)
-                        continue;
-                    if (t.best == -2 || ms < best_ms) { t.best = cand[c]; best_ms = ms; }
+                    if (hipEventSynchronize(t.ev[c][1]) == hipSuccess &&
+                        hipEventElapsedTime(&ms, t.ev[c][0], t.ev[c][1]) == hipSuccess && ms > 0 &&
+                        (t.ms[c] == 0 || ms < t.ms[c]))
+                        t.ms[c] = ms;
                 }
-                if (t.best == -2) t.best = 256;
+                if (t.calls >= 3 * ROUNDS) {
+                    t.best = 256;
+                    float best_ms = 0;
+                    for (int c = 0; c < 3; ++c)
+                        if (t.ms[c] > 0 && (best_ms == 0 || t.ms[c] < best_ms)) { t.best = cand[c]; best_ms = t.ms[c]; }
+                }
             }
             if (t.best != -2) {
                 wide = t.best;

@@ -107,6 +107,48 @@ __global__ __launch_bounds__(256) void k_store_wide(Args a) {
     }
 }
 
+// plane-major: the workgroup writes all its rows of one plane before moving to the next plane
+template <int TW>
+__global__ __launch_bounds__(256) void k_store_wide_pm(Args a) {
+    constexpr uint32_t W = 2048, H = 128, TR = 8192 / TW, TPF = (W / TW) * (H / TR);
+    constexpr uint32_t QPR = TW / 4, RPP = 256 / QPR;
+    const uint32_t xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    const uint32_t f = (i / TPF) * 8u + xcd, sub = i % TPF;
+    if (f >= a.frames) return;
+    const uint32_t tile = sub % (W / TW), rc = sub / (W / TW);
+    const uint32_t q = threadIdx.x % QPR, ty = threadIdx.x / QPR, col = tile * TW + 4 * q;
+    const size_t fpx = (size_t)f * H * W;
+    auto rowpx = [&](uint32_t k, size_t& px, size_t& dpx, uint32_t& r) {
+        r = rc * TR + k * RPP + ty;
+        px = fpx + (size_t)r * W + col;
+        uint32_t dc = (col + W + kShift[r & 3]) % W;
+        dpx = fpx + (size_t)r * W + dc;
+    };
+    size_t px, dpx; uint32_t r;
+#define PLANE(stmt) for (uint32_t k = 0; k < TR / RPP; ++k) { rowpx(k, px, dpx, r); const uint32_t v = (uint32_t)px; stmt; }
+    PLANE(st<4>(a.p[0] + px * 4, v))
+    PLANE(*(pk16*)(a.p[8] + dpx * 4) = (pk16{v, v, v, v}))
+    PLANE(st<1>(a.p[1] + px, v))
+    PLANE(st<1>(a.p[2] + px, v))
+    PLANE(*(pk4*)(a.p[10] + dpx) = pk4{v})
+    PLANE(st<2>(a.p[3] + px * 2, v))
+    PLANE(st<4>(a.p[4] + px * 4, v))
+    PLANE(*(pk16*)(a.p[9] + dpx * 4) = (pk16{v, v, v, v}))
+    PLANE(st<1>(a.p[5] + px, v))
+    PLANE(st<1>(a.p[6] + px, v))
+    PLANE(*(pk4*)(a.p[11] + dpx) = pk4{v})
+    PLANE(st<1>(a.p[7] + px, v))
+    for (int ret = 0; ret < 2; ++ret)
+        for (uint32_t k = 0; k < TR / RPP; ++k) {
+            rowpx(k, px, dpx, r);
+            const uint32_t v = (uint32_t)px;
+            uint4* d = (uint4*)(a.p[12 + ret] + (fpx + (size_t)r * W + tile * TW) * 12);
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) d[kk * QPR + q] = uint4{v, v, v, v};
+        }
+#undef PLANE
+}
+
 int main(int argc, char** argv) {
     const uint32_t F = 256;
     const size_t npx = (size_t)F * 128 * 2048;
@@ -139,7 +181,7 @@ int main(int argc, char** argv) {
             }
         }
         printf("%-22s", L.name);
-        for (int rm : {0, 128, 256, 512, 1024, 2048}) {
+        for (int rm : {0, 128, 256, 1128, 1256}) {
             a.variant = 0; a.fmod = 256; a.rowmode = rm; const int fm = rm;
             float best = 1e9;
             for (int rep = 0; rep < 5; ++rep) {
@@ -148,7 +190,8 @@ int main(int argc, char** argv) {
                 else if (rm == 256) hipLaunchKernelGGL(k_store_wide<256>, dim3(32 * F), dim3(256), 0, 0, a);
                 else if (rm == 512) hipLaunchKernelGGL(k_store_wide<512>, dim3(32 * F), dim3(256), 0, 0, a);
                 else if (rm == 1024) hipLaunchKernelGGL(k_store_wide<1024>, dim3(32 * F), dim3(256), 0, 0, a);
-                else if (rm == 2048) hipLaunchKernelGGL(k_store_wide<2048>, dim3(32 * F), dim3(256), 0, 0, a);
+                else if (rm == 1128) hipLaunchKernelGGL(k_store_wide_pm<128>, dim3(32 * F), dim3(256), 0, 0, a);
+                else if (rm == 1256) hipLaunchKernelGGL(k_store_wide_pm<256>, dim3(32 * F), dim3(256), 0, 0, a);
                 else hipLaunchKernelGGL(k_store, dim3(32 * F), dim3(256), 0, 0, a);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
