@@ -70,7 +70,7 @@ struct ouster_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevBuf map, offsets, luts, counts, scratch;
-    bool map_clean = false;              // map is all -1 (k_decode resets what it consumes)
+    uint32_t map_epoch = 0;              // tag of the last decode call's map entries; 0: map needs a memset
     std::vector<int32_t> offsets_host;   // cache key of `offsets`
     std::vector<LutDev> luts_host;       // cache key of `luts`
     bool timing = false;
@@ -536,10 +536,18 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     {
         const void* before = ctx->map.p;
         if (ctx->map.ensure(map_bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(map) failed");
-        if (ctx->map.p != before) ctx->map_clean = false;
+        if (ctx->map.p != before) ctx->map_epoch = 0;
     }
-    if (!ctx->map_clean) HIP_TRY(hipMemsetAsync(ctx->map.p, 0xFF, ctx->map.cap, st));
-    ctx->map_clean = false;  // dirty until k_decode has consumed it
+    // map entries are (epoch << 20) | source slot and k_colmap writes them with atomicMax: entries
+    // of earlier calls lose against this call's and read as "absent" in k_decode, so the map is
+    // only cleared when it is new or the 11-bit epoch wraps
+    if ((uint64_t)slots_per_frame * g.columns_per_packet >= (1u << 20))
+        return fail(OUSTER_HIP_ERR_UNSUPPORTED, "more than 2^20 column slots per frame");
+    if (ctx->map_epoch == 0 || ctx->map_epoch >= 2047) {
+        HIP_TRY(hipMemsetAsync(ctx->map.p, 0xFF, ctx->map.cap, st));
+        ctx->map_epoch = 0;
+    }
+    const uint32_t epoch = ++ctx->map_epoch;
     const uint32_t n_packets_out = W / g.columns_per_packet;
     if (out->packet_timestamp && host_timestamps)  // start_frame zeroes it (lidar_frame.cpp:1719)
         HIP_TRY(hipMemsetAsync(out->packet_timestamp, 0, (size_t)n_frames * n_packets_out * 8, st));
@@ -586,6 +594,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     ca.packet_counts = d_counts;
     ca.host_timestamps = host_timestamps;
     ca.map = (int32_t*)ctx->map.p;
+    ca.epoch = epoch;
     ca.packet_timestamp = out->packet_timestamp;
     ca.alert_flags = out->alert_flags;
     ca.frame_meta = out->frame_meta;
@@ -599,6 +608,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     da.slots_per_frame = slots_per_frame;
     da.n_frames = n_frames;
     da.map = (int32_t*)ctx->map.p;
+    da.epoch = epoch;
     da.dst_offsets = (const int32_t*)ctx->offsets.p;
     da.luts = (const LutDev*)ctx->luts.p;
     da.n_luts = n_luts ? n_luts : 1;
@@ -765,7 +775,6 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         ctx->last_tile_rows = (int)da.rows_per_tile;
         if (tuning) HIP_TRY(hipEventRecord(tuning->ev[tune_slot][1], st));
         if (e1) HIP_TRY(hipEventRecord(e1, st));
-        ctx->map_clean = false;  // several row chunks read an entry: cleared by the next call's memset
         return OUSTER_HIP_OK;
     }
     HIP_TRY(launch_decode(da, spec, tile, xyzm, st));
@@ -773,7 +782,6 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     ctx->last_tile_rows = (int)H;
     if (tuning) HIP_TRY(hipEventRecord(tuning->ev[tune_slot][1], st));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
-    ctx->map_clean = true;  // every entry k_colmap wrote has been read back and reset
     return OUSTER_HIP_OK;
 }
 

@@ -40,7 +40,8 @@ struct ColmapArgs {
     uint32_t n_packets_out;  // W / cpp
     const uint32_t* packet_counts;  // device, nullable
     const uint64_t* host_timestamps;
-    int32_t* map;  // [n_frames][W], pre-set to -1
+    int32_t* map;  // [n_frames][W]: (epoch << 20) | source slot; entries of other epochs are stale
+    uint32_t epoch;  // 1..2047, bumped per decode call (the map is only memset when it wraps)
     uint64_t* packet_timestamp;
     uint8_t* alert_flags;
     ouster_hip_frame_meta* frame_meta;
@@ -60,7 +61,8 @@ struct DecodeArgs {
     uint32_t row_chunks;      //   bytes of one column's LDS slot (tiles_per_frame = column tiles)
     uint32_t lds_col_slot;
     uint32_t dbg;             // experiments: 1 = stop after staging, 2 = skip the staging loads
-    int32_t* map;                // [n_frames][W]; every entry is consumed and reset to -1
+    int32_t* map;                // [n_frames][W]: (epoch << 20) | source slot, see ColmapArgs
+    uint32_t epoch;
     const int32_t* dst_offsets;  // [H] destination column offset per row (device)
     const LutDev* luts;          // [n_luts] (device)
     uint32_t n_luts;

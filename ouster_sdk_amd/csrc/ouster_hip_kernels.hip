@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_colmap(ColmapArgs a) {
             }
         }
         if ((status & 1u) && m_id < a.g.columns_per_frame)
-            atomicMax(&a.map[(size_t)f * a.g.columns_per_frame + m_id], (int32_t)sl[u]);
+            atomicMax(&a.map[(size_t)f * a.g.columns_per_frame + m_id], (int32_t)((a.epoch << 20) | sl[u]));
     }
 }
 
@@ -474,7 +474,8 @@ __global__ __launch_bounds__(OUSTER_DECODE_NT) void k_decode(DecodeArgs a) {
     // ---- phase 0: source map of this tile
     if (tid < TILE) {
         const uint32_t c = c0 + tid;
-        const int32_t src = (c < W) ? a.map[(size_t)f * W + c] : -1;
+        const int32_t raw = (c < W) ? a.map[(size_t)f * W + c] : -1;
+        const int32_t src = (raw >= 0 && ((uint32_t)raw >> 20) == a.epoch) ? (raw & 0xfffff) : -1;  // stale epoch = absent
         s_src[tid] = src;
         const uint32_t j0 = tid - tid % cpp;  // first column of my packet group in the tile
         // "group ok": my packet's cpp columns sit in order, packet-aligned, all present
@@ -565,9 +566,6 @@ __global__ __launch_bounds__(OUSTER_DECODE_NT) void k_decode(DecodeArgs a) {
     // ---- phase 2a: column headers (timestamp / measurement_id / status), one lane per column
     if (tid < TILE && c0 + tid < W) {
         const uint32_t c = c0 + tid;
-        // consume-and-reset: the map is left at -1 for the next call.  Done here, after the
-        // last barrier, so no workgroup barrier ever waits for this store to be acknowledged.
-        a.map[(size_t)f * W + c] = -1;
         const bool v = (validmask >> tid) & 1;
         const uint32_t cb = tid * col_size;
         if (a.timestamp)
@@ -809,7 +807,8 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
     for (uint32_t j = tid; j < (uint32_t)TW; j += NT) {
         const uint32_t c = c0 + j;
-        const int32_t src = (c < W) ? a.map[(size_t)f * W + c] : -1;
+        const int32_t raw = (c < W) ? a.map[(size_t)f * W + c] : -1;
+        const int32_t src = (raw >= 0 && ((uint32_t)raw >> 20) == a.epoch) ? (raw & 0xfffff) : -1;  // stale epoch = absent
         uint32_t ofs = 0xffffffffu;
         if (src >= 0) {
             const uint32_t p = (uint32_t)src / cpp, ic = (uint32_t)src - p * cpp;

@@ -604,3 +604,30 @@ def test_variant_tuner_is_transparent(oracle):
                               O.destagger(fr.plane("RANGE2"), cal.pixel_shift_by_row))
         want = O.cartesian(fr.plane("RANGE"), ldir, lofs)
         assert np.abs(_np(first["xyz:RANGE"][f]).astype(np.float64) - want).max() <= 4e-5
+
+
+def test_map_epoch_wraps(oracle):
+    """The column map is tagged with an 11-bit per-call epoch instead of being cleared: stale entries
+    (here: columns present in call k, dropped in call k+1) must read as absent, also across the wrap."""
+    O = oracle
+    cal = O.synthetic_calib(h=16, w=256, profile="RNG15_RFL8_NIR8")
+    full, src = O.synth_packets(cal, 1, with_window=True)
+    hp = HotPath("RNG15_RFL8_NIR8", 16, 256, 16)
+    d_full = torch.from_numpy(full).cuda()
+    part = full.copy()[:, :12]                      # the last 4 packets (64 columns) are missing
+    d_part = torch.zeros_like(d_full)
+    d_part[:, :12] = torch.from_numpy(part).cuda()
+    out = hp.alloc_outputs(1)
+    want_full = src[0].plane("RANGE")
+    want_part = want_full.copy()
+    want_part[:, 192:] = 0
+    for call in range(2 * 2047 + 40):
+        if call % 2 == 0:
+            hp.decode(d_full, out)
+        else:
+            hp.decode(d_part, out, packet_counts=np.array([12], np.uint32))
+        if call < 6 or call % 512 in (0, 1) or 2040 <= call <= 2055 or call >= 4090:
+            got = _np(out["RANGE"][0])
+            assert np.array_equal(got, want_full if call % 2 == 0 else want_part), call
+            st = _np(out["status"][0])
+            assert st[:192].all() and (st[192:].all() if call % 2 == 0 else not st[192:].any()), call
