@@ -1,10 +1,14 @@
 // ouster_hip_kernels.hip -- CDNA4 (gfx950) kernels for the Ouster per-pixel hot path.
 //
-//   k_colmap    column headers -> per-frame "destination column -> source column" map
-//   k_decode    fused field decode (+ destagger + cartesian), one workgroup per
-//               64/32/16-column tile of one frame
-//   k_destagger standalone per-row circular shift
-//   k_cartesian standalone range image -> XYZ
+//   k_colmap        column headers -> per-frame "destination column -> source column" map
+//   k_decode        fused field decode (+ destagger + cartesian), one workgroup per
+//                   64/32/16-column tile of one frame (whole columns staged in LDS)
+//   k_decode_wide   the same on wide, short tiles (128/256 columns x a chunk of rows); picked per
+//                   workload against k_decode by the tuner in ouster_hip_capi.hip
+//   k_destagger     standalone per-row circular shift
+//   k_cartesian(_tiled)   standalone range image -> XYZ
+//   k_dewarp(_tiled)      standalone per-column pose applied to a dense point cloud
+//   k_dwf_*         range-gated, compacting frame dewarp (count, scans, emit)
 //
 // What the kernels compute is defined by the reference loops
 //   PacketFormat::col_field/block_field      ouster_core/src/parsing.cpp:628-675
