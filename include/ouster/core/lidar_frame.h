@@ -258,7 +258,12 @@ inline img_t<T> stagger(const SensorInfo& info, const img_t<T>& img) {
 /** Destagger a whole Field (any element type, trailing dims allowed; field.cpp:329-340). */
 Field destagger(const SensorInfo& info, const Field& field, bool inverse = false);
 
-/** Column of the staggered image a destaggered pixel came from (lidar_frame.cpp:893-905). */
+/** Timestamp of the staggered column a destaggered pixel came from (lidar_frame.cpp:893-905).
+ *  @throw std::invalid_argument("row or column is out of range") */
+uint64_t column_timestamp_at_destaggered_pixel(size_t row, size_t col,
+                                               const std::vector<int>& pixel_shift_by_row,
+                                               const HeaderRef<const uint64_t>& column_timestamps);
+/** Convenience form over a frame and its sensor's shifts. */
 uint64_t column_timestamp_at_destaggered_pixel(const LidarFrame& frame, const SensorInfo& info,
                                                size_t row, size_t col);
 

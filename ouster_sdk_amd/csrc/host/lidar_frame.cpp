@@ -237,12 +237,23 @@ bool LidarFrame::equals(const LidarFrame& o) const {
 }
 bool operator==(const LidarFrame& a, const LidarFrame& b) { return a.equals(b); }
 
+uint64_t column_timestamp_at_destaggered_pixel(size_t row, size_t col,
+                                               const std::vector<int>& pixel_shift_by_row,
+                                               const HeaderRef<const uint64_t>& column_timestamps) {
+    const size_t width = column_timestamps.size();
+    if (row >= pixel_shift_by_row.size() || col >= width)
+        throw std::invalid_argument("row or column is out of range");
+    // the reference's signed int arithmetic: offset = (w + shift % w) % w
+    const int w = static_cast<int>(width);
+    const int offset = (w + pixel_shift_by_row[row] % w) % w;
+    const int staggered_col = (static_cast<int>(col) - offset + w) % w;
+    return column_timestamps[static_cast<size_t>(staggered_col)];
+}
+
 uint64_t column_timestamp_at_destaggered_pixel(const LidarFrame& frame, const SensorInfo& info,
                                                size_t row, size_t col) {
-    const int wi = static_cast<int>(frame.w);
-    const int shift = info.format.pixel_shift_by_row.at(row);
-    const int src = ((static_cast<int>(col) - shift) % wi + wi) % wi;
-    return frame.timestamp()[static_cast<size_t>(src)];
+    return column_timestamp_at_destaggered_pixel(row, col, info.format.pixel_shift_by_row,
+                                                 frame.timestamp());
 }
 
 // ---------------------------------------------------------------------------------------

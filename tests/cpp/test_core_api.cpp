@@ -250,6 +250,160 @@ static void test_batcher_roundtrip() {
     CHECK(throws_with<std::invalid_argument>([&] { b.batch(p, wrong); }, "unexpected frame dimensions"));
 }
 
+// The reference's FrameBatcher state-machine scenarios (tests/frame_batcher_test.cpp:771-836
+// cached_packet_test, :950-1010 reset, :1012-1069 new_framebatcher_clears_frame, :1071-1145 init_id /
+// init_id_2, :1259-1317 bad_roll_over_32_bit, :1147-1179 lost_frame with lidar packets).  Where the
+// reference inspects a frame that is still being assembled the mirror needs FrameBatcher::flush first
+// (pixel work is deferred to one GPU decode per frame).
+static void test_batcher_state_machine() {
+    std::printf("FrameBatcher state machine scenarios\n");
+    auto info = std::make_shared<SensorInfo>(
+        make_info(UDPProfileLidar::RNG15_RFL8_NIR8, HeaderType::STANDARD, 32, 256));
+    auto pf = std::make_shared<PacketFormat>(*info);
+    auto frame_packets = [&](uint64_t seed, int64_t frame_id, uint32_t init_id) {
+        LidarFrame f(info);
+        randomize(f, *pf, seed);
+        f.frame_id = frame_id;
+        return std::make_pair(f, impl::frame_to_packets(f, pf, init_id, info->sn));
+    };
+    {   // packets of the next frame are cached (not applied) until the current one is released
+        auto a = frame_packets(1, 1337, info->init_id);
+        auto b = frame_packets(2, 1338, info->init_id);
+        a.second.pop_back();  // frame 1337 never completes by itself
+        LidarFrame ref_b(info);
+        {
+            FrameBatcher rb(info);
+            bool done = false;
+            for (auto& p : b.second) done = rb(p, ref_b);
+            CHECK(done);
+        }
+        LidarFrame ls(info);
+        FrameBatcher batcher(info);
+        for (auto& p : a.second) CHECK(!batcher(p, ls));
+        batcher.flush(ls);
+        LidarFrame ref_a = ls;
+        for (size_t i = 0; i + 1 < batcher.get_max_cache_size(); ++i) {
+            CHECK(!batcher(b.second[i], ls));
+            CHECK(ls == ref_a);
+        }
+        CHECK(batcher(b.second[0], ls));  // cache full: releases 1337 (the packet itself is a re-send)
+        CHECK(ls == ref_a && ls.frame_id == 1337);
+        for (size_t i = 1; i + 1 < b.second.size(); ++i) CHECK(!batcher(b.second[i], ls));
+        CHECK(batcher(b.second.back(), ls));
+        CHECK(ls == ref_b);
+    }
+    {   // reset() drops the cached packets and the frame in flight
+        auto a = frame_packets(3, 700, info->init_id);
+        auto fut = frame_packets(4, 702, info->init_id);
+        auto nxt = frame_packets(5, 701, info->init_id);
+        LidarFrame ls(info);
+        FrameBatcher batcher(info);
+        for (size_t i = 0; i + 1 < a.second.size(); ++i) CHECK(!batcher.batch(a.second[i], ls));
+        CHECK(ls.frame_id == 700);
+        batcher.batch(fut.second[0], ls);          // cached: the frame id does not move
+        CHECK(ls.frame_id == 700);
+        batcher.reset();
+        for (auto& p : nxt.second) CHECK(pf->frame_id(p.buf.data()) == 701);
+        batcher.batch(nxt.second[0], ls);          // starts frame 701 right away
+        CHECK(ls.frame_id == 701);
+    }
+    {   // a brand-new batcher starts a new frame: stale headers of the caller's frame are zeroed
+        auto a = frame_packets(6, 700, info->init_id);
+        LidarFrame ls(info);
+        for (size_t i = 0; i < ls.w; ++i) { ls.timestamp()[i] = 100; ls.status()[i] = 0x0f; ls.measurement_id()[i] = 10000; }
+        for (size_t i = 0; i < ls.packet_count(); ++i) ls.packet_timestamp()[i] = 2000;
+        ls.frame_id = 123;
+        FrameBatcher batcher(info);
+        a.second[0].host_timestamp = 4242;
+        batcher.batch(a.second[0], ls);
+        batcher.flush(ls);
+        CHECK(ls.frame_id == 700 && ls.packet_timestamp()[0] == 4242);
+        bool rest_zero = true, first_ok = true;
+        for (size_t i = 1; i < ls.packet_count(); ++i) rest_zero &= ls.packet_timestamp()[i] == 0;
+        for (uint32_t i = 0; i < pf->columns_per_packet; ++i) {
+            const uint8_t* col = pf->nth_col(i, a.second[0].buf.data());
+            const uint16_t m = pf->col_measurement_id(col);
+            first_ok &= ls.timestamp()[m] == pf->col_timestamp(col) && ls.status()[m] == pf->col_status(col) &&
+                        ls.measurement_id()[m] == m;
+        }
+        for (size_t i = pf->columns_per_packet; i < ls.w; ++i)
+            rest_zero &= ls.timestamp()[i] == 0 && ls.status()[i] == 0 && ls.measurement_id()[i] == 0;
+        CHECK(rest_zero && first_ok);
+    }
+    {   // init id changes: between frames (both complete) and mid-frame (releases the old frame)
+        LidarFrame ls(info);
+        FrameBatcher batcher(info);
+        auto a = frame_packets(7, 700, info->init_id);
+        bool done = false;
+        for (auto& p : a.second) done = batcher.batch(p, ls);
+        CHECK(done);
+        auto b = frame_packets(8, 700, info->init_id + 1);
+        done = false;
+        for (size_t i = 0; i < b.second.size(); ++i) {
+            done = batcher.batch(b.second[i], ls);
+            CHECK(done == (i + 1 == b.second.size()));
+        }
+        FrameBatcher b2(info);
+        LidarFrame l2(info);
+        for (size_t i = 0; i + 1 < a.second.size(); ++i) CHECK(!b2.batch(a.second[i], l2));
+        LidarPacket other(pf);
+        pf->set_frame_id(other.buf.data(), 701);
+        pf->set_init_id(other.buf.data(), info->init_id + 1);
+        CHECK(b2.batch(other, l2));
+        CHECK(l2.frame_id == 700);
+    }
+    for (HeaderType ht : {HeaderType::STANDARD, HeaderType::FUSA}) {
+        // one packet per frame; 16-bit ids may wrap, a 32-bit FUSA id that does not increase throws
+        auto i1 = std::make_shared<SensorInfo>(make_info(
+            ht == HeaderType::FUSA ? UDPProfileLidar::FUSA_RNG15_RFL8_NIR8_DUAL : UDPProfileLidar::RNG15_RFL8_NIR8, ht, 16, 16));
+        auto f1 = std::make_shared<PacketFormat>(*i1);
+        FrameBatcher batcher(i1);
+        LidarFrame ls(i1);
+        CHECK(ls.frame_id == -1);
+        LidarPacket packet(f1);
+        f1->set_frame_id(packet.buf.data(), f1->max_frame_id);
+        f1->set_init_id(packet.buf.data(), i1->init_id);
+        packet.host_timestamp = 1234;
+        CHECK(batcher.batch(packet, ls));
+        CHECK(ls.frame_id == static_cast<int64_t>(f1->max_frame_id));
+        f1->set_frame_id(packet.buf.data(), 0);
+        if (ht == HeaderType::STANDARD) {
+            CHECK(batcher.batch(packet, ls));
+            CHECK(ls.frame_id == 0);
+            // a frame whose first packet arrives after a later frame was released is lost
+            f1->set_frame_id(packet.buf.data(), 2);
+            CHECK(batcher.batch(packet, ls));
+            f1->set_frame_id(packet.buf.data(), 1);
+            CHECK(!batcher.batch(packet, ls));
+        } else {
+            CHECK(throws_with<std::runtime_error>([&] { batcher.batch(packet, ls); },
+                                                  "32-bit frame id did not increase since the last frame"));
+            f1->set_init_id(packet.buf.data(), i1->init_id + 1);  // a re-initialised sensor may start over
+            CHECK(batcher.batch(packet, ls));
+        }
+    }
+    {   // destaggered pixel -> staggered column timestamp (destagger_test.cpp:135-161)
+        const size_t W = 512, H = 64;
+        std::mt19937 g(11);
+        std::vector<int> shifts(H);
+        for (int& v : shifts) v = static_cast<int>(g() % 61) - 30;
+        img_t<uint32_t> range(H, W);
+        for (size_t r = 0; r < H; ++r)
+            for (size_t c = 0; c < W; ++c) range(r, c) = static_cast<uint32_t>(c);
+        const auto dst = destagger<uint32_t>(range, shifts, false);
+        std::vector<uint64_t> ts(W);
+        for (size_t c = 0; c < W; ++c) ts[c] = c;
+        bool ok = true;
+        for (size_t r = 0; r < H; ++r)
+            for (size_t c = 0; c < W; ++c)
+                ok &= column_timestamp_at_destaggered_pixel(r, c, shifts, HeaderRef<const uint64_t>(ts.data(), W)) == dst(r, c);
+        CHECK(ok);
+        CHECK(throws_with<std::invalid_argument>(
+            [&] { column_timestamp_at_destaggered_pixel(H, 0, shifts, HeaderRef<const uint64_t>(ts.data(), W)); },
+            "row or column is out of range"));
+    }
+}
+
 // alternative encodings registered at run time decode identically (frame_batcher_test.cpp:644-747)
 static void test_custom_profile() {
     std::printf("add_custom_profile\n");
@@ -643,6 +797,7 @@ int main() {
     test_packet_format_tables();
     test_lidar_frame_container();
     test_batcher_roundtrip();
+    test_batcher_state_machine();
     test_custom_profile();
     test_col_and_block_field();
     test_destagger();

@@ -199,3 +199,16 @@ def test_geometry_matches_fixture_sizes(oracle):
                           ("RNG15_RFL8_NIR8_DUAL", 128, 16640), ("LEGACY", 32, 6464),
                           ("LEGACY", 64, 12608), ("RNG19_RFL8_SIG16_NIR16_DUAL", 128, 33024)]:
         assert O.packet_format(prof, h, 16, 1024).lidar_packet_size == size
+
+
+def test_legacy_col_status_is_all_ones(oracle):
+    """tests/frame_batcher_test.cpp:749-769 (FrameBatcherLegacyTest.legacy_col_status): every column of
+    the LEGACY capture reports status 0xFFFFFFFF (the last 4 bytes of a legacy column)."""
+    O = oracle
+    base = "OS-2-32-U0_v2.0.0_1024x10"
+    cal = O.calib_from_json(os.path.join(PCAPS, base + ".json"))
+    pf = cal.packet_format()
+    pk = O.lidar_packets_from_pcap(os.path.join(PCAPS, base + ".pcap"), pf)
+    assert len(pk) >= 64
+    for p in pk:
+        assert (O.packet_header(pf, "STATUS", p) == 0xFFFFFFFF).all()
