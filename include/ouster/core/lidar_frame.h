@@ -197,6 +197,16 @@ class LidarFrame {
      *  @throw std::runtime_error("No valid columns in LidarFrame") */
     int get_first_valid_column() const;
     int get_last_valid_column() const;
+    /** host timestamp of the first / last / earliest / latest lidar packet with a valid column
+     *  (lidar_frame.cpp:643-797; this mirror has no IMU / zone streams, so the stream-less overloads
+     *  look at lidar packets only).  @throw std::runtime_error("No valid packets in LidarFrame") */
+    uint64_t get_first_valid_packet_timestamp() const;
+    uint64_t get_last_valid_packet_timestamp() const;
+    uint64_t get_min_valid_packet_timestamp() const;
+    uint64_t get_max_valid_packet_timestamp() const;
+    /** same, 0 instead of throwing (lidar_frame.cpp:727-733) */
+    uint64_t get_first_valid_lidar_packet_timestamp() const;
+    uint64_t get_last_valid_lidar_packet_timestamp() const;
 
     bool equals(const LidarFrame& other) const;
 

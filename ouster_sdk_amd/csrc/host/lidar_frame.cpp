@@ -10,6 +10,7 @@
 // being assembled are collected in a staging buffer and decoded by one GPU launch when the
 // frame is released.
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <deque>
 
@@ -225,6 +226,71 @@ int LidarFrame::get_last_valid_column() const {
     for (size_t i = w; i-- > 0;)
         if (st[i] & 1u) return static_cast<int>(i);
     throw std::runtime_error("No valid columns in LidarFrame");
+}
+
+namespace {
+// index of the packets that carry at least one valid column, in the order asked for
+// (lidar_frame.cpp:735-797: columns_per_packet = w / number of packet slots)
+template <class F>
+void for_valid_packets(const LidarFrame& f, F&& fn) {
+    const size_t total = f.packet_count();
+    if (!total) return;
+    const size_t cpp = f.w / total;
+    const auto st = f.status();
+    for (size_t i = 0; i < total; ++i) {
+        bool any = false;
+        for (size_t c = i * cpp; c < (i + 1) * cpp && c < f.w; ++c) any |= (st[c] & 1u) != 0;
+        if (any) fn(i);
+    }
+}
+uint64_t ts_or_throw(bool found, uint64_t v) {
+    if (!found) throw std::runtime_error("No valid packets in LidarFrame");
+    return v;
+}
+}  // namespace
+
+uint64_t LidarFrame::get_first_valid_lidar_packet_timestamp() const {
+    bool found = false;
+    uint64_t v = 0;
+    for_valid_packets(*this, [&](size_t i) { if (!found) { found = true; v = packet_timestamp()[i]; } });
+    return v;
+}
+uint64_t LidarFrame::get_last_valid_lidar_packet_timestamp() const {
+    uint64_t v = 0;
+    for_valid_packets(*this, [&](size_t i) { v = packet_timestamp()[i]; });
+    return v;
+}
+uint64_t LidarFrame::get_first_valid_packet_timestamp() const {
+    bool found = false;
+    uint64_t v = 0;
+    for_valid_packets(*this, [&](size_t i) { if (!found) { found = true; v = packet_timestamp()[i]; } });
+    return ts_or_throw(found, v);
+}
+uint64_t LidarFrame::get_last_valid_packet_timestamp() const {
+    bool found = false;
+    uint64_t v = 0;
+    for_valid_packets(*this, [&](size_t i) { found = true; v = packet_timestamp()[i]; });
+    return ts_or_throw(found, v);
+}
+uint64_t LidarFrame::get_min_valid_packet_timestamp() const {
+    bool found = false;
+    uint64_t v = 0;
+    for_valid_packets(*this, [&](size_t i) {
+        const uint64_t t = packet_timestamp()[i];
+        v = found ? std::min(v, t) : t;
+        found = true;
+    });
+    return ts_or_throw(found, v);
+}
+uint64_t LidarFrame::get_max_valid_packet_timestamp() const {
+    bool found = false;
+    uint64_t v = 0;
+    for_valid_packets(*this, [&](size_t i) {
+        const uint64_t t = packet_timestamp()[i];
+        v = found ? std::max(v, t) : t;
+        found = true;
+    });
+    return ts_or_throw(found, v);
 }
 
 bool LidarFrame::equals(const LidarFrame& o) const {

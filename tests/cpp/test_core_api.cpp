@@ -149,6 +149,31 @@ static void test_packet_format_tables() {
 
 static void test_lidar_frame_container() {
     std::printf("LidarFrame container\n");
+    {   // lidar_frame_test.cpp:453-490 (first valid packet timestamp), :482-490 (packet slots), :604-609
+        LidarFrame frame(32, 1024, UDPProfileLidar::RNG15_RFL8_NIR8);
+        CHECK(frame.packet_timestamp().size() == 1024 / 16 && frame.packet_timestamp().count() == 0);
+        for (size_t i = 0; i < frame.packet_count(); ++i) frame.packet_timestamp()[i] = i + 1;
+        CHECK(throws_with<std::runtime_error>([&] { frame.get_first_valid_packet_timestamp(); }, "No valid packets"));
+        CHECK(frame.get_first_valid_lidar_packet_timestamp() == 0);
+        frame.status()[1] = 1;
+        CHECK(frame.get_first_valid_packet_timestamp() == 1);
+        frame.status()[1] = 0;
+        frame.status()[74] = 1;
+        CHECK(frame.get_first_valid_packet_timestamp() == 5 && frame.get_last_valid_packet_timestamp() == 5);
+        frame.status()[1023] = 1;
+        CHECK(frame.get_last_valid_packet_timestamp() == 64 && frame.get_min_valid_packet_timestamp() == 5 &&
+              frame.get_max_valid_packet_timestamp() == 64 && frame.get_last_valid_lidar_packet_timestamp() == 64);
+        CHECK(LidarFrame(64, 10, UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, 32).packet_timestamp().size() == 1);
+        CHECK(LidarFrame(64, 32, UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, 32).packet_timestamp().size() == 1);
+        CHECK(LidarFrame(64, 33, UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, 32).packet_timestamp().size() == 2);
+        LidarFrame none(10, 10, UDPProfileLidar::RNG15_RFL8_NIR8);
+        CHECK(throws_with<std::runtime_error>([&] { none.get_first_valid_column(); }, "No valid columns"));
+        CHECK(throws_with<std::runtime_error>([&] { none.get_last_valid_column(); }, "No valid columns"));
+        // lidar_frame_test.cpp:351-377: a batcher cannot be built for 0 columns per packet
+        SensorInfo bad = make_info(UDPProfileLidar::LEGACY, HeaderType::STANDARD, 32, 32);
+        bad.format.columns_per_packet = 0;
+        CHECK(throws_with<std::invalid_argument>([&] { FrameBatcher fb(bad); }, "unexpected columns_per_packet: 0"));
+    }
     CHECK(throws_with<std::invalid_argument>([] { LidarFrame f(0, 10, LidarFrameFieldTypes{}); },
                                              "zero width or height"));
     CHECK(throws_with<std::invalid_argument>([] { LidarFrame f(4, 16, LidarFrameFieldTypes{}, 0); },
