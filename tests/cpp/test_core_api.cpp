@@ -407,6 +407,33 @@ static void test_batcher_state_machine() {
             CHECK(batcher.batch(packet, ls));
         }
     }
+    {   // frame -> packets skips packets that never arrived and leaves invalid columns empty
+        // (packet_format_test.cpp:328-406)
+        auto i64 = std::make_shared<SensorInfo>(make_info(UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, HeaderType::STANDARD, 32, 1024));
+        auto f64 = std::make_shared<PacketFormat>(*i64);
+        LidarFrame src(i64);
+        randomize(src, *f64, 0xdeadbeef);
+        auto packets = impl::frame_to_packets(src, f64, 0, 0);
+        CHECK(packets.size() == 64);
+        packets.erase(packets.begin() + 14);
+        for (uint32_t icol = 0; icol < f64->columns_per_packet; icol += 2)
+            f64->set_col_status(f64->nth_col(icol, packets[0].buf.data()), 0);
+        LidarFrame repr(i64);
+        FrameBatcher batcher(i64);
+        for (auto& p : packets) CHECK(!batcher(p, repr));
+        batcher.flush(repr);
+        auto again = impl::frame_to_packets(repr, f64, 0, 0);
+        CHECK(again.size() == 63);
+        CHECK(again.size() > 14 && again[14].host_timestamp == 25);
+        bool empty = true;
+        for (uint32_t icol = 0; icol < f64->columns_per_packet; icol += 2) {
+            const uint8_t* col = f64->nth_col(icol, again[0].buf.data());
+            const uint8_t* begin = f64->nth_px(0, col);
+            const uint8_t* end = col + f64->col_size;
+            for (const uint8_t* b = begin; b < end; ++b) empty &= *b == 0;
+        }
+        CHECK(empty);
+    }
     {   // destaggered pixel -> staggered column timestamp (destagger_test.cpp:135-161)
         const size_t W = 512, H = 64;
         std::mt19937 g(11);
