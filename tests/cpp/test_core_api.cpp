@@ -407,6 +407,31 @@ static void test_batcher_state_machine() {
             CHECK(batcher.batch(packet, ls));
         }
     }
+    {   // a packet whose columns are all invalid contributes nothing but its packet timestamp and alert
+        // flags (frame_batcher_test.cpp:73-303, lidar_frame.cpp:1447-1450,1534-1539)
+        auto a = frame_packets(9, 700, info->init_id);
+        for (uint32_t icol = 0; icol < pf->columns_per_packet; ++icol)
+            pf->set_col_status(pf->nth_col(icol, a.second[5].buf.data()), 0);
+        LidarFrame ls(info);
+        for (auto& kv : ls.fields()) std::memset(kv.second.get(), 1, kv.second.bytes());
+        FrameBatcher batcher(info);
+        bool done = false;
+        for (auto& p : a.second) done = batcher(p, ls);
+        CHECK(done);
+        const size_t c0 = 5 * pf->columns_per_packet, c1 = c0 + pf->columns_per_packet;
+        bool zeroed = true, others = true;
+        const uint32_t* got = ls.field("RANGE").get<uint32_t>();
+        const uint32_t* want = a.first.field("RANGE").get<uint32_t>();
+        for (size_t r = 0; r < ls.h; ++r)
+            for (size_t c = 0; c < ls.w; ++c) {
+                if (c >= c0 && c < c1) zeroed &= got[r * ls.w + c] == 0;
+                else others &= got[r * ls.w + c] == want[r * ls.w + c];
+            }
+        for (size_t c = c0; c < c1; ++c) zeroed &= ls.status()[c] == 0 && ls.timestamp()[c] == 0 && ls.measurement_id()[c] == 0;
+        CHECK(zeroed && others);
+        CHECK(ls.packet_timestamp()[5] == a.second[5].host_timestamp && a.second[5].host_timestamp != 0);
+        CHECK(!ls.complete(info->format.column_window));
+    }
     {   // frame -> packets skips packets that never arrived and leaves invalid columns empty
         // (packet_format_test.cpp:328-406)
         auto i64 = std::make_shared<SensorInfo>(make_info(UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, HeaderType::STANDARD, 32, 1024));
