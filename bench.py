@@ -147,6 +147,11 @@ def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 12.0):
     rf = max(1, reps // 3)
     tf = run(rf, 1, False)
     res["f32_variant"] = {"value": n * rf * H * W * 2 / tf / 1e6, "cores": 1}
+    # the same algorithmic byte count as the GPU leg: bytes/s next to points/s
+    bpp = algorithmic_bytes_per_frame("dual") / (H * W * 2)
+    res["GBps"] = res["value"] * 1e6 * bpp / 1e9
+    if "all_cores" in res:
+        res["all_cores"]["GBps"] = res["all_cores"]["value"] * 1e6 * bpp / 1e9
     return res
 
 
