@@ -5,6 +5,7 @@ include/ouster_hip.h) and `lib/libouster_core_amd.so` (C++ host API with the ref
 names, include/ouster/core/*.h).  Python pieces:
   core      pybind11 module over the C++ mirror (XYZLut, destagger, FrameBatcher, LidarFrame,
             PacketFormat ...) -- the `ouster.sdk.core` call shapes for this path
+  sdk       device-aware front of `core`: numpy in -> numpy out, CUDA tensor in -> CUDA tensor out
   _capi     ctypes binding of the C ABI
   device    torch-owned HBM buffers + streams around the C ABI (batched, device resident)
   parallel  frame sharding across GPUs (torch.distributed)

@@ -230,3 +230,32 @@ def test_frame_dewarp_against_dense_path(oracle):
     op, oc, ot = O.dewarp_frame(rng, frame.status, frame.timestamp, frame.body_to_world.reshape(w, 16),
                                 ldir, lofs, 1.0, 80.0)
     assert np.array_equal(oc, cols) and np.array_equal(ot, ts) and np.abs(op - pts).max() < 1e-9
+
+
+def test_device_aware_front_keeps_tensors_in_hbm(meta):
+    """ouster_sdk_amd.sdk: the reference's call shapes; CUDA tensors in -> CUDA tensors out, equal to
+    the numpy path (XYZLut double: <1e-9 m, float: one rounding; destagger: bit-exact, any dtype)."""
+    import torch
+    from ouster_sdk_amd import sdk
+    info = meta
+    g = np.random.default_rng(5)
+    rng = g.integers(0, 2 ** 18, size=(info.h, info.w)).astype(np.uint32)
+    rng[g.random(rng.shape) < 0.3] = 0
+    for use_ext in (False, True):
+        lut = sdk.XYZLut(info, use_ext)
+        want = lut(rng)                                  # numpy path = core.XYZLut
+        assert isinstance(want, np.ndarray) and want.shape == (info.h, info.w, 3)
+        got = lut(torch.from_numpy(rng).cuda())
+        assert got.is_cuda and got.dtype == torch.float64 and tuple(got.shape) == (info.h, info.w, 3)
+        assert np.abs(got.cpu().numpy() - want).max() < 1e-9
+        got32 = sdk.XYZLutFloat(info, use_ext)(torch.from_numpy(rng).cuda())
+        assert got32.dtype == torch.float32 and np.abs(got32.cpu().numpy() - want).max() <= 4e-5
+        assert np.array_equal(np.from_dlpack(got32.cpu()), got32.cpu().numpy())
+    with pytest.raises(ValueError):
+        sdk.XYZLut(info)(torch.zeros((info.h, info.w - 1), dtype=torch.int32, device="cuda"))
+    for dt in (np.uint8, np.uint16, np.uint32, np.float32, np.float64):
+        img = (g.random((info.h, info.w, 2)) * 200).astype(dt)
+        for inv in (False, True):
+            want = sdk.destagger(info, img, inv)         # numpy path = core.destagger
+            got = sdk.destagger(info, torch.from_numpy(img).cuda(), inv)
+            assert got.is_cuda and np.array_equal(got.cpu().numpy(), want)
