@@ -29,6 +29,10 @@ struct BatchOptions {
     bool xyz = false;                     ///< project RANGE (and RANGE2 when present)
     bool xyz_f64 = false;                 ///< XYZ element type (default float)
     bool use_extrinsics = true;           ///< fold SensorInfo::sensor_to_body into the LUT
+    /// Treat every packet slot of every frame as filled (missing packets = zeroed slots, whose
+    /// columns are invalid by their status word) instead of uploading per-frame packet counts:
+    /// keeps decode() free of host synchronisation, for the streaming pipeline (FrameStream).
+    bool all_slots = false;
 };
 
 class DeviceFrameBatch {
@@ -59,6 +63,14 @@ class DeviceFrameBatch {
     void* plane_device(const std::string& name);
     void* destaggered_device(const std::string& name);
     void* xyz_device(int return_index);
+    uint64_t* timestamp_device() { return static_cast<uint64_t*>(d_ts_.data()); }
+    uint16_t* measurement_id_device() { return static_cast<uint16_t*>(d_mid_.data()); }
+    uint32_t* status_device() { return static_cast<uint32_t*>(d_status_.data()); }
+    size_t plane_bytes_per_frame(const std::string& name) const;
+    size_t xyz_bytes_per_frame() const { return static_cast<size_t>(h_) * w_ * 3 * (opt_.xyz_f64 ? 8 : 4); }
+    size_t lidar_packet_size() const { return pf_.lidar_packet_size; }
+    uint32_t h() const { return h_; }
+    uint32_t w() const { return w_; }
     /** Read one frame's result back (synchronous). */
     void download_plane(const std::string& name, uint32_t frame, void* host, bool destaggered = false);
     void download_xyz(int return_index, uint32_t frame, void* host);

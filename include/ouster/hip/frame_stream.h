@@ -1,0 +1,82 @@
+// frame_stream.h -- streaming form of the hot path for callers whose packets arrive on the HOST
+// (pcap replay, live sensors: PcapFrameSetSource / SensorFrameSetSource in the reference).
+//
+// Frames are collected into batches in pinned host memory; each batch then travels
+//     pinned packets --H2D copy stream--> HBM --decode (ctx stream)--> HBM --D2H copy stream--> pinned results
+// with `batches_in_flight` batches overlapping, so the link, not the host calls, bounds the rate:
+// the PCIe-inclusive counterpart of DeviceFrameBatch (which assumes the data already is in HBM).
+// Results are handed to a callback as pointers into pinned memory, in submission order.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ouster/hip/device_batch.h"
+
+namespace ouster {
+namespace sdk {
+namespace hip {
+
+struct StreamOptions {
+    uint32_t frames_per_batch = 32;   ///< multiple of the number of sensors
+    uint32_t batches_in_flight = 3;   ///< pinned + device buffer sets (>= 2 to overlap)
+    BatchOptions outputs;             ///< what the GPU produces (planes / destaggered / xyz)
+    bool download_xyz = true;         ///< which of it comes back to the host
+    std::vector<std::string> download_planes;
+    std::vector<std::string> download_destaggered;
+    bool download_headers = true;     ///< timestamp / measurement_id / status per column
+};
+
+/** One finished batch; the pointers stay valid during the callback only. */
+struct BatchResult {
+    uint64_t first_frame = 0;         ///< index (in push order) of frame 0 of this batch
+    uint32_t n_frames = 0;
+    uint32_t h = 0, w = 0;
+    const void* xyz[2] = {nullptr, nullptr};                 ///< [n_frames][h*w][3] float (or double)
+    std::map<std::string, const void*> planes, destaggered;  ///< [n_frames][h][w] elements
+    const uint64_t* timestamp = nullptr;                     ///< [n_frames][w]
+    const uint16_t* measurement_id = nullptr;
+    const uint32_t* status = nullptr;
+};
+
+class FrameStream {
+   public:
+    using Callback = std::function<void(const BatchResult&)>;
+
+    FrameStream(const std::vector<core::SensorInfo>& sensors, const StreamOptions& options,
+                Callback on_batch);
+    ~FrameStream();
+    FrameStream(const FrameStream&) = delete;
+    FrameStream& operator=(const FrameStream&) = delete;
+
+    /** Append one frame (the lidar packets that arrived for it, any order, gaps allowed).  Submits
+     *  the batch when it is full; blocks only when every buffer set is still in flight, and then
+     *  delivers the oldest batch to the callback first. */
+    void push_frame(const std::vector<const uint8_t*>& lidar_packets);
+    /** Submit a partial batch and deliver everything still in flight. */
+    void finish();
+
+    uint64_t frames_pushed() const { return pushed_; }
+    uint64_t frames_delivered() const { return delivered_; }
+
+   private:
+    struct Slot;
+    void submit(Slot& s);
+    void deliver(Slot& s);
+
+    StreamOptions opt_;
+    Callback cb_;
+    std::vector<std::unique_ptr<Slot>> slots_;
+    size_t cur_ = 0;
+    uint64_t pushed_ = 0, delivered_ = 0;
+    void* stream_h2d_ = nullptr;
+    void* stream_d2h_ = nullptr;
+};
+
+}  // namespace hip
+}  // namespace sdk
+}  // namespace ouster

@@ -119,12 +119,18 @@ void DeviceFrameBatch::decode() {
     }
     for (const auto& l : luts_) luts.push_back(l.device().handle);
     check(ouster_hip_decode(default_ctx(), fmt_, static_cast<const uint8_t*>(d_packets_.data()), stride_,
-                            slots_, counts_.data(), n_frames_, nullptr, &out,
+                            slots_, opt_.all_slots ? nullptr : counts_.data(), n_frames_, nullptr, &out,
                             d_dst_.empty() ? nullptr : shifts_.data(), luts.empty() ? nullptr : luts.data(),
                             static_cast<uint32_t>(luts.size())));
 }
 
 void DeviceFrameBatch::sync() { check(ouster_hip_sync(default_ctx())); }
+
+size_t DeviceFrameBatch::plane_bytes_per_frame(const std::string& name) const {
+    for (const auto& f : fields_)
+        if (f.first == name) return static_cast<size_t>(h_) * w_ * f.second;
+    throw std::out_of_range("DeviceFrameBatch: unknown plane '" + name + "'");
+}
 
 void* DeviceFrameBatch::plane_device(const std::string& name) { return d_planes_.at(name).data(); }
 void* DeviceFrameBatch::destaggered_device(const std::string& name) { return d_dst_.at(name).data(); }

@@ -1,0 +1,186 @@
+// frame_stream.cpp -- see include/ouster/hip/frame_stream.h
+#include "ouster/hip/frame_stream.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <stdexcept>
+
+#include "host_internal.h"
+
+namespace ouster {
+namespace sdk {
+namespace hip {
+
+namespace {
+void ok(hipError_t e, const char* what) {
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string("ouster_hip: ") + what + ": " + hipGetErrorString(e));
+}
+struct Pinned {
+    void* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t bytes) {
+        n = bytes;
+        if (bytes) ok(hipHostMalloc(&p, bytes, hipHostMallocDefault), "hipHostMalloc");
+    }
+    ~Pinned() {
+        if (p) (void)hipHostFree(p);
+    }
+};
+}  // namespace
+
+struct FrameStream::Slot {
+    std::unique_ptr<DeviceFrameBatch> batch;
+    Pinned packets;                      // [frames][slots][stride]
+    Pinned xyz[2], ts, mid, status;
+    std::map<std::string, Pinned> planes, destaggered;
+    hipEvent_t e_h2d = nullptr, e_dec = nullptr, e_done = nullptr;
+    uint32_t filled = 0;                 // frames copied into `packets`
+    bool in_flight = false;
+    uint64_t first_frame = 0;
+    uint32_t n_frames = 0;
+};
+
+FrameStream::FrameStream(const std::vector<core::SensorInfo>& sensors, const StreamOptions& options,
+                         Callback on_batch)
+    : opt_(options), cb_(std::move(on_batch)) {
+    if (sensors.empty()) throw std::invalid_argument("FrameStream: no sensors");
+    if (opt_.frames_per_batch == 0 || opt_.frames_per_batch % sensors.size() != 0)
+        throw std::invalid_argument("FrameStream: frames_per_batch must be a multiple of the sensor count");
+    if (opt_.batches_in_flight == 0) throw std::invalid_argument("FrameStream: batches_in_flight must be > 0");
+    opt_.outputs.all_slots = true;
+    if (opt_.download_xyz) opt_.outputs.xyz = true;
+    default_ctx();
+    hipStream_t a = nullptr, b = nullptr;
+    ok(hipStreamCreateWithFlags(&a, hipStreamNonBlocking), "hipStreamCreate");
+    ok(hipStreamCreateWithFlags(&b, hipStreamNonBlocking), "hipStreamCreate");
+    stream_h2d_ = a;
+    stream_d2h_ = b;
+    for (uint32_t i = 0; i < opt_.batches_in_flight; ++i) {
+        auto s = std::make_unique<Slot>();
+        s->batch = std::make_unique<DeviceFrameBatch>(sensors, opt_.frames_per_batch, opt_.outputs);
+        DeviceFrameBatch& bt = *s->batch;
+        const size_t n = opt_.frames_per_batch;
+        s->packets.alloc(n * bt.slots_per_frame() * bt.packet_stride());
+        std::memset(s->packets.p, 0, s->packets.n);
+        if (opt_.download_xyz)
+            for (int k = 0; k < 2; ++k)
+                if (bt.xyz_device(k)) s->xyz[k].alloc(n * bt.xyz_bytes_per_frame());
+        for (const auto& name : opt_.download_planes) s->planes[name].alloc(n * bt.plane_bytes_per_frame(name));
+        for (const auto& name : opt_.download_destaggered) {
+            (void)bt.destaggered_device(name);  // throws if it is not produced
+            s->destaggered[name].alloc(n * bt.plane_bytes_per_frame(name));
+        }
+        if (opt_.download_headers) {
+            s->ts.alloc(n * bt.w() * 8);
+            s->mid.alloc(n * bt.w() * 2);
+            s->status.alloc(n * bt.w() * 4);
+        }
+        ok(hipEventCreateWithFlags(&s->e_h2d, hipEventDisableTiming), "hipEventCreate");
+        ok(hipEventCreateWithFlags(&s->e_dec, hipEventDisableTiming), "hipEventCreate");
+        ok(hipEventCreateWithFlags(&s->e_done, hipEventDisableTiming), "hipEventCreate");
+        slots_.push_back(std::move(s));
+    }
+}
+
+FrameStream::~FrameStream() {
+    for (auto& s : slots_) {
+        if (s->in_flight) (void)hipEventSynchronize(s->e_done);
+        for (hipEvent_t e : {s->e_h2d, s->e_dec, s->e_done})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (stream_h2d_) (void)hipStreamDestroy(static_cast<hipStream_t>(stream_h2d_));
+    if (stream_d2h_) (void)hipStreamDestroy(static_cast<hipStream_t>(stream_d2h_));
+}
+
+void FrameStream::push_frame(const std::vector<const uint8_t*>& lidar_packets) {
+    Slot& s = *slots_[cur_];
+    if (s.in_flight) deliver(s);  // every buffer set busy: the oldest batch has to come home first
+    DeviceFrameBatch& bt = *s.batch;
+    if (lidar_packets.size() > bt.slots_per_frame())
+        throw std::invalid_argument("FrameStream: too many packets for a frame");
+    if (s.filled == 0) s.first_frame = pushed_;
+    uint8_t* base = static_cast<uint8_t*>(s.packets.p) +
+                    static_cast<size_t>(s.filled) * bt.slots_per_frame() * bt.packet_stride();
+    for (size_t i = 0; i < lidar_packets.size(); ++i)
+        std::memcpy(base + i * bt.packet_stride(), lidar_packets[i], bt.lidar_packet_size());
+    // slots without a packet keep their all-zero content (status 0 = invalid columns)
+    if (lidar_packets.size() < bt.slots_per_frame())
+        std::memset(base + lidar_packets.size() * bt.packet_stride(), 0,
+                    (bt.slots_per_frame() - lidar_packets.size()) * bt.packet_stride());
+    ++s.filled;
+    ++pushed_;
+    if (s.filled == opt_.frames_per_batch) submit(s);
+}
+
+void FrameStream::submit(Slot& s) {
+    DeviceFrameBatch& bt = *s.batch;
+    const size_t per_frame = static_cast<size_t>(bt.slots_per_frame()) * bt.packet_stride();
+    if (s.filled < opt_.frames_per_batch)  // partial batch: the unused frames decode to "empty"
+        std::memset(static_cast<uint8_t*>(s.packets.p) + s.filled * per_frame, 0,
+                    (opt_.frames_per_batch - s.filled) * per_frame);
+    auto h2d = static_cast<hipStream_t>(stream_h2d_);
+    auto d2h = static_cast<hipStream_t>(stream_d2h_);
+    auto comp = static_cast<hipStream_t>(ouster_hip_ctx_stream(default_ctx()));
+    ok(hipMemcpyAsync(bt.packets_device(), s.packets.p, s.packets.n, hipMemcpyHostToDevice, h2d), "H2D");
+    ok(hipEventRecord(s.e_h2d, h2d), "hipEventRecord");
+    ok(hipStreamWaitEvent(comp, s.e_h2d, 0), "hipStreamWaitEvent");
+    bt.decode();
+    ok(hipEventRecord(s.e_dec, comp), "hipEventRecord");
+    ok(hipStreamWaitEvent(d2h, s.e_dec, 0), "hipStreamWaitEvent");
+    const size_t n = opt_.frames_per_batch;
+    for (int k = 0; k < 2; ++k)
+        if (s.xyz[k].p)
+            ok(hipMemcpyAsync(s.xyz[k].p, bt.xyz_device(k), n * bt.xyz_bytes_per_frame(),
+                              hipMemcpyDeviceToHost, d2h), "D2H xyz");
+    for (auto& kv : s.planes)
+        ok(hipMemcpyAsync(kv.second.p, bt.plane_device(kv.first), kv.second.n, hipMemcpyDeviceToHost, d2h), "D2H plane");
+    for (auto& kv : s.destaggered)
+        ok(hipMemcpyAsync(kv.second.p, bt.destaggered_device(kv.first), kv.second.n, hipMemcpyDeviceToHost, d2h),
+           "D2H destaggered");
+    if (opt_.download_headers) {
+        ok(hipMemcpyAsync(s.ts.p, bt.timestamp_device(), s.ts.n, hipMemcpyDeviceToHost, d2h), "D2H ts");
+        ok(hipMemcpyAsync(s.mid.p, bt.measurement_id_device(), s.mid.n, hipMemcpyDeviceToHost, d2h), "D2H m_id");
+        ok(hipMemcpyAsync(s.status.p, bt.status_device(), s.status.n, hipMemcpyDeviceToHost, d2h), "D2H status");
+    }
+    ok(hipEventRecord(s.e_done, d2h), "hipEventRecord");
+    s.in_flight = true;
+    s.n_frames = s.filled;
+    s.filled = 0;
+    cur_ = (cur_ + 1) % slots_.size();
+}
+
+void FrameStream::deliver(Slot& s) {
+    ok(hipEventSynchronize(s.e_done), "hipEventSynchronize");
+    s.in_flight = false;
+    BatchResult r;
+    r.first_frame = s.first_frame;
+    r.n_frames = s.n_frames;
+    r.h = s.batch->h();
+    r.w = s.batch->w();
+    for (int k = 0; k < 2; ++k) r.xyz[k] = s.xyz[k].p;
+    for (auto& kv : s.planes) r.planes[kv.first] = kv.second.p;
+    for (auto& kv : s.destaggered) r.destaggered[kv.first] = kv.second.p;
+    r.timestamp = static_cast<const uint64_t*>(s.ts.p);
+    r.measurement_id = static_cast<const uint16_t*>(s.mid.p);
+    r.status = static_cast<const uint32_t*>(s.status.p);
+    delivered_ += s.n_frames;
+    if (cb_) cb_(r);
+}
+
+void FrameStream::finish() {
+    if (slots_[cur_]->filled) {
+        if (slots_[cur_]->in_flight) deliver(*slots_[cur_]);  // cannot happen (filled implies free), kept for safety
+        submit(*slots_[cur_]);
+    }
+    // oldest first: the slot after the last submitted one
+    for (size_t i = 0; i < slots_.size(); ++i) {
+        Slot& s = *slots_[(cur_ + i) % slots_.size()];
+        if (s.in_flight) deliver(s);
+    }
+}
+
+}  // namespace hip
+}  // namespace sdk
+}  // namespace ouster

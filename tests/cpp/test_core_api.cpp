@@ -16,6 +16,7 @@
 
 #include "ouster/core/lidar_scan.h"  // pulls in everything + the legacy aliases
 #include "ouster/hip/device_batch.h"
+#include "ouster/hip/frame_stream.h"
 
 using namespace ouster::sdk::core;
 
@@ -857,6 +858,76 @@ static void test_device_batch() {
     CHECK(wd <= 1e-4f);  // batch: f64 tables -> f32; XYZLutT<float>: the reference's f32 LUT arithmetic
 }
 
+// host packets in, host results out, batches overlapping on the copy / compute / copy streams
+static void test_frame_stream() {
+    std::printf("FrameStream (pinned staging, overlapped H2D / decode / D2H)\n");
+    auto a = make_info(UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, HeaderType::STANDARD, 64, 512);
+    auto pf = std::make_shared<PacketFormat>(a);
+    const uint32_t n = 11;  // 2 full batches of 4 + a partial one of 3
+    std::vector<LidarFrame> src;
+    std::vector<std::vector<LidarPacket>> pk;
+    for (uint32_t f = 0; f < n; ++f) {
+        src.emplace_back(a);
+        randomize(src.back(), *pf, 300 + f);
+        src.back().frame_id = 900 + f;
+        pk.push_back(impl::frame_to_packets(src.back(), pf, a.init_id, a.sn));
+    }
+    ouster::sdk::hip::StreamOptions opt;
+    opt.frames_per_batch = 4;
+    opt.batches_in_flight = 2;
+    opt.outputs.destagger = {"RANGE"};
+    opt.download_planes = {"RANGE", "REFLECTIVITY2"};
+    opt.download_destaggered = {"RANGE"};
+    XYZLut lut(a, true);
+    uint64_t next = 0;
+    bool order_ok = true, planes_ok = true, dst_ok = true, hdr_ok = true;
+    double worst = 0;
+    uint32_t batches = 0;
+    ouster::sdk::hip::FrameStream stream({a}, opt, [&](const ouster::sdk::hip::BatchResult& r) {
+        ++batches;
+        order_ok &= r.first_frame == next && r.h == 64 && r.w == 512;
+        next += r.n_frames;
+        const size_t npx = 64 * 512;
+        for (uint32_t i = 0; i < r.n_frames; ++i) {
+            const size_t f = r.first_frame + i;
+            img_t<uint32_t> want(64, 512);
+            std::memcpy(want.data(), src[f].field("RANGE").get(), npx * 4);
+            if (f == 5)
+                for (size_t row = 0; row < 64; ++row)
+                    for (size_t c = 32; c < 48; ++c) want(row, c) = 0;  // packet 2 of frame 5 never arrived
+            const uint32_t* got = static_cast<const uint32_t*>(r.planes.at("RANGE")) + i * npx;
+            planes_ok &= std::memcmp(got, want.data(), npx * 4) == 0;
+            if (f != 5)
+                planes_ok &= std::memcmp(static_cast<const uint8_t*>(r.planes.at("REFLECTIVITY2")) + i * npx,
+                                         src[f].field("REFLECTIVITY2").get(), npx) == 0;
+            const auto dwant = destagger<uint32_t>(a, want);
+            dst_ok &= std::memcmp(static_cast<const uint32_t*>(r.destaggered.at("RANGE")) + i * npx, dwant.data(), npx * 4) == 0;
+            PointCloudXYZd ref = lut(want);
+            const float* xyz = static_cast<const float*>(r.xyz[0]) + i * npx * 3;
+            for (size_t k = 0; k < npx * 3; ++k) worst = std::max(worst, std::abs(static_cast<double>(xyz[k]) - ref.data()[k]));
+            hdr_ok &= r.status[i * 512 + 31] == 1 && r.status[i * 512 + 40] == (f == 5 ? 0u : 1u) &&
+                      r.timestamp[i * 512 + 7] == 1007 && r.measurement_id[i * 512 + 100] == 100;
+        }
+    });
+    for (uint32_t f = 0; f < n; ++f) {
+        std::vector<const uint8_t*> ptrs;
+        for (size_t i = 0; i < pk[f].size(); ++i)
+            if (!(f == 5 && i == 2)) ptrs.push_back(pk[f][i].buf.data());
+        if (f == 3) std::swap(ptrs[0], ptrs[7]);  // any order within a frame
+        stream.push_frame(ptrs);
+    }
+    stream.finish();
+    CHECK(stream.frames_pushed() == n && stream.frames_delivered() == n && batches == 3 && next == n);
+    CHECK(order_ok);
+    CHECK(planes_ok);
+    CHECK(dst_ok);
+    CHECK(hdr_ok);
+    CHECK(worst <= 4e-5);
+    CHECK(throws_with<std::invalid_argument>([&] {
+        ouster::sdk::hip::StreamOptions bad; bad.frames_per_batch = 3;
+        ouster::sdk::hip::FrameStream s2({a, a}, bad, nullptr); }, "multiple of the sensor count"));
+}
+
 static void test_legacy_aliases() {
     std::printf("legacy aliases\n");
     ouster::sensor::sensor_info info =
@@ -882,6 +953,7 @@ int main() {
     test_dewarp();
     test_frame_dewarp();
     test_device_batch();
+    test_frame_stream();
     test_legacy_aliases();
     std::printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail ? 1 : 0;
