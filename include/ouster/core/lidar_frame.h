@@ -11,6 +11,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <memory>
 #include <queue>
@@ -309,6 +310,15 @@ class FrameBatcher {
      * continues normally afterwards.
      */
     void flush(LidarFrame& lidar_frame);
+    /**
+     * Extension: hand every released frame's packets (arrival order, each lidar_packet_size bytes,
+     * valid during the call) to `sink` instead of decoding them into `lidar_frame`.  The state
+     * machine (frame boundaries, reorder cache, init-id changes, completeness) runs unchanged and
+     * `lidar_frame` still receives the frame-level values and packet timestamps; its planes and
+     * column headers are left alone.  Used by hip::FrameStream to batch whole frames for the GPU.
+     */
+    using PacketSink = std::function<void(const std::vector<const uint8_t*>& packets)>;
+    void set_packet_sink(PacketSink sink);
     size_t batched_packets() const;
     size_t dropped_packets() const;
     void set_max_cache_size(size_t n);

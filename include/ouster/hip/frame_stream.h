@@ -57,6 +57,10 @@ class FrameStream {
      *  the batch when it is full; blocks only when every buffer set is still in flight, and then
      *  delivers the oldest batch to the callback first. */
     void push_frame(const std::vector<const uint8_t*>& lidar_packets);
+    /** Packet-level entry for a single-sensor stream: runs the reference's FrameBatcher state
+     *  machine (frame-id boundaries, reorder cache, init-id changes) on the host and pushes every
+     *  released frame.  A trailing incomplete frame is not emitted, like the reference's sources. */
+    void push_packet(const core::Packet& lidar_packet);
     /** Submit a partial batch and deliver everything still in flight. */
     void finish();
 
@@ -75,6 +79,9 @@ class FrameStream {
     uint64_t pushed_ = 0, delivered_ = 0;
     void* stream_h2d_ = nullptr;
     void* stream_d2h_ = nullptr;
+    std::vector<core::SensorInfo> sensors_;
+    std::unique_ptr<core::FrameBatcher> splitter_;   // push_packet only
+    std::unique_ptr<core::LidarFrame> splitter_frame_;
 };
 
 }  // namespace hip

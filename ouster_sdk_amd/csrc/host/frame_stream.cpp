@@ -44,7 +44,7 @@ struct FrameStream::Slot {
 
 FrameStream::FrameStream(const std::vector<core::SensorInfo>& sensors, const StreamOptions& options,
                          Callback on_batch)
-    : opt_(options), cb_(std::move(on_batch)) {
+    : opt_(options), cb_(std::move(on_batch)), sensors_(sensors) {
     if (sensors.empty()) throw std::invalid_argument("FrameStream: no sensors");
     if (opt_.frames_per_batch == 0 || opt_.frames_per_batch % sensors.size() != 0)
         throw std::invalid_argument("FrameStream: frames_per_batch must be a multiple of the sensor count");
@@ -112,6 +112,17 @@ void FrameStream::push_frame(const std::vector<const uint8_t*>& lidar_packets) {
     ++s.filled;
     ++pushed_;
     if (s.filled == opt_.frames_per_batch) submit(s);
+}
+
+void FrameStream::push_packet(const core::Packet& lidar_packet) {
+    if (sensors_.size() != 1)
+        throw std::logic_error("FrameStream::push_packet serves single-sensor streams; push_frame otherwise");
+    if (!splitter_) {
+        splitter_ = std::make_unique<core::FrameBatcher>(sensors_[0]);
+        splitter_frame_ = std::make_unique<core::LidarFrame>(sensors_[0]);
+        splitter_->set_packet_sink([this](const std::vector<const uint8_t*>& packets) { push_frame(packets); });
+    }
+    (void)splitter_->batch(lidar_packet, *splitter_frame_);
 }
 
 void FrameStream::submit(Slot& s) {

@@ -356,6 +356,7 @@ struct FrameBatcher::State {
     std::vector<std::string> fmt_fields;
     std::vector<uint32_t> fmt_elems;
     hip::DeviceBuffer d_packets, d_out;
+    FrameBatcher::PacketSink sink;  // set: released frames go here instead of being decoded
 
     ~State() {
         if (fmt) ouster_hip_format_destroy(fmt);
@@ -384,6 +385,7 @@ void FrameBatcher::reset() {
     s_->staged_count = 0;
     s_->cache.clear();
 }
+void FrameBatcher::set_packet_sink(PacketSink sink) { s_->sink = std::move(sink); }
 size_t FrameBatcher::batched_packets() const { return s_->batched_lidar_packets; }
 size_t FrameBatcher::dropped_packets() const { return s_->dropped_packets; }
 void FrameBatcher::set_max_cache_size(size_t n) {
@@ -439,7 +441,13 @@ struct BatcherOps {
 
     // finalize_frame (lidar_frame.cpp:1905-1927) + the deferred decode of the whole frame
     static void finalize_frame(FrameBatcher::State& s, const PacketFormat& pf, LidarFrame& frame) {
-        decode_staged(s, pf, frame);
+        if (s.sink) {
+            std::vector<const uint8_t*> ptrs(s.staged_count);
+            for (size_t i = 0; i < s.staged_count; ++i) ptrs[i] = s.staged.data() + i * s.stride;
+            s.sink(ptrs);
+        } else {
+            decode_staged(s, pf, frame);
+        }
         if (frame.sensor_info && frame.sensor_info->init_id == s.last_init_id &&
             frame.frame_id <= s.last_frame_id && pf.header_type == HeaderType::FUSA)
             throw std::runtime_error("32-bit frame id did not increase since the last frame");

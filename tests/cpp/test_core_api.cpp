@@ -923,6 +923,47 @@ static void test_frame_stream() {
     CHECK(dst_ok);
     CHECK(hdr_ok);
     CHECK(worst <= 4e-5);
+    {   // packet-level entry: the FrameBatcher state machine splits the stream, frames go to the GPU in batches
+        std::vector<const LidarPacket*> seq;
+        for (uint32_t f = 0; f < 6; ++f)
+            for (size_t i = 0; i < pk[f].size(); ++i)
+                if (!(f == 2 && i == 9)) seq.push_back(&pk[f][i]);       // frame 2 loses a packet
+        std::swap(seq[pk[0].size() - 1], seq[pk[0].size()]);             // swap across the 0 -> 1 boundary
+        for (auto* p : seq) const_cast<LidarPacket*>(p)->host_timestamp = 77;
+        // expectation: the decoding FrameBatcher on the same sequence
+        std::vector<LidarFrame> want;
+        {
+            FrameBatcher fb(a);
+            LidarFrame ls(a);
+            for (auto* p : seq)
+                if (fb(*p, ls)) want.push_back(ls);
+        }
+        CHECK(want.size() >= 5);
+        std::vector<std::vector<uint32_t>> got;
+        std::vector<std::vector<uint32_t>> got_status;
+        ouster::sdk::hip::StreamOptions o2;
+        o2.frames_per_batch = 2;
+        o2.batches_in_flight = 2;
+        o2.download_xyz = false;
+        o2.download_planes = {"RANGE"};
+        ouster::sdk::hip::FrameStream s2({a}, o2, [&](const ouster::sdk::hip::BatchResult& r) {
+            const size_t npx = 64 * 512;
+            for (uint32_t i = 0; i < r.n_frames; ++i) {
+                const uint32_t* p = static_cast<const uint32_t*>(r.planes.at("RANGE")) + i * npx;
+                got.emplace_back(p, p + npx);
+                got_status.emplace_back(r.status + i * 512, r.status + (i + 1) * 512);
+            }
+        });
+        for (auto* p : seq) s2.push_packet(*p);
+        s2.finish();
+        CHECK(got.size() == want.size());
+        bool same = true;
+        for (size_t f = 0; f < std::min(got.size(), want.size()); ++f) {
+            same &= std::memcmp(got[f].data(), want[f].field("RANGE").get(), got[f].size() * 4) == 0;
+            same &= std::memcmp(got_status[f].data(), want[f].status().data(), 512 * 4) == 0;
+        }
+        CHECK(same);
+    }
     CHECK(throws_with<std::invalid_argument>([&] {
         ouster::sdk::hip::StreamOptions bad; bad.frames_per_batch = 3;
         ouster::sdk::hip::FrameStream s2({a, a}, bad, nullptr); }, "multiple of the sensor count"));

@@ -52,3 +52,13 @@ def test_reference_snapshot_hashes_through_cpp_mirror(oracle):
             got[k] = int(v)
         for name, want in fields.items():
             assert got.get(name) == want, (base, name, p.stdout)
+        # the same capture through the streaming pipeline (FrameStream::push_packet)
+        p = subprocess.run(args + ["stream"], capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = p.stdout.splitlines()
+        if lines[0] == "stream frames 0":      # the 8-packet FUSA capture never completes a frame
+            assert "FUSA" in names[cal.profile]
+            continue
+        got = {k: int(v) for k, v in (ln.split() for ln in lines[1:])}
+        for name, want in fields.items():
+            assert got.get(name) == want, (base, name, "stream", p.stdout)
