@@ -18,6 +18,9 @@
  *     work is ordered on the context's stream (ouster_hip_ctx_stream) and is
  *     asynchronous unless stated otherwise; call ouster_hip_sync() to wait.
  *   - plain pointers and sizes only; no C++/torch types.
+ *   - a context is not thread-safe (like the reference's FrameBatcher, one per stream of work,
+ *     externally serialised); distinct contexts may be used from distinct threads.  Formats and
+ *     LUTs are immutable after creation and may be shared by the calls of their context.
  */
 #ifndef OUSTER_HIP_H
 #define OUSTER_HIP_H
