@@ -148,6 +148,36 @@ static void test_packet_format_tables() {
         "Unknown lidar udp profile"));
 }
 
+// header set / get round trips for every (profile, header type) of the reference's
+// PacketFormatTest.packet_packet_format_headers_test (packet_format_test.cpp:157-216)
+static void test_packet_headers() {
+    std::printf("packet / column header setters and getters\n");
+    for (UDPProfileLidar prof : {UDPProfileLidar::LEGACY, UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_DUAL,
+                                 UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, UDPProfileLidar::RNG15_RFL8_NIR8,
+                                 UDPProfileLidar::FUSA_RNG15_RFL8_NIR8_DUAL})
+        for (HeaderType ht : {HeaderType::STANDARD, HeaderType::FUSA}) {
+            SensorInfo info = make_info(prof, ht, 128, 1024);
+            PacketFormat pf(info);
+            LidarPacket p(static_cast<int>(pf.lidar_packet_size));
+            pf.set_col_status(pf.nth_col(9, p.buf.data()), 123);
+            CHECK(pf.col_status(pf.nth_col(9, p.buf.data())) == 123);
+            pf.set_col_timestamp(pf.nth_col(11, p.buf.data()), 80899);
+            CHECK(pf.col_timestamp(pf.nth_col(11, p.buf.data())) == 80899);
+            pf.set_col_measurement_id(pf.nth_col(7, p.buf.data()), 613);
+            CHECK(pf.col_measurement_id(pf.nth_col(7, p.buf.data())) == 613);
+            pf.set_frame_id(p.buf.data(), 777);
+            CHECK(pf.frame_id(p.buf.data()) == 777);
+            if (prof != UDPProfileLidar::LEGACY) {
+                pf.set_init_id(p.buf.data(), 0x123456);
+                CHECK(pf.init_id(p.buf.data()) == 0x123456);
+                pf.set_prod_sn(p.buf.data(), 0x1234567890ull);
+                CHECK(pf.prod_sn(p.buf.data()) == 0x1234567890ull);
+                // neighbours untouched by each other's read-modify-write
+                CHECK(pf.frame_id(p.buf.data()) == 777 && pf.col_measurement_id(pf.nth_col(7, p.buf.data())) == 613);
+            }
+        }
+}
+
 static void test_lidar_frame_container() {
     std::printf("LidarFrame container\n");
     {   // lidar_frame_test.cpp:453-490 (first valid packet timestamp), :482-490 (packet slots), :604-609
@@ -984,6 +1014,7 @@ static void test_legacy_aliases() {
 
 int main() {
     test_packet_format_tables();
+    test_packet_headers();
     test_lidar_frame_container();
     test_batcher_roundtrip();
     test_batcher_state_machine();
