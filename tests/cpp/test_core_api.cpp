@@ -205,6 +205,46 @@ static void test_lidar_frame_container() {
         bad.format.columns_per_packet = 0;
         CHECK(throws_with<std::invalid_argument>([&] { FrameBatcher fb(bad); }, "unexpected columns_per_packet: 0"));
     }
+    {   // constructors and equality (lidar_frame_test.cpp:100-335)
+        LidarFrame empty;
+        CHECK(empty.w == 0 && empty.h == 0 && empty.frame_id == -1 && empty.fields().empty());
+        CHECK(empty == LidarFrame());
+        LidarFrame legacy(20, 10, UDPProfileLidar::LEGACY);
+        std::vector<std::string> names;
+        for (const auto& kv : legacy.fields()) names.push_back(kv.first);
+        CHECK((names == std::vector<std::string>{"FLAGS", "NEAR_IR", "RANGE", "REFLECTIVITY", "SIGNAL"}));
+        CHECK(legacy.status().count() == 0 && legacy.timestamp().count() == 0 && legacy.measurement_id().count() == 0);
+        LidarFrame dual(60, 40, UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_DUAL);
+        CHECK(dual.has_field("RANGE2") && dual.has_field("SIGNAL2") && dual.has_field("REFLECTIVITY2") &&
+              dual.has_field("FLAGS2") && dual.fields().size() >= 9);
+        LidarFrameFieldTypes ft = {{"RANGE", ChanFieldType::UINT32}, {"SIGNAL", ChanFieldType::UINT16},
+                                   {"CUSTOM0", ChanFieldType::UINT64}, {"CUSTOM7", ChanFieldType::UINT16}};
+        LidarFrame custom(100, 80, ft);
+        auto got_ft = custom.field_types();
+        std::sort(ft.begin(), ft.end());
+        std::sort(got_ft.begin(), got_ft.end());
+        CHECK(got_ft == ft && custom.fields().size() == 4);
+        CHECK(custom.field("CUSTOM0").tag() == ChanFieldType::UINT64 && custom.field("CUSTOM0").bytes() == 100 * 80 * 8);
+        // equality looks at planes, headers and frame-level values
+        LidarFrame a1(20, 10, UDPProfileLidar::LEGACY), a2(20, 10, UDPProfileLidar::LEGACY);
+        CHECK(a1 == a2);
+        a2.frame_id = 5;
+        CHECK(!(a1 == a2));
+        a2.frame_id = -1;
+        a2.status()[3] = 1;
+        CHECK(!(a1 == a2));
+        a2.status()[3] = 0;
+        a2.field<uint16_t>("SIGNAL")(2, 2) = 9;
+        CHECK(!(a1 == a2));
+        CHECK(!(a1 == LidarFrame(20, 12, UDPProfileLidar::LEGACY)) && !(legacy == dual));
+        // user-added planes live next to the profile's
+        a1.add_field("my_plane", ChanFieldType::FLOAT32);
+        CHECK(a1.has_field("my_plane") && a1.field("my_plane").bytes() == 20 * 10 * 4);
+        a1.del_field("my_plane");
+        CHECK(!a1.has_field("my_plane"));
+        LidarFrame moved(std::move(dual));
+        CHECK(moved.w == 40 && moved.has_field("RANGE2"));
+    }
     CHECK(throws_with<std::invalid_argument>([] { LidarFrame f(0, 10, LidarFrameFieldTypes{}); },
                                              "zero width or height"));
     CHECK(throws_with<std::invalid_argument>([] { LidarFrame f(4, 16, LidarFrameFieldTypes{}, 0); },
