@@ -13,7 +13,10 @@
 
 #include <cstring>
 
+#include <pybind11/functional.h>
+
 #include "ouster/core/lidar_scan.h"
+#include "ouster/hip/frame_stream.h"
 
 namespace py = pybind11;
 using namespace ouster::sdk::core;
@@ -378,6 +381,65 @@ PYBIND11_MODULE(core, m) {
             return py::make_tuple(p, c, t);
         },
         py::arg("frame"), py::arg("xyzlut"), py::arg("min_range"), py::arg("max_range"));
+
+    // streaming pipeline for host-side packets (include/ouster/hip/frame_stream.h; extension over the
+    // reference's Python surface).  The callback receives a dict of numpy VIEWS of pinned memory that
+    // are valid only during the call: copy what must outlive it.
+    {
+        namespace oh = ouster::sdk::hip;
+        py::class_<oh::FrameStream>(m, "FrameStream")
+            .def(py::init([](const SensorInfo& info, py::function on_batch, uint32_t frames_per_batch,
+                             uint32_t batches_in_flight, std::vector<std::string> planes,
+                             std::vector<std::string> destaggered, bool xyz) {
+                     oh::StreamOptions opt;
+                     opt.frames_per_batch = frames_per_batch;
+                     opt.batches_in_flight = batches_in_flight;
+                     opt.download_xyz = xyz;
+                     opt.download_planes = planes;
+                     opt.download_destaggered = destaggered;
+                     opt.outputs.destagger = destaggered;
+                     LidarFrame layout(info);
+                     std::map<std::string, py::dtype> dts;
+                     for (const auto& n : planes) dts.emplace(n, dtype_of(layout.field(n).tag()));
+                     for (const auto& n : destaggered) dts.emplace(n, dtype_of(layout.field(n).tag()));
+                     auto cb = [on_batch, dts](const oh::BatchResult& r) {
+                         py::dict d;
+                         const py::ssize_t n = r.n_frames, h = r.h, w = r.w;
+                         auto view = [&](const py::dtype& dt, std::vector<py::ssize_t> shape, const void* p) {
+                             return py::array(dt, std::move(shape), p, py::none());  // non-owning view
+                         };
+                         d["first_frame"] = r.first_frame;
+                         d["n_frames"] = r.n_frames;
+                         for (int k = 0; k < 2; ++k)
+                             if (r.xyz[k])
+                                 d[k == 0 ? "xyz" : "xyz2"] = view(py::dtype::of<float>(), {n, h, w, 3}, r.xyz[k]);
+                         for (const auto& kv : r.planes) d[kv.first.c_str()] = view(dts.at(kv.first), {n, h, w}, kv.second);
+                         for (const auto& kv : r.destaggered)
+                             d[("destaggered:" + kv.first).c_str()] = view(dts.at(kv.first), {n, h, w}, kv.second);
+                         if (r.timestamp) {
+                             d["timestamp"] = view(py::dtype::of<uint64_t>(), {n, w}, r.timestamp);
+                             d["measurement_id"] = view(py::dtype::of<uint16_t>(), {n, w}, r.measurement_id);
+                             d["status"] = view(py::dtype::of<uint32_t>(), {n, w}, r.status);
+                         }
+                         on_batch(d);
+                     };
+                     return std::make_unique<oh::FrameStream>(std::vector<SensorInfo>{info}, opt, cb);
+                 }),
+                 py::arg("info"), py::arg("on_batch"), py::arg("frames_per_batch") = 32,
+                 py::arg("batches_in_flight") = 3, py::arg("planes") = std::vector<std::string>{},
+                 py::arg("destaggered") = std::vector<std::string>{}, py::arg("xyz") = true)
+            .def("push_frame",
+                 [](oh::FrameStream& s, const std::vector<py::bytes>& packets) {
+                     std::vector<std::string> keep(packets.begin(), packets.end());
+                     std::vector<const uint8_t*> ptrs;
+                     for (const auto& b : keep) ptrs.push_back(reinterpret_cast<const uint8_t*>(b.data()));
+                     s.push_frame(ptrs);
+                 })
+            .def("push_packet", [](oh::FrameStream& s, const LidarPacket& p) { s.push_packet(p); })
+            .def("finish", &oh::FrameStream::finish)
+            .def_property_readonly("frames_pushed", &oh::FrameStream::frames_pushed)
+            .def_property_readonly("frames_delivered", &oh::FrameStream::frames_delivered);
+    }
 
     m.def("default_lidar_to_sensor", [] { return mat_to(DEFAULT_LIDAR_TO_SENSOR); });
     m.def("default_beam_to_lidar_transform", [](const std::string& p) { return mat_to(default_beam_to_lidar_transform(p)); });

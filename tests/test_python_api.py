@@ -259,3 +259,40 @@ def test_device_aware_front_keeps_tensors_in_hbm(meta):
             want = sdk.destagger(info, img, inv)         # numpy path = core.destagger
             got = sdk.destagger(info, torch.from_numpy(img).cuda(), inv)
             assert got.is_cuda and np.array_equal(got.cpu().numpy(), want)
+
+
+def test_frame_stream_replays_a_capture(oracle):
+    """pcap packets -> core.FrameStream.push_packet (FrameBatcher state machine on the host, batched
+    GPU decode through pinned staging) -> the reference's digest of the first frame
+    (tests/pcaps/*_digest.json, _digest.py:69-82) and XYZ equal to XYZLut(frame)."""
+    O = oracle
+    base = "OS-2-128-U1_v2.3.0_1024x10"
+    info, cal = _meta(O, base)
+    pf = core.PacketFormat(info)
+    pk = O.lidar_packets_from_pcap(os.path.join(PCAPS, base + ".pcap"), cal.packet_format())
+    got = []
+
+    def on_batch(d):
+        got.append({k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()})
+
+    names = ["RANGE", "SIGNAL", "REFLECTIVITY", "NEAR_IR"]
+    stream = core.FrameStream(info, on_batch, frames_per_batch=1, batches_in_flight=2, planes=names,
+                              destaggered=["RANGE"], xyz=True)
+    for p in pk:
+        lp = core.LidarPacket(pf.lidar_packet_size)
+        lp.buf = p.tobytes()
+        lp.host_timestamp = 9
+        stream.push_packet(lp)
+    stream.finish()
+    assert stream.frames_delivered == len(got) >= 1 and got[0]["first_frame"] == 0
+    dig = json.load(open(os.path.join(PCAPS, base + "_digest.json")))["scans"][0]
+    md5 = lambda a: hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+    first = got[0]
+    for n in names:
+        assert md5(first[n][0]) == dig[n], n
+    assert md5(first["timestamp"][0].astype(np.uint64)) == dig["TIMESTAMP"]
+    assert md5(first["status"][0].astype(np.uint64)) == dig["STATUS"]
+    assert np.array_equal(first["destaggered:RANGE"][0], core.destagger(info, first["RANGE"][0]))
+    want = core.XYZLut(info, True)(first["RANGE"][0])
+    assert first["xyz"].shape == (1, info.h, info.w, 3)
+    assert np.abs(first["xyz"][0].astype(np.float64) - want).max() <= 4e-5
