@@ -652,7 +652,7 @@ static void test_destagger() {
     CHECK(std::memcmp(df.get(), dref.data(), df.bytes()) == 0);
     for (size_t i = 0; i < f.w; ++i) f.timestamp()[i] = 5000 + i;
     CHECK(column_timestamp_at_destaggered_pixel(f, info, 1, 10) ==
-          5000 + (10 - info.format.pixel_shift_by_row[1] + 1024) % 1024);
+          static_cast<uint64_t>(5000 + (10 - info.format.pixel_shift_by_row[1] + 1024) % 1024));
 }
 
 static void test_xyzlut() {
