@@ -631,3 +631,42 @@ def test_map_epoch_wraps(oracle):
             assert np.array_equal(got, want_full if call % 2 == 0 else want_part), call
             st = _np(out["status"][0])
             assert st[:192].all() and (st[192:].all() if call % 2 == 0 else not st[192:].any()), call
+
+
+def test_df_sensor_per_pixel_angles(oracle):
+    """make_xyz_lut's DF branch (xyzlut.cpp:49-59): azimuth / altitude given per PIXEL (w*h entries,
+    encoder angle 0, no sign flip).  The C ABI keeps a full LUT for it; decode + cartesian must match
+    the oracle's LUT."""
+    O = oracle
+    h, w = 32, 512
+    g = np.random.default_rng(8)
+    az = g.uniform(-60, 60, h * w)
+    alt = g.uniform(-25, 25, h * w)
+    b2l = np.eye(4); b2l[0, 3] = 12.5; b2l[2, 3] = 3.0   # z offset: n = sqrt(x^2 + z^2)
+    tf = np.array([[0, -1, 0, 10.0], [1, 0, 0, -4.0], [0, 0, 1, 36.18], [0, 0, 0, 1]])
+    ldir, lofs = O.make_xyz_lut(w, h, 0.001, b2l, tf, az, alt)
+    a, e = np.deg2rad(az), np.deg2rad(alt)                # closed form of the branch
+    n = np.hypot(12.5, 3.0)
+    d = np.stack([np.cos(a) * np.cos(e), np.sin(a) * np.cos(e), np.sin(e)], 1)
+    o = np.stack([12.5 - d[:, 0] * n, -d[:, 1] * n, -d[:, 2] * n + 3.0], 1)
+    assert np.abs(ldir - d @ tf[:3, :3].T * 0.001).max() < 1e-15
+    assert np.abs(lofs - (o @ tf[:3, :3].T + tf[:3, 3]) * 0.001).max() < 1e-12
+    hp = HotPath("RNG15_RFL8_NIR8", h, w, 16)
+    lut = hp.add_lut(b2l, tf, az, alt)
+    ed, eo = lut.export(w, h)
+    assert np.abs(ed - ldir).max() < 1e-15 and np.abs(eo - lofs).max() < 1e-12
+    r = g.integers(0, 2 ** 18, size=(2, h, w)).astype(np.uint32)
+    r[g.random(r.shape) < 0.3] = 0
+    want = np.stack([O.cartesian(r[k], ldir, lofs) for k in range(2)])
+    got = _np(hp.cartesian(torch.from_numpy(r).cuda(), dtype=torch.float64))
+    assert np.abs(got - want).max() < 1e-9                # full f64 LUT built by the library (equal to the
+                                                          # oracle's to 1e-15), the reference's own r*dir+ofs
+    # and through the fused decode kernel
+    cal = O.synthetic_calib(h=h, w=w, profile="RNG15_RFL8_NIR8")
+    packets, src = O.synth_packets(cal, 2, with_window=True)
+    out = hp.alloc_outputs(2, xyz=["RANGE"], xyz_dtype=torch.float64)
+    hp.decode(torch.from_numpy(packets).cuda(), out)
+    for f in range(2):
+        assert np.abs(_np(out["xyz:RANGE"][f]) - O.cartesian(src[f].plane("RANGE"), ldir, lofs)).max() < 1e-9
+    with pytest.raises(ValueError, match="unexpected frame dimensions"):
+        hp.add_lut(b2l, tf, az[:-1], alt[:-1])
