@@ -670,3 +670,66 @@ def test_df_sensor_per_pixel_angles(oracle):
         assert np.abs(_np(out["xyz:RANGE"][f]) - O.cartesian(src[f].plane("RANGE"), ldir, lofs)).max() < 1e-9
     with pytest.raises(ValueError, match="unexpected frame dimensions"):
         hp.add_lut(b2l, tf, az[:-1], alt[:-1])
+
+
+@pytest.mark.parametrize("profile,hdr", [("RNG15_RFL8_NIR8_DUAL", 0), ("FUSA_RNG15_RFL8_NIR8_DUAL", 1), ("LEGACY", 0)])
+def test_packet_level_outputs(oracle, profile, hdr):
+    """packet_timestamp / alert_flags (written per packet slot, valid columns or not,
+    lidar_frame.cpp:1534-1539) and the frame-level values latched from the first packet
+    (start_frame, :1709-1741), through the C ABI with device host_timestamps."""
+    O = oracle
+    h, w, cpp = 32, 512, 16
+    cal = O.synthetic_calib(h=h, w=w, cpp=cpp, profile=profile, header_type=hdr)
+    pf = cal.packet_format()
+    g = np.random.default_rng(13)
+    n = 3
+    frames, packets = [], []
+    for f in range(n):
+        fr = O.Frame.for_profile(cal.profile, h, w, cpp, with_window=True)
+        O.randomize_frame(fr, pf, 50 + f, frame_id=800 + f)
+        if profile != "LEGACY":
+            fr.alert_flags[:] = g.integers(0, 256, fr.alert_flags.shape).astype(np.uint8)
+            fr.s.frame_status = int(g.integers(0, 4)) | (int(g.integers(0, 4)) << 4)
+            fr.s.shutdown_countdown = int(g.integers(0, 200))
+            fr.s.shot_limiting_countdown = int(g.integers(0, 200))
+        pk, _ = O.frame_to_packets(fr, pf, cal.init_id & 0xFFFFFF, cal.prod_sn)
+        frames.append(fr)
+        packets.append(pk.copy())
+    ppf = w // cpp
+    packets[1] = np.delete(packets[1], 7, axis=0)                 # a packet that never arrived
+    if profile != "LEGACY":
+        for c in range(cpp):                                      # a packet whose columns are all invalid
+            packets[2][4, pf.packet_header_size + c * pf.col_size + 10] &= 0xFE
+    host = np.zeros((n, ppf, pf.lidar_packet_size), np.uint8)
+    counts = np.zeros(n, np.uint32)
+    hts = np.zeros((n, ppf), np.uint64)
+    for f in range(n):
+        host[f, :len(packets[f])] = packets[f]
+        counts[f] = len(packets[f])
+        hts[f, :len(packets[f])] = 1000 * (f + 1) + np.arange(len(packets[f]))
+    hp = HotPath(profile, h, w, cpp, header_type=hdr)
+    out = hp.alloc_outputs(n)
+    out["packet_timestamp"] = torch.full((n, ppf), 7, dtype=torch.int64, device="cuda").to(torch.uint64)
+    out["alert_flags"] = torch.zeros((n, ppf), dtype=torch.uint8, device="cuda")
+    hp.decode(torch.from_numpy(host).cuda(), out, packet_counts=counts,
+              host_timestamps=torch.from_numpy(hts).cuda())
+    hp.sync()
+    meta = _np(out["frame_meta"]).reshape(n, 24)
+    for f in range(n):
+        ref = O.Frame.for_profile(cal.profile, h, w, cpp, with_window=True)
+        ref.fill(0)
+        b = O.Batcher(pf, init_id=cal.init_id & 0xFFFFFF, expected_packets=len(packets[f]))
+        for i, p in enumerate(packets[f]):
+            b.batch(p, int(hts[f, i]), ref)
+        if len(packets[f]) < ppf:
+            b.finalize(ref)
+        assert np.array_equal(_np(out["packet_timestamp"][f]), ref.packet_timestamp), f
+        assert np.array_equal(_np(out["alert_flags"][f]), ref.alert_flags), f
+        assert np.array_equal(_np(out["status"][f]), ref.status), f
+        assert meta[f, :8].view(np.int64)[0] == ref.frame_id == 800 + f
+        assert meta[f, 8:16].view(np.uint64)[0] == ref.s.frame_status
+        assert meta[f, 16:18].view(np.uint16)[0] == ref.s.shutdown_countdown
+        assert meta[f, 18:20].view(np.uint16)[0] == ref.s.shot_limiting_countdown
+    assert _np(out["packet_timestamp"][1])[7] == 0 and _np(out["packet_timestamp"][0]).all()
+    if profile != "LEGACY":
+        assert _np(out["packet_timestamp"][2])[4] == 3004 and not _np(out["status"][2])[64:80].any()
