@@ -542,6 +542,8 @@ def test_decode_is_graph_capturable(oracle):
     ("RNG19_RFL8_SIG16_NIR16_DUAL", 64, 1024, 0),
     ("LEGACY", 64, 1024, 0),
     ("FIVE_WORD_PIXEL", 32, 512, 0),               # generic descriptors, 20 B/px
+    ("RNG19_RFL8_SIG16_NIR16_RGB16", 32, 512, 0),  # 3 x f16 plane (6 B elements, NaN for absent columns)
+    ("RNG19_RFL8_SIG16_ZONE16_DUAL", 16, 512, 0),
     ("RNG15_RFL8_NIR8", 30, 1000, 0),              # ragged last tile, W % 64 != 0, short last row chunk
 ])
 def test_wide_tiles_match_oracle(oracle, monkeypatch, tw, profile, h, w, hdr):
