@@ -735,3 +735,55 @@ def test_packet_level_outputs(oracle, profile, hdr):
     assert _np(out["packet_timestamp"][1])[7] == 0 and _np(out["packet_timestamp"][0]).all()
     if profile != "LEGACY":
         assert _np(out["packet_timestamp"][2])[4] == 3004 and not _np(out["status"][2])[64:80].any()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tile_variants_agree_on_random_geometries(oracle, monkeypatch, seed):
+    """Random (profile, H, W, columns per packet): the 64-column kernel and the 128 / 256-column wide
+    kernels must produce identical bytes for every output, and those bytes must be the oracle's."""
+    O = oracle
+    g = np.random.default_rng(1000 + seed)
+    profile = ["RNG15_RFL8_NIR8_DUAL", "RNG19_RFL8_SIG16_NIR16", "RNG15_RFL8_NIR8", "LEGACY",
+               "RNG19_RFL8_SIG16_NIR16_DUAL", "FIVE_WORD_PIXEL"][seed % 6]
+    cpp = int(g.choice([4, 8, 16]))
+    h = int(g.integers(3, 131))
+    w = cpp * int(g.integers(256 // cpp, 1300 // cpp))
+    cal = O.synthetic_calib(h=h, w=w, cpp=cpp, profile=profile)
+    pf = cal.packet_format()
+    n = 3
+    packets, src = O.synth_packets(cal, n, with_window=True)
+    by_frame = [packets[f] for f in range(n)]
+    by_frame[1] = np.delete(by_frame[1], [int(g.integers(0, len(by_frame[1])))], axis=0)
+    by_frame[2] = by_frame[2][g.permutation(len(by_frame[2]))]
+    slots = w // cpp
+    host = np.zeros((n, slots, pf.lidar_packet_size), np.uint8)
+    counts = np.zeros(n, np.uint32)
+    for f, pk in enumerate(by_frame):
+        host[f, :len(pk)] = pk
+        counts[f] = len(pk)
+    dev = torch.from_numpy(host).cuda()
+    monkeypatch.setenv("OUSTER_HIP_WIDE_MIN_BLOCKS", "0")
+    results = {}
+    for variant in ("0", "128", "256"):
+        monkeypatch.setenv("OUSTER_HIP_WIDE", variant)
+        hp = HotPath(profile, h, w, cpp)
+        hp.set_pixel_shift_by_row(cal.pixel_shift_by_row)
+        hp.add_lut(cal.beam_to_lidar, cal.lut_transform(True), cal.beam_azimuth_angles, cal.beam_altitude_angles)
+        names = [x for x, _ in hp.fields]
+        xyz = [x for x in ("RANGE", "RANGE2") if x in names]
+        out = hp.alloc_outputs(n, destagger=[x for x in ("RANGE", "REFLECTIVITY") if x in names], xyz=xyz)
+        for t in out.values():
+            t.view(torch.uint8).fill_(0x5C)
+        hp.decode(dev, out, packet_counts=counts)
+        hp.sync()
+        tc, _ = hp.ctx.last_decode_tile()
+        assert (tc <= 64) == (variant == "0") or w < int(variant), (variant, tc)
+        results[variant] = {k: v.cpu().numpy().copy() for k, v in out.items() if k != "frame_meta"}
+    for variant in ("128", "256"):
+        for k, v in results["0"].items():
+            assert np.array_equal(v.view(np.uint8), results[variant][k].view(np.uint8)), (variant, k, profile, h, w, cpp)
+    ref = _oracle_frames(O, cal, pf, by_frame, True)
+    for f, fr in enumerate(ref):
+        for name in names:
+            assert np.array_equal(results["256"][name][f], fr.plane(name)), (f, name)
+        assert np.array_equal(results["256"]["status"][f], fr.status)
