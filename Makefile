@@ -15,7 +15,7 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -I$(CSRC)/host -I$(ROCM
 PYEXT := ouster_sdk_amd/core$(shell python3-config --extension-suffix)
 PYINC := $(shell python3 -m pybind11 --includes)
 
-all: $(LIB)/libouster_hip.so $(LIB)/libouster_core_amd.so $(PYEXT) oracle
+all: $(LIB)/libouster_hip.so $(LIB)/libouster_core_amd.so $(PYEXT) oracle cpptests
 
 $(LIB)/libouster_hip.so: $(HIP_SRC) $(CSRC)/ouster_hip_dev.h include/ouster_hip.h
 	mkdir -p $(LIB)
