@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def test_cpp_core_api():
     exe = os.path.join(ROOT, "tests", "cpp", "_build", "test_core_api")
-    subprocess.check_call(["make", "-C", ROOT, "-s", "cpptests"])  # incremental: keeps the binary in step with the .so
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"])  # g++ only, incremental
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "ouster_sdk_amd", "lib") + ":/opt/rocm/lib:" + \
         env.get("LD_LIBRARY_PATH", "")
@@ -31,7 +31,7 @@ def test_reference_snapshot_hashes_through_cpp_mirror(oracle):
     from conftest import GOLDEN, PCAPS
     O = oracle
     exe = os.path.join(ROOT, "tests", "cpp", "_build", "snapshot_tool")
-    subprocess.check_call(["make", "-C", ROOT, "-s", "cpptests"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"])
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "ouster_sdk_amd", "lib") + ":/opt/rocm/lib:" + \
         env.get("LD_LIBRARY_PATH", "")
