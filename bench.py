@@ -142,7 +142,7 @@ def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 12.0):
         ta = run(1, threads, True, nv)
         ra = max(1, int(6.0 / max(ta, 1e-3)))
         ta = run(ra, threads, True, nv)
-        res["all_cores"] = {"value": nv * ra * H * W * 2 / ta / 1e6, "cores": threads,
+        res["all_cores"] = {"value": nv * ra * H * W * 2 / ta / 1e6, "cores": threads, "host_cores": cores,
                             "sample": f"{nv} frames x {ra} passes over {threads} OpenMP threads"}
     rf = max(1, reps // 3)
     tf = run(rf, 1, False)
@@ -158,7 +158,7 @@ def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames")
