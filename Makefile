@@ -7,8 +7,12 @@ CXX ?= g++
 LIB := ouster_sdk_amd/lib
 CSRC := ouster_sdk_amd/csrc
 HOST_SRC := $(wildcard $(CSRC)/host/*.cpp)
-HIP_SRC := $(CSRC)/ouster_hip_kernels.hip $(CSRC)/ouster_hip_capi.hip
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result
+# the fused decode kernels are compiled once per packet-profile specialisation (parallel with -j)
+OBJ := $(CSRC)/_build
+SPEC_IDS := 0 1 2 3 4 5
+HIP_OBJS := $(foreach i,$(SPEC_IDS),$(OBJ)/k_decode_$(i).o) $(OBJ)/k_standalone.o $(OBJ)/ouster_hip_capi.o
+HIP_HDRS := $(CSRC)/ouster_hip_dev.h $(CSRC)/kernels_common.h include/ouster_hip.h
 ROCM ?= /opt/rocm
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -I$(CSRC)/host -I$(ROCM)/include -D__HIP_PLATFORM_AMD__
 
@@ -17,9 +21,17 @@ PYINC := $(shell python3 -m pybind11 --includes)
 
 all: $(LIB)/libouster_hip.so $(LIB)/libouster_core_amd.so $(PYEXT) oracle cpptests
 
-$(LIB)/libouster_hip.so: $(HIP_SRC) $(CSRC)/ouster_hip_dev.h include/ouster_hip.h
+$(OBJ)/k_decode_%.o: $(CSRC)/k_decode.hip $(HIP_HDRS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -DOUSTER_SPEC_ID=$* -c -o $@ $<
+
+$(OBJ)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB)/libouster_hip.so: $(HIP_OBJS)
 	mkdir -p $(LIB)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_OBJS)
 
 $(LIB)/libouster_core_amd.so: $(HOST_SRC) $(wildcard include/ouster/core/*.h include/ouster/hip/*.h include/ouster/pcap/*.h) $(CSRC)/host/host_internal.h $(LIB)/libouster_hip.so
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -louster_hip -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN'
@@ -34,6 +46,6 @@ cpptests: $(LIB)/libouster_core_amd.so
 	$(MAKE) -C tests/cpp -s
 
 clean:
-	rm -rf $(LIB) oracle/_build tests/cpp/_build
+	rm -rf $(LIB) $(OBJ) oracle/_build tests/cpp/_build
 
 .PHONY: all oracle clean cpptests

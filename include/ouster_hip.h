@@ -127,7 +127,7 @@ typedef struct ouster_hip_frame_meta {
     uint64_t frame_status;     /* thermal&0xf | (shot&0xf)<<4, lidar_frame.cpp:1310-1323 */
     uint16_t shutdown_countdown;
     uint16_t shot_limiting_countdown;
-    uint32_t n_valid_columns;  /* columns written (not part of the reference struct) */
+    uint32_t n_valid_columns;  /* columns of the frame that received a valid column (not in the reference struct) */
 } ouster_hip_frame_meta;
 
 /* Device output pointers of one batched decode.  Every array is dense over
@@ -158,6 +158,15 @@ typedef struct ouster_hip_frame_out {
 int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out);
 void ouster_hip_ctx_destroy(ouster_hip_ctx* ctx);
 void* ouster_hip_ctx_stream(ouster_hip_ctx* ctx);
+int ouster_hip_ctx_device(ouster_hip_ctx* ctx); /* the HIP device ordinal the context was created on */
+/* Experiment / test knobs (not part of the behavioural contract; results are identical for every
+ * setting).  Their defaults come from OUSTER_HIP_<NAME> environment variables read once in
+ * ouster_hip_ctx_create -- the call path itself never touches the environment.
+ *   "wide"  -1 auto | 0 k_decode only | 64/128/256/512 force that k_decode_wide tile width
+ *   "tile"  force k_decode's tile width (64/32/16)      "wide_kb"  LDS budget of a wide tile
+ *   "wide_min_blocks"  smallest launch that may use wide tiles   "tune"  0: no variant timing
+ *   "xcd"   0: plain block -> frame mapping   "fast"  0: every frame through the general mapping */
+int ouster_hip_ctx_set_knob(ouster_hip_ctx* ctx, const char* name, int value);
 int ouster_hip_sync(ouster_hip_ctx* ctx);
 const char* ouster_hip_last_error(void);
 const char* ouster_hip_version(void);
@@ -196,14 +205,25 @@ void ouster_hip_lut_destroy(ouster_hip_lut* lut);
  * XYZLutT::operator() (xyzlut.h:139-150) on the result.
  *
  * packets: device buffer laid out [n_frames][slots_per_frame][packet_stride]
- *   bytes; packet_stride >= lidar_packet_size.  packet_counts (HOST array,
- *   nullable) gives the number of slots actually filled per frame (NULL: all).
+ *   bytes; packet_stride >= lidar_packet_size.  packet_counts (nullable: all
+ *   slots filled) gives the number of leading slots filled per frame; it may be a
+ *   DEVICE array (used in place, values clamped to slots_per_frame; the form to use
+ *   under stream capture), a pinned host array (copied on the stream; must stay
+ *   unchanged until the call has executed) or a plain host array (copied through the
+ *   context's pinned staging before the call returns).  No form synchronises the stream.
  *   Packets of a frame may be in any order; a frame's result is "all planes and
  *   column headers zero, then every received column with status&1 and
  *   measurement_id < W written at its measurement_id" -- the memset-then-scatter
  *   equivalent of the reference's incremental zero-fill.
  *   When two received columns carry the same measurement_id the one later in
  *   the buffer wins (the reference: the one batched later).
+ *   Fast path: when slots_per_frame * columns_per_packet == W and slot p holds the
+ *   packet with columns [p*cpp, (p+1)*cpp) (what a sensor sends, in order; missing
+ *   packets may be left as holes with status 0), no mapping work is done at all; any
+ *   other arrangement is detected on the device and redone by a second pass.
+ *   The call keeps no state between invocations and can be captured in a HIP graph
+ *   and replayed on changed packet contents (do one eager call first: scratch
+ *   allocations cannot happen during capture).
  * host_timestamps: device array [n_frames][slots_per_frame] of
  *   Packet::host_timestamp values, or NULL (packet_timestamp is then not written).
  * pixel_shift_by_row: HOST array [H] (needed iff any destaggered[] is set).
@@ -278,9 +298,9 @@ int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* l
 int ouster_hip_timing_enable(ouster_hip_ctx* ctx, int on);
 int ouster_hip_timing_read(ouster_hip_ctx* ctx, double* avg_ms, uint32_t* n_launches);
 /* Tile (columns x rows) of the decode kernel variant the last ouster_hip_decode launched: 64/32/16
- * columns x all rows (k_decode) or 128/256 columns x a row chunk (k_decode_wide).  The variant is
- * picked per workload by timing each candidate twice on the first six calls (OUSTER_HIP_TUNE=0 disables
- * that, OUSTER_HIP_WIDE=0|128|256 forces one). */
+ * columns x all rows (k_decode) or 64..512 columns x a row chunk (k_decode_wide).  The variant is
+ * picked per workload by timing each candidate twice on the first six calls (knob "tune" = 0 disables
+ * that, knob "wide" forces one). */
 int ouster_hip_last_decode_tile(ouster_hip_ctx* ctx, int* tile_cols, int* tile_rows);
 
 #ifdef __cplusplus

@@ -69,7 +69,8 @@ class FrameOut(C.Structure):
 
 # every symbol include/ouster_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ouster_hip_ctx_create", "ouster_hip_ctx_destroy", "ouster_hip_ctx_stream", "ouster_hip_sync",
+    "ouster_hip_ctx_create", "ouster_hip_ctx_destroy", "ouster_hip_ctx_stream", "ouster_hip_ctx_device",
+    "ouster_hip_ctx_set_knob", "ouster_hip_sync",
     "ouster_hip_last_error", "ouster_hip_version", "ouster_hip_format_create",
     "ouster_hip_format_destroy", "ouster_hip_lut_create", "ouster_hip_lut_create_from_arrays",
     "ouster_hip_lut_export", "ouster_hip_lut_destroy", "ouster_hip_decode", "ouster_hip_destagger",
@@ -103,6 +104,9 @@ def load_hip():
     L.ouster_hip_ctx_stream.restype = vp
     L.ouster_hip_ctx_stream.argtypes = [vp]
     L.ouster_hip_sync.argtypes = [vp]
+    if hasattr(L, "ouster_hip_ctx_set_knob"):   # absent only in older A/B builds loaded via OUSTER_HIP_SO
+        L.ouster_hip_ctx_device.argtypes = [vp]
+        L.ouster_hip_ctx_set_knob.argtypes = [vp, C.c_char_p, C.c_int]
     L.ouster_hip_last_error.restype = C.c_char_p
     L.ouster_hip_version.restype = C.c_char_p
     L.ouster_hip_format_create.argtypes = [vp, C.POINTER(FormatDesc), C.POINTER(vp)]
@@ -210,6 +214,10 @@ class Context:
 
     def sync(self):
         check(self.L.ouster_hip_sync(self.h))
+
+    def set_knob(self, name: str, value: int):
+        """Experiment / test knob of the context (see ouster_hip_ctx_set_knob)."""
+        check(self.L.ouster_hip_ctx_set_knob(self.h, name.encode(), int(value)))
 
     def make_format(self, desc: FormatDesc) -> "Format":
         return Format(self, desc)

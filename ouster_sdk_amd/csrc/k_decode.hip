@@ -1,0 +1,723 @@
+// k_decode.hip -- the fused decode (+ destagger + cartesian) kernels of the hot path, gfx950.
+// Compiled once per packet-profile specialisation (-DOUSTER_SPEC_ID=0..5, see the Makefile) so the
+// six specialisations build in parallel; kernels_common.h holds the pixel phase they all share.
+//
+//   k_decode        one workgroup per (frame, tile of 64/32/16 destination columns): whole columns
+//                   staged in LDS as wire bytes, then walked row-wise (decode_rows)
+//   k_decode_wide   the same on wide, short tiles (64..512 columns x a chunk of rows)
+//
+// What is computed is defined by the reference loops
+//   PacketFormat::col_field/block_field      ouster_core/src/parsing.cpp:628-675
+//   FrameBatcher::parse_by_col/_by_block     ouster_core/src/lidar_frame.cpp:1422-1528
+//   batch_lidar_packet / start_frame         ouster_core/src/lidar_frame.cpp:1530-1576, 1709-1741
+//   destagger_into<T>                        ouster_core/include/ouster/core/impl/lidar_frame_impl.h:733-760
+//   impl::make_xyz_lut / cartesianT<T>       ouster_core/src/xyzlut.cpp:11-89, impl/cartesian.h:36-66
+//
+// Column -> source slot ("which received column lands in destination column c?"), DESIGN.md 3.1:
+//   MODE_FAST     the optimistic pass.  When a frame's buffer has exactly W column slots, a sensor's
+//                 packets in order put column c in slot c.  The workgroup stages slots [c0, c0+TILE)
+//                 WITHOUT looking anything up (no map kernel, no dependent global round trip), then
+//                 checks the staged column headers: a slot is *dead* (no packet / status&1 == 0 /
+//                 m_id >= W  -> zeros, exactly the reference's skip rules lidar_frame.cpp:1432-1450),
+//                 *home* (m_id == its slot) or a *stray* (a live column somewhere else: dropped packet
+//                 with compacted slots, shuffled order, duplicate).  Every slot is checked by the
+//                 workgroup that owns it, so "no workgroup saw a stray" proves the identity mapping
+//                 for the whole frame; one stray flags the frame in frame_state.
+//   MODE_FIXUP    second launch behind the fast one (k_decode_fixup, a small persistent grid): reads the
+//                 flags, redoes the flagged frames with the general mapping below, retires the flags.
+//   MODE_GENERAL  destination column <- the LAST slot in buffer order whose live column carries that
+//                 measurement_id ("the packet batched later overwrites"): every
+//                 workgroup scans the frame's column headers (L2 resident after the first tile) and
+//                 keeps the winners of its own tile in LDS.  Used for every frame when the buffer does
+//                 not have exactly W slots.
+// The only thing that persists between calls is a sequence word in HBM that the fix-up pass advances
+// (flags are tagged with it instead of being cleared), so a captured graph can be replayed on changed
+// packet contents and eager calls may run in between.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+
+#include "kernels_common.h"
+
+#ifndef OUSTER_SPEC_ID
+#error "compile with -DOUSTER_SPEC_ID=0..5"
+#endif
+
+namespace ouster_hip_dev {
+
+#if OUSTER_SPEC_ID == 0
+using SpecT = SpecGeneric;
+#define OUSTER_SPEC_FN(name) name##_generic
+#elif OUSTER_SPEC_ID == 1
+using SpecT = SpecDualLB;
+#define OUSTER_SPEC_FN(name) name##_dual_lb
+#elif OUSTER_SPEC_ID == 2
+using SpecT = SpecLB;
+#define OUSTER_SPEC_FN(name) name##_lb
+#elif OUSTER_SPEC_ID == 3
+using SpecT = SpecSingle;
+#define OUSTER_SPEC_FN(name) name##_single
+#elif OUSTER_SPEC_ID == 4
+using SpecT = SpecDual;
+#define OUSTER_SPEC_FN(name) name##_dual
+#else
+using SpecT = SpecLegacy;
+#define OUSTER_SPEC_FN(name) name##_legacy
+#endif
+
+// blockIdx -> (frame, sub-block).  XCD-aware: block b is dispatched to XCD b % 8, so frame f is given
+// to XCD f % 8 and its blocks are consecutive there: neighbouring tiles' partial cache lines
+// (unaligned destaggered rows, 64 B u8 segments) merge in that XCD's L2 before they are written back.
+__device__ __forceinline__ bool block_to_frame(const DecodeArgs& a, uint32_t blocks_per_frame, uint32_t& f,
+                                               uint32_t& sub) {
+    if (a.xcd_map) {
+        const uint32_t xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        f = (i / blocks_per_frame) * 8u + xcd;
+        sub = i % blocks_per_frame;
+        return f < a.n_frames;
+    }
+    f = blockIdx.x / blocks_per_frame;
+    sub = blockIdx.x - f * blocks_per_frame;
+    return true;
+}
+
+// What the workgroup that owns column tile `tile` of frame f reports from the optimistic pass (one lane):
+// a stray raises the frame's word to this call's tag; the tile's valid-column count goes to its own
+// slot (plain store); the first workgroup of the launch records the tag for the fix-up pass.
+__device__ __forceinline__ void fast_publish(const DecodeArgs& a, uint32_t f, uint32_t tile, uint32_t n_valid,
+                                             bool stray) {
+    const uint64_t tag = a.frame_state[FS_SEQ] + 1;
+    if (stray) atomicMax((unsigned long long*)&a.frame_state[FS_WORDS + f], (unsigned long long)tag);
+    if (a.frame_meta) a.tile_valid[(size_t)f * a.tiles_per_frame + tile] = (uint16_t)n_valid;
+    if (f == 0 && tile == 0) a.frame_state[FS_TAG] = tag;
+}
+
+// ------------------------------------------------------------------------------------
+// k_decode: fused decode + destagger + cartesian for one (frame, column tile)
+// ------------------------------------------------------------------------------------
+// XYZM: 0 no xyz, 1 separable tables -> f32, 2 separable -> f64, 3 full LUT (runtime dtypes)
+// GENERAL_ONLY: the fix-up kernel's instantiation (no fast-mode code in it)
+template <class S, int TILE, int XYZM, bool GENERAL_ONLY>
+__device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem, uint32_t f, uint32_t tile) {
+    constexpr int NT = 256;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = a.g.columns_per_frame, H = a.g.pixels_per_column;
+    const uint32_t cpp = a.g.columns_per_packet, col_size = a.g.col_size;
+    const uint32_t npo = a.n_packets_out;
+    const uint32_t c0 = tile * TILE;
+
+    // ---- LDS carve-up (all offsets 16 B aligned)
+    uint32_t* s_tile = smem;                                    // TILE * col_size (+16) bytes
+    const uint32_t tile_bytes = (TILE * col_size + 16 + 15) & ~15u;
+    int32_t* s_src = (int32_t*)(smem + (tile_bytes >> 2));      // [TILE] source slot (general modes)
+    uint64_t* s_masks = (uint64_t*)(s_src + TILE);              // [0] valid, [1] group-ok / stray
+    int32_t* s_off = (int32_t*)(s_masks + 4);                   // [H] destagger offsets
+    float4* s_xyz = (float4*)(s_off + ((H + 3) & ~3u));         // [4 waves][192] xyz transpose
+    int32_t* s_pk = (int32_t*)(s_xyz + 4 * 192);                // general modes, tile 0: [npo] packet map
+    uint32_t* s_vb = (uint32_t*)(s_pk + npo);                   //   [(W+31)/32] valid-column bitmap, [+1] count
+
+    const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
+    uint32_t count = a.slots_per_frame;
+    if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
+    const bool fast = !GENERAL_ONLY && a.mode == MODE_FAST;
+
+    // ---- phase 0
+    uint64_t pk_ts = 0;
+    uint32_t pk_alert = 0, my_p = 0;
+    bool pk_lane = false;
+    if (fast) {
+        // packet-level values travel in the lane of the packet's first column; frame meta from slot 0
+        if (tid < TILE) {
+            const uint32_t c = c0 + tid;
+            my_p = c / cpp;
+            pk_lane = c < W && c == my_p * cpp;
+            if (pk_lane && my_p < count) {
+                if (a.packet_timestamp && a.host_timestamps)
+                    pk_ts = a.host_timestamps[(size_t)f * a.slots_per_frame + my_p];
+                if (a.alert_flags)
+                    pk_alert = (uint32_t)apply_bits(
+                        window_global(fbase + (size_t)my_p * a.packet_stride + a.g.alert_flags.offset),
+                        a.g.alert_flags.mask, a.g.alert_flags.shift);
+            }
+        }
+        if (tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_of(a.g, fbase, count > 0);
+    } else {
+        // general mapping: scan every received column header of the frame, keep the last slot per
+        // destination column of my tile; tile 0 also resolves the packet-level outputs and counts
+        for (uint32_t j = tid; j < (uint32_t)TILE; j += NT) s_src[j] = -1;
+        const uint32_t vwords = (W + 31) / 32;
+        if (tile == 0) {
+            for (uint32_t i = tid; i < npo; i += NT) s_pk[i] = -1;
+            for (uint32_t i = tid; i <= vwords; i += NT) s_vb[i] = 0;
+        }
+        __syncthreads();
+        const uint32_t nslots = count * cpp;
+        constexpr int U = 4;  // headers per thread per round, all loads in flight before the first use
+        for (uint32_t base = 0; base < nslots; base += NT * U) {
+            uint64_t w_mid[U], w_st[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t s = base + (uint32_t)u * NT + tid;
+                w_mid[u] = w_st[u] = 0;
+                if (s < nslots) {
+                    const uint32_t p = s / cpp, ic = s - p * cpp;
+                    const uint8_t* colp = fbase + (size_t)p * a.packet_stride + a.g.packet_header_size +
+                                          (size_t)ic * col_size;
+                    w_mid[u] = window_global_masked(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask);
+                    w_st[u] = window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t s = base + (uint32_t)u * NT + tid;
+                if (s >= nslots) continue;
+                const uint32_t m_id = (uint16_t)apply_bits(w_mid[u], a.g.col_measurement_id.mask,
+                                                           a.g.col_measurement_id.shift);
+                const uint32_t st = (uint32_t)apply_bits(w_st[u], a.g.col_status.mask, a.g.col_status.shift);
+                const bool live = (st & 1u) && m_id < W;
+                if (live && m_id - c0 < (uint32_t)TILE) atomicMax(&s_src[m_id - c0], (int32_t)s);
+                if (tile == 0) {
+                    if (live) atomicOr(&s_vb[m_id >> 5], 1u << (m_id & 31u));
+                    const uint32_t p = s / cpp;
+                    if (s == p * cpp && m_id / cpp < npo) atomicMax(&s_pk[m_id / cpp], (int32_t)p);
+                }
+            }
+        }
+        __syncthreads();
+        if (tile == 0) {
+            // packet_timestamp is zeroed at frame start (lidar_frame.cpp:1719), alert_flags is not
+            for (uint32_t i = tid; i < npo; i += NT) {
+                const int32_t p = s_pk[i];
+                if (a.packet_timestamp && a.host_timestamps)
+                    a.packet_timestamp[(size_t)f * npo + i] =
+                        p >= 0 ? a.host_timestamps[(size_t)f * a.slots_per_frame + p] : 0ull;
+                if (a.alert_flags && p >= 0)
+                    a.alert_flags[(size_t)f * npo + i] = (uint8_t)apply_bits(
+                        window_global(fbase + (size_t)p * a.packet_stride + a.g.alert_flags.offset),
+                        a.g.alert_flags.mask, a.g.alert_flags.shift);
+            }
+            if (a.frame_meta) {
+                uint32_t n = 0;
+                for (uint32_t i = tid; i < vwords; i += NT) n += (uint32_t)__popc(s_vb[i]);
+                if (n) atomicAdd(&s_vb[vwords], n);
+                __syncthreads();
+                if (tid == 0) {
+                    ouster_hip_frame_meta m = frame_meta_of(a.g, fbase, count > 0);
+                    m.n_valid_columns = s_vb[vwords];
+                    a.frame_meta[f] = m;
+                }
+            }
+        }
+        if (tid < TILE) {
+            const int32_t src = s_src[tid];
+            const uint32_t j0 = tid - tid % cpp;  // first column of my packet group in the tile
+            // "group ok": my packet's cpp columns sit in order, packet-aligned, all present
+            const int32_t head = __shfl(src, (int)(j0 & 63u));
+            const bool grp = (TILE % cpp == 0) && src >= 0 && head >= 0 && (uint32_t)head % cpp == 0 &&
+                             src == head + (int32_t)(tid - j0);
+            const uint64_t vb = __ballot(src >= 0);
+            const uint64_t gb = __ballot(grp);
+            if (tid == 0) { s_masks[0] = vb; s_masks[1] = gb; }
+        }
+    }
+    if (a.any_destagger)
+        for (uint32_t r = tid; r < H; r += NT) s_off[r] = a.dst_offsets[r];
+    const LutDev lut = (XYZM != 0) ? a.luts[f % a.n_luts] : LutDev{};
+    if (!fast) __syncthreads();
+
+    // ---- phase 1: stage the tile's columns in LDS, column j at byte j*col_size
+    const uint32_t ncols_here = min((uint32_t)TILE, W - c0);
+    const uint64_t existmask = ncols_here >= 64 ? ~0ull : ((1ull << ncols_here) - 1);
+    uint64_t validmask = fast ? existmask : s_masks[0];          // fast: refined after staging
+    const uint64_t groupmask = fast ? existmask : s_masks[1];    // fast: W % cpp == 0 (W slots per frame)
+    auto src_of = [&](uint32_t j) -> int32_t {
+        return fast ? (c0 + j < W ? (int32_t)(c0 + j) : -1) : s_src[j];
+    };
+    const uint64_t fullmask = ~0ull >> (64 - TILE);
+    const uint32_t gbytes_all = cpp * col_size;
+    const bool flat = (TILE % cpp == 0) && (TILE / cpp <= 4) && (groupmask == fullmask) &&
+                      (((gbytes_all | a.packet_stride | a.g.packet_header_size |
+                         (uint32_t)(uintptr_t)fbase) & 15u) == 0);
+    if (flat) {
+        // the common case: the tile is G whole packets, all present and in order.  One flat
+        // copy with every load of the thread in flight before the first LDS write.
+        const uint32_t G = TILE / cpp, n16 = gbytes_all >> 4, total = G * n16;
+        const u32x4* src[4];
+#pragma unroll
+        for (uint32_t g = 0; g < 4; ++g) {
+            const uint32_t p = (g < G) ? (uint32_t)src_of(g * cpp) / cpp : 0u;
+            src[g] = (const u32x4*)(fbase + (size_t)p * a.packet_stride + a.g.packet_header_size);
+        }
+        u32x4* dst = (u32x4*)s_tile;
+        constexpr int DEPTH = 17;  // 17 x 256 x 16 B = 68 KB: a 64-column dual-LB tile in one pass
+        for (uint32_t base = 0; base < total; base += NT * DEPTH) {
+            u32x4 t[DEPTH];
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                const uint32_t idx = base + k * NT + tid;
+                if (idx < total) {
+                    const uint32_t g = (idx >= n16) + (idx >= 2 * n16) + (idx >= 3 * n16);
+                    const u32x4* sp = g == 0 ? src[0] : g == 1 ? src[1] : g == 2 ? src[2] : src[3];
+                    t[k] = __builtin_nontemporal_load(sp + (idx - g * n16));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                const uint32_t idx = base + k * NT + tid;
+                if (idx < total) dst[idx] = t[k];
+            }
+        }
+    } else if (TILE % cpp == 0) {
+        const uint32_t gbytes = cpp * col_size;
+        for (uint32_t j0 = 0; j0 < TILE; j0 += cpp) {
+            const uint64_t gm = (cpp >= 64 ? ~0ull : ((1ull << cpp) - 1)) << j0;
+            if ((groupmask & gm) == gm) {  // whole packet, one linear copy
+                const uint32_t p = (uint32_t)src_of(j0) / cpp;
+                stage_range<NT>(s_tile, j0 * col_size,
+                                fbase + (size_t)p * a.packet_stride + a.g.packet_header_size,
+                                gbytes, tid);
+            } else if (validmask & gm) {
+                for (uint32_t j = j0; j < j0 + cpp; ++j) {
+                    const int32_t s = src_of(j);
+                    if (s < 0) continue;
+                    const uint32_t p = (uint32_t)s / cpp, ic = (uint32_t)s - p * cpp;
+                    stage_range<NT>(s_tile, j * col_size,
+                                    fbase + (size_t)p * a.packet_stride +
+                                        a.g.packet_header_size + (size_t)ic * col_size,
+                                    col_size, tid);
+                }
+            }
+        }
+    } else {
+        for (uint32_t j = 0; j < TILE; ++j) {
+            const int32_t s = src_of(j);
+            if (s < 0) continue;
+            const uint32_t p = (uint32_t)s / cpp, ic = (uint32_t)s - p * cpp;
+            stage_range<NT>(s_tile, j * col_size,
+                            fbase + (size_t)p * a.packet_stride + a.g.packet_header_size +
+                                (size_t)ic * col_size,
+                            col_size, tid);
+        }
+    }
+    if (tid < 4) s_tile[(TILE * col_size >> 2) + tid] = 0;  // slack read by 64-bit windows
+    __syncthreads();
+
+    if (fast) {
+        // ---- the check that makes the optimism safe: classify my slots from the staged headers
+        if (tid < TILE) {
+            const uint32_t c = c0 + tid;
+            const bool present = c < W && my_p < count;
+            uint32_t m_id = 0, st = 0;
+            if (present) col_header_lds(a.g, s_tile, tid * col_size, m_id, st);
+            const bool live = present && (st & 1u) && m_id < W;
+            bool stray = live && m_id != c;
+            if (pk_lane) {
+                // batch_lidar_packet (lidar_frame.cpp:1534-1539): packet-level values go to index
+                // m_id(first column) / cpp whether or not that column is valid
+                const bool want_pk = a.packet_timestamp || a.alert_flags;
+                const bool home = present && m_id / cpp == my_p;
+                if (present && !home && want_pk && m_id / cpp < npo) stray = true;
+                if (a.packet_timestamp && a.host_timestamps)
+                    a.packet_timestamp[(size_t)f * npo + my_p] = home ? pk_ts : 0ull;
+                if (a.alert_flags && home) a.alert_flags[(size_t)f * npo + my_p] = (uint8_t)pk_alert;
+            }
+            const uint64_t vb = __ballot(live && !stray);
+            const uint64_t sb = __ballot(stray);
+            if (tid == 0) {
+                s_masks[0] = vb;
+                s_masks[1] = sb;
+                fast_publish(a, f, tile, (uint32_t)__popcll(vb), sb != 0);
+            }
+        }
+        __syncthreads();
+        if (s_masks[1]) return;  // the fix-up pass redoes this frame
+        validmask = s_masks[0];
+    }
+
+    // ---- phase 2a: column headers (timestamp / measurement_id / status), one lane per column
+    if (tid < TILE && c0 + tid < W) {
+        const uint32_t c = c0 + tid;
+        const bool v = (validmask >> tid) & 1;
+        const uint32_t cb = tid * col_size;
+        if (a.timestamp)
+            a.timestamp[(size_t)f * W + c] =
+                v ? apply_bits(window_lds(s_tile, cb + a.g.col_timestamp.offset),
+                               a.g.col_timestamp.mask, a.g.col_timestamp.shift) : 0ull;
+        if (a.measurement_id) a.measurement_id[(size_t)f * W + c] = v ? (uint16_t)c : (uint16_t)0;
+        if (a.status)
+            a.status[(size_t)f * W + c] =
+                v ? (uint32_t)apply_bits(window_lds(s_tile, cb + a.g.col_status.offset),
+                                         a.g.col_status.mask, a.g.col_status.shift) : 0u;
+    }
+
+    // ---- phase 2b: pixels
+    const uint32_t q = tid % (TILE / 4);
+    const uint32_t vq = (uint32_t)(validmask >> (q * 4)) & 0xfu;
+    decode_rows<S, TILE / 4, XYZM>(a, s_tile, a.g.col_header_size >> 2, col_size >> 2, s_off, s_xyz, lut, f, c0,
+                                   0u, H, vq);
+}
+
+// one workgroup per (frame, tile): the optimistic pass (MODE_FAST) or every frame through the
+// general mapping (MODE_GENERAL)
+template <class S, int TILE, int XYZM>
+__global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
+    extern __shared__ __align__(16) uint32_t smem[];
+    uint32_t f, tile;
+    if (!block_to_frame(a, a.tiles_per_frame, f, tile)) return;
+    decode_tile<S, TILE, XYZM, false>(a, smem, f, tile);
+}
+
+// The fix-up pass behind an optimistic pass.  A small persistent grid (all workgroups resident at
+// once): every workgroup reads the frame words, lists the frames flagged with this call's tag in LDS
+// and takes its share of their tiles through the general mapping; for a clean batch that is one
+// coalesced read and out.  The clean frames' valid-column counts are summed from the tiles' slots.
+// Workgroup 0 finally advances the sequence word, which retires every flag of this call: nothing is
+// cleared, nothing is waited for, and a captured graph replays correctly (the tag lives in HBM).
+constexpr uint32_t FIXUP_CHUNK = 512;  // frames listed per round (u16 indices in LDS)
+template <class S, int TILE, int XYZM>
+__global__ __launch_bounds__(256) void k_decode_fixup(DecodeArgs a) {
+    constexpr int NT = 256;
+    extern __shared__ __align__(16) uint32_t smem[];
+    __shared__ uint32_t s_n;
+    const uint32_t tid = threadIdx.x, tpf = a.tiles_per_frame;
+    const uint32_t fast_tiles = a.lds_col_slot;  // column tiles of the optimistic pass (slots of tile_valid)
+    uint16_t* s_list = (uint16_t*)(smem + (a.rows_per_tile >> 2));  // rows_per_tile: byte offset of the list here
+    const uint64_t tag = a.frame_state[FS_TAG];
+    for (uint32_t base = 0; base < a.n_frames; base += FIXUP_CHUNK) {
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        const uint32_t nfr = min(FIXUP_CHUNK, a.n_frames - base);
+        for (uint32_t i = tid; i < nfr; i += NT)
+            if (a.frame_state[FS_WORDS + base + i] == tag) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)i;
+        __syncthreads();
+        const uint32_t items = s_n * tpf;
+        for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+            const uint32_t f = base + s_list[it / tpf], tile = it % tpf;
+            decode_tile<S, TILE, XYZM, true>(a, smem, f, tile);
+            __syncthreads();  // the tile image is reused
+        }
+    }
+    // valid-column counts of the clean frames (flagged ones got theirs from the general path)
+    if (a.frame_meta) {
+        for (uint32_t f = blockIdx.x * NT + tid; f < a.n_frames; f += gridDim.x * NT) {
+            if (a.frame_state[FS_WORDS + f] == tag) continue;
+            uint32_t n = 0;
+            for (uint32_t t = 0; t < fast_tiles; ++t) n += a.tile_valid[(size_t)f * fast_tiles + t];
+            a.frame_meta[f].n_valid_columns = n;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) a.frame_state[FS_SEQ] = tag;  // the next call tags with tag + 1
+}
+
+// ------------------------------------------------------------------------------------
+// k_decode_wide: the same fused decode + destagger + cartesian with WIDE, SHORT tiles:
+// a workgroup owns TW columns x TR rows (TW*TR*chan ~ 48-64 KB of LDS) instead of 64 columns x all
+// rows.  Every output row segment is then TW/64 times longer (1 KB of a u32 plane, 256 B of a u8
+// plane, 3 KB of xyz for TW = 256), which is what HBM wants: with 64-column tiles the achieved write
+// rate swings between 3.4 and 4.9 TB/s with the physical placement of the output planes
+// (tools/storebench.hip), with 256-column tiles it stays at 5.1-6.1 TB/s.
+// The price is on the (8x smaller) input side: a column is no longer read whole but in TR-row pieces
+// (TR*chan bytes, 256 B for dual-LB at TW = 256), staged into per-column LDS slots padded by one dword
+// (bank spread for the 4-columns-per-lane reads).  The column tiles of one row chunk are consecutive
+// blocks of one XCD, so neighbouring workgroups write whole rows together.
+// MODE_FAST only (the fix-up pass always runs k_decode): every row chunk reads the (measurement_id,
+// status) words of its columns next to its staging loads, the first row chunk of a column tile does
+// the stray check, the column headers and the packet-level outputs.
+// ------------------------------------------------------------------------------------
+template <class S, int TW, int XYZM>
+__global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
+    constexpr int NT = 256;
+    constexpr int NJ = (TW + NT - 1) / NT;        // columns per thread in the per-column phases
+    static_assert(TW % 64 == 0 && TW / 4 <= NT * 4, "tile width");
+    extern __shared__ __align__(16) uint32_t smem[];
+
+    const uint32_t TR = a.rows_per_tile, nch = a.row_chunks;
+    uint32_t f, sub;
+    if (!block_to_frame(a, a.tiles_per_frame * nch, f, sub)) return;
+    // the column tiles of one row chunk are neighbouring blocks of an XCD: together they write whole
+    // 8 KB rows at the same time (ordering the row chunks of a column tile next to each other instead
+    // shares input cache lines but measured 6 % slower)
+    const uint32_t tile = sub % a.tiles_per_frame, rc = sub / a.tiles_per_frame;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = a.g.columns_per_frame, H = a.g.pixels_per_column;
+    const uint32_t cpp = a.g.columns_per_packet, col_size = a.g.col_size;
+    const uint32_t chan = S::is_static ? S::chan : a.g.channel_data_size;
+    const uint32_t hdr = a.g.col_header_size, npo = a.n_packets_out;
+    const uint32_t c0 = tile * TW, r0 = rc * TR;
+    const uint32_t nrows = min(TR, H - r0);
+    const uint32_t slot = a.lds_col_slot >> 2;     // LDS dwords per column (piece + pad)
+
+    uint32_t* s_tile = smem;                                  // [TW][slot]
+    uint32_t* s_colofs = smem + TW * slot + 4;                // [TW] byte offset of the column in the frame buffer
+    uint32_t* s_valid = s_colofs + TW;                        // [TW] 1 = received, valid, at home
+    uint32_t* s_acc = s_valid + TW;                           // [0] valid columns, [1] strays (+2 pad)
+    int32_t* s_off = (int32_t*)(s_acc + 4);                   // [TR] destagger offsets of my rows
+    float4* s_xyz = (float4*)(s_off + ((TR + 3) & ~3u));      // [4 waves][192]
+
+    const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
+    uint32_t count = a.slots_per_frame;
+    if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
+
+    // ---- phase 0: where my columns live (slot c holds column c), their header words in flight
+    uint64_t w_mid[NJ], w_st[NJ], w_ts[NJ], pk_ts[NJ];
+    uint32_t pk_alert[NJ];
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        const uint32_t j = tid + (uint32_t)k * NT, c = c0 + j;
+        w_mid[k] = w_st[k] = w_ts[k] = pk_ts[k] = 0;
+        pk_alert[k] = 0;
+        if (j >= (uint32_t)TW) continue;
+        uint32_t ofs = 0xffffffffu;
+        if (c < W) {
+            const uint32_t p = c / cpp, ic = c - p * cpp;
+            ofs = p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
+            if (p < count) {
+                const uint8_t* colp = fbase + ofs;
+                w_mid[k] = window_global_masked(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask);
+                w_st[k] = window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask);
+                if (rc == 0) {
+                    if (a.timestamp) w_ts[k] = window_global_masked(colp + a.g.col_timestamp.offset, a.g.col_timestamp.mask);
+                    if (ic == 0) {
+                        if (a.packet_timestamp && a.host_timestamps)
+                            pk_ts[k] = a.host_timestamps[(size_t)f * a.slots_per_frame + p];
+                        if (a.alert_flags)
+                            pk_alert[k] = (uint32_t)apply_bits(
+                                window_global(fbase + (size_t)p * a.packet_stride + a.g.alert_flags.offset),
+                                a.g.alert_flags.mask, a.g.alert_flags.shift);
+                    }
+                }
+            }
+        }
+        s_colofs[j] = ofs;
+    }
+    if (tid < 4) s_acc[tid] = 0;
+    if (rc == 0 && tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_of(a.g, fbase, count > 0);
+    if (a.any_destagger)
+        for (uint32_t r = tid; r < nrows; r += NT) s_off[r] = a.dst_offsets[r0 + r];
+    const LutDev lut = (XYZM != 0) ? a.luts[f % a.n_luts] : LutDev{};
+    __syncthreads();
+
+    // ---- phase 1: stage my TR-row piece of every column, dword granular (packets are 4 B granular)
+    {
+        // 16 B aligned loads that keep each column piece's own 16 B phase: chunk ch of column j is
+        // the aligned 16 B at (piece start - delta) + 16*ch; its dwords land at piece-relative
+        // positions 4*ch - delta/4 + {0..3}, those outside [0, piece) are dropped.  Thread t owns
+        // chunks t, t + NT, ...; a wave reads 1 KB of (almost) consecutive bytes per instruction.
+        const uint32_t rowofs = hdr + r0 * chan;
+        const uint32_t piece = (nrows * chan) >> 2;        // dwords of a column piece in this chunk
+        const uint32_t NCH = (piece * 4u + 15u + 15u) >> 4;  // aligned 16 B chunks that can touch it
+        const uint32_t total = TW * NCH;
+        const uint8_t* fend = fbase + (size_t)a.slots_per_frame * a.packet_stride;
+        uint32_t j = tid / NCH, ch = tid - j * NCH;
+        const uint32_t dj = NT / NCH, dc = NT - dj * NCH;
+        constexpr int DEPTH = 18;  // 256 columns x 17 chunks = 17 per thread for 256 B pieces
+        for (uint32_t base = 0; base < total; base += NT * DEPTH) {
+            u32x4 t[DEPTH];
+            int32_t p0[DEPTH];   // piece-relative dword index of t[k].x, or a value that drops all four
+            uint32_t sj[DEPTH];
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                p0[k] = -1000000;
+                sj[k] = 0;
+                t[k] = u32x4{0, 0, 0, 0};
+                if (base + k * NT + tid < total) {
+                    const uint32_t ofs = s_colofs[j];
+                    if (ofs != 0xffffffffu) {
+                        const uint8_t* src = fbase + ofs + rowofs;
+                        const uint32_t delta = (uint32_t)((uintptr_t)src & 15u);
+                        const u32x4* q = (const u32x4*)(src - delta) + ch;
+                        if (ch * 16u < delta + piece * 4u) {
+                            if ((const uint8_t*)(q + 1) <= fend) t[k] = *q;
+                            else {  // last chunk of the frame buffer: stay inside it
+                                const uint32_t* qd = (const uint32_t*)q;
+                                for (int w = 0; w < 4; ++w)
+                                    if ((const uint8_t*)(qd + w + 1) <= fend) t[k][w] = qd[w];
+                            }
+                            p0[k] = (int32_t)(ch * 4u) - (int32_t)(delta >> 2);
+                            sj[k] = j * slot;
+                        }
+                    }
+                }
+                j += dj; ch += dc;
+                if (ch >= NCH) { ch -= NCH; ++j; }
+            }
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int32_t pp = p0[k] + w;
+                    if (pp >= 0 && pp < (int32_t)piece) s_tile[sj[k] + (uint32_t)pp] = t[k][w];
+                }
+            }
+        }
+        // dead columns and the rows past H keep whatever the LDS held: nothing reads them (vq / nrows)
+        if (tid < 4) s_tile[TW * slot + tid] = 0;  // slack read by 64-bit windows
+    }
+
+    // ---- classify my columns (every row chunk needs the validity; the first one also publishes)
+    {
+        uint32_t n_valid = 0, n_stray = 0;
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const uint32_t j = tid + (uint32_t)k * NT, c = c0 + j;
+            if (j >= (uint32_t)TW) continue;
+            const uint32_t p = c / cpp;
+            const bool present = c < W && p < count;
+            const uint32_t m_id = (uint16_t)apply_bits(w_mid[k], a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
+            const uint32_t st = (uint32_t)apply_bits(w_st[k], a.g.col_status.mask, a.g.col_status.shift);
+            const bool live = present && (st & 1u) && m_id < W;
+            bool stray = live && m_id != c;
+            const bool v = live && !stray;
+            s_valid[j] = v ? 1u : 0u;
+            if (rc != 0 || c >= W) continue;
+            if (c == p * cpp) {  // batch_lidar_packet, lidar_frame.cpp:1534-1539
+                const bool want_pk = a.packet_timestamp || a.alert_flags;
+                const bool home = present && m_id / cpp == p;
+                if (present && !home && want_pk && m_id / cpp < npo) stray = true;
+                if (a.packet_timestamp && a.host_timestamps)
+                    a.packet_timestamp[(size_t)f * npo + p] = home ? pk_ts[k] : 0ull;
+                if (a.alert_flags && home) a.alert_flags[(size_t)f * npo + p] = (uint8_t)pk_alert[k];
+            }
+            n_valid += v ? 1u : 0u;
+            n_stray += stray ? 1u : 0u;
+            if (a.timestamp)
+                a.timestamp[(size_t)f * W + c] = v ? apply_bits(w_ts[k], a.g.col_timestamp.mask, a.g.col_timestamp.shift) : 0ull;
+            if (a.measurement_id) a.measurement_id[(size_t)f * W + c] = v ? (uint16_t)c : (uint16_t)0;
+            if (a.status) a.status[(size_t)f * W + c] = v ? st : 0u;
+        }
+        if (rc == 0) {
+            if (n_valid) atomicAdd(&s_acc[0], n_valid);
+            if (n_stray) atomicAdd(&s_acc[1], n_stray);
+        }
+    }
+    __syncthreads();
+    if (rc == 0 && tid == 0) {
+        fast_publish(a, f, tile, s_acc[0], s_acc[1] != 0);
+    }
+
+    // ---- pixels.  lane = (row within pass, quad of 4 consecutive columns)
+    const uint32_t jq = (tid % (TW / 4)) * 4;
+    uint32_t vq = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_valid[jq + c]) ? (1u << c) : 0u;
+    decode_rows<S, TW / 4, XYZM>(a, s_tile, 0u, slot, s_off, s_xyz, lut, f, c0, r0, nrows, vq);
+}
+
+// ------------------------------------------------------------------------------------
+// launchers (host)
+// ------------------------------------------------------------------------------------
+// dynamic LDS above 48 KB needs the kernel's attribute raised (per kernel and device); remembered so
+// the steady state makes no runtime call
+struct LdsGrant {
+    std::atomic<uint32_t> bytes[16];
+    LdsGrant() { for (auto& b : bytes) b.store(0); }
+};
+template <class K>
+static hipError_t allow_lds(K kernel, size_t lds, int device, LdsGrant& g) {
+    if (lds <= 48 * 1024) return hipSuccess;
+    std::atomic<uint32_t>& have = g.bytes[device & 15];
+    if (have.load(std::memory_order_acquire) >= lds) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) have.store((uint32_t)lds, std::memory_order_release);
+    return e;
+}
+
+template <class S, int TILE, int XYZM>
+static hipError_t launch_decode_x(const DecodeArgs& a, dim3 grid, size_t lds, int device, hipStream_t st) {
+    static LdsGrant done;
+    hipError_t e = allow_lds(k_decode<S, TILE, XYZM>, lds, device, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode<S, TILE, XYZM>), grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <class S, int TILE>
+static hipError_t launch_decode_t(const DecodeArgs& a, int xyzm, dim3 grid, size_t lds, int device, hipStream_t st) {
+    switch (xyzm) {
+        case 0: return launch_decode_x<S, TILE, 0>(a, grid, lds, device, st);
+        case 1: return launch_decode_x<S, TILE, 1>(a, grid, lds, device, st);
+        case 2: return launch_decode_x<S, TILE, 2>(a, grid, lds, device, st);
+        default: return launch_decode_x<S, TILE, 3>(a, grid, lds, device, st);
+    }
+}
+
+template <class S, int TILE, int XYZM>
+static hipError_t launch_fixup_x(const DecodeArgs& a, dim3 grid, size_t lds, int device, hipStream_t st) {
+    static LdsGrant done;
+    hipError_t e = allow_lds(k_decode_fixup<S, TILE, XYZM>, lds, device, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode_fixup<S, TILE, XYZM>), grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <class S, int TILE>
+static hipError_t launch_fixup_t(const DecodeArgs& a, int xyzm, dim3 grid, size_t lds, int device, hipStream_t st) {
+    switch (xyzm) {
+        case 0: return launch_fixup_x<S, TILE, 0>(a, grid, lds, device, st);
+        case 1: return launch_fixup_x<S, TILE, 1>(a, grid, lds, device, st);
+        case 2: return launch_fixup_x<S, TILE, 2>(a, grid, lds, device, st);
+        default: return launch_fixup_x<S, TILE, 3>(a, grid, lds, device, st);
+    }
+}
+
+hipError_t OUSTER_SPEC_FN(launch_decode)(const DecodeArgs& a_in, int tile, int xyzm, int device, hipStream_t st) {
+    const uint32_t tpf = a_in.tiles_per_frame;
+    if (a_in.mode == MODE_FIXUP) {
+        DecodeArgs a = a_in;
+        const size_t body = decode_lds_bytes(a.g, tile, true);
+        a.rows_per_tile = (uint32_t)body;  // where the frame list starts
+        const size_t lds = body + FIXUP_CHUNK * 2;
+        const uint64_t items = (uint64_t)a.n_frames * tpf;
+        // row_chunks carries the number of workgroups the device keeps resident (2 per CU)
+        const dim3 grid((uint32_t)std::min<uint64_t>(items, a.row_chunks ? a.row_chunks : 512u));
+        switch (tile) {
+            case 64: return launch_fixup_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
+            case 32: return launch_fixup_t<SpecT, 32>(a, xyzm, grid, lds, device, st);
+            default: return launch_fixup_t<SpecT, 16>(a, xyzm, grid, lds, device, st);
+        }
+    }
+    const DecodeArgs& a = a_in;
+    const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * tpf : a.n_frames * tpf;
+    const dim3 grid(nblocks);
+    const size_t lds = decode_lds_bytes(a.g, tile, a.mode != MODE_FAST);
+    switch (tile) {
+        case 64: return launch_decode_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
+        case 32: return launch_decode_t<SpecT, 32>(a, xyzm, grid, lds, device, st);
+        default: return launch_decode_t<SpecT, 16>(a, xyzm, grid, lds, device, st);
+    }
+}
+
+template <class S, int TW, int XYZM>
+static hipError_t launch_decode_wide_x(const DecodeArgs& a, dim3 grid, size_t lds, int device, hipStream_t st) {
+    static LdsGrant done;
+    hipError_t e = allow_lds(k_decode_wide<S, TW, XYZM>, lds, device, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode_wide<S, TW, XYZM>), grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <class S, int TW>
+static hipError_t launch_decode_wide_t(const DecodeArgs& a, int xyzm, dim3 grid, size_t lds, int device, hipStream_t st) {
+    switch (xyzm) {
+        case 0: return launch_decode_wide_x<S, TW, 0>(a, grid, lds, device, st);
+        case 1: return launch_decode_wide_x<S, TW, 1>(a, grid, lds, device, st);
+        case 2: return launch_decode_wide_x<S, TW, 2>(a, grid, lds, device, st);
+        default: return launch_decode_wide_x<S, TW, 3>(a, grid, lds, device, st);
+    }
+}
+
+hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a, int tw, int xyzm, int device, hipStream_t st) {
+    const uint32_t bpf = a.tiles_per_frame * a.row_chunks;
+    const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * bpf : a.n_frames * bpf;
+    const dim3 grid(nblocks);
+    const size_t lds = decode_wide_lds_bytes(tw, a.rows_per_tile, a.lds_col_slot);
+    switch (tw) {
+        case 64: return launch_decode_wide_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
+        case 128: return launch_decode_wide_t<SpecT, 128>(a, xyzm, grid, lds, device, st);
+        case 512: return launch_decode_wide_t<SpecT, 512>(a, xyzm, grid, lds, device, st);
+        default: return launch_decode_wide_t<SpecT, 256>(a, xyzm, grid, lds, device, st);
+    }
+}
+
+}  // namespace ouster_hip_dev

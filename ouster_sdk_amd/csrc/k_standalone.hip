@@ -1,0 +1,771 @@
+// k_standalone.hip -- the standalone kernels of the hot path (gfx950) and the launch dispatch.
+//
+//   k_destagger           per-row circular shift
+//   k_cartesian(_tiled)   range image -> XYZ
+//   k_dewarp(_tiled)      per-column pose applied to a dense point cloud
+//   k_dwf_*               range-gated, compacting frame dewarp (count, scans, emit)
+// The fused decode kernels live in k_decode.hip (one object per profile specialisation).
+//
+// Reference loops:
+//   destagger_into<T>                        ouster_core/include/ouster/core/impl/lidar_frame_impl.h:733-760
+//   impl::make_xyz_lut / cartesianT<T>       ouster_core/src/xyzlut.cpp:11-89, impl/cartesian.h:36-66
+//   dewarp<T>                                ouster_core/include/ouster/core/pose_util.h:38-56, impl/dewarp_impl.h:23-115
+// Memory-bound byte/bit work: no MFMA anywhere.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "kernels_common.h"
+
+namespace ouster_hip_dev {
+
+const FieldC* spec_fields(int spec_id, int* nf, uint32_t* chan, int* r1, int* r2) {
+    switch (spec_id) {
+        case SPEC_DUAL_LB: *nf = SpecDualLB::nf; *chan = SpecDualLB::chan; *r1 = 0; *r2 = 4; return SpecDualLB::f;
+        case SPEC_LB: *nf = SpecLB::nf; *chan = SpecLB::chan; *r1 = 0; *r2 = -1; return SpecLB::f;
+        case SPEC_SINGLE: *nf = SpecSingle::nf; *chan = SpecSingle::chan; *r1 = 0; *r2 = -1; return SpecSingle::f;
+        case SPEC_DUAL: *nf = SpecDual::nf; *chan = SpecDual::chan; *r1 = 0; *r2 = 3; return SpecDual::f;
+        case SPEC_LEGACY: *nf = SpecLegacy::nf; *chan = SpecLegacy::chan; *r1 = 0; *r2 = -1; return SpecLegacy::f;
+        default: *nf = 0; *chan = 0; *r1 = *r2 = -1; return nullptr;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_destagger: dst[img][u][(v + off[u]) % w] = src[img][u][v], element = elem bytes.
+// One workgroup per (row, image); lanes walk the DESTINATION row in 16 B chunks so every
+// store is an aligned, coalesced 16 B vector; the source bytes for a chunk start at an
+// arbitrary byte offset of the source row and are fetched with three aligned dword loads
+// per output dword pair (the row is L1/L2 resident after first touch).
+//   offset arithmetic: destagger_into, impl/lidar_frame_impl.h:753-759
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_destagger(DestaggerArgs a) {
+    const uint32_t u = blockIdx.x, img = blockIdx.y;
+    const size_t row_bytes = (size_t)a.w * a.elem;
+    const uint8_t* srow = (const uint8_t*)a.src + ((size_t)img * a.h + u) * row_bytes;
+    uint8_t* drow = (uint8_t*)a.dst + ((size_t)img * a.h + u) * row_bytes;
+    const size_t shift_bytes = (size_t)a.offsets[u] * a.elem;  // dst byte b <- src byte (b - shift) mod row
+    const bool fast = ((row_bytes & 15) == 0) && ((((uintptr_t)a.src | (uintptr_t)a.dst) & 15) == 0);
+    if (fast) {
+        const uint32_t nchunk = (uint32_t)(row_bytes >> 4);
+        for (uint32_t i = threadIdx.x; i < nchunk; i += blockDim.x) {
+            const size_t db = (size_t)i << 4;
+            size_t sb = db + row_bytes - shift_bytes;
+            if (sb >= row_bytes) sb -= row_bytes;
+            uint32_t o[4];
+            if (sb + 16 <= row_bytes) {
+                const uint32_t sh = (uint32_t)(sb & 3) * 8;
+                const uint32_t* q = (const uint32_t*)(srow + (sb & ~(size_t)3));
+                if (sh == 0) {
+                    o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
+                } else {
+                    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                    o[0] = (d0 >> sh) | (d1 << (32 - sh));
+                    o[1] = (d1 >> sh) | (d2 << (32 - sh));
+                    o[2] = (d2 >> sh) | (d3 << (32 - sh));
+                    o[3] = (d3 >> sh) | (d4 << (32 - sh));
+                }
+            } else {  // the chunk straddles the wrap point of the source row
+                uint8_t b[16];
+                for (int k = 0; k < 16; ++k) {
+                    size_t s = sb + k;
+                    if (s >= row_bytes) s -= row_bytes;
+                    b[k] = srow[s];
+                }
+                for (int k = 0; k < 4; ++k)
+                    o[k] = b[4 * k] | (b[4 * k + 1] << 8) | (b[4 * k + 2] << 16) |
+                           ((uint32_t)b[4 * k + 3] << 24);
+            }
+            *(uint4*)(drow + db) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        for (size_t b = threadIdx.x; b < row_bytes; b += blockDim.x) {
+            size_t s = b + row_bytes - shift_bytes;
+            if (s >= row_bytes) s -= row_bytes;
+            drow[b] = srow[s];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_cartesian: standalone range image -> xyz, 4 consecutive pixels per lane
+//   (cartesianT<T>, impl/cartesian.h:36-66)
+// ------------------------------------------------------------------------------------
+template <int MODE /*1 sep->f32, 2 sep->f64, 3 full*/>
+__global__ __launch_bounds__(256) void k_cartesian(CartesianArgs a) {
+    const uint32_t W = a.w, H = a.h;
+    const size_t npix = (size_t)W * H;
+    const size_t quads = (npix + 3) / 4;
+    const LutDev lut = a.lut;
+    for (size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qi < quads * a.n_images;
+         qi += (size_t)gridDim.x * blockDim.x) {
+        const size_t img = qi / quads, q = qi - img * quads;
+        const size_t pix = q * 4;
+        const uint32_t n = (npix - pix) < 4 ? (uint32_t)(npix - pix) : 4;
+        const uint32_t* rp = a.range + img * npix + pix;
+        uint32_t r[4] = {0, 0, 0, 0};
+        const bool vec = (n == 4) && a.vec_ok;
+        if (vec) { uint4 t = *(const uint4*)rp; r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+        else for (uint32_t c = 0; c < n; ++c) r[c] = rp[c];
+        double p[4][3];
+        if constexpr (MODE == 1 || MODE == 2) {
+            for (uint32_t c = 0; c < n; ++c) {
+                const size_t i = pix + c;
+                const uint32_t row = (uint32_t)(i / W), cc = (uint32_t)(i - (size_t)row * W);
+                const double* b = lut.beam_tab + (size_t)row * 9;
+                const double* t = lut.col_tab + (size_t)cc * 5;
+                const double cxx = t[0], sxx = t[1];
+                const double rm = (double)r[c] - lut.n;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double d = fma(cxx, b[k], fma(sxx, b[3 + k], b[6 + k]));
+                    p[c][k] = r[c] ? fma(rm, d, t[2 + k]) : 0.0;
+                }
+            }
+        } else {
+            for (uint32_t c = 0; c < n; ++c) {
+                if (lut.full_dtype == OUSTER_HIP_F32)
+                    project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs,
+                                        pix + c, r[c], p[c]);
+                else
+                    project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs,
+                                         pix + c, r[c], p[c]);
+            }
+        }
+        if (a.xyz_dtype == OUSTER_HIP_F32) {
+            float* dst = (float*)a.xyz + (img * npix + pix) * 3;
+            if (vec) store_xyz4<float>(dst, p);
+            else for (uint32_t c = 0; c < n; ++c) store_xyz1<float>(dst + c * 3, p[c]);
+        } else {
+            double* dst = (double*)a.xyz + (img * npix + pix) * 3;
+            if (vec) store_xyz4<double>(dst, p);
+            else for (uint32_t c = 0; c < n; ++c) store_xyz1<double>(dst + c * 3, p[c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_dewarp: p' = R_col * p + t_col for every point (pose_util.h:38-56).  One thread per point;
+// a wave reads 64 consecutive points = 768 contiguous bytes (f32) of one row, the 64 column
+// poses come from the L2-resident pose table.  HBM bound: 2 x 3 x sizeof(T) B/point.
+// ------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_dewarp(DewarpArgs a) {
+    const size_t npix = (size_t)a.w * a.h, total = npix * a.n_images;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t img = i / npix, pix = i - img * npix;
+        const uint32_t col = (uint32_t)(pix % a.w);
+        const double* m = a.poses + (img * a.w + col) * 16;
+        const T* p = (const T*)a.points + i * 3;
+        const T x = p[0], y = p[1], z = p[2];
+        T* o = (T*)a.out + i * 3;
+        // rotation * s + translation in T, row by row, like the reference's Eigen expression
+        o[0] = (T)m[0] * x + (T)m[1] * y + (T)m[2] * z + (T)m[3];
+        o[1] = (T)m[4] * x + (T)m[5] * y + (T)m[6] * z + (T)m[7];
+        o[2] = (T)m[8] * x + (T)m[9] * y + (T)m[10] * z + (T)m[11];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_cartesian_tiled: the fast standalone form for W % 4 == 0 and 16 B aligned buffers.
+// Same lane mapping as k_decode's compute phase: a workgroup owns 64 columns x RC rows of one
+// image, lane = (row within pass, quad of 4 consecutive columns).  Per-column constants live in
+// registers for the whole row loop, the row's 9 beam constants come from the L1-resident table,
+// the range quad is one 16 B load and f32 XYZ goes out through the wave-private LDS transpose
+// (256 contiguous bytes per row per store instruction).
+//   MODE 1: separable tables -> f32, 2: separable -> f64, 3: full LUT (runtime dtypes)
+// ------------------------------------------------------------------------------------
+// full-LUT projection of a lane's 4 pixels from registers; LT = LUT element type
+template <class LT>
+__device__ __forceinline__ void project_full4(const LT (&dir)[12], const LT (&ofs)[12],
+                                              const uint32_t (&rng)[4], double (&p)[4][3]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const LT rr = (LT)rng[c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            LT m = rr * dir[3 * c + k];
+            asm volatile("" : "+v"(m));  // no fma contraction (cartesianT host build)
+            p[c][k] = rng[c] ? (double)(LT)(m + ofs[3 * c + k]) : 0.0;
+        }
+    }
+}
+
+template <int MODE, int TILE>
+__global__ __launch_bounds__(256) void k_cartesian_tiled(CartesianArgs a) {
+    constexpr int LPR = TILE / 4, RPP = 256 / LPR;
+    __shared__ float4 s_xyz[RPP * 6 * LPR];  // one 6-chunk scratch per lane-row
+    const uint32_t W = a.w, H = a.h;
+    const uint32_t tiles = (W + TILE - 1) / TILE;
+    const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const uint32_t img = blockIdx.y, tid = threadIdx.x;
+    const uint32_t q = tid % LPR, ty = tid / LPR;
+    const uint32_t c0 = tile * TILE, col = c0 + 4 * q;
+    const uint32_t r_begin = chunk * a.rows_per_block;
+    const uint32_t r_end = min(H, r_begin + a.rows_per_block);
+    const bool full_tile = c0 + TILE <= W;
+    const bool live = col < W;  // W % 4 == 0: a quad is entirely inside or outside
+    const LutDev lut = a.lut;
+    const size_t npix = (size_t)W * H;
+    float4* sc = s_xyz + ty * (6 * LPR);
+
+    double cx[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0}, kc[4][3] = {};
+    if constexpr (MODE == 1 || MODE == 2) {
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double* t = lut.col_tab + (size_t)(col + c) * 5;
+                cx[c] = t[0]; sx[c] = t[1]; kc[c][0] = t[2]; kc[c][1] = t[3]; kc[c][2] = t[4];
+            }
+        }
+    }
+    for (uint32_t r = r_begin + ty; r < r_end; r += RPP) {
+        const size_t rowpix = (size_t)r * W + col;
+        const size_t rowpix0 = (size_t)r * W + c0;
+        uint32_t rng[4] = {0, 0, 0, 0};
+        if (live) {
+            const uint4 t = *(const uint4*)(a.range + (size_t)img * npix + rowpix);
+            rng[0] = t.x; rng[1] = t.y; rng[2] = t.z; rng[3] = t.w;
+        }
+        double p[4][3];
+        if constexpr (MODE == 1 || MODE == 2) {
+            const double* b = lut.beam_tab + (size_t)r * 9;
+            const double u0 = b[0], u1 = b[1], u2 = b[2], v0 = b[3], v1 = b[4], v2 = b[5],
+                         w0 = b[6], w1 = b[7], w2 = b[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double d0 = fma(cx[c], u0, fma(sx[c], v0, w0));
+                const double d1 = fma(cx[c], u1, fma(sx[c], v1, w1));
+                const double d2 = fma(cx[c], u2, fma(sx[c], v2, w2));
+                const double rm = (double)rng[c] - lut.n;
+                p[c][0] = rng[c] ? fma(rm, d0, kc[c][0]) : 0.0;
+                p[c][1] = rng[c] ? fma(rm, d1, kc[c][1]) : 0.0;
+                p[c][2] = rng[c] ? fma(rm, d2, kc[c][2]) : 0.0;
+            }
+        } else {
+            // the LUT rows are streamed like the output: coalesced row segments, transposed
+            // to "lane owns 4 pixels" through the scratch
+            if (lut.full_dtype == OUSTER_HIP_F32) {
+                union { float4 f4[3]; float t[12]; } d, o;
+                if (full_tile) {
+                    load_quad_coalesced<3, LPR>(sc, (const float4*)((const float*)lut.full_dir + rowpix0 * 3), q, d.f4);
+                    load_quad_coalesced<3, LPR>(sc, (const float4*)((const float*)lut.full_ofs + rowpix0 * 3), q, o.f4);
+                } else if (live) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        d.f4[k] = ((const float4*)((const float*)lut.full_dir + rowpix * 3))[k];
+                        o.f4[k] = ((const float4*)((const float*)lut.full_ofs + rowpix * 3))[k];
+                    }
+                }
+                project_full4<float>(d.t, o.t, rng, p);
+            } else {
+                union { float4 f4[6]; double t[12]; } d, o;
+                if (full_tile) {
+                    load_quad_coalesced<6, LPR>(sc, (const float4*)((const double*)lut.full_dir + rowpix0 * 3), q, d.f4);
+                    load_quad_coalesced<6, LPR>(sc, (const float4*)((const double*)lut.full_ofs + rowpix0 * 3), q, o.f4);
+                } else if (live) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        d.f4[k] = ((const float4*)((const double*)lut.full_dir + rowpix * 3))[k];
+                        o.f4[k] = ((const float4*)((const double*)lut.full_ofs + rowpix * 3))[k];
+                    }
+                }
+                project_full4<double>(d.t, o.t, rng, p);
+            }
+        }
+        if (a.xyz_dtype == OUSTER_HIP_F32) {
+            float* dst = (float*)a.xyz + ((size_t)img * npix + rowpix) * 3;
+            if (full_tile) {
+                union { float4 f4[3]; float t[12]; } o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) o.t[3 * c + k] = (float)p[c][k];
+                store_quad_coalesced<3, LPR>(sc, (float4*)(dst - (size_t)(4 * q) * 3), q, o.f4);
+            } else if (live) store_xyz4<float>(dst, p);
+        } else {
+            double* dst = (double*)a.xyz + ((size_t)img * npix + rowpix) * 3;
+            if (full_tile) {
+                union { float4 f4[6]; double t[12]; } o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) o.t[3 * c + k] = p[c][k];
+                store_quad_coalesced<6, LPR>(sc, (float4*)(dst - (size_t)(4 * q) * 3), q, o.f4);
+            } else if (live) store_xyz4<double>(dst, p);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_dewarp_tiled: p' = R_col * p + t_col (pose_util.h:38-56) with the k_decode lane mapping:
+// each lane keeps the 3x4 poses of its 4 columns in registers for the whole row loop.
+// ------------------------------------------------------------------------------------
+template <class T, int TILE>
+__global__ __launch_bounds__(256) void k_dewarp_tiled(DewarpArgs a) {
+    constexpr int LPR = TILE / 4, RPP = 256 / LPR;
+    constexpr int NV = 3 * sizeof(T) / 4;  // 16 B chunks per lane quad: 3 (f32) or 6 (f64)
+    __shared__ float4 s_xyz[RPP * NV * LPR];
+    const uint32_t W = a.w, H = a.h;
+    const uint32_t tiles = (W + TILE - 1) / TILE;
+    const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const uint32_t img = blockIdx.y, tid = threadIdx.x;
+    const uint32_t q = tid % LPR, ty = tid / LPR;
+    const uint32_t c0 = tile * TILE, col = c0 + 4 * q;
+    const bool full_tile = c0 + TILE <= W;
+    const bool live = col < W;
+    const uint32_t r_begin = chunk * a.rows_per_block;
+    const uint32_t r_end = min(H, r_begin + a.rows_per_block);
+    const size_t npix = (size_t)W * H;
+    float4* sc = s_xyz + ty * (NV * LPR);
+    T m[4][12];
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double* pm = a.poses + ((size_t)img * W + col + c) * 16;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) m[c][k] = (T)pm[k];
+        }
+    }
+    for (uint32_t r = r_begin + ty; r < r_end; r += RPP) {
+        const size_t i = ((size_t)img * npix + (size_t)r * W + col) * 3;
+        union { float4 f4[NV]; T t[12]; } v, o;
+        if (full_tile) {
+            // coalesced row-segment read (LPR x 16 B contiguous per instruction), transposed
+            // to "lane owns 4 points" through the lane-row's private scratch
+            load_quad_coalesced<NV, LPR>(sc, (const float4*)((const T*)a.points + i - (size_t)(4 * q) * 3), q, v.f4);
+        } else if (live) {
+            const float4* src = (const float4*)((const T*)a.points + i);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v.f4[k] = src[k];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const T x = v.t[3 * c], y = v.t[3 * c + 1], z = v.t[3 * c + 2];
+            o.t[3 * c + 0] = m[c][0] * x + m[c][1] * y + m[c][2] * z + m[c][3];
+            o.t[3 * c + 1] = m[c][4] * x + m[c][5] * y + m[c][6] * z + m[c][7];
+            o.t[3 * c + 2] = m[c][8] * x + m[c][9] * y + m[c][10] * z + m[c][11];
+        }
+        if (full_tile) {
+            store_quad_coalesced<NV, LPR>(sc, (float4*)((T*)a.out + i - (size_t)(4 * q) * 3), q, o.f4);
+        } else if (live) {
+            float4* dst = (float4*)((T*)a.out + i);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) dst[k] = o.f4[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Range-gated, compacting frame dewarp: dewarp(LidarFrame|FrameSet, XYZLut, min_range, max_range)
+// (impl/dewarp_impl.h:23-115).  Output order is the reference's: frame, then column
+// first_valid..last_valid with status != 0, then row; a point is kept when min_r <= r <= max_r.
+//   k_dwf_count       kept points per (frame, column) from the range plane (ignores status)
+//   k_dwf_scan        per frame: first/last valid column (status & 1, lidar_frame.cpp:907-925),
+//                     mask, exclusive scan over the columns; frame total
+//   k_dwf_frame_scan  exclusive scan of the frame totals
+//   k_dwf_emit        stage a 64-row x 64-column range tile in LDS, wave = column, lane = row:
+//                     ballot-rank the kept rows, project (f64 tables or the full LUT), apply the
+//                     column pose in T, and write the compacted run through a wave-private LDS
+//                     buffer so the global stores are contiguous dwords.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dwf_count(DewarpFramesArgs a) {
+    constexpr int TILE = 64, LPR = 16, RPP = 16;
+    __shared__ uint32_t s_cnt[TILE];
+    const uint32_t W = a.w, H = a.h, f = blockIdx.y, tid = threadIdx.x;
+    const uint32_t q = tid % LPR, ty = tid / LPR;
+    const uint32_t c0 = blockIdx.x * TILE, col = c0 + 4 * q;
+    if (tid < TILE) s_cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t* rp = a.range + (size_t)f * W * H;
+    const bool vec = (W % 4 == 0) && ((((uintptr_t)a.range) & 15) == 0);
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    if (col < W) {
+        for (uint32_t r = ty; r < H; r += RPP) {
+            uint32_t v[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (vec) {
+                const uint4 t = *(const uint4*)(rp + (size_t)r * W + col);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                for (uint32_t c = 0; c < 4 && col + c < W; ++c) v[c] = rp[(size_t)r * W + col + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                cnt[c] += (col + c < W && v[c] >= a.min_r && v[c] <= a.max_r) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (cnt[c]) atomicAdd(&s_cnt[4 * q + c], cnt[c]);
+    }
+    __syncthreads();
+    if (tid < TILE && c0 + tid < W) a.col_off[(size_t)f * (W + 1) + c0 + tid] = s_cnt[tid];
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix,
+// *total = block sum
+__device__ __forceinline__ uint32_t block_exscan_256(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wave; ++k) base += s_wave[k];
+    *total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_dwf_scan(DewarpFramesArgs a) {
+    __shared__ int s_lo, s_hi;
+    __shared__ uint32_t s_wave[4];
+    const uint32_t W = a.w, f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* st = a.status + (size_t)f * W;
+    uint32_t* off = a.col_off + (size_t)f * (W + 1);
+    if (tid == 0) { s_lo = 0x7fffffff; s_hi = -1; }
+    __syncthreads();
+    int lo = 0x7fffffff, hi = -1;
+    for (uint32_t x = tid; x < W; x += 256)
+        if (st[x] & 1u) { lo = min(lo, (int)x); hi = max(hi, (int)x); }
+    if (hi >= 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    __syncthreads();
+    lo = s_lo; hi = s_hi;
+    // contiguous segment per thread
+    const uint32_t seg = (W + 255) / 256;
+    const uint32_t x0 = tid * seg, x1 = min(W, x0 + seg);
+    uint32_t sum = 0;
+    for (uint32_t x = x0; x < x1; ++x) {
+        const bool keep = (int)x >= lo && (int)x <= hi && st[x] != 0;
+        sum += keep ? off[x] : 0u;
+    }
+    uint32_t total;
+    uint32_t run = block_exscan_256(sum, s_wave, &total);
+    for (uint32_t x = x0; x < x1; ++x) {
+        const bool keep = (int)x >= lo && (int)x <= hi && st[x] != 0;
+        const uint32_t c = keep ? off[x] : 0u;
+        off[x] = run;
+        run += c;
+    }
+    if (tid == 0) {
+        off[W] = total;
+        a.frame_off[f + 1] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dwf_frame_scan(DewarpFramesArgs a) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t tid = threadIdx.x;
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < a.n_frames; base += 256) {
+        const uint32_t f = base + tid;
+        const uint32_t v = f < a.n_frames ? (uint32_t)a.frame_off[f + 1] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exscan_256(v, s_wave, &total);
+        if (f < a.n_frames) a.frame_off[f + 1] = carry + ex + v;
+        carry += total;
+    }
+    if (tid == 0) a.frame_off[0] = 0;
+}
+
+// wave-uniform broadcast of a register of lane `src` (v_readlane_b32 with an SGPR lane select)
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src);
+}
+__device__ __forceinline__ float bcast(float v, uint32_t src) {
+    return __uint_as_float(bcast_u32(__float_as_uint(v), src));
+}
+__device__ __forceinline__ double bcast(double v, uint32_t src) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint64_t r = (uint64_t)bcast_u32((uint32_t)u, src) | ((uint64_t)bcast_u32((uint32_t)(u >> 32), src) << 32);
+    return __longlong_as_double((long long)r);
+}
+template <class T> struct __attribute__((packed, aligned(4))) Pt3 { T x, y, z; };
+
+template <class T, bool SEP, int TILE>
+__global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
+    // tile = TILE columns, rows in chunks of ROWS = 4096 / TILE (64 x 64 or 32 x 128).  A wave owns
+    // CPW columns; lane l < CPW keeps the metadata of column l (output base, pose cast to T, table
+    // row, timestamp) in registers and each column iteration broadcasts it with v_readlane -- no
+    // dependent global loads and no LDS traffic in the column loop apart from the transposed
+    // range read.  Lane = row (NR rows per lane): the kept rows are ranked with ballots and every
+    // lane stores its own 12 / 24 B point, so one store instruction writes one dense run.
+    constexpr int LPR = TILE / 4, ROWS = 4096 / TILE, PITCH = TILE + 1, CPW = TILE / 4, NR = ROWS / 64;
+    constexpr int RPP = 256 / LPR;  // rows staged per pass
+    __shared__ uint32_t s_rng[ROWS * PITCH];
+    const uint32_t W = a.w, H = a.h, f = blockIdx.y, tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t q = tid % LPR, ty = tid / LPR;
+    const uint32_t c0 = blockIdx.x * TILE;
+    const uint32_t ncol = min((uint32_t)TILE, W - c0);
+    const uint32_t* rp = a.range + (size_t)f * W * H;
+    const uint32_t* off = a.col_off + (size_t)f * (W + 1);
+    // nothing kept in this tile: leave before touching the range plane (uniform over the workgroup)
+    if (off[c0 + ncol] == off[c0]) return;
+    const uint64_t fbase = a.frame_off[f];
+    const LutDev lut = a.luts[f % a.n_luts];
+    const bool vec = (W % 4 == 0) && ((((uintptr_t)a.range) & 15) == 0);
+    // column metadata: lane l of the wave holds column wave*CPW + l % CPW
+    const uint32_t ml = lane % CPW, mj = wave * CPW + ml, mx = c0 + mj;
+    uint32_t m_base = 0, m_cnt = 0;
+    uint64_t m_ts = 0;
+    T m_pose[12];
+    double m_col[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m_pose[k] = (T)0;
+    if (mj < ncol) {
+        m_base = off[mx];
+        m_cnt = off[mx + 1] - m_base;
+        if (m_cnt) {
+            const double* pm = a.poses + ((size_t)f * W + mx) * 16;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) m_pose[k] = (T)pm[k];
+            if constexpr (SEP) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) m_col[k] = lut.col_tab[(size_t)mx * 5 + k];
+            }
+            if (a.timestamps_ns) m_ts = a.timestamp[(size_t)f * W + mx];
+        }
+    }
+    uint32_t m_run = 0;  // points of column l already written (previous row chunks)
+    for (uint32_t r0 = 0; r0 < H; r0 += ROWS) {
+        __syncthreads();  // previous chunk consumed
+#pragma unroll
+        for (uint32_t rr = ty; rr < (uint32_t)ROWS; rr += RPP) {
+            const uint32_t r = r0 + rr, col = c0 + 4 * q;
+            uint32_t v[4] = {0, 0, 0, 0};
+            if (r < H && col < W) {
+                if (vec) {
+                    const uint4 t = *(const uint4*)(rp + (size_t)r * W + col);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+                    for (uint32_t c = 0; c < 4 && col + c < W; ++c) v[c] = rp[(size_t)r * W + col + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_rng[rr * PITCH + 4 * q + c] = v[c];
+        }
+        __syncthreads();
+        uint32_t row[NR];
+        double bt[NR][9];
+#pragma unroll
+        for (int hh = 0; hh < NR; ++hh) {
+            row[hh] = r0 + lane + 64 * hh;
+            if constexpr (SEP) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) bt[hh][k] = row[hh] < H ? lut.beam_tab[(size_t)row[hh] * 9 + k] : 0.0;
+            }
+        }
+        for (uint32_t jj = 0; jj < (uint32_t)CPW; ++jj) {
+            const uint32_t j = wave * CPW + jj, x = c0 + j;  // wave-uniform
+            if (j >= ncol) break;
+            if (bcast_u32(m_cnt, jj) == 0) continue;  // masked out or empty column
+            uint32_t r[NR], rank[NR];
+            bool keep[NR];
+            uint32_t n_keep = 0;
+#pragma unroll
+            for (int hh = 0; hh < NR; ++hh) {
+                r[hh] = s_rng[(lane + 64 * hh) * PITCH + j];
+                keep[hh] = row[hh] < H && r[hh] >= a.min_r && r[hh] <= a.max_r;
+                const uint64_t mask = __ballot(keep[hh]);
+                rank[hh] = n_keep + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                n_keep += (uint32_t)__popcll(mask);
+            }
+            if (n_keep == 0) continue;
+            const uint64_t g0 = fbase + bcast_u32(m_base, jj) + bcast_u32(m_run, jj);  // first point of this run
+            const uint64_t room = g0 < a.capacity ? a.capacity - g0 : 0;
+#pragma unroll
+            for (int hh = 0; hh < NR; ++hh) {
+                if (!(keep[hh] && rank[hh] < room)) continue;
+                double p[3];
+                if constexpr (SEP) {
+                    const double cx = bcast(m_col[0], jj), sx = bcast(m_col[1], jj);
+                    const double rm = (double)r[hh] - lut.n;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double d = fma(cx, bt[hh][k], fma(sx, bt[hh][3 + k], bt[hh][6 + k]));
+                        p[k] = r[hh] ? fma(rm, d, bcast(m_col[2 + k], jj)) : 0.0;
+                    }
+                } else {
+                    const size_t pix = (size_t)row[hh] * W + x;
+                    if (lut.full_dtype == OUSTER_HIP_F32)
+                        project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs, pix, r[hh], p);
+                    else
+                        project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs, pix, r[hh], p);
+                }
+                const T px = (T)p[0], py = (T)p[1], pz = (T)p[2];
+                Pt3<T> o;
+                o.x = bcast(m_pose[0], jj) * px + bcast(m_pose[1], jj) * py + bcast(m_pose[2], jj) * pz + bcast(m_pose[3], jj);
+                o.y = bcast(m_pose[4], jj) * px + bcast(m_pose[5], jj) * py + bcast(m_pose[6], jj) * pz + bcast(m_pose[7], jj);
+                o.z = bcast(m_pose[8], jj) * px + bcast(m_pose[9], jj) * py + bcast(m_pose[10], jj) * pz + bcast(m_pose[11], jj);
+                ((Pt3<T>*)a.points)[g0 + rank[hh]] = o;
+            }
+            // every point of the run carries the same provenance: dense lanes 0..n_keep-1
+            if (a.col_idxs || a.frame_idxs || a.timestamps_ns) {
+                const uint64_t ts = (uint64_t)bcast_u32((uint32_t)m_ts, jj) |
+                                    ((uint64_t)bcast_u32((uint32_t)(m_ts >> 32), jj) << 32);
+                for (uint32_t i = lane; i < n_keep && i < room; i += 64) {
+                    if (a.col_idxs) a.col_idxs[g0 + i] = x;
+                    if (a.frame_idxs) a.frame_idxs[g0 + i] = f;
+                    if (a.timestamps_ns) a.timestamps_ns[g0 + i] = ts;
+                }
+            }
+            if (ml == jj) m_run += n_keep;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launchers (host)
+// ------------------------------------------------------------------------------------
+size_t decode_lds_bytes(const Geometry& g, int tile, bool general) {
+    size_t tile_bytes = ((size_t)tile * g.col_size + 16 + 15) & ~(size_t)15;
+    size_t h4 = (g.pixels_per_column + 3) & ~3u;
+    size_t n = tile_bytes + (size_t)tile * 4 + 32 + h4 * 4 + 4 * 192 * 16;
+    if (general) {  // tile 0: packet map [W / cpp] + valid-column bitmap [(W + 31) / 32] + its count
+        const size_t npo = g.columns_per_frame / g.columns_per_packet;
+        n += (npo + (g.columns_per_frame + 31) / 32 + 1) * 4;
+        n = (n + 15) & ~(size_t)15;
+    }
+    return n;
+}
+
+size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_slot) {
+    return ((size_t)tw * (lds_col_slot >> 2) + 4 + 2 * (size_t)tw + 4 + ((rows_per_tile + 3) & ~3u)) * 4 + 4 * 192 * 16;
+}
+
+#define OUSTER_DECL_SPEC(sfx)                                                                             \
+    hipError_t launch_decode_##sfx(const DecodeArgs& a, int tile, int xyzm, int device, hipStream_t st); \
+    hipError_t launch_decode_wide_##sfx(const DecodeArgs& a, int tw, int xyzm, int device, hipStream_t st);
+OUSTER_DECL_SPEC(generic)
+OUSTER_DECL_SPEC(dual_lb)
+OUSTER_DECL_SPEC(lb)
+OUSTER_DECL_SPEC(single)
+OUSTER_DECL_SPEC(dual)
+OUSTER_DECL_SPEC(legacy)
+#undef OUSTER_DECL_SPEC
+
+hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, int device, hipStream_t st) {
+    switch (spec_id) {
+        case SPEC_DUAL_LB: return launch_decode_dual_lb(a, tile, xyzm, device, st);
+        case SPEC_LB: return launch_decode_lb(a, tile, xyzm, device, st);
+        case SPEC_SINGLE: return launch_decode_single(a, tile, xyzm, device, st);
+        case SPEC_DUAL: return launch_decode_dual(a, tile, xyzm, device, st);
+        case SPEC_LEGACY: return launch_decode_legacy(a, tile, xyzm, device, st);
+        default: return launch_decode_generic(a, tile, xyzm, device, st);
+    }
+}
+
+hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, int device, hipStream_t st) {
+    switch (spec_id) {
+        case SPEC_DUAL_LB: return launch_decode_wide_dual_lb(a, tw, xyzm, device, st);
+        case SPEC_LB: return launch_decode_wide_lb(a, tw, xyzm, device, st);
+        case SPEC_SINGLE: return launch_decode_wide_single(a, tw, xyzm, device, st);
+        case SPEC_DUAL: return launch_decode_wide_dual(a, tw, xyzm, device, st);
+        case SPEC_LEGACY: return launch_decode_wide_legacy(a, tw, xyzm, device, st);
+        default: return launch_decode_wide_generic(a, tw, xyzm, device, st);
+    }
+}
+
+hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st) {
+    dim3 grid(a.h, n_images);
+    hipLaunchKernelGGL(k_destagger, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// tile width of the standalone tiled kernels.  Unlike the 14-stream k_decode these one/two-stream
+// kernels gain nothing from 256-column tiles (same-box A/B: equal for f32, 5-10 % slower for f64 and
+// full-LUT), so 64 stays the default; OUSTER_HIP_CT_TILE=256 is kept for experiments.
+static uint32_t standalone_tile_width(uint32_t w) {
+    static const int env = [] { const char* e = getenv("OUSTER_HIP_CT_TILE"); return e ? atoi(e) : 0; }();
+    (void)w;
+    return env == 256 ? 256u : 64u;
+}
+
+hipError_t launch_cartesian(const CartesianArgs& a_in, int mode, hipStream_t st) {
+    CartesianArgs a = a_in;
+    if (a.vec_ok && a.w % 4 == 0) {
+        // enough workgroups to fill the chip: split the rows when the batch is small
+        const uint32_t tw = standalone_tile_width(a.w);
+        const uint32_t tiles = (a.w + tw - 1) / tw;
+        uint32_t rpb = a.h;
+        while (rpb > 16 && (size_t)tiles * a.n_images * ((a.h + rpb - 1) / rpb) < 1024) rpb = (rpb + 1) / 2;
+        rpb = (rpb + 15) / 16 * 16;
+        a.rows_per_block = rpb;
+        dim3 grid(tiles * ((a.h + rpb - 1) / rpb), a.n_images);
+        if (tw == 256) {
+            switch (mode) {
+                case 1: hipLaunchKernelGGL((k_cartesian_tiled<1, 256>), grid, dim3(256), 0, st, a); break;
+                case 2: hipLaunchKernelGGL((k_cartesian_tiled<2, 256>), grid, dim3(256), 0, st, a); break;
+                default: hipLaunchKernelGGL((k_cartesian_tiled<3, 256>), grid, dim3(256), 0, st, a); break;
+            }
+        } else {
+            switch (mode) {
+                case 1: hipLaunchKernelGGL((k_cartesian_tiled<1, 64>), grid, dim3(256), 0, st, a); break;
+                case 2: hipLaunchKernelGGL((k_cartesian_tiled<2, 64>), grid, dim3(256), 0, st, a); break;
+                default: hipLaunchKernelGGL((k_cartesian_tiled<3, 64>), grid, dim3(256), 0, st, a); break;
+            }
+        }
+        return hipGetLastError();
+    }
+    const size_t quads = ((size_t)a.w * a.h + 3) / 4 * a.n_images;
+    size_t blocks = (quads + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks == 0) blocks = 1;
+    dim3 grid((uint32_t)blocks);
+    switch (mode) {
+        case 1: hipLaunchKernelGGL(k_cartesian<1>, grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(k_cartesian<2>, grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(k_cartesian<3>, grid, dim3(256), 0, st, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_dewarp(const DewarpArgs& a_in, hipStream_t st) {
+    DewarpArgs a = a_in;
+    if (a.w % 4 == 0 && (((uintptr_t)a.points | (uintptr_t)a.out) & 15) == 0) {
+        const uint32_t tw = standalone_tile_width(a.w);
+        const uint32_t tiles = (a.w + tw - 1) / tw;
+        uint32_t rpb = a.h;
+        while (rpb > 16 && (size_t)tiles * a.n_images * ((a.h + rpb - 1) / rpb) < 1024) rpb = (rpb + 1) / 2;
+        rpb = (rpb + 15) / 16 * 16;
+        a.rows_per_block = rpb;
+        dim3 grid(tiles * ((a.h + rpb - 1) / rpb), a.n_images);
+        if (tw == 256) {
+            if (a.dtype == OUSTER_HIP_F32) hipLaunchKernelGGL((k_dewarp_tiled<float, 256>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_dewarp_tiled<double, 256>), grid, dim3(256), 0, st, a);
+        } else {
+            if (a.dtype == OUSTER_HIP_F32) hipLaunchKernelGGL((k_dewarp_tiled<float, 64>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_dewarp_tiled<double, 64>), grid, dim3(256), 0, st, a);
+        }
+        return hipGetLastError();
+    }
+    const size_t total = (size_t)a.w * a.h * a.n_images;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks == 0) blocks = 1;
+    if (a.dtype == OUSTER_HIP_F32) hipLaunchKernelGGL(k_dewarp<float>, dim3((uint32_t)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_dewarp<double>, dim3((uint32_t)blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st) {
+    const uint32_t tiles = (a.w + 63) / 64;
+    hipLaunchKernelGGL(k_dwf_count, dim3(tiles, a.n_frames), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dwf_scan, dim3(a.n_frames), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dwf_frame_scan, dim3(1), dim3(256), 0, st, a);
+    const dim3 grid(tiles, a.n_frames);  // 64 x 64 emit tiles (32 x 128 measured 15 % slower)
+    if (a.dtype == OUSTER_HIP_F32) {
+        if (separable) hipLaunchKernelGGL((k_dwf_emit<float, true, 64>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_dwf_emit<float, false, 64>), grid, dim3(256), 0, st, a);
+    } else {
+        if (separable) hipLaunchKernelGGL((k_dwf_emit<double, true, 64>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_dwf_emit<double, false, 64>), grid, dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ouster_hip_dev

@@ -1,0 +1,558 @@
+// kernels_common.h -- device helpers shared by the kernel translation units
+// (k_decode.hip is compiled once per packet-profile specialisation, k_standalone.hip once).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "ouster_hip_dev.h"
+
+namespace ouster_hip_dev {
+
+// ------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t apply_bits(uint64_t word, uint64_t mask, int shift) {
+    word &= mask;
+    if (shift > 0) word >>= shift;
+    else if (shift < 0) word <<= -shift;
+    return word;
+}
+
+__device__ __forceinline__ uint64_t funnel3(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t sh) {
+    uint64_t lo = ((uint64_t)d1 << 32) | d0;
+    uint64_t v = lo >> sh;
+    if (sh) v |= ((uint64_t)d2) << (64 - sh);
+    return v;
+}
+
+// 64-bit little-endian window at an arbitrary byte address in global memory
+__device__ __forceinline__ uint64_t window_global(const uint8_t* p) {
+    uintptr_t a = (uintptr_t)p;
+    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+    uint32_t sh = (uint32_t)(a & 3) * 8;
+    uint32_t d0 = q[0], d1 = q[1];
+    uint32_t d2 = sh ? q[2] : 0u;
+    return funnel3(d0, d1, d2, sh);
+}
+
+// like window_global, but only the dwords that `mask` (applied to the window) can see are
+// loaded; header fields are 1-4 bytes wide, so this is usually a single dword
+__device__ __forceinline__ uint64_t window_global_masked(const uint8_t* p, uint64_t mask) {
+    if (mask == 0) return 0;
+    const uint32_t lo = (uint32_t)__builtin_ctzll(mask) >> 3, hi = (63u - (uint32_t)__builtin_clzll(mask)) >> 3;
+    const uintptr_t a = (uintptr_t)p;
+    const uintptr_t first = (a + lo) & ~(uintptr_t)3, last = (a + hi) & ~(uintptr_t)3;
+    uint64_t v = 0;
+    for (uintptr_t q = first; q <= last; q += 4) {
+        const uint64_t d = *(const uint32_t*)q;
+        const long sh = (long)(q - a) * 8;  // bit position of this dword inside the window
+        v |= sh >= 0 ? (sh < 64 ? d << sh : 0) : d >> (-sh);
+    }
+    return v;
+}
+
+// same, from the LDS tile (byte offset into the tile)
+__device__ __forceinline__ uint64_t window_lds(const uint32_t* tile, uint32_t byte_off) {
+    const uint32_t* q = tile + (byte_off >> 2);
+    uint32_t sh = (byte_off & 3) * 8;
+    return funnel3(q[0], q[1], q[2], sh);
+}
+
+__device__ __forceinline__ uint64_t trunc_elem(uint64_t v, uint32_t elem) {
+    return elem >= 8 ? v : (v & ((1ull << (elem * 8)) - 1));
+}
+
+// unaligned-capable vector stores (gfx950 global stores only need the HW
+// "unaligned access mode", which amdhsa enables; the compiler emits single
+// global_store_dword{,x2,x4} for these packed types)
+struct __attribute__((packed, aligned(1))) pk4 { uint32_t a; };
+struct __attribute__((packed, aligned(1))) pk8 { uint32_t a, b; };
+struct __attribute__((packed, aligned(1))) pk16 { uint32_t a, b, c, d; };
+
+__device__ __forceinline__ void st4(void* p, uint32_t a) { ((pk4*)p)->a = a; }
+__device__ __forceinline__ void st8(void* p, uint32_t a, uint32_t b) {
+    pk8 v{a, b};
+    *((pk8*)p) = v;
+}
+__device__ __forceinline__ void st16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    pk16 v{a, b, c, d};
+    *((pk16*)p) = v;
+}
+
+// store 4 consecutive elements of `elem` bytes each starting at byte pointer p
+__device__ __forceinline__ void store4(uint8_t* p, const uint64_t v[4], uint32_t elem) {
+    switch (elem) {
+        case 1:
+            st4(p, (uint32_t)(v[0] & 0xff) | ((uint32_t)(v[1] & 0xff) << 8) |
+                       ((uint32_t)(v[2] & 0xff) << 16) | ((uint32_t)(v[3] & 0xff) << 24));
+            break;
+        case 2:
+            st8(p, (uint32_t)(v[0] & 0xffff) | ((uint32_t)(v[1] & 0xffff) << 16),
+                (uint32_t)(v[2] & 0xffff) | ((uint32_t)(v[3] & 0xffff) << 16));
+            break;
+        case 4:
+            st16(p, (uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
+            break;
+        case 6: {
+            // 4 x 48 bit, little endian, 24 contiguous bytes
+            uint64_t a = (v[0] & 0xffffffffffffull) | (v[1] << 48);
+            uint64_t b = ((v[1] >> 16) & 0xffffffffull) | (v[2] << 32);
+            uint64_t c = ((v[2] >> 32) & 0xffffull) | (v[3] << 16);
+            st8(p, (uint32_t)a, (uint32_t)(a >> 32));
+            st8(p + 8, (uint32_t)b, (uint32_t)(b >> 32));
+            st8(p + 16, (uint32_t)c, (uint32_t)(c >> 32));
+            break;
+        }
+        default:  // 8
+            st16(p, (uint32_t)v[0], (uint32_t)(v[0] >> 32), (uint32_t)v[1], (uint32_t)(v[1] >> 32));
+            st16(p + 16, (uint32_t)v[2], (uint32_t)(v[2] >> 32), (uint32_t)v[3],
+                 (uint32_t)(v[3] >> 32));
+    }
+}
+
+__device__ __forceinline__ void store1(uint8_t* p, uint64_t v, uint32_t elem) {
+    switch (elem) {
+        case 1: *p = (uint8_t)v; break;
+        case 2: *(uint16_t*)p = (uint16_t)v; break;
+        case 4: *(uint32_t*)p = (uint32_t)v; break;
+        case 6:
+            *(uint16_t*)p = (uint16_t)v;
+            *(uint16_t*)(p + 2) = (uint16_t)(v >> 16);
+            *(uint16_t*)(p + 4) = (uint16_t)(v >> 32);
+            break;
+        default: *(uint64_t*)p = v;
+    }
+}
+
+__device__ __forceinline__ uint64_t zero_value(uint32_t f16_nan) {
+    return f16_nan ? 0x7e007e007e007e00ull : 0ull;
+}
+
+// ------------------------------------------------------------------------------------
+// global -> LDS staging of one contiguous byte range, all threads of the block
+// ------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__device__ __forceinline__ void stage_range(uint32_t* lds_tile, uint32_t lds_byte_off,
+                                            const uint8_t* __restrict__ src, uint32_t nbytes,
+                                            uint32_t tid) {
+    if ((((uintptr_t)src | lds_byte_off | nbytes) & 15u) == 0) {
+        const u32x4* s = (const u32x4*)src;
+        u32x4* d = (u32x4*)(lds_tile + (lds_byte_off >> 2));
+        const uint32_t n = nbytes >> 4;
+#pragma unroll 4
+        for (uint32_t i = tid; i < n; i += NT) d[i] = __builtin_nontemporal_load(s + i);
+    } else {  // packets are 4-byte granular (parsing.cpp:459-469), so is everything in them
+        const uint32_t* s = (const uint32_t*)src;
+        uint32_t* d = lds_tile + (lds_byte_off >> 2);
+        const uint32_t n = nbytes >> 2;
+#pragma unroll 4
+        for (uint32_t i = tid; i < n; i += NT) d[i] = s[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// static field tables for the standard profiles (bit layouts: parsing.cpp:170-363,
+// plane element sizes: lidar_frame.cpp:73-187).  A runtime format descriptor is
+// matched against these at format_create; anything else runs the generic spec.
+// ------------------------------------------------------------------------------------
+struct SpecDualLB {  // RNG15_RFL8_NIR8_DUAL / FUSA_RNG15_RFL8_NIR8_DUAL, 8 B/px
+    static constexpr bool is_static = true;
+    static constexpr uint32_t chan = 8;
+    static constexpr int nf = 8;
+    static constexpr int range_idx = 0, range2_idx = 4;
+    static constexpr FieldC f[8] = {{0, 0x7fff, -3, 4}, {1, 0x80, 7, 1},  {2, 0xff, 0, 1},
+                                    {3, 0xff, -4, 2},   {4, 0x7fff, -3, 4}, {5, 0x80, 7, 1},
+                                    {6, 0xff, 0, 1},    {7, 0xff, 0, 1}};
+};
+struct SpecLB {  // RNG15_RFL8_NIR8, 4 B/px
+    static constexpr bool is_static = true;
+    static constexpr uint32_t chan = 4;
+    static constexpr int nf = 4;
+    static constexpr int range_idx = 0, range2_idx = -1;
+    static constexpr FieldC f[4] = {{0, 0x7fff, -3, 4}, {1, 0x80, 7, 1}, {2, 0xff, 0, 1},
+                                    {3, 0xff, -4, 2}};
+};
+struct SpecSingle {  // RNG19_RFL8_SIG16_NIR16, 12 B/px
+    static constexpr bool is_static = true;
+    static constexpr uint32_t chan = 12;
+    static constexpr int nf = 6;
+    static constexpr int range_idx = 0, range2_idx = -1;
+    static constexpr FieldC f[6] = {{0, 0x7ffff, 0, 4}, {2, 0xf8, 3, 1},   {4, 0xff, 0, 1},
+                                    {6, 0xffff, 0, 2},  {8, 0xffff, 0, 2}, {11, 0xff, 0, 1}};
+};
+struct SpecDual {  // RNG19_RFL8_SIG16_NIR16_DUAL, 16 B/px
+    static constexpr bool is_static = true;
+    static constexpr uint32_t chan = 16;
+    static constexpr int nf = 10;
+    static constexpr int range_idx = 0, range2_idx = 3;
+    static constexpr FieldC f[10] = {{0, 0x7ffff, 0, 4},  {2, 0xf8, 3, 1},   {3, 0xff, 0, 1},
+                                     {4, 0x7ffff, 0, 4},  {6, 0xf8, 3, 1},   {7, 0xff, 0, 1},
+                                     {8, 0xffff, 0, 2},   {10, 0xffff, 0, 2}, {12, 0xffff, 0, 2},
+                                     {15, 0xff, 0, 1}};
+};
+struct SpecLegacy {  // LEGACY, 12 B/px
+    static constexpr bool is_static = true;
+    static constexpr uint32_t chan = 12;
+    static constexpr int nf = 5;
+    static constexpr int range_idx = 0, range2_idx = -1;
+    static constexpr FieldC f[5] = {{0, 0xfffff, 0, 4}, {3, 0xf0, 4, 1}, {4, 0xff, 0, 1},
+                                    {6, 0xffff, 0, 2},  {8, 0xffff, 0, 2}};
+};
+struct SpecGeneric {  // everything else: descriptors read from the kernel arguments
+    static constexpr bool is_static = false;
+    static constexpr uint32_t chan = 0;
+    static constexpr int nf = 0;
+    static constexpr int range_idx = -1, range2_idx = -1;
+};
+
+// compile-time field extraction from the pixel's dwords held in registers
+template <class S, int K, int CW>
+__device__ __forceinline__ uint64_t extract_static(const uint32_t (&w)[CW]) {
+    constexpr uint32_t off = S::f[K].offset;
+    constexpr uint32_t i0 = off / 4, sh = (off % 4) * 8;
+    uint64_t lo = w[i0];
+    if constexpr (i0 + 1 < CW) lo |= (uint64_t)w[i0 + 1] << 32;
+    uint64_t win = lo >> sh;
+    if constexpr (sh != 0 && i0 + 2 < CW) win |= (uint64_t)w[i0 + 2] << (64 - sh);
+    return trunc_elem(apply_bits(win, S::f[K].mask, S::f[K].shift), S::f[K].elem);
+}
+
+// ------------------------------------------------------------------------------------
+// XYZ projection of 4 consecutive pixels of one row.
+//   separable tables (per-beam x per-column, double math, one rounding on store):
+//     dir  = cx*U + sx*V + Wb          (already x range_unit and rotated by `transform`)
+//     xyz  = (r - n) * dir + Kc        (Kc: per-column part of the offset)
+//   == r*direction + offset of make_xyz_lut (xyzlut.cpp:63-86) up to ~1e-13 m.
+//   full LUT (user arrays / per-pixel angle sensors): xyz = r*dir + ofs in the
+//   LUT's own precision, as cartesianT<T> does (cartesian.h:53-65).
+// ------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void store_xyz4(T* dst, const double (&p)[4][3]);
+
+template <>
+__device__ __forceinline__ void store_xyz4<float>(float* dst, const double (&p)[4][3]) {
+    float4* d = (float4*)dst;  // 48 B, 16 B aligned (pixel index multiple of 4)
+    d[0] = make_float4((float)p[0][0], (float)p[0][1], (float)p[0][2], (float)p[1][0]);
+    d[1] = make_float4((float)p[1][1], (float)p[1][2], (float)p[2][0], (float)p[2][1]);
+    d[2] = make_float4((float)p[2][2], (float)p[3][0], (float)p[3][1], (float)p[3][2]);
+}
+template <>
+__device__ __forceinline__ void store_xyz4<double>(double* dst, const double (&p)[4][3]) {
+    double2* d = (double2*)dst;
+    d[0] = make_double2(p[0][0], p[0][1]);
+    d[1] = make_double2(p[0][2], p[1][0]);
+    d[2] = make_double2(p[1][1], p[1][2]);
+    d[3] = make_double2(p[2][0], p[2][1]);
+    d[4] = make_double2(p[2][2], p[3][0]);
+    d[5] = make_double2(p[3][1], p[3][2]);
+}
+
+// f32 xyz of 4 consecutive pixels per lane = 48 contiguous bytes per lane.  Stored directly,
+// each of the three 16 B store instructions would touch every third 16 B chunk of the row
+// segment.  Instead the wave transposes through a private LDS scratch so that instruction k
+// writes chunks [k*LPR, (k+1)*LPR) of the row segment: LPR x 16 B contiguous per row.
+//   row_base: xyz address of the first pixel of this lane's row segment (tile column 0)
+template <int LPR>
+__device__ __forceinline__ void store_xyz4_coalesced(float4* s_xyz, uint32_t tid, float* row_base,
+                                                     uint32_t q, const double (&p)[4][3]) {
+    const uint32_t wave = tid >> 6, lane = tid & 63u, rho = lane / LPR;
+    float4* sc = s_xyz + wave * 192 + rho * (3 * LPR);
+    sc[3 * q + 0] = make_float4((float)p[0][0], (float)p[0][1], (float)p[0][2], (float)p[1][0]);
+    sc[3 * q + 1] = make_float4((float)p[1][1], (float)p[1][2], (float)p[2][0], (float)p[2][1]);
+    sc[3 * q + 2] = make_float4((float)p[2][2], (float)p[3][0], (float)p[3][1], (float)p[3][2]);
+    // same-wave LDS write -> read: DS ops of a wave execute in order; keep the compiler from
+    // reordering and wait for the writes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float4* d = (float4*)row_base;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 v = sc[k * LPR + q];
+        d[k * LPR + q] = v;
+    }
+    // the next use of the scratch (second return / next row) must not overtake these reads
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// Generic forms of the same transpose for a "lane owns 4 consecutive pixels x NV 16 B chunks"
+// register block (NV = 3: 4 x f32 xyz, NV = 6: 4 x f64 xyz).  sc = this lane-row's private
+// scratch of NV*LPR float4; row_base = address of tile column 0 of the lane's row.
+template <int NV, int LPR>
+__device__ __forceinline__ void store_quad_coalesced(float4* sc, float4* row_base, uint32_t q,
+                                                     const float4 (&v)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sc[NV * q + k] = v[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NV; ++k) row_base[k * LPR + q] = sc[k * LPR + q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <int NV, int LPR>
+__device__ __forceinline__ void load_quad_coalesced(float4* sc, const float4* row_base, uint32_t q,
+                                                    float4 (&v)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sc[k * LPR + q] = row_base[k * LPR + q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = sc[NV * q + k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <class T>
+__device__ __forceinline__ void store_xyz1(T* dst, const double (&p)[3]) {
+    dst[0] = (T)p[0]; dst[1] = (T)p[1]; dst[2] = (T)p[2];
+}
+
+// full-LUT projection of one pixel; LT = LUT element type
+template <class LT>
+__device__ __forceinline__ void project_full(const LT* dir, const LT* ofs, size_t pix, uint32_t r,
+                                             double (&p)[3]) {
+    if (r == 0) { p[0] = p[1] = p[2] = 0.0; return; }
+    const LT rr = (LT)r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // separate multiply and add like a default (non-FMA) host build of cartesianT
+        LT m = rr * dir[pix * 3 + k];
+        asm volatile("" : "+v"(m));  // keep the compiler from contracting into an fma
+        p[k] = (double)(LT)(m + ofs[pix * 3 + k]);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------
+// frame_state: u64 words shared by the optimistic decode pass and the fix-up pass behind it
+// (DESIGN.md section 3.1).
+//   [FS_SEQ]        sequence number, advanced by the fix-up pass of every call
+//   [FS_TAG]        tag (= sequence + 1) the last optimistic pass flagged with
+//   [FS_WORDS + f]  frame f was flagged by the call whose tag this is ("a live column sits outside
+//                   its home slot"); any other value means clean.  Flags are never cleared: the next
+//                   call uses a larger tag.  64 bits do not wrap.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t FS_SEQ = 0, FS_TAG = 1, FS_WORDS = 2;
+
+// (measurement_id, status) of a column header staged in LDS at byte offset cb
+__device__ __forceinline__ void col_header_lds(const Geometry& g, const uint32_t* s_tile, uint32_t cb,
+                                               uint32_t& m_id, uint32_t& status) {
+    m_id = (uint16_t)apply_bits(window_lds(s_tile, cb + g.col_measurement_id.offset),
+                                g.col_measurement_id.mask, g.col_measurement_id.shift);
+    status = (uint32_t)apply_bits(window_lds(s_tile, cb + g.col_status.offset), g.col_status.mask,
+                                  g.col_status.shift);
+}
+
+// frame-level values latched from the first packet of a frame (start_frame, lidar_frame.cpp:1709-1741)
+__device__ __forceinline__ ouster_hip_frame_meta frame_meta_of(const Geometry& g, const uint8_t* pkt,
+                                                               bool any_packet) {
+    ouster_hip_frame_meta m;
+    m.frame_id = -1; m.frame_status = 0; m.shutdown_countdown = 0;
+    m.shot_limiting_countdown = 0; m.n_valid_columns = 0;
+    if (any_packet) {
+        m.frame_id = (int64_t)(uint32_t)apply_bits(window_global(pkt + g.frame_id.offset), g.frame_id.mask,
+                                                    g.frame_id.shift);
+        const uint8_t th = (uint8_t)apply_bits(window_global(pkt + g.thermal_shutdown.offset),
+                                               g.thermal_shutdown.mask, g.thermal_shutdown.shift);
+        const uint8_t sl = (uint8_t)apply_bits(window_global(pkt + g.shot_limiting.offset),
+                                               g.shot_limiting.mask, g.shot_limiting.shift);
+        m.frame_status = (uint64_t)(th & 0x0f) | ((uint64_t)(sl & 0x0f) << 4);
+        m.shutdown_countdown = (uint16_t)apply_bits(window_global(pkt + g.countdown_thermal_shutdown.offset),
+                                                    g.countdown_thermal_shutdown.mask,
+                                                    g.countdown_thermal_shutdown.shift);
+        m.shot_limiting_countdown = (uint16_t)apply_bits(window_global(pkt + g.countdown_shot_limiting.offset),
+                                                         g.countdown_shot_limiting.mask,
+                                                         g.countdown_shot_limiting.shift);
+    }
+    return m;
+}
+
+// ------------------------------------------------------------------------------------
+// decode_rows: the pixel phase shared by k_decode and k_decode_wide.
+// The workgroup's tile (QPR*4 columns x nrows rows, rows r0.. of frame f, columns c0..) sits in LDS,
+// column j at dword  col0_dw + j*colstride_dw, its rows `S::chan` (or a.g.channel_data_size) bytes
+// apart.  lane = (row within pass, quad of 4 consecutive columns): every global store is a vector
+// store of 4 consecutive elements of a plane row (16 B for u32, 8 B for u16, 4 B for u8).
+//   field decode   FieldDecodeInfo::get, field_decode_info.h:41-54 (compile-time masks for the
+//                  standard profiles, run-time descriptors for SpecGeneric = add_custom_profile)
+//   destagger      destagger_into<T>, impl/lidar_frame_impl.h:733-760: the same 4 values go to column
+//                  (col + offset[row]) mod W of the destaggered plane
+//   cartesian      cartesianT<T>, impl/cartesian.h:36-66 on the separable tables (XYZM 1/2) or the
+//                  full LUT (XYZM 3); f32 xyz leaves through the wave-private LDS transpose
+// vq: bit c set = my column c holds a received, valid column (else zeros / f16 NaN are written).
+// ------------------------------------------------------------------------------------
+template <class S, int QPR, int XYZM>
+__device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t* s_tile,
+                                            uint32_t col0_dw, uint32_t colstride_dw, const int32_t* s_off,
+                                            float4* s_xyz, const LutDev& lut, uint32_t f, uint32_t c0,
+                                            uint32_t r0, uint32_t nrows, uint32_t vq) {
+    constexpr int NT = 256;
+    constexpr int LPR = QPR < 64 ? QPR : 64;             // lanes of one wave in a row segment
+    constexpr int RPP = NT / QPR > 0 ? NT / QPR : 1;     // rows per pass of the workgroup
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = a.g.columns_per_frame, H = a.g.pixels_per_column;
+    const uint32_t q = tid % QPR, ty = tid / QPR;
+    const uint32_t jq = q * 4, col = c0 + jq;
+    if (col >= W) return;
+    const bool vec = a.vec_ok && (col + 3 < W);
+    const uint32_t ncol = (W - col) < 4 ? (W - col) : 4;  // < 4 only when W % 4 != 0
+    const size_t plane_px = (size_t)H * W;
+    const uint32_t ql = q % LPR;                 // lane position inside its wave's row segment
+    const uint32_t seg0 = c0 + (q - ql) * 4;     // first column of that segment
+    const uint32_t chan = S::is_static ? S::chan : a.g.channel_data_size;
+
+    double cx[4], sx[4], kc[4][3];
+    if (XYZM == 1 || XYZM == 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t cc = (col + c < W) ? col + c : W - 1;
+            const double* t = lut.col_tab + (size_t)cc * 5;
+            cx[c] = t[0]; sx[c] = t[1]; kc[c][0] = t[2]; kc[c][1] = t[3]; kc[c][2] = t[4];
+        }
+    }
+
+    for (uint32_t rrel = ty; rrel < nrows; rrel += RPP) {
+        const uint32_t r = r0 + rrel;
+        const size_t rowpix = (size_t)r * W + col;  // pixel index of my first column
+        uint32_t doff = 0;                          // destaggered column of my first column
+        bool dvec = false;
+        if (a.any_destagger) {
+            doff = col + (uint32_t)s_off[rrel];
+            if (doff >= W) doff -= W;
+            dvec = vec && (doff + 3 < W);
+        }
+        uint32_t rng[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+
+        if constexpr (S::is_static) {
+            constexpr int CW = S::chan / 4;
+            uint32_t w[4][CW];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t* px = s_tile + col0_dw + (jq + c) * colstride_dw + rrel * CW;
+#pragma unroll
+                for (int k = 0; k < CW; ++k) w[c][k] = px[k];
+            }
+            auto do_field = [&](auto kc_) {
+                constexpr int K = decltype(kc_)::value;
+                const int di = a.desc_of_spec[K];
+                if (di < 0) return;
+                uint64_t v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    v[c] = ((vq >> c) & 1) ? extract_static<S, K, CW>(w[c])
+                                           : trunc_elem(zero_value(a.f16_nan[di]), S::f[K].elem);
+                if (K == S::range_idx) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
+                if (K == S::range2_idx) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
+                constexpr uint32_t e = S::f[K].elem;
+                uint8_t* pl = (uint8_t*)a.planes[di];
+                if (pl) {
+                    uint8_t* d = pl + ((size_t)f * plane_px + rowpix) * e;
+                    if (vec) store4(d, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) store1(d + c * e, v[c], e);
+                }
+                uint8_t* dp = (uint8_t*)a.destaggered[di];
+                if (dp) {
+                    uint8_t* drow = dp + ((size_t)f * plane_px + (size_t)r * W) * e;
+                    if (dvec) store4(drow + (size_t)doff * e, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) {
+                        uint32_t dc = doff + c; if (dc >= W) dc -= W;
+                        store1(drow + (size_t)dc * e, v[c], e);
+                    }
+                }
+            };
+            [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+                (do_field(std::integral_constant<int, Ks>{}), ...);
+            }(std::make_integer_sequence<int, S::nf>{});
+        } else {
+            for (uint32_t i = 0; i < a.n_fields; ++i) {
+                const bool want_xyz = (XYZM != 0) && ((int)i == a.xyz_field[0] || (int)i == a.xyz_field[1]);
+                uint8_t* pl = (uint8_t*)a.planes[i];
+                uint8_t* dp = (uint8_t*)a.destaggered[i];
+                if (!pl && !dp && !want_xyz) continue;
+                const uint32_t e = a.elem[i];
+                uint64_t v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t bo = ((col0_dw + (jq + c) * colstride_dw) << 2) + rrel * chan + a.bits[i].offset;
+                    v[c] = ((vq >> c) & 1)
+                               ? trunc_elem(apply_bits(window_lds(s_tile, bo), a.bits[i].mask, a.bits[i].shift), e)
+                               : trunc_elem(zero_value(a.f16_nan[i]), e);
+                }
+                if ((int)i == a.xyz_field[0]) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
+                if ((int)i == a.xyz_field[1]) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
+                if (pl) {
+                    uint8_t* d = pl + ((size_t)f * plane_px + rowpix) * e;
+                    if (vec) store4(d, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) store1(d + c * e, v[c], e);
+                }
+                if (dp) {
+                    uint8_t* drow = dp + ((size_t)f * plane_px + (size_t)r * W) * e;
+                    if (dvec) store4(drow + (size_t)doff * e, v, e);
+                    else for (uint32_t c = 0; c < ncol; ++c) {
+                        uint32_t dc = doff + c; if (dc >= W) dc -= W;
+                        store1(drow + (size_t)dc * e, v[c], e);
+                    }
+                }
+            }
+        }
+
+        if constexpr (XYZM == 1 || XYZM == 2) {
+            using XT = typename std::conditional<XYZM == 1, float, double>::type;
+            const double* b = lut.beam_tab + (size_t)r * 9;  // 9 KB table, L1/L2 resident
+            const double u0 = b[0], u1 = b[1], u2 = b[2], v0 = b[3], v1 = b[4], v2 = b[5],
+                         w0 = b[6], w1 = b[7], w2 = b[8];
+            double d[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                d[c][0] = fma(cx[c], u0, fma(sx[c], v0, w0));
+                d[c][1] = fma(cx[c], u1, fma(sx[c], v1, w1));
+                d[c][2] = fma(cx[c], u2, fma(sx[c], v2, w2));
+            }
+#pragma unroll
+            for (int ret = 0; ret < 2; ++ret) {
+                XT* out = (XT*)a.xyz[ret];
+                if (!out) continue;
+                double p[4][3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t rr = rng[ret][c];
+                    const double rm = (double)rr - lut.n;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) p[c][k] = rr ? fma(rm, d[c][k], kc[c][k]) : 0.0;
+                }
+                XT* dst = out + ((size_t)f * plane_px + rowpix) * 3;
+                if constexpr (XYZM == 1) {
+                    if (a.vec_ok && seg0 + 4 * LPR <= W) {  // my wave's whole row segment exists
+                        store_xyz4_coalesced<LPR>(s_xyz, tid, dst - (size_t)(4 * ql) * 3, ql, p);
+                        continue;
+                    }
+                }
+                if (vec) store_xyz4<XT>(dst, p);
+                else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<XT>(dst + c * 3, p[c]);
+            }
+        } else if constexpr (XYZM == 3) {
+#pragma unroll
+            for (int ret = 0; ret < 2; ++ret) {
+                if (!a.xyz[ret]) continue;
+                double p[4][3];
+                for (uint32_t c = 0; c < ncol; ++c) {
+                    if (lut.full_dtype == OUSTER_HIP_F32)
+                        project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs,
+                                            rowpix + c, rng[ret][c], p[c]);
+                    else
+                        project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs,
+                                             rowpix + c, rng[ret][c], p[c]);
+                }
+                if (a.xyz_dtype == OUSTER_HIP_F32) {
+                    float* dst = (float*)a.xyz[ret] + ((size_t)f * plane_px + rowpix) * 3;
+                    if (vec) store_xyz4<float>(dst, p);
+                    else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<float>(dst + c * 3, p[c]);
+                } else {
+                    double* dst = (double*)a.xyz[ret] + ((size_t)f * plane_px + rowpix) * 3;
+                    if (vec) store_xyz4<double>(dst, p);
+                    else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<double>(dst + c * 3, p[c]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace ouster_hip_dev

@@ -5,6 +5,7 @@
 // reference too: ouster_core/src/xyzlut.cpp:11-89, cached per sensor in sensor_info.cpp:260-275).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -65,25 +66,47 @@ struct DevBuf {
 
 }  // namespace
 
+// experiment / test knobs of a context: defaults from OUSTER_HIP_* environment variables read ONCE in
+// ouster_hip_ctx_create, changed afterwards with ouster_hip_ctx_set_knob (never getenv on the call path)
+struct Knobs {
+    int tile = 0;             // OUSTER_HIP_TILE: force k_decode's tile width (64/32/16)
+    int wide = -1;            // OUSTER_HIP_WIDE: -1 auto (tuner), 0 narrow, 64/128/256/512 force k_decode_wide
+    int wide_kb = 64;         // OUSTER_HIP_WIDE_KB: LDS budget of a wide tile image
+    int wide_min_blocks = 512;  // OUSTER_HIP_WIDE_MIN_BLOCKS: smaller launches stay on k_decode
+    int tune = 1;             // OUSTER_HIP_TUNE: 0 pins the default wide variant
+    int xcd = 1;              // OUSTER_HIP_XCD: 0 disables the XCD-aware block -> frame mapping
+    int fast = 1;             // OUSTER_HIP_FAST: 0 sends every frame through the general mapping
+    int fixup = 1;            // tests only: 0 skips the fix-up pass (flagged frames are then left undone)
+};
+
 struct ouster_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf map, offsets, luts, counts, scratch;
-    uint32_t map_epoch = 0;              // tag of the last decode call's map entries; 0: map needs a memset
+    DevBuf state, tile_valid, offsets, luts, counts, scratch;
+    uint32_t resident_wgs = 512;         // 2 workgroups (80 KB LDS each) per CU
+    bool state_dirty = false;            // `state` may hold leftovers (fix-up pass skipped / a failed launch)
     std::vector<int32_t> offsets_host;   // cache key of `offsets`
+    std::vector<int32_t> shifts_host;    // pixel_shift_by_row the cached offsets were derived from
     std::vector<LutDev> luts_host;       // cache key of `luts`
+    // pageable host packet_counts go through a small pinned ring (no stream synchronisation)
+    static constexpr int RING = 4;
+    uint32_t* ring_buf[RING] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ring_cap[RING] = {0, 0, 0, 0};
+    hipEvent_t ring_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
+    int ring_next = 0;
+    Knobs knobs;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     // k_decode variant (64-column tiles / wide tiles of 128 or 256 columns) per workload, picked by
-    // timing each candidate once on the first calls: which one is faster depends on how the output
-    // planes happen to be placed in HBM (DESIGN.md section 3.3)
+    // timing each candidate on the first calls: which one is faster depends on how the output
+    // planes happen to be placed in HBM (DESIGN.md section 3.2b)
     struct Tune {
         int best = -2;  // -2: still measuring; 0: narrow; 128 / 256: wide
         int calls = 0;
-        hipEvent_t ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-        float ms[3] = {0, 0, 0};  // fastest sample of each candidate so far
+        hipEvent_t ev[6][2] = {};  // two rounds x three candidates
+        float ms[3] = {0, 0, 0};   // fastest sample of each candidate
     };
     std::map<uint64_t, Tune> tune;
     int last_tile_cols = 0, last_tile_rows = 0;  // tile of the last k_decode launch
@@ -235,6 +258,22 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
     ouster_hip_ctx* c = new (std::nothrow) ouster_hip_ctx();
     if (!c) return fail(OUSTER_HIP_ERR_RUNTIME, "out of memory");
     c->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            c->resident_wgs = 2u * (uint32_t)cus;
+    }
+    {   // the only place the environment is read
+        auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        Knobs& k = c->knobs;
+        k.tile = env_int("OUSTER_HIP_TILE", k.tile);
+        k.wide = env_int("OUSTER_HIP_WIDE", k.wide);
+        k.wide_kb = env_int("OUSTER_HIP_WIDE_KB", k.wide_kb);
+        k.wide_min_blocks = env_int("OUSTER_HIP_WIDE_MIN_BLOCKS", k.wide_min_blocks);
+        k.tune = env_int("OUSTER_HIP_TUNE", k.tune);
+        k.xcd = env_int("OUSTER_HIP_XCD", k.xcd);
+        k.fast = env_int("OUSTER_HIP_FAST", k.fast);
+    }
     if (stream == OUSTER_HIP_STREAM_NULL) {
         c->stream = nullptr;  // the null stream
     } else if (stream) {
@@ -255,7 +294,12 @@ void ouster_hip_ctx_destroy(ouster_hip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->map.release();
+    c->state.release();
+    c->tile_valid.release();
+    for (int i = 0; i < ouster_hip_ctx::RING; ++i) {
+        if (c->ring_buf[i]) (void)hipHostFree(c->ring_buf[i]);
+        if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
+    }
     c->offsets.release();
     c->luts.release();
     c->counts.release();
@@ -273,6 +317,24 @@ void ouster_hip_ctx_destroy(ouster_hip_ctx* c) {
 }
 
 void* ouster_hip_ctx_stream(ouster_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int ouster_hip_ctx_device(ouster_hip_ctx* c) { return c ? c->device : -1; }
+
+int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
+    if (!c || !name) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    const std::string n = name;
+    Knobs& k = c->knobs;
+    if (n == "tile") k.tile = value;
+    else if (n == "wide") k.wide = value;
+    else if (n == "wide_kb") k.wide_kb = value;
+    else if (n == "wide_min_blocks") k.wide_min_blocks = value;
+    else if (n == "tune") k.tune = value;
+    else if (n == "xcd") k.xcd = value;
+    else if (n == "fast") k.fast = value;
+    else if (n == "fixup") k.fixup = value;
+    else return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unknown knob '%s'", name);
+    return OUSTER_HIP_OK;
+}
 
 int ouster_hip_sync(ouster_hip_ctx* c) {
     if (!c) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
@@ -299,7 +361,8 @@ int ouster_hip_format_create(ouster_hip_ctx* ctx, const ouster_hip_format_desc* 
         return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "inconsistent packet geometry");
     if (d->lidar_packet_size > 65535)
         return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "lidar_packet_size cannot exceed 65535");
-    if ((d->col_size & 3) || (d->packet_header_size & 3) || (d->lidar_packet_size & 3))
+    if ((d->col_size & 3) || (d->packet_header_size & 3) || (d->lidar_packet_size & 3) ||
+        (d->col_header_size & 3))
         return fail(OUSTER_HIP_ERR_UNSUPPORTED, "packet geometry must be 4-byte granular");
     for (uint32_t i = 0; i < d->n_fields; ++i) {
         const uint32_t e = d->fields[i].dst_elem_size;
@@ -491,6 +554,50 @@ static int ensure_luts(ouster_hip_ctx* c, const std::vector<LutDev>& l) {
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // ---- decode ------------------------------------------------------------------------------
+// packet_counts may live anywhere: device memory is used in place; host memory is copied with the
+// stream (pinned: directly; pageable: through the context's pinned ring) -- never a stream sync
+static int stage_counts(ouster_hip_ctx* ctx, const uint32_t* packet_counts, uint32_t n_frames,
+                        uint32_t slots_per_frame, const uint32_t** d_counts) {
+    hipPointerAttribute_t attr{};
+    const hipError_t pe = hipPointerGetAttributes(&attr, packet_counts);
+    if (pe != hipSuccess) (void)hipGetLastError();  // an unregistered host pointer is not an error
+    if (pe == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged)) {
+        *d_counts = packet_counts;  // values above slots_per_frame are clamped by the kernels
+        return OUSTER_HIP_OK;
+    }
+    for (uint32_t f = 0; f < n_frames; ++f)
+        if (packet_counts[f] > slots_per_frame)
+            return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "packet_counts[%u] > slots_per_frame", f);
+    const size_t bytes = (size_t)n_frames * 4;
+    if (ctx->counts.ensure(bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(counts) failed");
+    const void* src = packet_counts;
+    const bool pinned = pe == hipSuccess && attr.type == hipMemoryTypeHost;
+    int slot = -1;
+    if (!pinned) {
+        slot = ctx->ring_next;
+        ctx->ring_next = (slot + 1) % ouster_hip_ctx::RING;
+        if (!ctx->ring_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->ring_ev[slot], hipEventDisableTiming));
+        else HIP_TRY(hipEventSynchronize(ctx->ring_ev[slot]));  // RING calls ago: long done
+        if (ctx->ring_cap[slot] < bytes) {
+            if (ctx->ring_buf[slot]) (void)hipHostFree(ctx->ring_buf[slot]);
+            ctx->ring_buf[slot] = nullptr;
+            ctx->ring_cap[slot] = 0;
+            HIP_TRY(hipHostMalloc((void**)&ctx->ring_buf[slot], bytes + bytes / 2, hipHostMallocDefault));
+            ctx->ring_cap[slot] = bytes + bytes / 2;
+        }
+        memcpy(ctx->ring_buf[slot], packet_counts, bytes);
+        src = ctx->ring_buf[slot];
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->counts.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (slot >= 0) HIP_TRY(hipEventRecord(ctx->ring_ev[slot], ctx->stream));
+    *d_counts = (const uint32_t*)ctx->counts.p;
+    return OUSTER_HIP_OK;
+}
+
+static bool fast_possible(const Knobs& kn, uint32_t slots_per_frame, const Geometry& g) {
+    return kn.fast && (uint64_t)slots_per_frame * g.columns_per_packet == g.columns_per_frame;
+}
+
 int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const uint8_t* packets,
                       size_t packet_stride, uint32_t slots_per_frame,
                       const uint32_t* packet_counts, uint32_t n_frames,
@@ -501,12 +608,17 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     if (n_frames == 0) return OUSTER_HIP_OK;
     if (!packets) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "packets is NULL");
     const Geometry& g = fmt->g;
+    const Knobs& kn = ctx->knobs;
     const uint32_t W = g.columns_per_frame, H = g.pixels_per_column;
     if (packet_stride < g.lidar_packet_size || (packet_stride & 3) || ((uintptr_t)packets & 3))
         return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT,
                     "packet_stride must be >= lidar_packet_size and 4-byte granular");
     if ((uint64_t)slots_per_frame * g.columns_per_packet > 0x7fffffffull || slots_per_frame == 0)
         return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "bad slots_per_frame");
+    if ((uint64_t)slots_per_frame * packet_stride > 0xffffffffull)
+        return fail(OUSTER_HIP_ERR_UNSUPPORTED, "a frame's packet buffer cannot exceed 4 GiB");
+    if (W > 65536 || W / g.columns_per_packet > 8192)
+        return fail(OUSTER_HIP_ERR_UNSUPPORTED, "more than 65536 columns or 8192 packets per frame");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
@@ -531,84 +643,64 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
                 return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unexpected image dimensions");
     }
 
-    // ---- scratch: column map, destagger offsets, LUT descriptors, packet counts
-    const size_t map_bytes = (size_t)n_frames * W * 4;
+    // ---- scratch: per-frame state words (all-zero between calls: the fix-up pass cleans up after
+    // itself), destagger offsets, LUT descriptors, packet counts
     {
-        const void* before = ctx->map.p;
-        if (ctx->map.ensure(map_bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(map) failed");
-        if (ctx->map.p != before) ctx->map_epoch = 0;
+        const void* before = ctx->state.p;
+        if (ctx->state.ensure(((size_t)n_frames + 2) * 8)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(state) failed");
+        if (ctx->state.p != before || ctx->state_dirty) HIP_TRY(hipMemsetAsync(ctx->state.p, 0, ctx->state.cap, st));
+        ctx->state_dirty = fast_possible(kn, slots_per_frame, g);  // until the fix-up pass has been queued
     }
-    // map entries are (epoch << 20) | source slot and k_colmap writes them with atomicMax: entries
-    // of earlier calls lose against this call's and read as "absent" in k_decode, so the map is
-    // only cleared when it is new or the 11-bit epoch wraps
-    if ((uint64_t)slots_per_frame * g.columns_per_packet >= (1u << 20))
-        return fail(OUSTER_HIP_ERR_UNSUPPORTED, "more than 2^20 column slots per frame");
-    if (ctx->map_epoch == 0 || ctx->map_epoch >= 2047) {
-        HIP_TRY(hipMemsetAsync(ctx->map.p, 0xFF, ctx->map.cap, st));
-        ctx->map_epoch = 0;
-    }
-    const uint32_t epoch = ++ctx->map_epoch;
+    if (out->frame_meta && ctx->tile_valid.ensure((size_t)n_frames * ((W + 15) / 16) * 2))
+        return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(tile_valid) failed");
     const uint32_t n_packets_out = W / g.columns_per_packet;
-    if (out->packet_timestamp && host_timestamps)  // start_frame zeroes it (lidar_frame.cpp:1719)
-        HIP_TRY(hipMemsetAsync(out->packet_timestamp, 0, (size_t)n_frames * n_packets_out * 8, st));
     const uint32_t* d_counts = nullptr;
     if (packet_counts) {
-        for (uint32_t f = 0; f < n_frames; ++f)
-            if (packet_counts[f] > slots_per_frame)
-                return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "packet_counts[%u] > slots_per_frame", f);
-        if (ctx->counts.ensure((size_t)n_frames * 4))
-            return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(counts) failed");
-        HIP_TRY(hipMemcpyAsync(ctx->counts.p, packet_counts, (size_t)n_frames * 4,
-                               hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        d_counts = (const uint32_t*)ctx->counts.p;
+        const int rc = stage_counts(ctx, packet_counts, n_frames, slots_per_frame, &d_counts);
+        if (rc) return rc;
     }
     if (any_dst) {
-        std::vector<int32_t> off;
-        dest_offsets(pixel_shift_by_row, H, W, 0, off);
-        if (ensure_offsets(ctx, off)) return fail(OUSTER_HIP_ERR_RUNTIME, "offset upload failed");
+        // the offsets only change with the sensor: key the cache on the shifts themselves
+        if (!(ctx->offsets.p && ctx->shifts_host.size() == H &&
+              memcmp(ctx->shifts_host.data(), pixel_shift_by_row, (size_t)H * 4) == 0 &&
+              ctx->offsets_host.size() == H)) {
+            std::vector<int32_t> off;
+            dest_offsets(pixel_shift_by_row, H, W, 0, off);
+            if (ensure_offsets(ctx, off)) return fail(OUSTER_HIP_ERR_RUNTIME, "offset upload failed");
+            ctx->shifts_host.assign(pixel_shift_by_row, pixel_shift_by_row + H);
+        }
     }
     int xyzm = 0;
     if (any_xyz) {
-        std::vector<LutDev> l(n_luts);
-        bool all_sep = true;
+        bool all_sep = true, none_sep = true;
+        bool same = ctx->luts.p && ctx->luts_host.size() == n_luts;
         for (uint32_t i = 0; i < n_luts; ++i) {
-            l[i] = luts[i]->dev;
             all_sep &= luts[i]->separable;
+            none_sep &= !luts[i]->separable;
+            same = same && memcmp(&luts[i]->dev, &ctx->luts_host[i], sizeof(LutDev)) == 0;
         }
-        bool none_sep = true;
-        for (uint32_t i = 0; i < n_luts; ++i) none_sep &= !luts[i]->separable;
         if (!all_sep && !none_sep)
             return fail(OUSTER_HIP_ERR_UNSUPPORTED, "cannot mix separable and full LUTs in one batch");
-        if (ensure_luts(ctx, l)) return fail(OUSTER_HIP_ERR_RUNTIME, "LUT descriptor upload failed");
+        if (!same) {
+            std::vector<LutDev> l(n_luts);
+            for (uint32_t i = 0; i < n_luts; ++i) l[i] = luts[i]->dev;
+            if (ensure_luts(ctx, l)) return fail(OUSTER_HIP_ERR_RUNTIME, "LUT descriptor upload failed");
+        }
         xyzm = all_sep ? (out->xyz_dtype == OUSTER_HIP_F32 ? 1 : 2) : 3;
     }
 
-    // ---- k_colmap
-    ColmapArgs ca{};
-    ca.g = g;
-    ca.packets = packets;
-    ca.packet_stride = packet_stride;
-    ca.slots_per_frame = slots_per_frame;
-    ca.n_packets_out = n_packets_out;
-    ca.packet_counts = d_counts;
-    ca.host_timestamps = host_timestamps;
-    ca.map = (int32_t*)ctx->map.p;
-    ca.epoch = epoch;
-    ca.packet_timestamp = out->packet_timestamp;
-    ca.alert_flags = out->alert_flags;
-    ca.frame_meta = out->frame_meta;
-    HIP_TRY(launch_colmap(ca, n_frames, st));
-
-    // ---- k_decode
+    // ---- kernel arguments
     DecodeArgs da{};
     da.g = g;
     da.packets = packets;
     da.packet_stride = packet_stride;
     da.slots_per_frame = slots_per_frame;
     da.n_frames = n_frames;
-    da.map = (int32_t*)ctx->map.p;
-    da.epoch = epoch;
+    da.n_packets_out = n_packets_out;
+    da.packet_counts = d_counts;
+    da.host_timestamps = host_timestamps;
+    da.frame_state = (uint64_t*)ctx->state.p;
+    da.tile_valid = (uint16_t*)ctx->tile_valid.p;
     da.dst_offsets = (const int32_t*)ctx->offsets.p;
     da.luts = (const LutDev*)ctx->luts.p;
     da.n_luts = n_luts ? n_luts : 1;
@@ -617,6 +709,9 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     da.timestamp = out->timestamp;
     da.measurement_id = out->measurement_id;
     da.status = out->status;
+    da.packet_timestamp = out->packet_timestamp;
+    da.alert_flags = out->alert_flags;
+    da.frame_meta = out->frame_meta;
     da.xyz[0] = out->xyz[0];
     da.xyz[1] = out->xyz[1];
     da.xyz_field[0] = out->xyz[0] ? out->xyz_field[0] : -1;
@@ -649,83 +744,94 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         if (out->xyz[1] && fmt->spec_of_desc[out->xyz_field[1]] != fmt->spec_r2) spec = SPEC_GENERIC;
     }
 
+    // optimistic pass + fix-up pass when the buffer has one slot per column of the frame; everything
+    // through the general mapping otherwise
+    const bool fast = fast_possible(kn, slots_per_frame, g);
+
     // tile width: widest tile that still lets two workgroups share a CU's 160 KiB LDS
     int tile = 0;
     for (int t : {64, 32, 16})
-        if (decode_lds_bytes(g, t) <= 80 * 1024) { tile = t; break; }
+        if (decode_lds_bytes(g, t, true) <= 80 * 1024) { tile = t; break; }
     if (!tile)
         for (int t : {64, 32, 16})
-            if (decode_lds_bytes(g, t) <= 160 * 1024) { tile = t; break; }
+            if (decode_lds_bytes(g, t, true) <= 160 * 1024) { tile = t; break; }
     if (!tile) return fail(OUSTER_HIP_ERR_UNSUPPORTED, "column of %u bytes does not fit in LDS", g.col_size);
     // small batches: prefer narrower tiles so that at least ~2 workgroups per CU exist
     // (one 128x2048 frame is only 32 tiles of 64 columns -- latency, not bandwidth, bound)
     while (tile > 16 && (size_t)n_frames * ((W + tile - 1) / tile) < 512) tile /= 2;
-    // tuning knobs for experiments (not part of the API contract)
-    if (const char* e = getenv("OUSTER_HIP_TILE")) {
-        const int t = atoi(e);
-        if ((t == 64 || t == 32 || t == 16) && decode_lds_bytes(g, t) <= 160 * 1024) tile = t;
-    }
-    // wide, short tiles (k_decode_wide): TW columns x TR rows with TW*TR*chan ~ 64 KB.  Needs the
-    // 4 B granular wire layout every standard profile has and a batch large enough to fill the chip.
+    if ((kn.tile == 64 || kn.tile == 32 || kn.tile == 16) && decode_lds_bytes(g, kn.tile, true) <= 160 * 1024)
+        tile = kn.tile;
+    // wide, short tiles (k_decode_wide): TW columns x TR rows with TW*TR*chan <= ~64 KB, TR chosen so that
+    // the row chunks are equal.  Needs a batch large enough to fill the chip; fast mode only.
     const uint32_t narrow_tiles = (W + tile - 1) / tile;
     auto setup_wide = [&](int want) -> bool {
         const uint32_t chan = g.channel_data_size;
-        if (!((want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 && g.col_size % 4 == 0 &&
-              packet_stride % 4 == 0 && g.packet_header_size % 4 == 0 && g.col_header_size % 4 == 0 &&
-              ((uintptr_t)packets & 3) == 0 && W >= (uint32_t)want))
+        if (!(fast && (want == 64 || want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 &&
+              W >= (uint32_t)want))
             return false;
         const uint32_t rpp = 1024u / (uint32_t)want;  // rows per pass of the 256-thread workgroup
-        uint32_t budget_kb = 64;                       // LDS for the tile image
-        if (const char* e = getenv("OUSTER_HIP_WIDE_KB")) budget_kb = (uint32_t)atoi(e);
-        uint32_t tr = (budget_kb * 1024u) / ((uint32_t)want * chan);
-        tr = tr / rpp * rpp;
-        if (tr > H) tr = (H + rpp - 1) / rpp * rpp;
-        if (tr < rpp) return false;
-        const uint32_t nch = (H + tr - 1) / tr, tiles = (W + want - 1) / want;
-        size_t min_blocks = 512;  // below that the narrow tiles' small-batch heuristic does better
-        if (const char* e = getenv("OUSTER_HIP_WIDE_MIN_BLOCKS")) min_blocks = (size_t)atol(e);
-        if ((size_t)n_frames * tiles * nch < min_blocks) return false;
+        const uint32_t budget = (uint32_t)(kn.wide_kb > 0 ? kn.wide_kb : 64) * 1024u;
+        uint32_t tr_max = budget / ((uint32_t)want * chan) / rpp * rpp;
+        if (tr_max < rpp) return false;
+        auto up = [&](uint32_t v) { return (v + rpp - 1) / rpp * rpp; };
+        uint32_t nch = (H + tr_max - 1) / tr_max, tr = std::min(up((H + nch - 1) / nch), tr_max);
+        for (uint32_t n2 = nch; n2 <= nch + 8 && n2 <= H; ++n2) {  // prefer equal chunks
+            const uint32_t t2 = up((H + n2 - 1) / n2);
+            if (t2 <= tr_max && t2 * n2 == H) { nch = n2; tr = t2; break; }
+        }
+        nch = (H + tr - 1) / tr;
+        const uint32_t tiles = (W + want - 1) / want;
+        if ((size_t)n_frames * tiles * nch < (size_t)std::max(kn.wide_min_blocks, 0)) return false;
         da.rows_per_tile = tr;
         da.row_chunks = nch;
         da.lds_col_slot = (tr * chan / 4 + 1) * 4;  // +1 dword: bank spread
         da.tiles_per_frame = tiles;
-        return true;
+        return decode_wide_lds_bytes(want, tr, da.lds_col_slot) <= 160 * 1024;
     };
     int wide = 0;
     ouster_hip_ctx::Tune* tuning = nullptr;
     int tune_slot = -1;
-    if (const char* e = getenv("OUSTER_HIP_WIDE")) {  // forced (experiments, tests)
-        const int want = atoi(e);
-        if (want && setup_wide(want)) wide = want;
+    if (kn.wide >= 0) {  // forced (experiments, tests)
+        if (kn.wide && setup_wide(kn.wide)) wide = kn.wide;
     } else if (setup_wide(256)) {
         wide = 256;
-        const char* te = getenv("OUSTER_HIP_TUNE");
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cap);
-        if (!(te && atoi(te) == 0) && cap == hipStreamCaptureStatusNone) {
+        if (kn.tune && cap == hipStreamCaptureStatusNone) {
             uint64_t key = 1469598103934665603ull;
             auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
-            mix((uint64_t)spec); mix(W); mix(H); mix(g.channel_data_size); mix(n_frames); mix((uint64_t)xyzm);
+            uint32_t lg = 0;  // batches of similar size share a verdict
+            while ((2u << lg) <= n_frames) ++lg;
+            mix((uint64_t)spec); mix(W); mix(H); mix(g.channel_data_size); mix(lg); mix((uint64_t)xyzm);
             uint64_t pm = 0, dm = 0;
             for (uint32_t i = 0; i < nf; ++i) {
                 pm |= da.planes[i] ? (1ull << i) : 0;
                 dm |= da.destaggered[i] ? (1ull << i) : 0;
             }
             mix(pm); mix(dm); mix((da.xyz[0] ? 1u : 0u) | (da.xyz[1] ? 2u : 0u));
+            if (ctx->tune.size() > 64 && !ctx->tune.count(key)) {  // bounded: forget everything, re-learn
+                for (auto& kv : ctx->tune)
+                    for (auto& pr : kv.second.ev)
+                        for (hipEvent_t e : pr)
+                            if (e) (void)hipEventDestroy(e);
+                ctx->tune.clear();
+            }
             ouster_hip_ctx::Tune& t = ctx->tune[key];
             static const int cand[3] = {256, 128, 0};
-            // two rounds over the candidates (single launches vary by ~10 %, mostly upwards: keep each
-            // candidate's faster sample); the clocks of a round are read when the next one starts
-            constexpr int ROUNDS = 2;
-            if (t.best == -2 && t.calls > 0 && t.calls % 3 == 0) {
-                for (int c = 0; c < 3; ++c) {
-                    float ms = 0;
-                    if (hipEventSynchronize(t.ev[c][1]) == hipSuccess &&
-                        hipEventElapsedTime(&ms, t.ev[c][0], t.ev[c][1]) == hipSuccess && ms > 0 &&
-                        (t.ms[c] == 0 || ms < t.ms[c]))
-                        t.ms[c] = ms;
-                }
-                if (t.calls >= 3 * ROUNDS) {
+            // two rounds over the candidates (single launches vary by ~10 %, mostly upwards: each
+            // candidate's faster sample counts).  The clocks are polled, never waited for: until all
+            // six samples have landed the default variant runs.
+            if (t.best == -2 && t.calls >= 6) {
+                bool all = true;
+                for (int i = 0; i < 6 && all; ++i) all = hipEventQuery(t.ev[i][1]) == hipSuccess;
+                if (!all) (void)hipGetLastError();
+                else {
+                    for (int i = 0; i < 6; ++i) {
+                        float ms = 0;
+                        if (hipEventElapsedTime(&ms, t.ev[i][0], t.ev[i][1]) == hipSuccess && ms > 0 &&
+                            (t.ms[i % 3] == 0 || ms < t.ms[i % 3]))
+                            t.ms[i % 3] = ms;
+                    }
                     t.best = 256;
                     float best_ms = 0;
                     for (int c = 0; c < 3; ++c)
@@ -734,9 +840,9 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             }
             if (t.best != -2) {
                 wide = t.best;
-            } else {
-                tune_slot = t.calls % 3;
-                wide = cand[tune_slot];
+            } else if (t.calls < 6) {
+                tune_slot = t.calls;
+                wide = cand[tune_slot % 3];
                 tuning = &t;
                 ++t.calls;
             }
@@ -747,8 +853,8 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         da.rows_per_tile = da.row_chunks = da.lds_col_slot = 0;
         da.tiles_per_frame = narrow_tiles;
     }
-    da.xcd_map = n_frames >= 8 ? 1u : 0u;
-    if (const char* e = getenv("OUSTER_HIP_XCD")) da.xcd_map = (atoi(e) != 0 && n_frames >= 8) ? 1u : 0u;
+    da.xcd_map = (kn.xcd && n_frames >= 8) ? 1u : 0u;
+    da.mode = fast ? MODE_FAST : MODE_GENERAL;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
@@ -769,19 +875,27 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         HIP_TRY(hipEventRecord(tuning->ev[tune_slot][0], st));
     }
     if (wide) {
-        if (const char* e = getenv("OUSTER_HIP_DBG")) da.dbg = (uint32_t)atoi(e);
-        HIP_TRY(launch_decode_wide(da, spec, wide, xyzm, st));
+        HIP_TRY(launch_decode_wide(da, spec, wide, xyzm, ctx->device, st));
         ctx->last_tile_cols = wide;
         ctx->last_tile_rows = (int)da.rows_per_tile;
-        if (tuning) HIP_TRY(hipEventRecord(tuning->ev[tune_slot][1], st));
-        if (e1) HIP_TRY(hipEventRecord(e1, st));
-        return OUSTER_HIP_OK;
+    } else {
+        HIP_TRY(launch_decode(da, spec, tile, xyzm, ctx->device, st));
+        ctx->last_tile_cols = tile;
+        ctx->last_tile_rows = (int)H;
     }
-    HIP_TRY(launch_decode(da, spec, tile, xyzm, st));
-    ctx->last_tile_cols = tile;
-    ctx->last_tile_rows = (int)H;
     if (tuning) HIP_TRY(hipEventRecord(tuning->ev[tune_slot][1], st));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
+    if (fast && kn.fixup) {
+        // fix-up pass: frames the optimistic pass flagged are redone with the general mapping; the
+        // workgroups of clean frames leave after one atomic.  Always k_decode.
+        da.mode = MODE_FIXUP;
+        da.rows_per_tile = 0;
+        da.lds_col_slot = da.tiles_per_frame;  // column tiles of the pass above (slots of tile_valid)
+        da.row_chunks = ctx->resident_wgs;     // persistent grid: what the device keeps resident
+        da.tiles_per_frame = narrow_tiles;
+        HIP_TRY(launch_decode(da, spec, tile, xyzm, ctx->device, st));
+        ctx->state_dirty = false;
+    }
     return OUSTER_HIP_OK;
 }
 
@@ -799,6 +913,7 @@ int ouster_hip_destagger(ouster_hip_ctx* ctx, const void* src, void* dst, uint32
     std::vector<int32_t> off;
     dest_offsets(shifts, h, w, inverse, off);
     if (ensure_offsets(ctx, off)) return fail(OUSTER_HIP_ERR_RUNTIME, "offset upload failed");
+    ctx->shifts_host.clear();  // ouster_hip_decode's cache key no longer describes `offsets`
     DestaggerArgs a{};
     a.src = src;
     a.dst = dst;

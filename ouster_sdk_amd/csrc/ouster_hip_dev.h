@@ -32,19 +32,12 @@ struct LutDev {
     int32_t pad;
 };
 
-struct ColmapArgs {
-    Geometry g;
-    const uint8_t* packets;
-    size_t packet_stride;
-    uint32_t slots_per_frame;
-    uint32_t n_packets_out;  // W / cpp
-    const uint32_t* packet_counts;  // device, nullable
-    const uint64_t* host_timestamps;
-    int32_t* map;  // [n_frames][W]: (epoch << 20) | source slot; entries of other epochs are stale
-    uint32_t epoch;  // 1..2047, bumped per decode call (the map is only memset when it wraps)
-    uint64_t* packet_timestamp;
-    uint8_t* alert_flags;
-    ouster_hip_frame_meta* frame_meta;
+// how a decode launch finds the source column of a destination column
+enum DecodeMode : uint32_t {
+    MODE_FAST = 0,     // optimistic: slot s holds column s; verified against the staged headers, strays
+                       //   flag their frame in frame_state
+    MODE_FIXUP = 1,    // second pass: redo the frames the fast pass flagged (the others return at once)
+    MODE_GENERAL = 2,  // every frame through the scan-the-frame path (slots_per_frame*cpp != W)
 };
 
 struct DecodeArgs {
@@ -60,9 +53,12 @@ struct DecodeArgs {
     uint32_t rows_per_tile;   // k_decode_wide: rows of a tile, row chunks per column tile,
     uint32_t row_chunks;      //   bytes of one column's LDS slot (tiles_per_frame = column tiles)
     uint32_t lds_col_slot;
-    uint32_t dbg;             // experiments: 1 = stop after staging, 2 = skip the staging loads
-    int32_t* map;                // [n_frames][W]: (epoch << 20) | source slot, see ColmapArgs
-    uint32_t epoch;
+    uint32_t mode;            // DecodeMode
+    uint32_t n_packets_out;   // W / cpp: length of the packet-level outputs
+    const uint32_t* packet_counts;    // device [n_frames], nullable (= slots_per_frame)
+    const uint64_t* host_timestamps;  // device [n_frames][slots_per_frame], nullable
+    uint64_t* frame_state;            // device [2 + n_frames] scratch, see FS_* in kernels_common.h
+    uint16_t* tile_valid;             // device [n_frames][column tiles]: valid columns per tile (fast pass)
     const int32_t* dst_offsets;  // [H] destination column offset per row (device)
     const LutDev* luts;          // [n_luts] (device)
     uint32_t n_luts;
@@ -76,6 +72,9 @@ struct DecodeArgs {
     uint64_t* timestamp;
     uint16_t* measurement_id;
     uint32_t* status;
+    uint64_t* packet_timestamp;
+    uint8_t* alert_flags;
+    ouster_hip_frame_meta* frame_meta;
     void* xyz[2];
     int32_t xyz_field[2];
     int32_t xyz_dtype;
@@ -136,11 +135,12 @@ struct FieldC {
 };
 const FieldC* spec_fields(int spec_id, int* nf, uint32_t* chan, int* r1, int* r2);
 
-size_t decode_lds_bytes(const Geometry& g, int tile);
-hipError_t launch_colmap(const ColmapArgs& a, uint32_t n_frames, hipStream_t st);
-hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, hipStream_t st);
+// LDS of one k_decode workgroup (the general modes add the per-frame packet map and valid bitmap)
+size_t decode_lds_bytes(const Geometry& g, int tile, bool general);
 size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_slot);
-hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, hipStream_t st);
+// device: HIP device ordinal of the stream (per-device cache of the one-off kernel attributes)
+hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, int device, hipStream_t st);
+hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, int device, hipStream_t st);
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st);
 hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
 hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);

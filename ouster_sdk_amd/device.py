@@ -97,7 +97,7 @@ class HotPath:
 
     # -- the three operations --------------------------------------------------------------
     def decode(self, packets: torch.Tensor, out: Dict[str, torch.Tensor],
-               packet_counts: Optional[np.ndarray] = None,
+               packet_counts=None,
                host_timestamps: Optional[torch.Tensor] = None):
         """packets: uint8 CUDA tensor [n_frames, slots, packet_stride]."""
         assert packets.is_cuda and packets.dtype == torch.uint8 and packets.is_contiguous()
@@ -133,8 +133,14 @@ class HotPath:
             n_luts = len(self.luts)
             luts_arr = (C.c_void_p * max(n_luts, 1))(*[l.h for l in self.luts])
         counts_p = None
-        if packet_counts is not None:
+        if isinstance(packet_counts, torch.Tensor):
+            # device tensor (used in place; the graph-capturable form) or pinned host tensor
+            assert packet_counts.dtype in (torch.uint32, torch.int32) and packet_counts.is_contiguous()
+            assert packet_counts.numel() == n_frames
+            counts_p = packet_counts.data_ptr()
+        elif packet_counts is not None:
             packet_counts = np.ascontiguousarray(packet_counts, dtype=np.uint32)
+            assert packet_counts.size == n_frames
             counts_p = packet_counts.ctypes.data
         capi.check(self.ctx.L.ouster_hip_decode(
             self.ctx.h, self.fmt.h, packets.data_ptr(), stride, slots, counts_p, n_frames,

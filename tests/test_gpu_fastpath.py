@@ -1,0 +1,317 @@
+"""GPU parity for the optimistic decode pass + fix-up pass and for the sizes that
+bench.py actually runs (the benchmarked batch was never checked).
+
+  * home-slot frames with holes / invalid columns / out-of-range ids never leave the fast pass
+    (asserted by switching the fix-up pass OFF) and equal the oracle;
+  * compacted drops, shuffles and duplicates are caught on the device and redone by the fix-up pass;
+  * the call keeps no state: alternating workloads, a captured graph replayed on changing loss
+    patterns with eager calls in between (stale column map on replay);
+  * packet_counts as a device tensor, a pinned host tensor and a plain numpy array;
+  * configs[2] at 256 frames, configs[1] at 512 frames, configs[4]'s 4-sensor batch at W = 2048 through
+    the narrow and the 256-wide kernels: frames {0, 7, 8, 255, ...} against the oracle.
+Mirrors tests/frame_batcher_test.cpp:73-303 (dropped / invalid / custom) and
+tests/packet_format_test.cpp:218-326 (encode -> decode identity) of the reference.
+"""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = pytest.mark.gpu
+
+if has_gpu():
+    import torch
+    from ouster_sdk_amd.device import HotPath
+
+from test_gpu_parity import _np, _oracle_frames  # noqa: E402
+
+VARIANTS = [("narrow", 0), ("wide64", 64), ("wide128", 128), ("wide256", 256)]
+
+
+def _hotpath(cal, profile, wide=None, fixup=True, use_extrinsics=False, **kw):
+    hp = HotPath(profile, cal.h, cal.w, cal.cpp, header_type=cal.header_type, **kw)
+    hp.set_pixel_shift_by_row(cal.pixel_shift_by_row)
+    hp.add_lut(cal.beam_to_lidar, cal.lut_transform(use_extrinsics), cal.beam_azimuth_angles,
+               cal.beam_altitude_angles)
+    if wide is not None:
+        hp.ctx.set_knob("wide", wide)
+        hp.ctx.set_knob("wide_min_blocks", 0)
+    if not fixup:
+        hp.ctx.set_knob("fixup", 0)
+    return hp
+
+
+def _compare(O, cal, hp, out, ref_frames, dst_names, xyz_names, use_extrinsics=False, frames=None,
+             check_nvalid=True):
+    ldir, lofs = cal.xyz_lut(use_extrinsics)
+    names = [n for n, _ in hp.fields]
+    worst = 0.0
+    for f, fr in (enumerate(ref_frames) if frames is None else frames):
+        for n in names:
+            if n in out:
+                assert np.array_equal(_np(out[n][f]), fr.plane(n)), (f, n)
+        assert np.array_equal(_np(out["timestamp"][f]), fr.timestamp), f
+        assert np.array_equal(_np(out["measurement_id"][f]), fr.measurement_id), f
+        assert np.array_equal(_np(out["status"][f]), fr.status), f
+        for n in dst_names:
+            assert np.array_equal(_np(out["destaggered:" + n][f]),
+                                  O.destagger(fr.plane(n), cal.pixel_shift_by_row)), (f, n)
+        for n in xyz_names:
+            want = O.cartesian(fr.plane(n), ldir, lofs)
+            err = np.abs(_np(out["xyz:" + n][f]).astype(np.float64) - want).max()
+            worst = max(worst, float(err))
+            assert err <= 1e-4, (f, n, err)
+        meta = _np(out["frame_meta"][f])
+        if not check_nvalid:     # published by the fix-up pass
+            continue
+        assert meta[20:24].view(np.uint32)[0] == int((fr.status & 1).sum()), ("n_valid_columns", f)
+    return worst
+
+
+@pytest.mark.parametrize("label,wide", VARIANTS)
+def test_home_slots_with_holes_stay_on_the_fast_pass(oracle, label, wide):
+    """Packets in their home slots; lost packets are holes (zeroed slots), some columns invalid, one
+    column with an out-of-range measurement id, one frame entirely empty.  With the fix-up pass
+    switched off the result must still be the oracle's: the optimistic pass alone handles loss."""
+    O = oracle
+    cal = O.synthetic_calib(h=64, w=1024, profile="RNG15_RFL8_NIR8_DUAL")
+    pf = cal.packet_format()
+    n = 9
+    packets, _ = O.synth_packets(cal, n, with_window=True)
+    host = packets.copy()
+    rng = np.random.default_rng(3)
+    lost = {2: [5, 6, 40], 6: [0], 8: list(range(64))}       # frame 8: nothing arrived
+    for f, ps in lost.items():
+        host[f, ps] = 0
+    for p in rng.integers(0, 64, 4):                          # invalid columns (status bit 0 clear)
+        for c in rng.integers(0, 16, 5):
+            host[4, p, pf.packet_header_size + c * pf.col_size + 10] &= 0xFE
+    off = pf.packet_header_size + 3 * pf.col_size + 8          # a column beyond the frame: dropped
+    host[5, 7, off:off + 2] = np.frombuffer(np.uint16(5000).tobytes(), np.uint8)
+    by_frame = [np.delete(host[f], lost.get(f, []), axis=0) for f in range(n)]
+    hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL", wide=wide, fixup=False)
+    dst, xyz = ["RANGE", "REFLECTIVITY2"], ["RANGE", "RANGE2"]
+    out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
+    for t in out.values():
+        t.view(torch.uint8).fill_(0xCD)
+    hp.decode(torch.from_numpy(host).cuda(), out)
+    hp.sync()
+    tc, _ = hp.ctx.last_decode_tile()
+    assert (tc == wide) if wide else (tc <= 64), (tc, wide)
+    ref = _oracle_frames(O, cal, pf, by_frame, True)
+    _compare(O, cal, hp, out, ref, dst, xyz, check_nvalid=False)
+    hp.ctx.set_knob("fixup", 1)                               # the normal two-pass call: same bytes + counts
+    for t in out.values():
+        t.view(torch.uint8).fill_(0xCD)
+    hp.decode(torch.from_numpy(host).cuda(), out)
+    hp.sync()
+    _compare(O, cal, hp, out, ref, dst, xyz)
+
+
+@pytest.mark.parametrize("label,wide", VARIANTS)
+def test_strays_are_caught_and_redone(oracle, label, wide):
+    """One slot per column of the frame, but the slots are compacted after a drop / shuffled /
+    carry a duplicate: the fast pass flags those frames, the fix-up pass redoes them; clean frames of
+    the same batch stay untouched.  Without the fix-up pass the flagged frames are visibly undone."""
+    O = oracle
+    cal = O.synthetic_calib(h=32, w=1024, profile="RNG19_RFL8_SIG16_NIR16")
+    pf = cal.packet_format()
+    n = 10
+    packets, _ = O.synth_packets(cal, n, with_window=True)
+    rng = np.random.default_rng(11)
+    by_frame = [packets[f] for f in range(n)]
+    by_frame[1] = np.delete(by_frame[1], [9], axis=0)                     # compacted after a drop
+    by_frame[3] = by_frame[3][rng.permutation(64)]                        # any order
+    by_frame[5] = np.concatenate([np.delete(by_frame[5], [20], axis=0), by_frame[5][30:31]])  # duplicate
+    sw = by_frame[7].copy(); sw[[10, 11]] = sw[[11, 10]]; by_frame[7] = sw   # two neighbours swapped
+    host = np.zeros((n, 64, pf.lidar_packet_size), np.uint8)
+    counts = np.zeros(n, np.uint32)
+    for f, pk in enumerate(by_frame):
+        host[f, :len(pk)] = pk
+        counts[f] = len(pk)
+    dev = torch.from_numpy(host).cuda()
+    dst, xyz = ["RANGE"], ["RANGE"]
+    ref = _oracle_frames(O, cal, pf, by_frame, True)
+    for counts_arg in (counts, torch.from_numpy(counts.astype(np.int32)).cuda(),
+                       torch.from_numpy(counts.astype(np.int32)).pin_memory()):
+        hp = _hotpath(cal, "RNG19_RFL8_SIG16_NIR16", wide=wide)
+        out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
+        for t in out.values():
+            t.view(torch.uint8).fill_(0xCD)
+        hp.decode(dev, out, packet_counts=counts_arg)
+        hp.sync()
+        _compare(O, cal, hp, out, ref, dst, xyz)
+    # detection really is what routes them: with the second pass off, exactly the odd frames are wrong
+    hp = _hotpath(cal, "RNG19_RFL8_SIG16_NIR16", wide=wide, fixup=False)
+    out = hp.alloc_outputs(n)
+    for t in out.values():
+        t.view(torch.uint8).fill_(0xCD)
+    hp.decode(dev, out, packet_counts=counts)
+    hp.sync()
+    for f in range(n):
+        same = np.array_equal(_np(out["RANGE"][f]), ref[f].plane("RANGE"))
+        assert same == (f not in (1, 3, 5, 7)), f
+
+
+def test_decode_keeps_no_state_between_calls(oracle):
+    """Alternating full / compacted-partial / hole frames through ONE context for many calls (the r01
+    build kept an epoch-tagged column map between calls)."""
+    O = oracle
+    cal = O.synthetic_calib(h=16, w=256, profile="RNG15_RFL8_NIR8")
+    full, src = O.synth_packets(cal, 1, with_window=True)
+    hp = HotPath("RNG15_RFL8_NIR8", 16, 256, 16)
+    d_full = torch.from_numpy(full).cuda()
+    d_part = torch.zeros_like(d_full)
+    d_part[:, :11] = d_full[:, [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11]]   # packet 5 lost, compacted; 12..15 missing
+    d_hole = d_full.clone()
+    d_hole[:, 5] = 0
+    cnt_part = torch.tensor([11], dtype=torch.int32, device="cuda")
+    want_full = src[0].plane("RANGE")
+    want_part = want_full.copy(); want_part[:, 80:96] = 0; want_part[:, 192:] = 0
+    want_hole = want_full.copy(); want_hole[:, 80:96] = 0
+    out = hp.alloc_outputs(1)
+    for call in range(300):
+        kind = call % 3
+        if kind == 0:
+            hp.decode(d_full, out)
+        elif kind == 1:
+            hp.decode(d_part, out, packet_counts=cnt_part)
+        else:
+            hp.decode(d_hole, out)
+        if call < 9 or call % 37 == 0 or call >= 290:
+            got = _np(out["RANGE"][0])
+            assert np.array_equal(got, (want_full, want_part, want_hole)[kind]), call
+            nv = _np(out["frame_meta"][0])[20:24].view(np.uint32)[0]
+            assert nv == (256, 176, 240)[kind], (call, nv)
+
+
+def test_graph_replay_on_changing_loss_patterns(oracle):
+    """Capture ouster_hip_decode once, replay it on new packet contents in the same buffers: full
+    frames, swapped packets (strays -> fix-up), holes, with an eager decode of the same context in
+    between (the epoch map of the r01 build went stale in exactly these cases)."""
+    O = oracle
+    cal = O.synthetic_calib(h=64, w=512, profile="RNG15_RFL8_NIR8_DUAL")
+    pf = cal.packet_format()
+    variants = []
+    for seed in (5, 6, 7, 8):
+        pk, _ = O.synth_packets(cal, 2, seed=seed, with_window=True)
+        variants.append(pk)
+    swapped = variants[1].copy(); swapped[0, [3, 20]] = swapped[0, [20, 3]]
+    holes = variants[2].copy(); holes[1, [0, 9, 31]] = 0
+    contents = [("full", variants[0], [variants[0][0], variants[0][1]]),
+                ("swapped", swapped, [swapped[0], swapped[1]]),
+                ("holes", holes, [holes[0], np.delete(holes[1], [0, 9, 31], axis=0)]),
+                ("full2", variants[3], [variants[3][0], variants[3][1]])]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL", use_extrinsics=True)
+        d_pk = torch.from_numpy(variants[0]).cuda()
+        d_other = torch.from_numpy(variants[3]).cuda()
+        dst, xyz = ["RANGE"], ["RANGE", "RANGE2"]
+        out = hp.alloc_outputs(2, destagger=dst, xyz=xyz)
+        out_other = hp.alloc_outputs(2)
+        hp.decode(d_pk, out)          # warm: scratch allocation, offsets / LUT descriptor upload
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            hp.decode(d_pk, out)
+        for i, (label, pk, by_frame) in enumerate(contents):
+            d_pk.copy_(torch.from_numpy(pk))
+            for t in out.values():
+                t.view(torch.uint8).fill_(0xEE)
+            g.replay()
+            if i % 2 == 0:
+                g.replay()
+            s.synchronize()
+            ref = _oracle_frames(O, cal, pf, by_frame, True)
+            _compare(O, cal, hp, out, ref, dst, xyz, use_extrinsics=True)
+            hp.decode(d_other, out_other)   # an eager call between replays must not disturb them
+            s.synchronize()
+            assert np.array_equal(_np(out_other["status"][0]) & 1, np.ones(512, np.uint32)), label
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------
+# the benchmarked sizes
+# ---------------------------------------------------------------------------------------------
+def _bench_size_case(O, profile, n, dst, xyz, wide, n_luts=1, check=(0, 7, 8, 255, 256, 511)):
+    cal = O.synthetic_calib(h=128, w=2048, profile=profile)
+    packets, src = O.synth_packets(cal, 8, with_window=True)     # 8 distinct frames
+    hp = HotPath(profile, 128, 2048, 16)
+    hp.set_pixel_shift_by_row(cal.pixel_shift_by_row)
+    cals = []
+    for k in range(n_luts):
+        c = O.synthetic_calib(h=128, w=2048, profile=profile)
+        if n_luts > 1:
+            a = 0.5 * np.pi * k
+            ext = np.eye(4)
+            ext[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+            ext[:3, 3] = [1.0 * k, -0.5 * k, 0.25]
+            c.extrinsic = ext
+        cals.append(c)
+        hp.add_lut(c.beam_to_lidar, c.lut_transform(n_luts > 1), c.beam_azimuth_angles, c.beam_altitude_angles)
+    if wide is not None:
+        hp.ctx.set_knob("wide", wide)
+    d_pk = torch.from_numpy(packets).cuda().repeat(n // 8, 1, 1).contiguous()
+    out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
+    for t in out.values():
+        t.view(torch.uint8).fill_(0xA5)
+    hp.decode(d_pk, out)
+    hp.sync()
+    tc, tr = hp.ctx.last_decode_tile()
+    names = [x for x, _ in hp.fields]
+    luts = [c.xyz_lut(n_luts > 1) for c in cals]
+    worst = 0.0
+    for f in [f for f in check if f < n]:
+        fr = src[f % 8]
+        for name in names:
+            assert np.array_equal(_np(out[name][f]), fr.plane(name)), (f, name)
+        assert np.array_equal(_np(out["timestamp"][f]), fr.timestamp), f
+        assert np.array_equal(_np(out["status"][f]), fr.status), f
+        for name in dst:
+            assert np.array_equal(_np(out["destaggered:" + name][f]),
+                                  O.destagger(fr.plane(name), cal.pixel_shift_by_row)), (f, name)
+        d, o = luts[f % n_luts]
+        for name in xyz:
+            want = O.cartesian(fr.plane(name), d, o)
+            err = np.abs(_np(out["xyz:" + name][f]).astype(np.float64) - want).max()
+            worst = max(worst, float(err))
+            assert err <= 1e-4, (f, name, err)
+    # every other frame: identical inputs + identical LUT -> identical bytes (period lcm(8, n_luts) = 8)
+    for k, v in out.items():
+        if k == "frame_meta":
+            continue
+        v8 = v.view(torch.uint8).reshape(n // 8, 8, -1)
+        assert torch.equal(v8, v8[:1].expand_as(v8)), k
+    return tc, tr, worst
+
+
+def test_bench_size_dual_256_frames(oracle):
+    """configs[2] exactly as bench.py runs it: 256 frames of 128x2048 dual return, all outputs; the
+    variant the tuner would pick from (256-wide) and the 64-column kernel."""
+    dst = ["RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"]
+    for wide, want_tc in ((256, 256), (0, 64), (128, 128)):
+        tc, tr, worst = _bench_size_case(oracle, "RNG15_RFL8_NIR8_DUAL", 256, dst, ["RANGE", "RANGE2"], wide)
+        assert tc == want_tc, (tc, tr)
+        assert worst <= 4e-5
+
+
+def test_bench_size_single_512_frames(oracle):
+    """configs[1] / configs[3]: 512 frames of 128x2048 RNG19_RFL8_SIG16_NIR16 (the XCD-aware block ->
+    frame map with 64 frames per XCD), default variant selection and the forced ones."""
+    for wide in (None, 0, 128):
+        tc, tr, worst = _bench_size_case(oracle, "RNG19_RFL8_SIG16_NIR16", 512, ["RANGE", "REFLECTIVITY"],
+                                         ["RANGE"], wide)
+        assert worst <= 4e-5
+
+
+def test_bench_size_fused4_w2048(oracle):
+    """configs[4]'s per-GPU share as `bench.py --workload fused4` runs it: 4 sensors interleaved
+    (frame % 4), each with its own extrinsics folded into its LUT, W = 2048, through the 256-wide
+    kernel AND the narrow one."""
+    dst = ["RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"]
+    for wide, want_tc in ((256, 256), (0, 64)):
+        tc, tr, worst = _bench_size_case(oracle, "RNG15_RFL8_NIR8_DUAL", 256, dst, ["RANGE", "RANGE2"], wide,
+                                         n_luts=4)
+        assert tc == want_tc
+        assert worst <= 4e-5

@@ -499,9 +499,10 @@ def test_odd_geometries(oracle, profile, h, w, cpp):
 
 
 def test_decode_is_graph_capturable(oracle):
-    """The launch sequence of ouster_hip_decode (k_colmap, k_decode, the packet_timestamp memset) is
-    stream-capturable once the LUT / offset caches are warm and packet_counts is NULL: capture it in
-    a HIP graph, replay it on new packet contents in the same buffers, compare with the oracle."""
+    """The launch sequence of ouster_hip_decode (optimistic k_decode pass + fix-up pass) is
+    stream-capturable once the scratch / LUT / offset caches are warm and packet_counts is NULL or a
+    device array: capture it in a HIP graph, replay it on new packet contents in the same buffers,
+    compare with the oracle (loss patterns across replays: tests/test_gpu_fastpath.py)."""
     O = oracle
     cal = O.synthetic_calib(h=64, w=512, profile="RNG15_RFL8_NIR8_DUAL")
     pk_a, _ = O.synth_packets(cal, 2, seed=5, with_window=True)
@@ -514,14 +515,14 @@ def test_decode_is_graph_capturable(oracle):
                    cal.beam_altitude_angles)
         d_pk = torch.from_numpy(pk_a).cuda()
         out = hp.alloc_outputs(2, destagger=["RANGE"], xyz=["RANGE", "RANGE2"])
-        hp.decode(d_pk, out)          # warm: uploads the offsets / LUT descriptors, cleans the map
+        hp.decode(d_pk, out)          # warm: uploads the offsets / LUT descriptors, allocates scratch
         s.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
             hp.decode(d_pk, out)
         d_pk.copy_(torch.from_numpy(pk_b))
         g.replay()
-        g.replay()                     # replays leave the column map clean for the next one
+        g.replay()                     # no state survives a replay
         s.synchronize()
     torch.cuda.synchronize()
     ldir, lofs = cal.xyz_lut(True)
@@ -606,33 +607,6 @@ def test_variant_tuner_is_transparent(oracle):
                               O.destagger(fr.plane("RANGE2"), cal.pixel_shift_by_row))
         want = O.cartesian(fr.plane("RANGE"), ldir, lofs)
         assert np.abs(_np(first["xyz:RANGE"][f]).astype(np.float64) - want).max() <= 4e-5
-
-
-def test_map_epoch_wraps(oracle):
-    """The column map is tagged with an 11-bit per-call epoch instead of being cleared: stale entries
-    (here: columns present in call k, dropped in call k+1) must read as absent, also across the wrap."""
-    O = oracle
-    cal = O.synthetic_calib(h=16, w=256, profile="RNG15_RFL8_NIR8")
-    full, src = O.synth_packets(cal, 1, with_window=True)
-    hp = HotPath("RNG15_RFL8_NIR8", 16, 256, 16)
-    d_full = torch.from_numpy(full).cuda()
-    part = full.copy()[:, :12]                      # the last 4 packets (64 columns) are missing
-    d_part = torch.zeros_like(d_full)
-    d_part[:, :12] = torch.from_numpy(part).cuda()
-    out = hp.alloc_outputs(1)
-    want_full = src[0].plane("RANGE")
-    want_part = want_full.copy()
-    want_part[:, 192:] = 0
-    for call in range(2 * 2047 + 40):
-        if call % 2 == 0:
-            hp.decode(d_full, out)
-        else:
-            hp.decode(d_part, out, packet_counts=np.array([12], np.uint32))
-        if call < 6 or call % 512 in (0, 1) or 2040 <= call <= 2055 or call >= 4090:
-            got = _np(out["RANGE"][0])
-            assert np.array_equal(got, want_full if call % 2 == 0 else want_part), call
-            st = _np(out["status"][0])
-            assert st[:192].all() and (st[192:].all() if call % 2 == 0 else not st[192:].any()), call
 
 
 def test_df_sensor_per_pixel_angles(oracle):
