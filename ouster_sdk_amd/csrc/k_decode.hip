@@ -113,8 +113,8 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     int32_t* s_src = (int32_t*)(smem + (tile_bytes >> 2));      // [TILE] source slot (general modes)
     uint64_t* s_masks = (uint64_t*)(s_src + TILE);              // [0] valid, [1] group-ok / stray
     int32_t* s_off = (int32_t*)(s_masks + 4);                   // [H] destagger offsets
-    float4* s_xyz = (float4*)(s_off + ((H + 3) & ~3u));         // [4 waves][192] xyz transpose
-    int32_t* s_pk = (int32_t*)(s_xyz + 4 * 192);                // general modes, tile 0: [npo] packet map
+    float4* s_xyz = (float4*)(s_off + ((H + 3) & ~3u));         // [4 waves][192] xyz transpose (OUSTER_XYZ_PERMUTE=0 builds)
+    int32_t* s_pk = (int32_t*)((uint8_t*)s_xyz + XYZ_SCRATCH_BYTES);  // general modes, tile 0: [npo] packet map
     uint32_t* s_vb = (uint32_t*)(s_pk + npo);                   //   [(W+31)/32] valid-column bitmap, [+1] count
 
     const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;

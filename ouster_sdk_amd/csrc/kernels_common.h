@@ -7,7 +7,15 @@
 
 #include "ouster_hip_dev.h"
 
+// 1: the f32 xyz transpose of the fused kernels goes through ds_bpermute (no LDS scratch);
+// 0: through a 12 KB wave-private LDS scratch (the r01 form, kept for A/B builds)
+#ifndef OUSTER_XYZ_PERMUTE
+#define OUSTER_XYZ_PERMUTE 1
+#endif
+
 namespace ouster_hip_dev {
+
+constexpr size_t XYZ_SCRATCH_BYTES = OUSTER_XYZ_PERMUTE ? 0 : 4 * 192 * 16;
 
 // ------------------------------------------------------------------------------------
 // small helpers
@@ -276,6 +284,43 @@ __device__ __forceinline__ void store_xyz4_coalesced(float4* s_xyz, uint32_t tid
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// The same transpose without any LDS memory: three rounds of ds_bpermute (the LDS crossbar moves
+// registers between lanes, nothing is allocated).  A lane's 48 B are chunks 3q, 3q+1, 3q+2 of its
+// LPR-lane row segment; store instruction k must write chunk k*LPR + q.  In round j every lane offers
+// its chunk j (the same register in all lanes, as bpermute requires): lane d receives chunk
+// 3s + j == d (mod LPR) from lane s = (d - j) * 3^-1 mod LPR -- a bijection because LPR is a power
+// of two -- and files it under k = (3s + j) / LPR.  Frees the 12 KB scratch (one more 12 B/px
+// workgroup per CU).
+template <int LPR>
+__device__ __forceinline__ void store_xyz4_permuted(float* row_base, uint32_t q, const double (&p)[4][3]) {
+    static_assert(LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32 || LPR == 64, "row segment lanes");
+    constexpr uint32_t INV3 = LPR == 64 ? 43u : (LPR >= 16 ? 11u : 3u);  // 3 * INV3 == 1 (mod LPR)
+    const uint32_t lane = threadIdx.x & 63u, seg = lane - q;             // first lane of my row segment
+    const float v[12] = {(float)p[0][0], (float)p[0][1], (float)p[0][2], (float)p[1][0],
+                         (float)p[1][1], (float)p[1][2], (float)p[2][0], (float)p[2][1],
+                         (float)p[2][2], (float)p[3][0], (float)p[3][1], (float)p[3][2]};
+    float o[3][4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t s = ((q + LPR - j) * INV3) & (LPR - 1);   // source lane within the segment
+        const uint32_t k = (3u * s + j) / LPR;                   // which of my three stores it feeds
+        const int addr = (int)((seg + s) << 2);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float r = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v[4 * j + w])));
+            if (j == 0) { o[0][w] = r; o[1][w] = r; o[2][w] = r; }
+            else {
+                o[0][w] = k == 0 ? r : o[0][w];
+                o[1][w] = k == 1 ? r : o[1][w];
+                o[2][w] = k == 2 ? r : o[2][w];
+            }
+        }
+    }
+    float4* d = (float4*)row_base;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[k * LPR + q] = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+}
+
 // Generic forms of the same transpose for a "lane owns 4 consecutive pixels x NV 16 B chunks"
 // register block (NV = 3: 4 x f32 xyz, NV = 6: 4 x f64 xyz).  sc = this lane-row's private
 // scratch of NV*LPR float4; row_base = address of tile column 0 of the lane's row.
@@ -521,7 +566,11 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                 XT* dst = out + ((size_t)f * plane_px + rowpix) * 3;
                 if constexpr (XYZM == 1) {
                     if (a.vec_ok && seg0 + 4 * LPR <= W) {  // my wave's whole row segment exists
+#if OUSTER_XYZ_PERMUTE
+                        store_xyz4_permuted<LPR>(dst - (size_t)(4 * ql) * 3, ql, p);
+#else
                         store_xyz4_coalesced<LPR>(s_xyz, tid, dst - (size_t)(4 * ql) * 3, ql, p);
+#endif
                         continue;
                     }
                 }

@@ -72,6 +72,7 @@ struct Knobs {
     int tile = 0;             // OUSTER_HIP_TILE: force k_decode's tile width (64/32/16)
     int wide = -1;            // OUSTER_HIP_WIDE: -1 auto (tuner), 0 narrow, 64/128/256/512 force k_decode_wide
     int wide_kb = 64;         // OUSTER_HIP_WIDE_KB: LDS budget of a wide tile image
+    int wide_rows = 0;        // OUSTER_HIP_WIDE_ROWS: force the rows of a wide tile (experiments)
     int wide_min_blocks = 512;  // OUSTER_HIP_WIDE_MIN_BLOCKS: smaller launches stay on k_decode
     int tune = 1;             // OUSTER_HIP_TUNE: 0 pins the default wide variant
     int xcd = 1;              // OUSTER_HIP_XCD: 0 disables the XCD-aware block -> frame mapping
@@ -269,6 +270,7 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.tile = env_int("OUSTER_HIP_TILE", k.tile);
         k.wide = env_int("OUSTER_HIP_WIDE", k.wide);
         k.wide_kb = env_int("OUSTER_HIP_WIDE_KB", k.wide_kb);
+        k.wide_rows = env_int("OUSTER_HIP_WIDE_ROWS", k.wide_rows);
         k.wide_min_blocks = env_int("OUSTER_HIP_WIDE_MIN_BLOCKS", k.wide_min_blocks);
         k.tune = env_int("OUSTER_HIP_TUNE", k.tune);
         k.xcd = env_int("OUSTER_HIP_XCD", k.xcd);
@@ -327,6 +329,7 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     if (n == "tile") k.tile = value;
     else if (n == "wide") k.wide = value;
     else if (n == "wide_kb") k.wide_kb = value;
+    else if (n == "wide_rows") k.wide_rows = value;
     else if (n == "wide_min_blocks") k.wide_min_blocks = value;
     else if (n == "tune") k.tune = value;
     else if (n == "xcd") k.xcd = value;
@@ -779,6 +782,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             const uint32_t t2 = up((H + n2 - 1) / n2);
             if (t2 <= tr_max && t2 * n2 == H) { nch = n2; tr = t2; break; }
         }
+        if (kn.wide_rows > 0) tr = std::min((uint32_t)kn.wide_rows, H);
         nch = (H + tr - 1) / tr;
         const uint32_t tiles = (W + want - 1) / want;
         if ((size_t)n_frames * tiles * nch < (size_t)std::max(kn.wide_min_blocks, 0)) return false;
