@@ -344,17 +344,40 @@ def main():
         elapsed = float(t.item())
 
     exchange = None
-    if args.exchange and world > 1 and backend == "nccl":
-        # the only real exchange step of the path: rank 0 scatters raw packets, gathers XYZ
-        xyz = out["xyz:RANGE"]
-        torch.cuda.synchronize(); barrier()
-        e0 = time.perf_counter()
-        recv = torch.empty_like(packets)
-        dist.scatter(recv, [packets for _ in range(world)] if rank == 0 else None, src=0)
-        gl = [torch.empty_like(xyz) for _ in range(world)] if rank == 0 else None
-        dist.gather(xyz, gl, dst=0)
-        torch.cuda.synchronize(); barrier()
-        exchange = {"scatter_packets_gather_xyz_ms": (time.perf_counter() - e0) * 1e3}
+    if args.exchange and world > 1:
+        # the only real exchange step of the path: the batch of all ranks' frames lives on
+        # rank 0, every rank receives ITS shard (grouped point-to-point sends, one peer per xGMI link),
+        # decodes it, and the XYZ clouds are gathered back.  Reported per stage, never part of `value`.
+        from ouster_sdk_amd import parallel
+        xdev = "cuda" if backend == "nccl" else "cpu"
+        total = F * world
+        batch_all = packets.repeat(world, 1, 1).to(xdev) if rank == 0 else None
+        ts = [0.0, 0.0, 0.0]
+        for rep in range(3):                       # rep 0 warms the RCCL channels
+            torch.cuda.synchronize(); barrier()
+            e0 = time.perf_counter()
+            mine = parallel.scatter_frames(batch_all, total, tuple(packets.shape[1:]), torch.uint8, xdev).cuda()
+            torch.cuda.synchronize(); barrier()
+            e1 = time.perf_counter()
+            hp.decode(mine, out)
+            torch.cuda.synchronize(); barrier()
+            e2 = time.perf_counter()
+            for n in xyz_names:
+                x = out["xyz:" + n]
+                parallel.gather_frames(x if backend == "nccl" else x.cpu(), total)
+            torch.cuda.synchronize(); barrier()
+            e3 = time.perf_counter()
+            if rep:
+                ts = [ts[0] + e1 - e0, ts[1] + e2 - e1, ts[2] + e3 - e2]
+        del batch_all
+        pk_bytes = total * packets[0].numel() * (world - 1) / world
+        xyz_bytes = len(xyz_names) * total * H * W * 12 * (world - 1) / world
+        exchange = {"frames_total": total, "scatter_packets_ms": round(ts[0] / 2 * 1e3, 3),
+                    "decode_ms": round(ts[1] / 2 * 1e3, 3), "gather_xyz_ms": round(ts[2] / 2 * 1e3, 3),
+                    "scatter_GBps": round(pk_bytes / (ts[0] / 2) / 1e9, 1),
+                    "gather_GBps": round(xyz_bytes / (ts[2] / 2) / 1e9, 1),
+                    "Mpoints_per_s_with_exchange": round(total * H * W * len(xyz_names) / (sum(ts) / 2) / 1e6, 1),
+                    "transport": "RCCL p2p (xGMI)" if backend == "nccl" else backend + " (test transport)"}
 
     n_ret = len(xyz_names)
     points_per_step = F * H * W * n_ret * world

@@ -319,6 +319,13 @@ class FrameBatcher {
      */
     using PacketSink = std::function<void(const std::vector<const uint8_t*>& packets)>;
     void set_packet_sink(PacketSink sink);
+    /**
+     * Extension: the GPU this batcher decodes on (default: ouster::sdk::hip::current_device() of the
+     * thread that triggers its first decode).  Every batcher owns its own HIP stream and scratch, so
+     * distinct batchers may be driven from distinct threads, one per sensor, like the reference's.
+     * @throw std::logic_error once it has started working on another GPU
+     */
+    void set_device(int device);
     size_t batched_packets() const;
     size_t dropped_packets() const;
     void set_max_cache_size(size_t n);

@@ -32,6 +32,7 @@ namespace impl {
 /** Shared handle to the device-side tables of a LUT. */
 struct DeviceLut {
     ::ouster_hip_lut* handle = nullptr;
+    int device = 0;  ///< GPU the tables live on (ouster::sdk::hip::set_device at creation time)
     ~DeviceLut();
 };
 

@@ -15,6 +15,7 @@
 
 #include "ouster/core/lidar_frame.h"
 #include "ouster/core/xyzlut.h"
+#include "ouster/hip/context.h"
 #include "ouster/hip/device_buffer.h"
 
 struct ouster_hip_format;
@@ -33,6 +34,8 @@ struct BatchOptions {
     /// columns are invalid by their status word) instead of uploading per-frame packet counts:
     /// keeps decode() free of host synchronisation, for the streaming pipeline (FrameStream).
     bool all_slots = false;
+    int device = -1;                      ///< GPU to work on (-1: hip::current_device() of the constructing thread)
+    std::shared_ptr<Context> context;     ///< share this context (stream + scratch) instead of owning one
 };
 
 class DeviceFrameBatch {
@@ -46,6 +49,17 @@ class DeviceFrameBatch {
     DeviceFrameBatch(const DeviceFrameBatch&) = delete;
     DeviceFrameBatch& operator=(const DeviceFrameBatch&) = delete;
 
+    /** The context (GPU, stream) this batch works on: its own unless BatchOptions::context was given. */
+    const std::shared_ptr<Context>& context() const { return ctx_; }
+    const core::PacketFormat& packet_format() const { return pf_; }
+    /** Slot of a frame's packet buffer a lidar packet belongs in: the index of the packet inside its
+     *  frame, measurement_id(first column) / columns_per_packet -- its "home" slot, where the decode
+     *  kernels find it without any mapping work.  -1: outside the frame (the packet is dropped, as
+     *  the reference drops its columns, lidar_frame.cpp:1432-1434). */
+    int home_slot(const uint8_t* lidar_packet) const {
+        const uint32_t p = pf_.col_measurement_id(pf_.nth_col(0, lidar_packet)) / pf_.columns_per_packet;
+        return p < slots_ ? static_cast<int>(p) : -1;
+    }
     uint32_t n_frames() const { return n_frames_; }
     size_t packet_stride() const { return stride_; }
     uint32_t slots_per_frame() const { return slots_; }
@@ -92,6 +106,7 @@ class DeviceFrameBatch {
     void download_dewarped(void* points, uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns);
 
    private:
+    std::shared_ptr<Context> ctx_;
     core::PacketFormat pf_;
     uint32_t n_frames_, h_, w_, slots_;
     size_t stride_;

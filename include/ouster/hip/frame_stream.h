@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "ouster/hip/context.h"
 #include "ouster/hip/device_batch.h"
 
 namespace ouster {
@@ -29,6 +30,7 @@ struct StreamOptions {
     std::vector<std::string> download_planes;
     std::vector<std::string> download_destaggered;
     bool download_headers = true;     ///< timestamp / measurement_id / status per column
+    int device = -1;                  ///< GPU to stream through (-1: hip::current_device())
 };
 
 /** One finished batch; the pointers stay valid during the callback only. */
@@ -72,6 +74,7 @@ class FrameStream {
     void submit(Slot& s);
     void deliver(Slot& s);
 
+    std::shared_ptr<Context> ctx_;    // compute stream + scratch, shared by the buffer sets
     StreamOptions opt_;
     Callback cb_;
     std::vector<std::unique_ptr<Slot>> slots_;

@@ -85,9 +85,12 @@ int ouster_core_default_planes(const char* profile_name, int with_window, char* 
 /** Read every UDP payload with destination port `port` (0 = any) and, if `exact_size` != 0,
  * exactly that size, from a classic pcap into out (capacity cap bytes, payloads back to back);
  * sizes[i] receives each payload's length (up to max_n).  Returns the number of payloads, or
- * -1 on error (msg filled). */
+ * -1 on error (msg filled); *truncated (nullable) is set when matching payloads were left behind
+ * because `cap` or `max_n` was reached. */
 int ouster_pcap_read_udp(const char* path, int port, size_t exact_size, uint8_t* out, size_t cap,
-                         uint32_t* sizes, int* ports, uint32_t max_n, char* msg, size_t msg_len) {
+                         uint32_t* sizes, int* ports, uint32_t max_n, char* msg, size_t msg_len,
+                         int* truncated) {
+    if (truncated) *truncated = 0;
     try {
         ouster::sdk::pcap::PcapReader r(path);
         size_t used = 0;
@@ -96,7 +99,10 @@ int ouster_pcap_read_udp(const char* path, int port, size_t exact_size, uint8_t*
             const auto& info = r.current_info();
             if (port && info.dst_port != port) continue;
             if (exact_size && r.current_length() != exact_size) continue;
-            if (n >= max_n || used + r.current_length() > cap) break;
+            if (n >= max_n || used + r.current_length() > cap) {  // more matching payloads than room
+                if (truncated) *truncated = 1;
+                break;
+            }
             std::memcpy(out + used, r.current_data(), r.current_length());
             used += r.current_length();
             if (sizes) sizes[n] = static_cast<uint32_t>(r.current_length());

@@ -14,7 +14,10 @@ using namespace core;
 
 DeviceFrameBatch::DeviceFrameBatch(const std::vector<SensorInfo>& sensors, uint32_t n_frames,
                                    const BatchOptions& options)
-    : pf_(sensors.at(0)), n_frames_(n_frames), opt_(options) {
+    : ctx_(options.context ? options.context
+                           : std::make_shared<Context>(options.device >= 0 ? options.device : current_device())),
+      pf_(sensors.at(0)), n_frames_(n_frames), opt_(options) {
+    ScopedContext on_my_context(ctx_);
     if (n_frames == 0) throw std::invalid_argument("DeviceFrameBatch: n_frames must be > 0");
     const SensorInfo& s0 = sensors[0];
     h_ = s0.format.pixels_per_column;
@@ -86,21 +89,26 @@ DeviceFrameBatch::DeviceFrameBatch(const std::vector<SensorInfo>& sensors, uint3
 }
 
 DeviceFrameBatch::~DeviceFrameBatch() {
+    ScopedContext on_my_context(ctx_);
     if (fmt_) ouster_hip_format_destroy(fmt_);
 }
 
 void DeviceFrameBatch::upload_frame_packets(uint32_t frame, const std::vector<const uint8_t*>& packets) {
+    ScopedContext on_my_context(ctx_);
     if (frame >= n_frames_) throw std::out_of_range("DeviceFrameBatch: frame index");
-    if (packets.size() > slots_) throw std::invalid_argument("DeviceFrameBatch: too many packets for a frame");
-    std::vector<uint8_t> staging(packets.size() * stride_, 0);
-    for (size_t i = 0; i < packets.size(); ++i)
-        std::memcpy(staging.data() + i * stride_, packets[i], pf_.lidar_packet_size);
-    if (!staging.empty())
-        d_packets_.upload(staging.data(), staging.size(), static_cast<size_t>(frame) * slots_ * stride_);
-    counts_[frame] = static_cast<uint32_t>(packets.size());
+    // every packet goes to its home slot (a later duplicate replaces the earlier one, as the packet
+    // batched later overwrites in the reference); slots without a packet are zero = invalid columns
+    std::vector<uint8_t> staging(static_cast<size_t>(slots_) * stride_, 0);
+    for (const uint8_t* pkt : packets) {
+        const int p = home_slot(pkt);
+        if (p >= 0) std::memcpy(staging.data() + static_cast<size_t>(p) * stride_, pkt, pf_.lidar_packet_size);
+    }
+    d_packets_.upload(staging.data(), staging.size(), static_cast<size_t>(frame) * slots_ * stride_);
+    counts_[frame] = slots_;
 }
 
 void DeviceFrameBatch::decode() {
+    ScopedContext on_my_context(ctx_);
     ouster_hip_frame_out out{};
     for (size_t i = 0; i < fields_.size(); ++i) {
         auto p = d_planes_.find(fields_[i].first);
@@ -124,7 +132,7 @@ void DeviceFrameBatch::decode() {
                             static_cast<uint32_t>(luts.size())));
 }
 
-void DeviceFrameBatch::sync() { check(ouster_hip_sync(default_ctx())); }
+void DeviceFrameBatch::sync() { ctx_->sync(); }
 
 size_t DeviceFrameBatch::plane_bytes_per_frame(const std::string& name) const {
     for (const auto& f : fields_)
@@ -137,17 +145,20 @@ void* DeviceFrameBatch::destaggered_device(const std::string& name) { return d_d
 void* DeviceFrameBatch::xyz_device(int k) { return d_xyz_[k].data(); }
 
 void DeviceFrameBatch::download_plane(const std::string& name, uint32_t frame, void* host, bool destaggered) {
+    ScopedContext on_my_context(ctx_);
     DeviceBuffer& b = destaggered ? d_dst_.at(name) : d_planes_.at(name);
     const size_t bytes = b.size() / n_frames_;
     sync();
     b.download(host, bytes, bytes * frame);
 }
 void DeviceFrameBatch::download_xyz(int k, uint32_t frame, void* host) {
+    ScopedContext on_my_context(ctx_);
     const size_t bytes = d_xyz_[k].size() / n_frames_;
     sync();
     d_xyz_[k].download(host, bytes, bytes * frame);
 }
 void DeviceFrameBatch::download_headers(uint32_t frame, uint64_t* ts, uint16_t* mid, uint32_t* st) {
+    ScopedContext on_my_context(ctx_);
     sync();
     if (ts) d_ts_.download(ts, static_cast<size_t>(w_) * 8, static_cast<size_t>(frame) * w_ * 8);
     if (mid) d_mid_.download(mid, static_cast<size_t>(w_) * 2, static_cast<size_t>(frame) * w_ * 2);
@@ -155,6 +166,7 @@ void DeviceFrameBatch::download_headers(uint32_t frame, uint64_t* ts, uint16_t* 
 }
 
 void DeviceFrameBatch::upload_poses(uint32_t frame, const double* poses) {
+    ScopedContext on_my_context(ctx_);
     if (frame >= n_frames_) throw std::out_of_range("DeviceFrameBatch: frame index");
     const size_t per = static_cast<size_t>(w_) * 128;
     if (d_poses_.size() == 0) {  // identity for every column, like a fresh LidarFrame
@@ -167,6 +179,7 @@ void DeviceFrameBatch::upload_poses(uint32_t frame, const double* poses) {
 }
 
 uint64_t DeviceFrameBatch::dewarp(double min_range, double max_range, bool provenance) {
+    ScopedContext on_my_context(ctx_);
     auto rp = d_planes_.find(ChanField::RANGE);
     if (rp == d_planes_.end() || luts_.empty())
         throw std::invalid_argument("DeviceFrameBatch::dewarp needs the RANGE plane and options.xyz");
@@ -197,6 +210,7 @@ uint64_t DeviceFrameBatch::dewarp(double min_range, double max_range, bool prove
 }
 
 void DeviceFrameBatch::download_dewarped(void* points, uint32_t* fi, uint32_t* ci, uint64_t* ts) {
+    ScopedContext on_my_context(ctx_);
     if (dw_offsets_.empty()) throw std::logic_error("DeviceFrameBatch: dewarp() has not run");
     const size_t n = dw_offsets_.back();
     if (!n) return;

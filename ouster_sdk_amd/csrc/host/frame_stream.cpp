@@ -44,14 +44,16 @@ struct FrameStream::Slot {
 
 FrameStream::FrameStream(const std::vector<core::SensorInfo>& sensors, const StreamOptions& options,
                          Callback on_batch)
-    : opt_(options), cb_(std::move(on_batch)), sensors_(sensors) {
+    : ctx_(std::make_shared<Context>(options.device >= 0 ? options.device : current_device())),
+      opt_(options), cb_(std::move(on_batch)), sensors_(sensors) {
+    ScopedContext on_my_context(ctx_);
     if (sensors.empty()) throw std::invalid_argument("FrameStream: no sensors");
     if (opt_.frames_per_batch == 0 || opt_.frames_per_batch % sensors.size() != 0)
         throw std::invalid_argument("FrameStream: frames_per_batch must be a multiple of the sensor count");
     if (opt_.batches_in_flight == 0) throw std::invalid_argument("FrameStream: batches_in_flight must be > 0");
     opt_.outputs.all_slots = true;
     if (opt_.download_xyz) opt_.outputs.xyz = true;
-    default_ctx();
+    opt_.outputs.context = ctx_;
     hipStream_t a = nullptr, b = nullptr;
     ok(hipStreamCreateWithFlags(&a, hipStreamNonBlocking), "hipStreamCreate");
     ok(hipStreamCreateWithFlags(&b, hipStreamNonBlocking), "hipStreamCreate");
@@ -85,6 +87,7 @@ FrameStream::FrameStream(const std::vector<core::SensorInfo>& sensors, const Str
 }
 
 FrameStream::~FrameStream() {
+    ScopedContext on_my_context(ctx_);
     for (auto& s : slots_) {
         if (s->in_flight) (void)hipEventSynchronize(s->e_done);
         for (hipEvent_t e : {s->e_h2d, s->e_dec, s->e_done})
@@ -95,20 +98,25 @@ FrameStream::~FrameStream() {
 }
 
 void FrameStream::push_frame(const std::vector<const uint8_t*>& lidar_packets) {
+    ScopedContext on_my_context(ctx_);
     Slot& s = *slots_[cur_];
     if (s.in_flight) deliver(s);  // every buffer set busy: the oldest batch has to come home first
     DeviceFrameBatch& bt = *s.batch;
-    if (lidar_packets.size() > bt.slots_per_frame())
-        throw std::invalid_argument("FrameStream: too many packets for a frame");
     if (s.filled == 0) s.first_frame = pushed_;
     uint8_t* base = static_cast<uint8_t*>(s.packets.p) +
                     static_cast<size_t>(s.filled) * bt.slots_per_frame() * bt.packet_stride();
-    for (size_t i = 0; i < lidar_packets.size(); ++i)
-        std::memcpy(base + i * bt.packet_stride(), lidar_packets[i], bt.lidar_packet_size());
-    // slots without a packet keep their all-zero content (status 0 = invalid columns)
-    if (lidar_packets.size() < bt.slots_per_frame())
-        std::memset(base + lidar_packets.size() * bt.packet_stride(), 0,
-                    (bt.slots_per_frame() - lidar_packets.size()) * bt.packet_stride());
+    // home slots: packet p of the frame in slot p, so the decode pass needs no mapping even when
+    // packets were lost (holes stay zero = invalid columns); a later duplicate replaces the earlier
+    // packet, a packet outside the frame is dropped
+    std::vector<bool> have(bt.slots_per_frame(), false);
+    for (const uint8_t* pkt : lidar_packets) {
+        const int p = bt.home_slot(pkt);
+        if (p < 0) continue;
+        std::memcpy(base + static_cast<size_t>(p) * bt.packet_stride(), pkt, bt.lidar_packet_size());
+        have[static_cast<size_t>(p)] = true;
+    }
+    for (size_t p = 0; p < have.size(); ++p)
+        if (!have[p]) std::memset(base + p * bt.packet_stride(), 0, bt.packet_stride());
     ++s.filled;
     ++pushed_;
     if (s.filled == opt_.frames_per_batch) submit(s);
@@ -126,6 +134,7 @@ void FrameStream::push_packet(const core::Packet& lidar_packet) {
 }
 
 void FrameStream::submit(Slot& s) {
+    ScopedContext on_my_context(ctx_);
     DeviceFrameBatch& bt = *s.batch;
     const size_t per_frame = static_cast<size_t>(bt.slots_per_frame()) * bt.packet_stride();
     if (s.filled < opt_.frames_per_batch)  // partial batch: the unused frames decode to "empty"
@@ -133,7 +142,7 @@ void FrameStream::submit(Slot& s) {
                     (opt_.frames_per_batch - s.filled) * per_frame);
     auto h2d = static_cast<hipStream_t>(stream_h2d_);
     auto d2h = static_cast<hipStream_t>(stream_d2h_);
-    auto comp = static_cast<hipStream_t>(ouster_hip_ctx_stream(default_ctx()));
+    auto comp = static_cast<hipStream_t>(ctx_->stream());
     ok(hipMemcpyAsync(bt.packets_device(), s.packets.p, s.packets.n, hipMemcpyHostToDevice, h2d), "H2D");
     ok(hipEventRecord(s.e_h2d, h2d), "hipEventRecord");
     ok(hipStreamWaitEvent(comp, s.e_h2d, 0), "hipStreamWaitEvent");
@@ -163,6 +172,7 @@ void FrameStream::submit(Slot& s) {
 }
 
 void FrameStream::deliver(Slot& s) {
+    ScopedContext on_my_context(ctx_);
     ok(hipEventSynchronize(s.e_done), "hipEventSynchronize");
     s.in_flight = false;
     BatchResult r;
@@ -181,6 +191,7 @@ void FrameStream::deliver(Slot& s) {
 }
 
 void FrameStream::finish() {
+    ScopedContext on_my_context(ctx_);
     if (slots_[cur_]->filled) {
         if (slots_[cur_]->in_flight) deliver(*slots_[cur_]);  // cannot happen (filled implies free), kept for safety
         submit(*slots_[cur_]);

@@ -7,8 +7,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
-#include <mutex>
+#include <map>
 #include <stdexcept>
 #include <string>
 
@@ -16,6 +17,7 @@
 #include "ouster/core/lidar_frame.h"
 #include "ouster/core/pose_util.h"
 #include "ouster/core/xyzlut.h"
+#include "ouster/hip/context.h"
 #include "ouster/hip/device_buffer.h"
 
 namespace ouster {
@@ -29,12 +31,69 @@ void check(int rc) {
     throw std::runtime_error("ouster_hip: " + msg);
 }
 
+// ---------------------------------------------------------------------------------------
+// contexts: one per object that owns GPU state, one default per (thread, device) for the rest
+// ---------------------------------------------------------------------------------------
+namespace {
+thread_local int t_device = -1;                                   // -1: not chosen yet
+thread_local std::shared_ptr<Context> t_bound;                    // innermost ScopedContext
+thread_local std::map<int, std::shared_ptr<Context>> t_defaults;  // this thread's default contexts
+
+int initial_device() {
+    if (const char* e = std::getenv("OUSTER_HIP_DEVICE")) return std::atoi(e);  // read once per thread
+    return 0;
+}
+}  // namespace
+
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int current_device() {
+    if (t_device < 0) t_device = initial_device();
+    return t_device;
+}
+
+void set_device(int device) {
+    const int n = device_count();
+    if (device < 0 || device >= std::max(n, 1))
+        throw std::invalid_argument("ouster_hip: device " + std::to_string(device) + " out of range [0," +
+                                    std::to_string(n) + ")");
+    t_device = device;
+}
+
+Context::Context(int device) : device_(device) { check(ouster_hip_ctx_create(device, nullptr, &ctx_)); }
+Context::~Context() {
+    if (ctx_) ouster_hip_ctx_destroy(ctx_);
+}
+void* Context::stream() const { return ouster_hip_ctx_stream(ctx_); }
+void Context::sync() const { check(ouster_hip_sync(ctx_)); }
+
+std::shared_ptr<Context> Context::for_device(int device) {
+    auto& slot = t_defaults[device];
+    if (!slot) slot = std::make_shared<Context>(device);
+    return slot;
+}
+std::shared_ptr<Context> Context::current() { return t_bound ? t_bound : for_device(current_device()); }
+
+ScopedContext::ScopedContext(std::shared_ptr<Context> ctx) : prev_(std::move(t_bound)) {
+    t_bound = std::move(ctx);
+    if (t_bound) (void)hipSetDevice(t_bound->device());
+}
+ScopedContext::~ScopedContext() {
+    t_bound = std::move(prev_);
+    if (t_bound) (void)hipSetDevice(t_bound->device());
+}
+
 ouster_hip_ctx* default_ctx() {
-    static std::mutex mx;
-    static ouster_hip_ctx* ctx = nullptr;
-    std::lock_guard<std::mutex> lk(mx);
-    if (!ctx) check(ouster_hip_ctx_create(0, nullptr, &ctx));
-    return ctx;
+    const std::shared_ptr<Context> c = Context::current();
+    (void)hipSetDevice(c->device());  // allocations of the caller land on the context's GPU
+    return c->handle();
 }
 
 static void hip_ok(hipError_t e, const char* what) {
@@ -136,6 +195,7 @@ DeviceLut::~DeviceLut() {
 std::shared_ptr<DeviceLut> device_lut_from_arrays(const void* direction, const void* offset,
                                                   size_t h, size_t w, bool f64) {
     auto d = std::make_shared<DeviceLut>();
+    d->device = hip::Context::current()->device();
     hip::check(ouster_hip_lut_create_from_arrays(hip::default_ctx(), direction, offset,
                                                  static_cast<uint32_t>(h), static_cast<uint32_t>(w),
                                                  f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32, &d->handle));
@@ -161,6 +221,7 @@ std::shared_ptr<DeviceLut> device_lut_from_calib(size_t w, size_t h, double rang
     c.altitude_angles_deg = alt.data();
     c.n_angles = az.size();
     auto d = std::make_shared<DeviceLut>();
+    d->device = hip::Context::current()->device();
     hip::check(ouster_hip_lut_create(hip::default_ctx(), &c, &d->handle));
     if (direction && offset) {
         *direction = ArrayX3R<double>(w * h);
@@ -198,6 +259,8 @@ void cartesian_device(const DeviceLut& dev, const uint32_t* range, size_t n, voi
                       bool points_f64) {
     if (n == 0) return;
     const size_t pbytes = n * 3 * (points_f64 ? 8 : 4);
+    hip::ScopedContext on_lut_device(hip::Context::current()->device() == dev.device
+                                         ? hip::Context::current() : hip::Context::for_device(dev.device));
     hip::DeviceBuffer d_range(n * 4), d_xyz(pbytes);
     d_range.upload(range, n * 4);
     hip::check(ouster_hip_cartesian(hip::default_ctx(), dev.handle,

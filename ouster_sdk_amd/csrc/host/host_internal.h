@@ -8,6 +8,7 @@
 
 #include "ouster/core/chanfield.h"
 #include "ouster/core/data_format.h"
+#include "ouster/hip/context.h"
 #include "ouster_hip.h"
 
 namespace ouster {
@@ -22,7 +23,9 @@ std::vector<std::pair<std::string, ChanFieldType>> default_planes(UDPProfileLida
 namespace hip {
 /** Throws std::invalid_argument / std::runtime_error for a failed C ABI call. */
 void check(int rc);
-/** Process-wide default context on device 0 (created on first use). */
+/** C handle of Context::current(): the innermost ScopedContext of the calling thread, else the
+ *  thread's default context on its current device (include/ouster/hip/context.h).  Also makes that
+ *  device the HIP-current one. */
 ouster_hip_ctx* default_ctx();
 }  // namespace hip
 }  // namespace sdk

@@ -357,6 +357,14 @@ struct FrameBatcher::State {
     std::vector<uint32_t> fmt_elems;
     hip::DeviceBuffer d_packets, d_out;
     FrameBatcher::PacketSink sink;  // set: released frames go here instead of being decoded
+    // this batcher's own context (stream + scratch) on the GPU that was current when it first needed
+    // one: distinct batchers never share mutable GPU state, like the reference's CPU batchers
+    std::shared_ptr<hip::Context> ctx;
+    int device = -1;
+    const std::shared_ptr<hip::Context>& context() {
+        if (!ctx) ctx = std::make_shared<hip::Context>(device >= 0 ? device : hip::current_device());
+        return ctx;
+    }
 
     ~State() {
         if (fmt) ouster_hip_format_destroy(fmt);
@@ -377,6 +385,11 @@ FrameBatcher::FrameBatcher(const std::shared_ptr<SensorInfo>& info)
 FrameBatcher::FrameBatcher(const SensorInfo& info) : FrameBatcher(std::make_shared<SensorInfo>(info)) {}
 FrameBatcher::FrameBatcher(FrameBatcher&&) noexcept = default;
 FrameBatcher::~FrameBatcher() = default;
+void FrameBatcher::set_device(int device) {
+    if (s_->ctx && s_->ctx->device() != device)
+        throw std::logic_error("FrameBatcher::set_device: the batcher already works on another GPU");
+    s_->device = device;
+}
 
 void FrameBatcher::reset() {
     s_->reset_frame = true;
@@ -459,6 +472,7 @@ struct BatcherOps {
 
     // one GPU launch: every plane the frame shares with the packet format + column headers
     static void decode_staged(FrameBatcher::State& s, const PacketFormat& pf, LidarFrame& frame) {
+        hip::ScopedContext on_my_context(s.context());
         std::vector<std::pair<std::string, uint32_t>> fields;
         std::vector<bool> nan;
         std::vector<Field*> dst;

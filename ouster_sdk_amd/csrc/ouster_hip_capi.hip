@@ -122,7 +122,7 @@ struct ouster_hip_format {
 };
 
 struct ouster_hip_lut {
-    ouster_hip_ctx* ctx = nullptr;
+    int device = 0;  // the tables outlive the context that uploaded them
     uint32_t w = 0, h = 0;
     bool separable = false;
     LutDev dev{};
@@ -431,7 +431,7 @@ int ouster_hip_lut_create(ouster_hip_ctx* ctx, const ouster_hip_calib* c, ouster
     HIP_TRY(hipSetDevice(ctx->device));
     ouster_hip_lut* L = new (std::nothrow) ouster_hip_lut();
     if (!L) return fail(OUSTER_HIP_ERR_RUNTIME, "out of memory");
-    L->ctx = ctx;
+    L->device = ctx->device;
     L->w = c->w;
     L->h = c->h;
     host_full_lut(*c, L->direction, L->offset);
@@ -475,7 +475,7 @@ int ouster_hip_lut_create_from_arrays(ouster_hip_ctx* ctx, const void* direction
     const size_t hw = (size_t)w * h, es = dtype == OUSTER_HIP_F32 ? 4 : 8;
     ouster_hip_lut* L = new (std::nothrow) ouster_hip_lut();
     if (!L) return fail(OUSTER_HIP_ERR_RUNTIME, "out of memory");
-    L->ctx = ctx;
+    L->device = ctx->device;
     L->w = w;
     L->h = h;
     L->direction.resize(hw * 3);
@@ -506,7 +506,7 @@ int ouster_hip_lut_export(const ouster_hip_lut* L, double* direction, double* of
 
 void ouster_hip_lut_destroy(ouster_hip_lut* L) {
     if (!L) return;
-    if (L->ctx) (void)hipSetDevice(L->ctx->device);
+    (void)hipSetDevice(L->device);
     if (L->d_beam) (void)hipFree(L->d_beam);
     if (L->d_col) (void)hipFree(L->d_col);
     if (L->d_dir) (void)hipFree(L->d_dir);
@@ -644,6 +644,9 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         for (uint32_t i = 0; i < n_luts; ++i)
             if (!luts[i] || luts[i]->w != W || luts[i]->h != H)
                 return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unexpected image dimensions");
+            else if (luts[i]->device != ctx->device)
+                return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "LUT %u lives on GPU %d, the context on GPU %d", i,
+                            luts[i]->device, ctx->device);
     }
 
     // ---- scratch: per-frame state words (all-zero between calls: the fix-up pass cleans up after

@@ -63,25 +63,34 @@ def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float
     return float(t.item())
 
 
+def _p2p(ops):
+    """Run a list of point-to-point ops as ONE group (ncclGroupStart/End on RCCL: the root's sends to
+    its 7 peers go out concurrently, one xGMI link each) and wait for all of them."""
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
 def scatter_frames(batch: Optional[torch.Tensor], n_frames: int, frame_shape, dtype, device,
                    src: int = 0) -> torch.Tensor:
     """Root holds `batch` [n_frames, *frame_shape]; every rank receives its shard_range block.
-    Implemented with point-to-point sends so blocks may differ in size by one frame."""
+    Point-to-point, grouped: blocks may differ in size by one frame, and nothing but the shard a rank
+    owns ever travels to it."""
     rank, world = dist.get_rank(), dist.get_world_size()
     b, e = shard_range(n_frames, rank, world)
     mine = torch.empty((e - b, *frame_shape), dtype=dtype, device=device)
+    ops = []
     if rank == src:
-        reqs = []
         for r in range(world):
             rb, re = shard_range(n_frames, r, world)
             if r == src:
                 mine.copy_(batch[rb:re])
             elif re > rb:
-                reqs.append(dist.isend(batch[rb:re].contiguous(), dst=r))
-        for q in reqs:
-            q.wait()
+                ops.append(dist.P2POp(dist.isend, batch[rb:re], r))   # a contiguous slice of the batch
     elif e > b:
-        dist.recv(mine, src=src)
+        ops.append(dist.P2POp(dist.irecv, mine, src))
+    _p2p(ops)
     return mine
 
 
@@ -90,13 +99,15 @@ def gather_frames(mine: torch.Tensor, n_frames: int, dst: int = 0) -> Optional[t
     rank, world = dist.get_rank(), dist.get_world_size()
     if rank == dst:
         out = torch.empty((n_frames, *mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        ops = []
         for r in range(world):
             rb, re = shard_range(n_frames, r, world)
             if r == dst:
                 out[rb:re].copy_(mine)
             elif re > rb:
-                dist.recv(out[rb:re], src=r)
+                ops.append(dist.P2POp(dist.irecv, out[rb:re], r))
+        _p2p(ops)
         return out
     if mine.shape[0] > 0:
-        dist.send(mine.contiguous(), dst=dst)
+        _p2p([dist.P2POp(dist.isend, mine.contiguous(), dst)])
     return None

@@ -15,13 +15,14 @@ from ouster_sdk_amd import _capi as capi
 def _read(path, port=0, size=0, cap=8 << 20):
     L = capi.load_core()
     L.ouster_pcap_read_udp.argtypes = [C.c_char_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
-                                       C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
+                                       C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t,
+                                       C.POINTER(C.c_int)]
     out = np.zeros(cap, dtype=np.uint8)
     sizes = np.zeros(4096, dtype=np.uint32)
     ports = np.zeros(4096, dtype=np.int32)
     msg = C.create_string_buffer(256)
     n = L.ouster_pcap_read_udp(path.encode(), port, size, out.ctypes.data, cap, sizes.ctypes.data,
-                               ports.ctypes.data, 4096, msg, 256)
+                               ports.ctypes.data, 4096, msg, 256, C.byref(_read.truncated))
     if n < 0:
         raise RuntimeError(msg.value.decode())
     res, off = [], 0
@@ -29,6 +30,18 @@ def _read(path, port=0, size=0, cap=8 << 20):
         res.append(out[off:off + sizes[i]].copy())
         off += int(sizes[i])
     return res, ports[:n]
+
+
+_read.truncated = C.c_int(0)
+
+
+def test_truncation_is_reported():
+    """the reader used to stop silently when the caller's buffer was full."""
+    path = os.path.join(PCAPS, "OS-2-128-U1_v2.3.0_1024x10.pcap")
+    full, _ = _read(path)
+    assert _read.truncated.value == 0 and len(full) > 4
+    part, _ = _read(path, cap=sum(len(p) for p in full[:3]) + 10)
+    assert len(part) == 3 and _read.truncated.value == 1
 
 
 @pytest.mark.parametrize("base", ["OS-2-128-U1_v2.3.0_1024x10", "OS-0-32-U1_v2.2.0_1024x10",
