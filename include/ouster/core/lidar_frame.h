@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "ouster/core/array_view.h"
 #include "ouster/core/packet.h"
 #include "ouster/core/types.h"
 
@@ -88,10 +89,64 @@ class Field {
     bool operator==(const Field& o) const;
     bool operator!=(const Field& o) const { return !(*this == o); }
 
+    // ---- the reference's FieldView conversions (ouster_core/include/ouster/core/field.h:374-470) ----
+    /** Typed pointer; `void` always converts.
+     *  @throw std::invalid_argument("FieldView: ineligible dereference type ...") on a type mismatch */
+    template <typename T> operator T*() { return conv_ptr<T>(); }
+    template <typename T> operator const T*() const { return conv_ptr<const T>(); }
+    /** n-d view.  @throw std::invalid_argument on a type or dimension mismatch */
+    template <typename T, size_t Dim> operator ArrayView<T, Dim>() {
+        check_rank<Dim>();
+        return ArrayView<T, Dim>(conv_ptr<T>(), shape_);
+    }
+    template <typename T, size_t Dim> operator ConstArrayView<T, Dim>() const {
+        check_rank<Dim>();
+        return ConstArrayView<T, Dim>(conv_ptr<const T>(), shape_);
+    }
+    /** 2-D image view (the stand-in for the reference's `operator Eigen::Ref<img_t<T>>`). */
+    template <typename T> operator ImgRef<T>() {
+        check_2d();
+        return ImgRef<T>(conv_ptr<T>(), shape_[0], shape_[1]);
+    }
+    template <typename T> operator ImgRef<const T>() const {
+        check_2d();
+        return ImgRef<const T>(conv_ptr<const T>(), shape_[0], shape_[1]);
+    }
+#ifdef OUSTER_HIP_USE_EIGEN
+    template <typename T> operator Eigen::Ref<EigenImg<T>>() {
+        check_2d();
+        return Eigen::Map<EigenImg<T>>(conv_ptr<T>(), static_cast<Eigen::Index>(shape_[0]),
+                                       static_cast<Eigen::Index>(shape_[1]));
+    }
+    template <typename T> operator Eigen::Ref<const EigenImg<T>>() const {
+        check_2d();
+        return Eigen::Map<const EigenImg<T>>(conv_ptr<const T>(), static_cast<Eigen::Index>(shape_[0]),
+                                             static_cast<Eigen::Index>(shape_[1]));
+    }
+#endif
+
    private:
     template <typename T> void check() const {
         if (FieldTag<T>::tag != tag_)
             throw std::invalid_argument("Field: ineligible dereference type");
+    }
+    template <typename T> T* conv_ptr() const {
+        using NC = typename std::remove_const<T>::type;
+        if (!std::is_void<NC>::value && FieldTag<NC>::tag != tag_)
+            throw std::invalid_argument("FieldView: ineligible dereference type for field of element type " +
+                                        to_string(tag_) + ". Dereference type must match or be void.");
+        return static_cast<T*>(ptr_);
+    }
+    template <size_t Dim> void check_rank() const {
+        if (shape_.size() != Dim)
+            throw std::invalid_argument("FieldView: ArrayView conversion failed due to dimension mismatch. Expected " +
+                                        std::to_string(shape_.size()) + " got " + std::to_string(Dim) + " dimensions.");
+    }
+    void check_2d() const {
+        if (shape_.size() != 2)
+            throw std::invalid_argument("Field: Eigen array conversion failed due to dimension mismatch. "
+                                        "Underlying data has " + std::to_string(shape_.size()) +
+                                        " dimensions but must have 2 dimensions.");
     }
     ChanFieldType tag_ = ChanFieldType::VOID;
     std::vector<size_t> shape_;

@@ -9,6 +9,14 @@
 // impl/cartesian.h:43-48, impl/lidar_frame_impl.h:750-758), so this header ships a minimal
 // row-major stand-in with the same observable interface (.data() .rows() .cols() .size()
 // operator()(r,c)).  Row-major storage is part of the API contract: XYZ index i = row*W+col.
+//
+// -DOUSTER_HIP_USE_EIGEN (with Eigen3 on the include path) adds the real Eigen types at the API
+// boundary for callers written against the reference:  EigenImg<T> = the reference's img_t<T>,
+// EigenX3R<T> = its ArrayX3R<T>.  Every stand-in then converts from / to them implicitly
+// (ArrayXXR <-> EigenImg by copy, ImgRef from any dense row-major Eigen expression or Eigen::Ref
+// without a copy, `.eigen()` maps a stand-in's storage as an Eigen::Map), and Field grows the
+// reference's `operator Eigen::Ref<img_t<T>>` (field.h:433-470).  The compiled library's ABI does
+// not change with the switch: it always speaks the stand-ins.
 #pragma once
 
 #include <algorithm>
@@ -20,9 +28,21 @@
 #include <type_traits>
 #include <vector>
 
+#ifdef OUSTER_HIP_USE_EIGEN
+#include <Eigen/Core>
+#endif
+
 namespace ouster {
 namespace sdk {
 namespace core {
+
+#ifdef OUSTER_HIP_USE_EIGEN
+/** The reference's img_t<T> / ArrayX3R<T> (ouster_core/include/ouster/core/typedefs.h). */
+template <typename T>
+using EigenImg = Eigen::Array<T, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>;
+template <typename T>
+using EigenX3R = Eigen::Array<T, Eigen::Dynamic, 3, Eigen::RowMajor>;
+#endif
 
 /** Dense row-major 2-D array owning its storage (zero initialised). */
 template <typename T>
@@ -55,6 +75,19 @@ class ArrayXXR {
         for (size_t i = 0; i < d_.size(); ++i) r.data()[i] = static_cast<U>(d_[i]);
         return r;
     }
+#ifdef OUSTER_HIP_USE_EIGEN
+    /** from any dense Eigen expression (copied element by element: any storage order) */
+    template <typename D>
+    ArrayXXR(const Eigen::DenseBase<D>& e)
+        : rows_(static_cast<size_t>(e.rows())), cols_(static_cast<size_t>(e.cols())), d_(rows_ * cols_) {
+        for (size_t r = 0; r < rows_; ++r)
+            for (size_t c = 0; c < cols_; ++c) d_[r * cols_ + c] = static_cast<T>(e.derived().coeff(r, c));
+    }
+    /** the storage as an Eigen array, no copy */
+    Eigen::Map<EigenImg<T>> eigen() { return Eigen::Map<EigenImg<T>>(d_.data(), rows_, cols_); }
+    Eigen::Map<const EigenImg<T>> eigen() const { return Eigen::Map<const EigenImg<T>>(d_.data(), rows_, cols_); }
+    operator EigenImg<T>() const { return eigen(); }
+#endif
 
    private:
     size_t rows_ = 0, cols_ = 0;
@@ -79,6 +112,15 @@ class ArrayX3R : public ArrayXXR<T> {
         for (size_t i = 0; i < this->size(); ++i) r.data()[i] = static_cast<U>(this->data()[i]);
         return r;
     }
+#ifdef OUSTER_HIP_USE_EIGEN
+    template <typename D>
+    ArrayX3R(const Eigen::DenseBase<D>& e) : ArrayXXR<T>(e) {
+        if (e.cols() != 3) throw std::invalid_argument("ArrayX3R needs 3 columns");
+    }
+    operator EigenX3R<T>() const {
+        return Eigen::Map<const EigenX3R<T>>(this->data(), static_cast<Eigen::Index>(this->rows()), 3);
+    }
+#endif
 };
 
 template <typename T>
@@ -97,6 +139,21 @@ class ImgRef {
     ImgRef(const ArrayXXR<NC>& a) : p_(a.data()), rows_(a.rows()), cols_(a.cols()) {}
     template <typename U = T, typename = typename std::enable_if<std::is_const<U>::value>::type>
     ImgRef(const ImgRef<NC>& o) : p_(o.data()), rows_(o.rows()), cols_(o.cols()) {}
+#ifdef OUSTER_HIP_USE_EIGEN
+    /** A view of an Eigen array / Map / Ref / block whose storage is one dense row-major block
+     *  (what Eigen::Ref<img_t<T>> guarantees in the reference's signatures).
+     *  @throw std::invalid_argument for a strided or column-major expression */
+    template <typename D, typename = typename std::enable_if<
+                              std::is_same<typename D::Scalar, NC>::value &&
+                              (std::is_const<T>::value || !std::is_const<D>::value)>::type>
+    ImgRef(D& e, decltype(std::declval<D&>().data())* = nullptr)
+        : p_(e.data()), rows_(static_cast<size_t>(e.rows())), cols_(static_cast<size_t>(e.cols())) {
+        if (!(D::IsRowMajor || e.rows() == 1 || e.cols() == 1) ||
+            (e.rows() > 1 && static_cast<size_t>(e.outerStride()) != cols_) || e.innerStride() != 1)
+            throw std::invalid_argument("ImgRef: the Eigen expression is not a dense row-major image");
+    }
+    Eigen::Map<EigenImg<NC>> eigen() const { return Eigen::Map<EigenImg<NC>>(const_cast<NC*>(p_), rows_, cols_); }
+#endif
     T* data() const { return p_; }
     size_t rows() const { return rows_; }
     size_t cols() const { return cols_; }

@@ -619,6 +619,234 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_dwf_single: the same range-gated, compacting frame dewarp in ONE pass over the range planes.
+// A workgroup owns a 64-column tile of one frame for ALL rows (H x 65 dwords of LDS), counts the kept
+// points of its columns from LDS, and learns where its output starts from a decoupled look-back over
+// the tiles before it (Merrill & Garland: every tile publishes {aggregate | inclusive prefix} in one
+// 64-bit word; a wave inspects 64 predecessors per step).  Tiles take their index from ticket
+// counters -- eight of them, one per blockIdx & 7 class (tile = 8 * ticket + class): a single counter
+// serialises 8192 returning atomics (~90 us measured), eight run side by side.  Within a class a tile's
+// predecessors have always started; across classes that holds because workgroups are dispatched in
+// index order (a class would have to fall > 1000 workgroups behind the others for a wait to stall).  Output order, counts and provenance are exactly k_dwf_count/scan/emit's (= the reference's,
+// impl/dewarp_impl.h:23-115); the range plane is read once instead of twice and three launches
+// disappear.
+//   tile_state[16 * c]   ticket counter of class c, c < 8  (the buffer is zeroed before the launch)
+//   tile_state[128 + t]  [63:62] 0 nothing / 1 aggregate / 2 inclusive prefix, [61:0] points
+// ------------------------------------------------------------------------------------
+#ifndef OUSTER_DWF_NT
+#define OUSTER_DWF_NT 256
+#endif
+constexpr int DWF_NT = OUSTER_DWF_NT;  // threads per tile of k_dwf_single
+constexpr uint32_t DWF_WORDS = 128;  // tile words start behind the eight padded ticket counters
+constexpr uint64_t DWF_AGG = 1ull << 62, DWF_INC = 2ull << 62, DWF_VAL = (1ull << 62) - 1;
+
+// NT threads share one tile.  Measured (256 frames 128x2048, gate 0.5-400 m, same box): NT 256 0.428 ms,
+// 512 0.500 ms, 1024 0.698 ms against 0.344 ms for the count / scan / emit kernels -- the emit loop is
+// instruction bound (rocprofv3 --pmc: ~2600 VALU + ~1600 SALU per wave, the v_readlane broadcasts of the
+// column metadata), and the whole-column tile (33 KB of LDS) halves the waves per CU that hide it; the
+// range plane read it saves (65-75 us of k_dwf_count) does not pay for that.  Kept behind the
+// "dewarp_single_pass" knob; the three kernels stay the default.
+template <class T, bool SEP, int NT>
+__global__ __launch_bounds__(NT) void k_dwf_single(DewarpFramesArgs a) {
+    constexpr int TILE = 64, PITCH = TILE + 1, LPR = 16, RPP = NT / LPR, CPW = TILE / (NT / 64);
+    extern __shared__ __align__(16) uint32_t s_rng[];   // [H][PITCH]
+    __shared__ uint32_t s_cnt[TILE], s_ticket;
+    __shared__ int s_lo, s_hi;
+    __shared__ uint64_t s_base;
+    const uint32_t W = a.w, H = a.h, tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tiles = (W + TILE - 1) / TILE;
+    if (tid == 0) {
+        const uint32_t cls = blockIdx.x & 7u;
+        s_ticket = (uint32_t)atomicAdd((unsigned long long*)&a.tile_state[16 * cls], 1ull) * 8u + cls;
+        s_lo = 0x7fffffff;
+        s_hi = -1;
+    }
+    if (tid < TILE) s_cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t t = s_ticket, f = t / tiles, tile = t - f * tiles;
+    const uint32_t c0 = tile * TILE, ncol = min((uint32_t)TILE, W - c0);
+    const uint32_t* rp = a.range + (size_t)f * W * H;
+    const uint32_t* st = a.status + (size_t)f * W;
+    const LutDev lut = a.luts[f % a.n_luts];
+    const bool vec = (W % 4 == 0) && ((((uintptr_t)a.range) & 15) == 0);
+
+    // ---- first / last valid column of the frame (status & 1, lidar_frame.cpp:907-925)
+    {
+        int lo = 0x7fffffff, hi = -1;
+        for (uint32_t x = tid; x < W; x += NT)
+            if (st[x] & 1u) { lo = min(lo, (int)x); hi = max(hi, (int)x); }
+        if (hi >= 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    }
+    // ---- stage the tile's range values, all rows, coalesced row segments
+    {
+        const uint32_t q = tid % LPR, ty = tid / LPR, col = c0 + 4 * q;
+        for (uint32_t r = ty; r < H; r += RPP) {
+            uint32_t v[4] = {0, 0, 0, 0};
+            if (col < W) {
+                if (vec) {
+                    const uint4 x = *(const uint4*)(rp + (size_t)r * W + col);
+                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+                } else {
+                    for (uint32_t c = 0; c < 4 && col + c < W; ++c) v[c] = rp[(size_t)r * W + col + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_rng[r * PITCH + 4 * q + c] = v[c];
+        }
+    }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
+
+    // ---- column metadata: lane l of the wave holds column wave*CPW + l % CPW
+    const uint32_t ml = lane % CPW, mj = wave * CPW + ml, mx = c0 + mj;
+    const bool col_on = mj < ncol && (int)mx >= lo && (int)mx <= hi && st[mx] != 0;
+    // kept points per column: wave = 16 columns, lane = row
+    for (uint32_t jj = 0; jj < (uint32_t)CPW; ++jj) {
+        const uint32_t j = wave * CPW + jj;
+        if (j >= ncol) break;
+        uint32_t n = 0;
+        for (uint32_t r0 = 0; r0 < H; r0 += 64) {
+            const uint32_t row = r0 + lane;
+            const uint32_t r = row < H ? s_rng[row * PITCH + j] : 0u;
+            n += (uint32_t)__popcll(__ballot(row < H && r >= a.min_r && r <= a.max_r));
+        }
+        if (lane == jj) s_cnt[j] = n;   // lane jj is the metadata lane of column j (ml == jj)
+    }
+    __syncthreads();
+    // exclusive scan of the 64 column counts (masked), by every wave for itself
+    uint32_t m_cnt = 0, m_base = 0, tile_total = 0;
+    {
+        const uint32_t jx = lane;  // column of the tile
+        const bool on = jx < ncol && (int)(c0 + jx) >= lo && (int)(c0 + jx) <= hi && st[min(c0 + jx, W - 1)] != 0;
+        const uint32_t v = on ? s_cnt[jx] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if (lane >= (uint32_t)d) inc += up;
+        }
+        tile_total = __shfl(inc, 63, 64);
+        const uint32_t ex = inc - v;
+        // hand column mj's numbers to its metadata lane
+        m_base = __shfl(ex, (int)mj, 64);
+        m_cnt = __shfl(v, (int)mj, 64);
+        if (!col_on) m_cnt = 0;
+    }
+
+    // ---- where does this tile's output start?  publish, then look back (wave 0)
+    if (wave == 0) {
+        uint64_t excl = 0;
+        unsigned long long* my = (unsigned long long*)&a.tile_state[DWF_WORDS + t];
+        if (t == 0) {
+            if (lane == 0) __hip_atomic_store(my, DWF_INC | (uint64_t)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(my, DWF_AGG | (uint64_t)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t back = (int64_t)t - 1;        // nearest predecessor not yet accounted for
+            while (true) {
+                const int64_t i = back - (int64_t)lane;
+                uint64_t w = DWF_INC;             // lanes before the first tile: a zero inclusive prefix
+                if (i >= 0) {
+                    do {
+                        w = __hip_atomic_load((unsigned long long*)&a.tile_state[DWF_WORDS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((w >> 62) == 0);
+                }
+                const uint64_t inc_mask = __ballot((w >> 62) == 2);
+                const uint32_t first_inc = inc_mask ? (uint32_t)__builtin_ctzll(inc_mask) : 64u;
+                uint64_t part = lane <= first_inc ? (w & DWF_VAL) : 0ull;   // aggregates up to (incl.) the first inclusive word
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+                excl += part;
+                if (first_inc < 64u) break;
+                back -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(my, DWF_INC | (excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_base = excl;
+            if (tile == 0) a.frame_off[f] = excl;
+            if (t + 1 == a.n_frames * tiles) a.frame_off[a.n_frames] = excl + tile_total;
+        }
+    }
+    __syncthreads();
+    const uint64_t fbase = s_base;
+    if (tile_total == 0) return;
+
+    // ---- emit (as k_dwf_emit, from the resident tile)
+    uint64_t m_ts = 0;
+    T m_pose[12];
+    double m_col[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m_pose[k] = (T)0;
+    if (m_cnt) {
+        const double* pm = a.poses + ((size_t)f * W + mx) * 16;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) m_pose[k] = (T)pm[k];
+        if constexpr (SEP) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) m_col[k] = lut.col_tab[(size_t)mx * 5 + k];
+        }
+        if (a.timestamps_ns) m_ts = a.timestamp[(size_t)f * W + mx];
+    }
+    uint32_t m_run = 0;  // points of my column already written (previous row chunks)
+    for (uint32_t r0 = 0; r0 < H; r0 += 64) {
+        const uint32_t row = r0 + lane;
+        double bt[9];
+        if constexpr (SEP) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) bt[k] = row < H ? lut.beam_tab[(size_t)row * 9 + k] : 0.0;
+        }
+        for (uint32_t jj = 0; jj < (uint32_t)CPW; ++jj) {
+            const uint32_t j = wave * CPW + jj, x = c0 + j;  // wave-uniform
+            if (j >= ncol) break;
+            if (bcast_u32(m_cnt, jj) == 0) continue;  // masked out or empty column
+            const uint32_t r = row < H ? s_rng[row * PITCH + j] : 0u;
+            const bool keep = row < H && r >= a.min_r && r <= a.max_r;
+            const uint64_t mask = __ballot(keep);
+            const uint32_t n_keep = (uint32_t)__popcll(mask);
+            if (n_keep == 0) continue;
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const uint64_t g0 = fbase + bcast_u32(m_base, jj) + bcast_u32(m_run, jj);  // first point of this run
+            const uint64_t room = g0 < a.capacity ? a.capacity - g0 : 0;
+            if (keep && rank < room) {
+                double p[3];
+                if constexpr (SEP) {
+                    const double cx = bcast(m_col[0], jj), sx = bcast(m_col[1], jj);
+                    const double rm = (double)r - lut.n;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double d = fma(cx, bt[k], fma(sx, bt[3 + k], bt[6 + k]));
+                        p[k] = r ? fma(rm, d, bcast(m_col[2 + k], jj)) : 0.0;
+                    }
+                } else {
+                    const size_t pix = (size_t)row * W + x;
+                    if (lut.full_dtype == OUSTER_HIP_F32)
+                        project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs, pix, r, p);
+                    else
+                        project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs, pix, r, p);
+                }
+                const T px = (T)p[0], py = (T)p[1], pz = (T)p[2];
+                Pt3<T> o;
+                o.x = bcast(m_pose[0], jj) * px + bcast(m_pose[1], jj) * py + bcast(m_pose[2], jj) * pz + bcast(m_pose[3], jj);
+                o.y = bcast(m_pose[4], jj) * px + bcast(m_pose[5], jj) * py + bcast(m_pose[6], jj) * pz + bcast(m_pose[7], jj);
+                o.z = bcast(m_pose[8], jj) * px + bcast(m_pose[9], jj) * py + bcast(m_pose[10], jj) * pz + bcast(m_pose[11], jj);
+                ((Pt3<T>*)a.points)[g0 + rank] = o;
+            }
+            if (a.col_idxs || a.frame_idxs || a.timestamps_ns) {
+                const uint64_t ts = (uint64_t)bcast_u32((uint32_t)m_ts, jj) |
+                                    ((uint64_t)bcast_u32((uint32_t)(m_ts >> 32), jj) << 32);
+                for (uint32_t i = lane; i < n_keep && i < room; i += 64) {
+                    if (a.col_idxs) a.col_idxs[g0 + i] = x;
+                    if (a.frame_idxs) a.frame_idxs[g0 + i] = f;
+                    if (a.timestamps_ns) a.timestamps_ns[g0 + i] = ts;
+                }
+            }
+            if (ml == jj) m_run += n_keep;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------
 size_t decode_lds_bytes(const Geometry& g, int tile, bool general) {
@@ -754,6 +982,24 @@ hipError_t launch_dewarp(const DewarpArgs& a_in, hipStream_t st) {
 
 hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st) {
     const uint32_t tiles = (a.w + 63) / 64;
+    const size_t lds = (size_t)a.h * 65 * 4;
+    if (a.tile_state && lds <= 96 * 1024) {
+        // single pass with a decoupled look-back over the tiles (the state buffer must be zero)
+        hipError_t e = hipMemsetAsync(a.tile_state, 0, ((size_t)a.n_frames * tiles + DWF_WORDS) * 8, st);
+        if (e != hipSuccess) return e;
+        const dim3 grid(a.n_frames * tiles);
+        auto go = [&](auto kernel) -> hipError_t {
+            if (lds > 48 * 1024) {
+                hipError_t ee = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (ee != hipSuccess) return ee;
+            }
+            hipLaunchKernelGGL(kernel, grid, dim3(DWF_NT), lds, st, a);
+            return hipGetLastError();
+        };
+        if (a.dtype == OUSTER_HIP_F32)
+            return separable ? go(k_dwf_single<float, true, DWF_NT>) : go(k_dwf_single<float, false, DWF_NT>);
+        return separable ? go(k_dwf_single<double, true, DWF_NT>) : go(k_dwf_single<double, false, DWF_NT>);
+    }
     hipLaunchKernelGGL(k_dwf_count, dim3(tiles, a.n_frames), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dwf_scan, dim3(a.n_frames), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dwf_frame_scan, dim3(1), dim3(256), 0, st, a);

@@ -77,6 +77,7 @@ struct Knobs {
     int tune = 1;             // OUSTER_HIP_TUNE: 0 pins the default wide variant
     int xcd = 1;              // OUSTER_HIP_XCD: 0 disables the XCD-aware block -> frame mapping
     int fast = 1;             // OUSTER_HIP_FAST: 0 sends every frame through the general mapping
+    int dewarp_single_pass = 0;  // OUSTER_HIP_DWF_SINGLE: 1 = k_dwf_single instead of count / scan / emit (slower)
     int fixup = 1;            // tests only: 0 skips the fix-up pass (flagged frames are then left undone)
 };
 
@@ -275,6 +276,7 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.tune = env_int("OUSTER_HIP_TUNE", k.tune);
         k.xcd = env_int("OUSTER_HIP_XCD", k.xcd);
         k.fast = env_int("OUSTER_HIP_FAST", k.fast);
+        k.dewarp_single_pass = env_int("OUSTER_HIP_DWF_SINGLE", k.dewarp_single_pass);
     }
     if (stream == OUSTER_HIP_STREAM_NULL) {
         c->stream = nullptr;  // the null stream
@@ -335,6 +337,7 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "xcd") k.xcd = value;
     else if (n == "fast") k.fast = value;
     else if (n == "fixup") k.fixup = value;
+    else if (n == "dewarp_single_pass") k.dewarp_single_pass = value;
     else return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unknown knob '%s'", name);
     return OUSTER_HIP_OK;
 }
@@ -1015,7 +1018,10 @@ int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* l
     std::vector<LutDev> l(n_luts);
     for (uint32_t i = 0; i < n_luts; ++i) l[i] = luts[i]->dev;
     if (ensure_luts(ctx, l)) return fail(OUSTER_HIP_ERR_RUNTIME, "LUT descriptor upload failed");
-    if (ctx->scratch.ensure((size_t)n_frames * (w + 1) * sizeof(uint32_t)))
+    // scratch: the three-kernel path's per-column offsets, then the single-pass path's tile words
+    const size_t col_off_bytes = ((size_t)n_frames * (w + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
+    const size_t tile_words = (size_t)n_frames * ((w + 63) / 64) + 128;
+    if (ctx->scratch.ensure(col_off_bytes + tile_words * 8))
         return fail(OUSTER_HIP_ERR_RUNTIME, "scratch allocation failed");
     DewarpFramesArgs a{};
     a.range = range;
@@ -1031,6 +1037,7 @@ int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* l
     a.max_r = hi >= 4294967295.0 ? 0xffffffffu : (uint32_t)hi;
     a.dtype = dtype;
     a.col_off = (uint32_t*)ctx->scratch.p;
+    a.tile_state = ctx->knobs.dewarp_single_pass ? (uint64_t*)((uint8_t*)ctx->scratch.p + col_off_bytes) : nullptr;
     a.frame_off = frame_offsets;
     a.points = points;
     a.frame_idxs = frame_idxs;

@@ -117,7 +117,8 @@ struct DewarpFramesArgs {
     uint32_t w, h, n_frames;
     uint32_t min_r, max_r;      // raw range units (mm), inclusive
     int32_t dtype;              // element type of points
-    uint32_t* col_off;          // scratch [n_frames][w + 1]
+    uint32_t* col_off;          // scratch [n_frames][w + 1] (three-kernel path)
+    uint64_t* tile_state;       // scratch [128 + n_frames * tiles] (single-pass path; nullptr: three kernels)
     uint64_t* frame_off;        // out [n_frames + 1]: exclusive prefix of points per frame
     void* points;               // [capacity][3]
     uint32_t* frame_idxs;       // nullable provenance outputs, [capacity]

@@ -1126,8 +1126,40 @@ static void test_threads_and_contexts() {
     CHECK(distinct);   // per-thread default contexts really are separate streams
 }
 
+// FieldView conversions of a Field (ouster_core/include/ouster/core/field.h:374-470; the reference's
+// tests/field_test.cpp exercise the same operators on FieldView).
+static void test_field_conversions() {
+    std::printf("Field conversions (operator T*, ArrayView, 2-D image)\n");
+    Field f(ChanFieldType::UINT16, {4, 6, 3}, FieldClass::PIXEL_FIELD);
+    uint16_t* p = f;
+    for (size_t i = 0; i < f.size(); ++i) p[i] = static_cast<uint16_t>(i);
+    const Field& cf = f;
+    const uint16_t* cp = cf;
+    void* vp = f;
+    const void* cvp = cf;
+    CHECK(cp == p && vp == p && cvp == p);
+    ArrayView3<uint16_t> v3 = f;
+    ConstArrayView3<uint16_t> c3 = cf;
+    CHECK(v3(2, 5, 1) == 2 * 18 + 5 * 3 + 1 && c3(3, 0, 2) == 3 * 18 + 2);
+    CHECK(v3.shape[0] == 4 && v3.shape[1] == 6 && v3.shape[2] == 3 && v3.strides[0] == 18 && !v3.sparse());
+    ArrayView2<uint16_t> row = v3.subview(1);
+    CHECK(row(4, 2) == 18 + 4 * 3 + 2 && row.shape[0] == 6);
+    v3(0, 0, 0) = 77;
+    CHECK(p[0] == 77);
+    CHECK(throws_with<std::invalid_argument>([&] { uint32_t* w = f; (void)w; }, "ineligible dereference type for field of element type"));
+    CHECK(throws_with<std::invalid_argument>([&] { ArrayView2<uint16_t> w = f; (void)w; }, "dimension mismatch. Expected 3 got 2"));
+    CHECK(throws_with<std::invalid_argument>([&] { ArrayView3<uint8_t> w = f; (void)w; }, "ineligible dereference type"));
+    CHECK(throws_with<std::invalid_argument>([&] { ImgRef<uint16_t> w = f; (void)w; }, "must have 2 dimensions"));
+    CHECK(throws_with<std::invalid_argument>([&] { v3.subview(4); }, "invalid subview"));
+    LidarFrame frame(8, 32, UDPProfileLidar::RNG15_RFL8_NIR8);
+    ImgRef<uint32_t> img = frame.field(ChanField::RANGE);
+    ConstArrayView2<uint8_t> refl = const_cast<const LidarFrame&>(frame).field(ChanField::REFLECTIVITY);
+    CHECK(img.rows() == 8 && img.cols() == 32 && refl.shape[1] == 32);
+}
+
 int main() {
     test_threads_and_contexts();
+    test_field_conversions();
     test_packet_format_tables();
     test_packet_headers();
     test_lidar_frame_container();

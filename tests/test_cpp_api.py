@@ -24,6 +24,20 @@ def test_cpp_core_api():
     assert "0 failed" in p.stdout
 
 
+@pytest.mark.parametrize("switch", ["off", "on"])
+def test_eigen_boundary_switch_compiles_and_runs(switch):
+    """include/ouster/core/typedefs.h with and without -DOUSTER_HIP_USE_EIGEN: the reference-style
+    snippet (Field -> image -> destagger -> cartesian) builds and gives the same answers both ways.
+    (Eigen3 is mocked by tests/cpp/mock_eigen: it is not installed in this image.)"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "ouster_sdk_amd", "lib") + ":/opt/rocm/lib:" + \
+        env.get("LD_LIBRARY_PATH", "")
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "eigen_switch_" + switch)
+    p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "0 mismatches" in p.stdout, p.stdout + p.stderr[-2000:]
+
+
 def test_reference_snapshot_hashes_through_cpp_mirror(oracle):
     """The reference's FrameBatcherSnapshotTest goldens (tests/frame_batcher_test.cpp:553-595),
     reproduced by the C++ mirror: PcapReader -> FrameBatcher (GPU decode) -> matrix_hash."""

@@ -69,3 +69,29 @@ def test_config4_recorded_frames_same_result_for_1_and_2_ranks():
     assert a["recorded_frames"] == b["recorded_frames"] > 0
     assert a["xyz_checksum"] == b["xyz_checksum"] and a["nonzero_points"] == b["nonzero_points"] > 0
     print("config 4:", backend, b)
+
+
+def test_rccl_backend_runs_the_p2p_group_on_this_box():
+    """RCCL itself (backend "nccl") on the one GPU that is here: a world-size-1 process group and a
+    grouped self send / recv through the same `parallel._p2p` helper scatter_frames / gather_frames use
+    (two ranks cannot share a GPU under RCCL, so the 2-rank tests above fall back to gloo)."""
+    code = r'''
+import os, torch, torch.distributed as dist
+from ouster_sdk_amd import parallel
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["PORT"], RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+a = torch.arange(1 << 20, dtype=torch.int32, device="cuda")
+b = torch.zeros_like(a)
+parallel._p2p([dist.P2POp(dist.isend, a, 0), dist.P2POp(dist.irecv, b, 0)])
+torch.cuda.synchronize()
+assert torch.equal(a, b)
+mine = parallel.scatter_frames(a.view(64, -1), 64, (a.numel() // 64,), torch.int32, "cuda")
+out = parallel.gather_frames(mine, 64)
+assert torch.equal(out.view(-1), a)
+print("rccl ok", parallel.max_over_ranks(1.5, torch.device("cuda")))
+dist.destroy_process_group()
+'''
+    env = dict(os.environ, PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode == 0 and "rccl ok 1.5" in p.stdout, p.stdout[-1000:] + p.stderr[-3000:]
