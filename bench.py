@@ -398,13 +398,13 @@ def main():
     # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot wrap a run from inside):
     # only quoted when the committed profile is of exactly this workload and output set.
     traffic, traffic_src = None, None
-    if args.workload == "dual" and args.outputs == "full":
+    if args.outputs == "full":
         import glob
         for pj in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                 "profiles", "*", "pmc_traffic.json")), reverse=True):
             try:
                 t = json.load(open(pj))
-                if t.get("workload") == "dual" and t.get("frames_per_launch"):
+                if t.get("workload") == args.workload and t.get("frames_per_launch"):
                     v = t.get("variants_by_tile_columns", {}).get(str(tc), t)  # the variant that ran here
                     traffic = int(round(v["total_bytes"] * F / t["frames_per_launch"]))
                     traffic_src = (os.path.relpath(pj, os.path.dirname(os.path.abspath(__file__))) +

@@ -7,6 +7,7 @@ import re
 import sys
 
 d = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else "dual"
 
 
 def rows(path):
@@ -14,7 +15,7 @@ def rows(path):
 
 
 print(f"# rocprofv3 summary ({os.path.basename(d)})\n")
-print("Command: `python bench.py --steps 20 --warmup 3 --no-cpu` (kernel trace); PMC passes use "
+print(f"Command: `python bench.py --workload {workload} --steps 20 --warmup 3 --no-cpu` (kernel trace); PMC passes use "
       "`--steps 3 --warmup 1`.\n")
 print("## kernel stats (rocprofv3 --kernel-trace --stats)\n")
 print("| kernel | calls | avg us | min us | max us | % |")
@@ -46,7 +47,7 @@ print("\nFETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read str
 # (the variant the tuner settled on = the decode kernel with the most launches)
 dom = None
 for (k, c), v in agg.items():
-    if "k_decode" in k and c == "WRITE_SIZE" and (dom is None or len(v) > len(agg[(dom, c)])):
+    if "k_decode" in k and "fixup" not in k and c == "WRITE_SIZE" and (dom is None or len(v) > len(agg[(dom, c)])):
         dom = k
 parts = {}
 for (k, c), v in agg.items():
@@ -62,7 +63,7 @@ for (k, c), v in agg.items():
 for v in variants.values():
     v["total_bytes"] = v["fetch_bytes"] + v["write_bytes"]
 if len(parts) == 2:
-    json.dump({"kernel": dom.strip(), "workload": "dual", "frames_per_launch": 256, "variants_by_tile_columns": variants,
+    json.dump({"kernel": dom.strip(), "workload": workload, "frames_per_launch": 256, "variants_by_tile_columns": variants,
                "fetch_bytes": round(parts["FETCH_SIZE"]), "write_bytes": round(parts["WRITE_SIZE"]),
                "total_bytes": round(parts["FETCH_SIZE"] + parts["WRITE_SIZE"]),
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of "
