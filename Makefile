@@ -33,8 +33,8 @@ $(LIB)/libouster_hip.so: $(HIP_OBJS)
 	mkdir -p $(LIB)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_OBJS)
 
-$(LIB)/libouster_core_amd.so: $(HOST_SRC) $(wildcard include/ouster/core/*.h include/ouster/hip/*.h include/ouster/pcap/*.h) $(CSRC)/host/host_internal.h $(LIB)/libouster_hip.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -louster_hip -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN'
+$(LIB)/libouster_core_amd.so: $(HOST_SRC) $(wildcard include/ouster/core/*.h include/ouster/hip/*.h include/ouster/pcap/*.h include/ouster/osf/*.h) $(CSRC)/host/host_internal.h $(LIB)/libouster_hip.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -louster_hip -L$(ROCM)/lib -lamdhip64 -lz -l:libzstd.so.1 -Wl,-rpath,'$$ORIGIN'
 
 $(PYEXT): $(CSRC)/python/bindings.cpp $(LIB)/libouster_core_amd.so $(wildcard include/ouster/core/*.h)
 	$(CXX) -O2 -std=c++17 -fPIC -shared -fvisibility=hidden -Iinclude $(PYINC) -o $@ $(CSRC)/python/bindings.cpp -L$(LIB) -louster_core_amd -louster_hip -Wl,-rpath,'$$ORIGIN/lib'

@@ -1,0 +1,119 @@
+// osf.h -- reading LidarFrame field planes out of OSF files.
+//
+// Mirrors, for the hot path only, what the reference's ouster_osf does between an .osf file and a
+// LidarFrame: the container walk (ouster_osf/src/file.cpp, reader.cpp, fb_utils.cpp; flatbuffer
+// schemas ouster_osf/fb/*.fbs) and restore_lidar_frame (ouster_osf/src/stream_lidar_frame.cpp:165-340)
+// with decode_field (ouster_osf/src/png_tools.cpp:664-745).  The split is by what each processor is
+// good at: the HOST walks the flatbuffers and undoes the entropy coding (zlib inflate + PNG scanline
+// filters, zstd for ZPNG) into pinned staging; the GPU (ouster_hip_osf_unpack) turns the pixel bytes
+// of every field of every frame of a batch into typed planes -- ZPNG left-delta prefix sums, PNG
+// sample byte order, stagger() -- in the [frames][H][W] layout the rest of the path (destagger,
+// cartesian, dewarp) consumes unchanged.
+// Out of scope: writing OSF, non-lidar streams, object lists, the streaming-info index.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ouster/core/lidar_frame.h"
+#include "ouster/hip/context.h"
+
+namespace ouster {
+namespace sdk {
+namespace osf {
+
+/** A whole .osf file in memory with its blocks located and checked. */
+class OsfFile {
+   public:
+    /** @throw std::runtime_error when the file cannot be read, is not an OSF file, was not finished
+     *  (header status != VALID) or its header / metadata block fails its CRC32 */
+    explicit OsfFile(const std::string& path);
+
+    struct MetadataEntry {
+        uint32_t id = 0;
+        std::string type;        ///< e.g. "ouster/v1/os_sensor/LidarSensor"
+        const uint8_t* buffer = nullptr;  ///< size-prefixed flatbuffer of that type
+        size_t size = 0;
+    };
+    struct Message {
+        uint64_t ts = 0;        ///< StampedMessage.ts (host nanoseconds)
+        uint32_t id = 0;        ///< metadata entry id of the stream it belongs to
+        const uint8_t* buffer = nullptr;  ///< size-prefixed flatbuffer of the stream's message type
+        size_t size = 0;
+    };
+
+    uint64_t version() const { return version_; }
+    const std::string& id() const { return id_; }
+    const std::vector<MetadataEntry>& metadata_entries() const { return entries_; }
+    /** sensor metadata id -> the sensor's metadata JSON (LidarSensor entries) */
+    std::map<uint32_t, std::string> sensor_metadata_json() const;
+    /** LidarScanStream id -> sensor metadata id */
+    std::map<uint32_t, uint32_t> lidar_scan_streams() const;
+    /** Every message of every chunk, sorted by ts.  @throw std::runtime_error on a chunk CRC mismatch */
+    std::vector<Message> messages() const;
+
+   private:
+    std::vector<uint8_t> buf_;
+    uint64_t version_ = 0, metadata_offset_ = 0, chunks_base_ = 0;
+    std::string id_;
+    std::vector<MetadataEntry> entries_;
+    std::vector<uint64_t> chunk_offsets_;
+};
+
+/** One encoded field of a LidarScanMsg. */
+struct EncodedField {
+    std::string name;
+    core::ChanFieldType type = core::ChanFieldType::VOID;
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+};
+
+/** The parts of a LidarScanMsg the hot path uses (views into the file's memory). */
+struct LidarScanMsgView {
+    int32_t frame_id = 0;
+    uint64_t frame_status = 0;
+    uint8_t shutdown_countdown = 0, shot_limiting_countdown = 0;
+    std::vector<EncodedField> fields;
+    const uint64_t* timestamp = nullptr;      size_t n_timestamp = 0;
+    const uint16_t* measurement_id = nullptr; size_t n_measurement_id = 0;
+    const uint32_t* status = nullptr;         size_t n_status = 0;
+    const uint64_t* packet_timestamp = nullptr; size_t n_packet_timestamp = 0;
+    const uint8_t* alert_flags = nullptr;     size_t n_alert_flags = 0;
+    const double* pose = nullptr;             size_t n_pose = 0;
+    /** @throw std::runtime_error on a malformed buffer */
+    static LidarScanMsgView parse(const OsfFile::Message& msg);
+};
+
+/** What the host leaves for the GPU of one encoded field: pixel bytes + how to read them. */
+struct StagedField {
+    uint32_t encoding = 0;         ///< OUSTER_HIP_OSF_*
+    uint32_t src_pixel_bytes = 0;
+    std::vector<uint8_t> bytes;    ///< PNG: unfiltered scanlines; ZPNG: zstd-decompressed residuals
+};
+/** Host half of decode_field: inflate / unfilter (PNG) or zstd (ZPNG).  h, w: expected image size.
+ *  @throw std::runtime_error("decodeField: could not decode field") like the reference */
+StagedField stage_field(const EncodedField& f, size_t h, size_t w);
+
+/** Decodes LidarScan messages of one sensor into LidarFrames, the pixel work on the GPU. */
+class OsfFrameDecoder {
+   public:
+    explicit OsfFrameDecoder(const core::SensorInfo& info, int device = -1);
+    ~OsfFrameDecoder();
+    /** restore_lidar_frame for a batch: one ouster_hip_osf_unpack launch covers every field of every
+     *  message.  Frames get exactly the fields their message carries (restore_lidar_frame :176-199).
+     *  @throw std::runtime_error / std::invalid_argument like the reference's reader */
+    std::vector<core::LidarFrame> decode(const std::vector<OsfFile::Message>& msgs);
+    core::LidarFrame decode(const OsfFile::Message& msg) { return std::move(decode(std::vector<OsfFile::Message>{msg})[0]); }
+
+   private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+}  // namespace osf
+}  // namespace sdk
+}  // namespace ouster

@@ -291,6 +291,38 @@ int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* l
                              uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
                              uint64_t capacity, uint64_t* frame_offsets);
 
+/* ---- OSF field planes -------------------------------------------------------- */
+/* The device half of decode_field (ouster_osf/src/png_tools.cpp:664-745) for a batch of encoded
+ * LidarFrame fields whose entropy coding the host has already undone (PNG: zlib inflate + scanline
+ * filters; ZPNG: zstd): pixel bytes -> typed plane elements, and for PNG planes -- which the OSF
+ * writer stored destaggered (png_lidarframe_encoder.cpp:112-125) -- the stagger() back, so that the
+ * planes land in the same [H][W] staggered layout ouster_hip_decode produces and
+ * ouster_hip_destagger / ouster_hip_cartesian / ouster_hip_dewarp_frames run on them unchanged.
+ *   PNG_*   src = h rows of w pixels, unfiltered, no filter bytes.  Value = little-endian composition
+ *           of the pixel's bytes; 16-bit samples are stored byte-swapped (png_set_swap in the writer).
+ *   ZPNG    src = the zstd-decompressed residuals (thirdparty/zpng/zpng.cpp:101-352): per row and
+ *           byte lane a running sum mod 256 of the left deltas; 3- and 4-byte pixels come as colour
+ *           planes with the GB-RG transform.  Undone on the device (row-wise prefix sums).  Never
+ *           staggered: ZPNG planes are stored as they are.
+ * The decoded value is truncated / zero-extended to dst_elem_size like the reference's
+ * static_cast<T>.  pixel_shift_by_row: HOST array [h] (needed iff any job is a PNG plane). */
+#define OUSTER_HIP_OSF_PNG_GRAY8 1
+#define OUSTER_HIP_OSF_PNG_GRAY16 2
+#define OUSTER_HIP_OSF_PNG_RGB8 3    /* 24-bit values */
+#define OUSTER_HIP_OSF_PNG_RGBA8 4   /* 32-bit values */
+#define OUSTER_HIP_OSF_PNG_RGBA16 5  /* 64-bit values */
+#define OUSTER_HIP_OSF_ZPNG 6        /* src_pixel_bytes = channels * bytes per channel (1..8) */
+typedef struct ouster_hip_osf_plane {
+    const void* src;          /* device */
+    void* dst;                /* device, [h][w] elements of dst_elem_size bytes */
+    uint32_t encoding;        /* OUSTER_HIP_OSF_* */
+    uint32_t src_pixel_bytes; /* bytes of one source pixel */
+    uint32_t dst_elem_size;   /* 1, 2, 4 or 8 */
+    uint32_t reserved;
+} ouster_hip_osf_plane;
+int ouster_hip_osf_unpack(ouster_hip_ctx* ctx, const ouster_hip_osf_plane* planes, uint32_t n_planes,
+                          uint32_t h, uint32_t w, const int32_t* pixel_shift_by_row);
+
 /* ---- instrumentation ------------------------------------------------------ */
 /* Average duration in ms of the dominant decode kernel over the launches made
  * since the last reset, measured with HIP events on the context's stream

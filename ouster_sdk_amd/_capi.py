@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "ouster_hip_last_error", "ouster_hip_version", "ouster_hip_format_create",
     "ouster_hip_format_destroy", "ouster_hip_lut_create", "ouster_hip_lut_create_from_arrays",
     "ouster_hip_lut_export", "ouster_hip_lut_destroy", "ouster_hip_decode", "ouster_hip_destagger",
-    "ouster_hip_cartesian", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_timing_enable", "ouster_hip_timing_read", "ouster_hip_last_decode_tile",
+    "ouster_hip_cartesian", "ouster_hip_osf_unpack", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_timing_enable", "ouster_hip_timing_read", "ouster_hip_last_decode_tile",
 ]
 
 _hip = None

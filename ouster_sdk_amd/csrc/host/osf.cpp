@@ -1,0 +1,484 @@
+// osf.cpp -- see include/ouster/osf/osf.h.  Host side: flatbuffer walk, CRC32, zlib / zstd, PNG
+// scanline filters; the per-pixel work goes to ouster_hip_osf_unpack.
+#include "ouster/osf/osf.h"
+
+#include <hip/hip_runtime_api.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+
+#include "host_internal.h"
+#include "ouster/hip/device_buffer.h"
+
+// libzstd ships without headers in this image; these are its stable C entry points
+extern "C" {
+size_t ZSTD_decompress(void* dst, size_t dst_capacity, const void* src, size_t compressed_size);
+unsigned ZSTD_isError(size_t code);
+}
+
+namespace ouster {
+namespace sdk {
+namespace osf {
+
+using namespace core;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// bounds-checked FlatBuffers reads (little endian; tables, vectors, strings)
+// ---------------------------------------------------------------------------------------
+struct Span {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+};
+
+[[noreturn]] void bad(const char* what) { throw std::runtime_error(std::string("OSF: malformed buffer (") + what + ")"); }
+
+template <typename T>
+T rd(const Span& b, size_t pos) {
+    if (pos + sizeof(T) > b.n) bad("read past the end");
+    T v;
+    std::memcpy(&v, b.p + pos, sizeof(T));
+    return v;
+}
+
+struct Table {
+    Span b;
+    size_t pos = 0, vt = 0;
+    uint16_t vt_len = 0;
+    Table() = default;
+    Table(const Span& buf, size_t at) : b(buf), pos(at) {
+        const int32_t so = rd<int32_t>(b, pos);
+        const int64_t v = static_cast<int64_t>(pos) - so;
+        if (v < 0 || static_cast<size_t>(v) + 4 > b.n) bad("vtable");
+        vt = static_cast<size_t>(v);
+        vt_len = rd<uint16_t>(b, vt);
+        if (vt + vt_len > b.n) bad("vtable length");
+    }
+    bool valid() const { return b.p != nullptr; }
+    size_t field_offset(int field) const {
+        const size_t o = 4 + 2 * static_cast<size_t>(field);
+        if (o + 2 > vt_len) return 0;
+        return rd<uint16_t>(b, vt + o);
+    }
+    template <typename T>
+    T scalar(int field, T dflt) const {
+        const size_t o = field_offset(field);
+        return o ? rd<T>(b, pos + o) : dflt;
+    }
+    size_t indirect(int field) const {  // absolute position of the referenced object, 0 = absent
+        const size_t o = field_offset(field);
+        if (!o) return 0;
+        const size_t p = pos + o;
+        return p + rd<uint32_t>(b, p);
+    }
+    Table table(int field) const {
+        const size_t p = indirect(field);
+        return p ? Table(b, p) : Table();
+    }
+    std::string string(int field) const {
+        const size_t p = indirect(field);
+        if (!p) return {};
+        const uint32_t n = rd<uint32_t>(b, p);
+        if (p + 4 + n > b.n) bad("string");
+        return std::string(reinterpret_cast<const char*>(b.p + p + 4), n);
+    }
+    /** vector of `elem` byte scalars / structs: pointer + count */
+    Span vector(int field, size_t elem, size_t* count) const {
+        *count = 0;
+        const size_t p = indirect(field);
+        if (!p) return {};
+        const uint32_t n = rd<uint32_t>(b, p);
+        if (p + 4 + static_cast<size_t>(n) * elem > b.n) bad("vector");
+        *count = n;
+        return Span{b.p + p + 4, static_cast<size_t>(n) * elem};
+    }
+    std::vector<Table> tables(int field) const {
+        std::vector<Table> out;
+        const size_t p = indirect(field);
+        if (!p) return out;
+        const uint32_t n = rd<uint32_t>(b, p);
+        if (p + 4 + 4ull * n > b.n) bad("table vector");
+        for (uint32_t i = 0; i < n; ++i) {
+            const size_t e = p + 4 + 4ull * i;
+            out.emplace_back(b, e + rd<uint32_t>(b, e));
+        }
+        return out;
+    }
+};
+
+// [u32 size][flatbuffer: u32 root offset, 4-byte identifier, ...][u32 crc32] (fb_utils.cpp:60-110)
+Table prefixed_root(const Span& file, size_t pos, size_t* body_size) {
+    const uint32_t size = rd<uint32_t>(file, pos);
+    if (pos + 4 + size > file.n) bad("block size");
+    if (body_size) *body_size = size;
+    return Table(file, pos + 4 + rd<uint32_t>(file, pos + 4));
+}
+
+bool block_crc_ok(const Span& file, size_t pos) {
+    const uint32_t size = rd<uint32_t>(file, pos);
+    if (pos + 8 + size > file.n) return false;
+    const uint32_t stored = rd<uint32_t>(file, pos + 4 + size);
+    return static_cast<uint32_t>(::crc32(0L, file.p + pos, 4 + size)) == stored;
+}
+
+// CHAN_FIELD enum of ouster_osf/fb/os_sensor/lidar_scan_stream.fbs
+std::string chan_field_name(uint8_t v) {
+    switch (v) {
+        case 1: return ChanField::RANGE;
+        case 2: return ChanField::RANGE2;
+        case 3: return ChanField::SIGNAL;
+        case 4: return ChanField::SIGNAL2;
+        case 5: return ChanField::REFLECTIVITY;
+        case 6: return ChanField::REFLECTIVITY2;
+        case 7: return ChanField::NEAR_IR;
+        case 8: return ChanField::FLAGS;
+        case 9: return ChanField::FLAGS2;
+        case 40: return "RAW_HEADERS";
+        default: break;
+    }
+    if (v >= 45 && v <= 49) return "RAW32_WORD" + std::to_string(v - 40);
+    if (v >= 50 && v <= 59) return "CUSTOM" + std::to_string(v - 50);
+    if (v >= 60 && v <= 63) return "RAW32_WORD" + std::to_string(v - 59);
+    throw std::runtime_error("OSF: unknown channel field " + std::to_string(v));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// OsfFile
+// ---------------------------------------------------------------------------------------
+OsfFile::OsfFile(const std::string& path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw std::runtime_error("OSF: cannot open " + path);
+    const std::streamsize n = f.tellg();
+    f.seekg(0);
+    buf_.resize(static_cast<size_t>(std::max<std::streamsize>(n, 0)));
+    if (n > 0 && !f.read(reinterpret_cast<char*>(buf_.data()), n)) throw std::runtime_error("OSF: cannot read " + path);
+    const Span file{buf_.data(), buf_.size()};
+    if (buf_.size() < 16 || std::memcmp(buf_.data() + 8, "OSF$", 4) != 0) throw std::runtime_error("OSF: not an OSF file: " + path);
+    size_t hsize = 0;
+    const Table hdr = prefixed_root(file, 0, &hsize);
+    if (!block_crc_ok(file, 0)) throw std::runtime_error("OSF: header crc32 mismatch");
+    version_ = hdr.scalar<uint64_t>(0, 0);
+    const uint8_t status = hdr.scalar<uint8_t>(1, 0);
+    metadata_offset_ = hdr.scalar<uint64_t>(2, 1);
+    if (status != 2) throw std::runtime_error("OSF: file was not finished (header status is not VALID)");
+    chunks_base_ = 4 + hsize + 4;
+    if (metadata_offset_ + 8 > buf_.size() || !block_crc_ok(file, metadata_offset_))
+        throw std::runtime_error("OSF: metadata crc32 mismatch");
+    const Table meta = prefixed_root(file, metadata_offset_, nullptr);
+    id_ = meta.string(0);
+    size_t n_chunks = 0;
+    const Span ch = meta.vector(3, 24, &n_chunks);  // struct ChunkOffset {start_ts, end_ts, offset}
+    for (size_t i = 0; i < n_chunks; ++i) chunk_offsets_.push_back(rd<uint64_t>(ch, i * 24 + 16));
+    for (const Table& e : meta.tables(4)) {
+        MetadataEntry me;
+        me.id = e.scalar<uint32_t>(0, 0);
+        me.type = e.string(1);
+        size_t nb = 0;
+        const Span b = e.vector(2, 1, &nb);
+        me.buffer = b.p;
+        me.size = nb;
+        entries_.push_back(std::move(me));
+    }
+}
+
+std::map<uint32_t, std::string> OsfFile::sensor_metadata_json() const {
+    std::map<uint32_t, std::string> out;
+    for (const auto& e : entries_) {
+        if (e.type.size() < 11 || e.type.compare(e.type.size() - 11, 11, "LidarSensor") != 0) continue;
+        const Table t = prefixed_root(Span{e.buffer, e.size}, 0, nullptr);
+        out[e.id] = t.string(0);
+    }
+    return out;
+}
+
+std::map<uint32_t, uint32_t> OsfFile::lidar_scan_streams() const {
+    std::map<uint32_t, uint32_t> out;
+    for (const auto& e : entries_) {
+        if (e.type.size() < 15 || e.type.compare(e.type.size() - 15, 15, "LidarScanStream") != 0) continue;
+        const Table t = prefixed_root(Span{e.buffer, e.size}, 0, nullptr);
+        out[e.id] = t.scalar<uint32_t>(0, 0);
+    }
+    return out;
+}
+
+std::vector<OsfFile::Message> OsfFile::messages() const {
+    std::vector<Message> out;
+    const Span file{buf_.data(), buf_.size()};
+    for (uint64_t off : chunk_offsets_) {
+        const size_t pos = chunks_base_ + off;
+        if (pos + 8 > buf_.size() || !block_crc_ok(file, pos)) throw std::runtime_error("OSF: chunk crc32 mismatch");
+        const Table chunk = prefixed_root(file, pos, nullptr);
+        for (const Table& m : chunk.tables(0)) {
+            Message msg;
+            msg.ts = m.scalar<uint64_t>(0, 0);
+            msg.id = m.scalar<uint32_t>(1, 0);
+            size_t nb = 0;
+            const Span b = m.vector(2, 1, &nb);
+            msg.buffer = b.p;
+            msg.size = nb;
+            out.push_back(msg);
+        }
+    }
+    std::stable_sort(out.begin(), out.end(), [](const Message& a, const Message& b) { return a.ts < b.ts; });
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------
+// LidarScanMsg (ouster_osf/fb/os_sensor/lidar_scan_stream.fbs)
+// ---------------------------------------------------------------------------------------
+LidarScanMsgView LidarScanMsgView::parse(const OsfFile::Message& msg) {
+    if (!msg.buffer || msg.size < 8) bad("empty message");
+    const Span b{msg.buffer, msg.size};
+    const Table t = prefixed_root(b, 0, nullptr);
+    LidarScanMsgView v;
+    v.frame_id = t.scalar<int32_t>(5, 0);
+    v.frame_status = t.scalar<uint64_t>(9, 0);
+    v.shutdown_countdown = t.scalar<uint8_t>(10, 0);
+    v.shot_limiting_countdown = t.scalar<uint8_t>(11, 0);
+    size_t n_types = 0;
+    const Span types = t.vector(1, 2, &n_types);  // struct ChannelField {chan_field u8, chan_field_type u8}
+    const std::vector<Table> channels = t.tables(0);
+    for (size_t i = 0; i < channels.size() && i < n_types; ++i) {
+        EncodedField f;
+        f.name = chan_field_name(types.p[2 * i]);
+        f.type = static_cast<ChanFieldType>(types.p[2 * i + 1]);
+        size_t nb = 0;
+        const Span d = channels[i].vector(0, 1, &nb);
+        f.data = d.p;
+        f.size = nb;
+        v.fields.push_back(std::move(f));
+    }
+    size_t n = 0;
+    v.timestamp = reinterpret_cast<const uint64_t*>(t.vector(2, 8, &n).p); v.n_timestamp = n;
+    v.measurement_id = reinterpret_cast<const uint16_t*>(t.vector(3, 2, &n).p); v.n_measurement_id = n;
+    v.status = reinterpret_cast<const uint32_t*>(t.vector(4, 4, &n).p); v.n_status = n;
+    v.pose = reinterpret_cast<const double*>(t.vector(6, 8, &n).p); v.n_pose = n;
+    v.packet_timestamp = reinterpret_cast<const uint64_t*>(t.vector(7, 8, &n).p); v.n_packet_timestamp = n;
+    v.alert_flags = t.vector(12, 1, &n).p; v.n_alert_flags = n;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// host half of decode_field: entropy decoding only
+// ---------------------------------------------------------------------------------------
+namespace {
+
+[[noreturn]] void cannot_decode() { throw std::runtime_error("decodeField: could not decode field"); }
+
+uint32_t be32(const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
+
+// PNG scanline filters 0-4 (PNG specification, section 9), in place over the inflated stream
+void png_unfilter(const uint8_t* raw, size_t h, size_t stride, size_t bpp, uint8_t* out) {
+    const uint8_t* prev = nullptr;
+    for (size_t y = 0; y < h; ++y) {
+        const uint8_t ft = raw[y * (stride + 1)];
+        const uint8_t* in = raw + y * (stride + 1) + 1;
+        uint8_t* cur = out + y * stride;
+        switch (ft) {
+            case 0: std::memcpy(cur, in, stride); break;
+            case 1:
+                for (size_t x = 0; x < stride; ++x) cur[x] = static_cast<uint8_t>(in[x] + (x >= bpp ? cur[x - bpp] : 0));
+                break;
+            case 2:
+                for (size_t x = 0; x < stride; ++x) cur[x] = static_cast<uint8_t>(in[x] + (prev ? prev[x] : 0));
+                break;
+            case 3:
+                for (size_t x = 0; x < stride; ++x) {
+                    const unsigned a = x >= bpp ? cur[x - bpp] : 0, b = prev ? prev[x] : 0;
+                    cur[x] = static_cast<uint8_t>(in[x] + ((a + b) >> 1));
+                }
+                break;
+            case 4:
+                for (size_t x = 0; x < stride; ++x) {
+                    const int a = x >= bpp ? cur[x - bpp] : 0, b = prev ? prev[x] : 0,
+                              c = (prev && x >= bpp) ? prev[x - bpp] : 0;
+                    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                    const int pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    cur[x] = static_cast<uint8_t>(in[x] + pred);
+                }
+                break;
+            default: cannot_decode();
+        }
+        prev = cur;
+    }
+}
+
+}  // namespace
+
+StagedField stage_field(const EncodedField& f, size_t h, size_t w) {
+    StagedField out;
+    const size_t esz = field_type_size(f.type);
+    if (esz != 1 && esz != 2 && esz != 4 && esz != 8) cannot_decode();
+    // ZPNG first, as decode_field does (png_tools.cpp:688-706)
+    if (f.size >= 8 && f.data[0] == 0xF8 && f.data[1] == 0xFB) {
+        const size_t zw = f.data[2] | (f.data[3] << 8), zh = f.data[4] | (f.data[5] << 8);
+        const size_t pixel_bytes = static_cast<size_t>(f.data[6]) * f.data[7];
+        if (zw != w || zh != h || pixel_bytes != esz) throw std::runtime_error("Invalid allocation");
+        out.encoding = OUSTER_HIP_OSF_ZPNG;
+        out.src_pixel_bytes = static_cast<uint32_t>(pixel_bytes);
+        out.bytes.resize(w * h * pixel_bytes);
+        const size_t n = ZSTD_decompress(out.bytes.data(), out.bytes.size(), f.data + 8, f.size - 8);
+        if (ZSTD_isError(n) || n != out.bytes.size()) cannot_decode();
+        return out;
+    }
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (f.size < 8 || std::memcmp(f.data, sig, 8) != 0) cannot_decode();
+    size_t pos = 8;
+    uint32_t pw = 0, ph = 0;
+    int depth = 0, colour = -1, interlace = 0;
+    std::vector<uint8_t> idat;
+    while (pos + 12 <= f.size) {
+        const uint32_t n = be32(f.data + pos);
+        const uint8_t* typ = f.data + pos + 4;
+        if (pos + 12 + n > f.size) cannot_decode();
+        const uint8_t* body = f.data + pos + 8;
+        if (!std::memcmp(typ, "IHDR", 4) && n >= 13) {
+            pw = be32(body);
+            ph = be32(body + 4);
+            depth = body[8];
+            colour = body[9];
+            interlace = body[12];
+        } else if (!std::memcmp(typ, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + n);
+        } else if (!std::memcmp(typ, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + n;
+    }
+    if (pw != w || ph != h || interlace) cannot_decode();
+    size_t bpp = 0;
+    if (colour == 0 && depth == 8) { out.encoding = OUSTER_HIP_OSF_PNG_GRAY8; bpp = 1; }
+    else if (colour == 0 && depth == 16) { out.encoding = OUSTER_HIP_OSF_PNG_GRAY16; bpp = 2; }
+    else if (colour == 2 && depth == 8) { out.encoding = OUSTER_HIP_OSF_PNG_RGB8; bpp = 3; }
+    else if (colour == 6 && depth == 8) { out.encoding = OUSTER_HIP_OSF_PNG_RGBA8; bpp = 4; }
+    else if (colour == 6 && depth == 16) { out.encoding = OUSTER_HIP_OSF_PNG_RGBA16; bpp = 8; }
+    else cannot_decode();
+    // the reference picks the decoder by the FIELD's type and rejects a PNG of another depth
+    // (decode_{8,16,32,64}bit_image: "bad sample depth / color type", png_tools.cpp:232-250, 623-643);
+    // 24-bit RGB is what encode_24bit_image writes for 32-bit fields
+    const bool ok = (esz == 1 && bpp == 1) || (esz == 2 && bpp == 2) || (esz == 4 && (bpp == 4 || bpp == 3)) ||
+                    (esz == 8 && bpp == 8);
+    if (!ok) cannot_decode();
+    out.src_pixel_bytes = static_cast<uint32_t>(bpp);
+    const size_t stride = w * bpp;
+    std::vector<uint8_t> raw(h * (stride + 1));
+    uLongf got = static_cast<uLongf>(raw.size());
+    if (::uncompress(raw.data(), &got, idat.data(), static_cast<uLong>(idat.size())) != Z_OK || got != raw.size())
+        cannot_decode();
+    out.bytes.resize(h * stride);
+    png_unfilter(raw.data(), h, stride, bpp, out.bytes.data());
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------
+// OsfFrameDecoder
+// ---------------------------------------------------------------------------------------
+struct OsfFrameDecoder::Impl {
+    SensorInfo info;
+    std::shared_ptr<hip::Context> ctx;
+    int device = -1;
+    hip::DeviceBuffer d_src, d_dst;
+    const std::shared_ptr<hip::Context>& context() {
+        if (!ctx) ctx = std::make_shared<hip::Context>(device >= 0 ? device : hip::current_device());
+        return ctx;
+    }
+};
+
+OsfFrameDecoder::OsfFrameDecoder(const SensorInfo& info, int device) : impl_(new Impl) {
+    impl_->info = info;
+    impl_->device = device;
+}
+OsfFrameDecoder::~OsfFrameDecoder() = default;
+
+std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Message>& msgs) {
+    Impl& s = *impl_;
+    const size_t h = s.info.format.pixels_per_column, w = s.info.format.columns_per_frame;
+    std::vector<LidarFrame> frames;
+    struct Job { size_t frame; std::string name; size_t esz; StagedField st; size_t src_off, dst_off; };
+    std::vector<Job> jobs;
+    size_t src_total = 0, dst_total = 0;
+    auto al = [](size_t x) { return (x + 255) & ~size_t{255}; };
+    for (const auto& m : msgs) {
+        const LidarScanMsgView v = LidarScanMsgView::parse(m);
+        LidarFrameFieldTypes types;
+        for (const auto& f : v.fields) types.emplace_back(f.name, f.type, std::vector<size_t>{}, FieldClass::PIXEL_FIELD);
+        LidarFrame fr(h, w, types, s.info.format.columns_per_packet);
+        fr.frame_id = v.frame_id;
+        fr.frame_status = v.frame_status;
+        fr.shutdown_countdown = v.shutdown_countdown;
+        fr.shot_limiting_countdown = v.shot_limiting_countdown;
+        auto header = [&](const char* what, size_t have, size_t want) {  // stream_lidar_frame.cpp:213-301
+            if (have == want) return true;
+            if (have != 0)
+                throw std::runtime_error(std::string("OSF: LidarScanMsg has ") + what + " of length " +
+                                         std::to_string(have) + ", expected " + std::to_string(want));
+            return false;
+        };
+        if (header("header_timestamp", v.n_timestamp, w)) std::memcpy(fr.timestamp().data(), v.timestamp, w * 8);
+        if (header("header_measurement_id", v.n_measurement_id, w))
+            std::memcpy(fr.measurement_id().data(), v.measurement_id, w * 2);
+        if (header("header_status", v.n_status, w)) std::memcpy(fr.status().data(), v.status, w * 4);
+        if (header("pose", v.n_pose, fr.body_to_world().size()))
+            std::memcpy(fr.body_to_world().get<double>(), v.pose, v.n_pose * 8);
+        if (header("packet_timestamp", v.n_packet_timestamp, fr.packet_timestamp().size()))
+            std::memcpy(fr.packet_timestamp().data(), v.packet_timestamp, v.n_packet_timestamp * 8);
+        if (header("alert_flags", v.n_alert_flags, fr.alert_flags().size()))
+            std::memcpy(fr.alert_flags().data(), v.alert_flags, v.n_alert_flags);
+        for (const auto& f : v.fields) {
+            Job j;
+            j.frame = frames.size();
+            j.name = f.name;
+            j.esz = field_type_size(f.type);
+            if (f.size == 0) continue;  // empty field: stays zero
+            j.st = stage_field(f, h, w);
+            j.src_off = src_total;
+            j.dst_off = dst_total;
+            src_total += al(j.st.bytes.size());
+            dst_total += al(h * w * j.esz);
+            jobs.push_back(std::move(j));
+        }
+        frames.push_back(std::move(fr));
+    }
+    if (jobs.empty()) return frames;
+
+    hip::ScopedContext on_my_context(s.context());
+    s.d_src.resize(src_total);
+    s.d_dst.resize(dst_total);
+    // one staging buffer, one copy in; one launch over every (frame, field); one copy out
+    std::vector<uint8_t> staging(src_total);
+    for (const auto& j : jobs) std::memcpy(staging.data() + j.src_off, j.st.bytes.data(), j.st.bytes.size());
+    s.d_src.upload(staging.data(), src_total);
+    std::vector<ouster_hip_osf_plane> planes(jobs.size());
+    bool any_png = false;
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        planes[i].src = static_cast<const uint8_t*>(s.d_src.data()) + jobs[i].src_off;
+        planes[i].dst = static_cast<uint8_t*>(s.d_dst.data()) + jobs[i].dst_off;
+        planes[i].encoding = jobs[i].st.encoding;
+        planes[i].src_pixel_bytes = jobs[i].st.src_pixel_bytes;
+        planes[i].dst_elem_size = static_cast<uint32_t>(jobs[i].esz);
+        planes[i].reserved = 0;
+        any_png |= jobs[i].st.encoding != OUSTER_HIP_OSF_ZPNG;
+    }
+    std::vector<int32_t> shifts(s.info.format.pixel_shift_by_row.begin(), s.info.format.pixel_shift_by_row.end());
+    if (any_png && !shifts.empty() && shifts.size() != h)
+        throw std::invalid_argument("image height does not match shifts size");
+    hip::check(ouster_hip_osf_unpack(s.ctx->handle(), planes.data(), static_cast<uint32_t>(planes.size()),
+                                     static_cast<uint32_t>(h), static_cast<uint32_t>(w),
+                                     shifts.empty() ? nullptr : shifts.data()));
+    std::vector<uint8_t> host(dst_total);
+    s.d_dst.download(host.data(), dst_total);
+    for (const auto& j : jobs)
+        std::memcpy(frames[j.frame].field(j.name).get(), host.data() + j.dst_off, h * w * j.esz);
+    return frames;
+}
+
+}  // namespace osf
+}  // namespace sdk
+}  // namespace ouster

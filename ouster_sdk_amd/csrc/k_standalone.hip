@@ -847,6 +847,84 @@ __global__ __launch_bounds__(NT) void k_dwf_single(DewarpFramesArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_osf_unpack: the device half of the OSF field decode.  One workgroup per
+// (row, plane job).
+//   PNG   decode_{8,16,24,32,64}bit_image, ouster_osf/src/png_tools.cpp:182-660: pixel bytes -> value
+//         (16-bit samples byte-swapped), then stagger(): dst[r][(c + off[r]) % w] = value(r, c) with
+//         off[] = destagger's offsets for inverse = true (impl/lidar_frame_impl.h:733-760)
+//   ZPNG  UnpackAndUnfilter<N>, thirdparty/zpng/zpng.cpp:101-352: every byte lane of a row is the
+//         running sum (mod 256) of its deltas -- a 256-thread block scan per lane; 3 / 4-byte pixels
+//         arrive as colour planes and go through the inverse GB-RG transform first
+// HBM bound: src bytes + dst bytes per pixel, each read / written once.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_incl_scan_u8(uint32_t v, uint32_t* s_wave) {
+    // inclusive scan of one value per thread over the 256-thread block (only the low 8 bits matter)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wave; ++k) base += s_wave[k];
+    __syncthreads();
+    return v + base;
+}
+
+__global__ __launch_bounds__(256) void k_osf_unpack(OsfUnpackArgs a) {
+    __shared__ uint32_t s_wave[4];
+    const ouster_hip_osf_plane job = a.planes[blockIdx.y];
+    const uint32_t r = blockIdx.x, W = a.w, tid = threadIdx.x;
+    const uint32_t pb = job.src_pixel_bytes, es = job.dst_elem_size;
+    uint8_t* drow = (uint8_t*)job.dst + (size_t)r * W * es;
+    const uint64_t keep = es >= 8 ? ~0ull : ((1ull << (8 * es)) - 1);
+    if (job.encoding != OUSTER_HIP_OSF_ZPNG) {
+        const uint8_t* srow = (const uint8_t*)job.src + (size_t)r * W * pb;
+        const bool swap16 = job.encoding == OUSTER_HIP_OSF_PNG_GRAY16 || job.encoding == OUSTER_HIP_OSF_PNG_RGBA16;
+        const uint32_t off = a.offsets ? (uint32_t)a.offsets[r] : 0u;
+        for (uint32_t c = tid; c < W; c += 256) {
+            uint64_t v = 0;
+            for (uint32_t k = 0; k < pb; ++k) v |= (uint64_t)srow[(size_t)c * pb + (swap16 ? (k ^ 1u) : k)] << (8 * k);
+            uint32_t dc = c + off;
+            if (dc >= W) dc -= W;
+            store1(drow + (size_t)dc * es, v & keep, es);
+        }
+        return;
+    }
+    // ZPNG: thread t owns the contiguous pixels [t*seg, (t+1)*seg) of the row
+    const uint32_t seg = (W + 255) / 256, x0 = tid * seg, x1 = min(W, x0 + seg);
+    const uint8_t* src = (const uint8_t*)job.src;
+    const size_t plane = (size_t)W * a.h;   // bytes of one colour plane (3 / 4-byte pixels)
+    const bool planar = pb == 3 || pb == 4;
+    // residual of byte lane k of pixel x in this row (after the inverse colour transform)
+    auto resid = [&](uint32_t x, uint32_t k) -> uint32_t {
+        if (!planar) return src[((size_t)r * W + x) * pb + k];
+        const size_t i = (size_t)r * W + x;
+        const uint32_t y = src[i], u = src[plane + i], v = src[2 * plane + i];
+        const uint32_t G = (u + y) & 0xffu;
+        return k == 0 ? ((G - v) & 0xffu) : k == 1 ? G : k == 2 ? y : src[3 * plane + i];
+    };
+    uint64_t carry_in = 0;   // byte lane k of the running value just before my segment
+    for (uint32_t k = 0; k < pb; ++k) {
+        uint32_t sum = 0;
+        for (uint32_t x = x0; x < x1; ++x) sum += resid(x, k);
+        const uint32_t incl = block_incl_scan_u8(sum, s_wave);
+        carry_in |= (uint64_t)((incl - sum) & 0xffu) << (8 * k);
+    }
+    for (uint32_t x = x0; x < x1; ++x) {
+        uint64_t v = 0;
+        for (uint32_t k = 0; k < pb; ++k) {
+            const uint32_t b = (uint32_t)((carry_in >> (8 * k)) & 0xffu) + resid(x, k);
+            v |= (uint64_t)(b & 0xffu) << (8 * k);
+        }
+        carry_in = v;
+        store1(drow + (size_t)x * es, v & keep, es);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------
 size_t decode_lds_bytes(const Geometry& g, int tile, bool general) {
@@ -1011,6 +1089,11 @@ hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipSt
         if (separable) hipLaunchKernelGGL((k_dwf_emit<double, true, 64>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_dwf_emit<double, false, 64>), grid, dim3(256), 0, st, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_osf_unpack(const OsfUnpackArgs& a, uint32_t n_planes, hipStream_t st) {
+    hipLaunchKernelGGL(k_osf_unpack, dim3(a.h, n_planes), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -1048,6 +1048,51 @@ int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* l
     return OUSTER_HIP_OK;
 }
 
+// ---- OSF field planes ---------------------------------------------------------------------------
+int ouster_hip_osf_unpack(ouster_hip_ctx* ctx, const ouster_hip_osf_plane* planes, uint32_t n_planes,
+                          uint32_t h, uint32_t w, const int32_t* pixel_shift_by_row) {
+    if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n_planes == 0 || h == 0 || w == 0) return OUSTER_HIP_OK;
+    if (!planes) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "planes is NULL");
+    bool any_png = false;
+    for (uint32_t i = 0; i < n_planes; ++i) {
+        const ouster_hip_osf_plane& p = planes[i];
+        if (!p.src || !p.dst) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: NULL pointer", i);
+        const uint32_t e = p.dst_elem_size;
+        if (!(e == 1 || e == 2 || e == 4 || e == 8))
+            return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: unsupported element size %u", i, e);
+        static const uint32_t want[6] = {0, 1, 2, 3, 4, 8};
+        if (p.encoding >= OUSTER_HIP_OSF_PNG_GRAY8 && p.encoding <= OUSTER_HIP_OSF_PNG_RGBA16) {
+            if (p.src_pixel_bytes != want[p.encoding])
+                return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: pixel size does not match its PNG type", i);
+            any_png = true;
+        } else if (p.encoding == OUSTER_HIP_OSF_ZPNG) {
+            if (p.src_pixel_bytes == 0 || p.src_pixel_bytes > 8)
+                return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: ZPNG pixels are 1..8 bytes", i);
+        } else {
+            return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: unknown encoding %u", i, p.encoding);
+        }
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    OsfUnpackArgs a{};
+    a.h = h;
+    a.w = w;
+    if (any_png && pixel_shift_by_row) {  // stagger(img, px_offset) = destagger with inverse offsets
+        std::vector<int32_t> off;
+        dest_offsets(pixel_shift_by_row, h, w, 1, off);
+        if (ensure_offsets(ctx, off)) return fail(OUSTER_HIP_ERR_RUNTIME, "offset upload failed");
+        ctx->shifts_host.clear();
+        a.offsets = (const int32_t*)ctx->offsets.p;
+    }
+    const size_t bytes = (size_t)n_planes * sizeof(ouster_hip_osf_plane);
+    if (ctx->scratch.ensure(bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "scratch allocation failed");
+    HIP_TRY(hipMemcpyAsync(ctx->scratch.p, planes, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // `planes` is the caller's memory
+    a.planes = (const ouster_hip_osf_plane*)ctx->scratch.p;
+    HIP_TRY(launch_osf_unpack(a, n_planes, ctx->stream));
+    return OUSTER_HIP_OK;
+}
+
 int ouster_hip_last_decode_tile(ouster_hip_ctx* ctx, int* tile_cols, int* tile_rows) {
     if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (tile_cols) *tile_cols = ctx->last_tile_cols;

@@ -127,6 +127,13 @@ struct DewarpFramesArgs {
     uint64_t capacity;
 };
 
+// OSF field planes (ouster_hip_osf_unpack): the jobs live in a device array
+struct OsfUnpackArgs {
+    const ouster_hip_osf_plane* planes;  // device [n]
+    const int32_t* offsets;              // device [h]: stagger = destagger with inverse offsets
+    uint32_t h, w;
+};
+
 // one compile-time field of a standard profile (see the Spec* tables in the kernels file)
 struct FieldC {
     uint32_t offset;
@@ -146,5 +153,6 @@ hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream
 hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
 hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);
 hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st);
+hipError_t launch_osf_unpack(const OsfUnpackArgs& a, uint32_t n_planes, hipStream_t st);
 
 }  // namespace ouster_hip_dev

@@ -17,6 +17,7 @@
 
 #include "ouster/core/lidar_scan.h"
 #include "ouster/hip/frame_stream.h"
+#include "ouster/osf/osf.h"
 
 namespace py = pybind11;
 using namespace ouster::sdk::core;
@@ -439,6 +440,57 @@ PYBIND11_MODULE(core, m) {
             .def("finish", &oh::FrameStream::finish)
             .def_property_readonly("frames_pushed", &oh::FrameStream::frames_pushed)
             .def_property_readonly("frames_delivered", &oh::FrameStream::frames_delivered);
+    }
+
+    // OSF field planes (include/ouster/osf/osf.h): the container walk and the
+    // entropy decoding on the host, the pixel work of every field of a batch in one GPU launch
+    {
+        namespace oo = ouster::sdk::osf;
+        py::class_<oo::OsfFile>(m, "OsfFile")
+            .def(py::init<const std::string&>())
+            .def_property_readonly("version", &oo::OsfFile::version)
+            .def_property_readonly("id", &oo::OsfFile::id)
+            .def("metadata_types",
+                 [](const oo::OsfFile& f) {
+                     std::map<uint32_t, std::string> out;
+                     for (const auto& e : f.metadata_entries()) out[e.id] = e.type;
+                     return out;
+                 })
+            .def("sensor_metadata_json", &oo::OsfFile::sensor_metadata_json)
+            .def("lidar_scan_streams", &oo::OsfFile::lidar_scan_streams)
+            .def("messages", [](const oo::OsfFile& f) {
+                py::list out;
+                for (const auto& msg : f.messages())
+                    out.append(py::make_tuple(msg.ts, msg.id,
+                                              py::bytes(reinterpret_cast<const char*>(msg.buffer), msg.size)));
+                return out;
+            });
+        // host half only (no GPU): what is staged for the device per field of a LidarScanMsg
+        m.def("osf_stage_fields", [](const py::bytes& msg, size_t h, size_t w) {
+            const std::string b = msg;
+            oo::OsfFile::Message mm;
+            mm.buffer = reinterpret_cast<const uint8_t*>(b.data());
+            mm.size = b.size();
+            const oo::LidarScanMsgView v = oo::LidarScanMsgView::parse(mm);
+            py::list out;
+            for (const auto& f : v.fields) {
+                const oo::StagedField st = oo::stage_field(f, h, w);
+                out.append(py::make_tuple(f.name, static_cast<int>(f.type), st.encoding, st.src_pixel_bytes,
+                                          py::bytes(reinterpret_cast<const char*>(st.bytes.data()), st.bytes.size())));
+            }
+            return out;
+        });
+        py::class_<oo::OsfFrameDecoder>(m, "OsfFrameDecoder")
+            .def(py::init<const SensorInfo&, int>(), py::arg("info"), py::arg("device") = -1)
+            .def("decode", [](oo::OsfFrameDecoder& d, const std::vector<py::bytes>& msgs) {
+                std::vector<std::string> keep(msgs.begin(), msgs.end());
+                std::vector<oo::OsfFile::Message> mm(keep.size());
+                for (size_t i = 0; i < keep.size(); ++i) {
+                    mm[i].buffer = reinterpret_cast<const uint8_t*>(keep[i].data());
+                    mm[i].size = keep[i].size();
+                }
+                return d.decode(mm);
+            });
     }
 
     m.def("default_lidar_to_sensor", [] { return mat_to(DEFAULT_LIDAR_TO_SENSOR); });

@@ -12,6 +12,8 @@ import os
 import re
 import shutil
 
+import numpy as np
+
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 CAPTURES = [
@@ -25,7 +27,54 @@ CAPTURES = [
 ]
 
 
+# OSF fixtures of the reference (tests/osfs/): PNG-encoded (16-bit gray, RGBA), PNG with 8-bit planes,
+# ZPNG-encoded dual-return
+OSFS = ["OS-1-128_v2.3.0_1024x10_lb_n3.osf", "OS-0-128_v3.0.1_1024x10_20241017_141645.osf", "single_scan_016.osf"]
+
+
+def osf_goldens():
+    """Copies the OSF fixtures and pins the first one on the capture the reference wrote it from:
+    tests/pcaps/OS-1-128_v2.3.0_1024x10_lb_n3.pcap (too big to carry along) is decoded here with the
+    packet oracle (itself pinned on the reference's digests / snapshot hashes) and the sha256 of every
+    plane and column header of its three frames goes to osf/lb_n3_pcap_planes.json."""
+    import ctypes as C
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import oracle as O
+    dst = os.path.join(HERE, "osf")
+    os.makedirs(dst, exist_ok=True)
+    for name in OSFS:
+        shutil.copyfile(os.path.join(REF, "tests", "osfs", name), os.path.join(dst, name))
+    cal = O.calib_from_json(os.path.join(REF, "tests", "pcaps", "OS-1-128_v2.3.0_1024x10.json"))
+    pf = cal.packet_format()
+    pk = O.lidar_packets_from_pcap(os.path.join(REF, "tests", "pcaps", "OS-1-128_v2.3.0_1024x10_lb_n3.pcap"), pf)
+    fids = [O.lib().ora_frame_id(C.byref(pf), p.ctypes.data) for p in pk]
+    out = {}
+    for fid in sorted(set(fids)):
+        sel = [i for i, x in enumerate(fids) if x == fid]
+        fr = O.Frame.for_profile(cal.profile, cal.h, cal.w, cal.cpp, with_window=False)
+        fr.fill(0)
+        b = O.Batcher(pf, init_id=O.lib().ora_init_id(C.byref(pf), pk[sel[0]].ctypes.data), expected_packets=len(sel))
+        done = False
+        for i in sel:
+            done = b.batch(pk[i], 1 + i, fr)
+        if not done:
+            b.finalize(fr)
+        sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        entry = {"packets": len(sel)}
+        for n in ("RANGE", "REFLECTIVITY", "NEAR_IR"):
+            entry[n] = sha(fr.plane(n).astype(np.uint64))     # value digests: the OSF widens REFLECTIVITY to u16
+        entry["timestamp"], entry["status"], entry["measurement_id"] = sha(fr.timestamp), sha(fr.status), sha(fr.measurement_id)
+        out[str(fid)] = entry
+    with open(os.path.join(dst, "lb_n3_pcap_planes.json"), "w") as f:
+        json.dump({"source": "tests/pcaps/OS-1-128_v2.3.0_1024x10_lb_n3.pcap decoded by oracle/ (sha256 of the "
+                             "uint64-widened planes, raw headers)", "frames": out}, f, indent=1, sort_keys=True)
+    print("osf goldens:", {k: v["packets"] for k, v in out.items()})
+
+
 def main():
+    osf_goldens()
     dst = os.path.join(HERE, "pcaps")
     os.makedirs(dst, exist_ok=True)
     for base in CAPTURES:
