@@ -113,7 +113,8 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     int32_t* s_src = (int32_t*)(smem + (tile_bytes >> 2));      // [TILE] source slot (general modes)
     uint64_t* s_masks = (uint64_t*)(s_src + TILE);              // [0] valid, [1] group-ok / stray
     int32_t* s_off = (int32_t*)(s_masks + 4);                   // [H] destagger offsets
-    float4* s_xyz = (float4*)(s_off + ((H + 3) & ~3u));         // [4 waves][192] xyz transpose (OUSTER_XYZ_PERMUTE=0 builds)
+    double* s_beam = (double*)(s_off + ((H + 3) & ~3u));        // [H][9] per-beam xyz constants (a.beam_lds)
+    float4* s_xyz = (float4*)(s_beam + (a.beam_lds ? H * 9 + (H & 1) : 0));  // [4 waves][192] (OUSTER_XYZ_PERMUTE=0 builds)
     int32_t* s_pk = (int32_t*)((uint8_t*)s_xyz + XYZ_SCRATCH_BYTES);  // general modes, tile 0: [npo] packet map
     uint32_t* s_vb = (uint32_t*)(s_pk + npo);                   //   [(W+31)/32] valid-column bitmap, [+1] count
 
@@ -224,6 +225,8 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     if (a.any_destagger)
         for (uint32_t r = tid; r < H; r += NT) s_off[r] = a.dst_offsets[r];
     const LutDev lut = (XYZM != 0) ? a.luts[f % a.n_luts] : LutDev{};
+    if ((XYZM == 1 || XYZM == 2) && a.beam_lds)
+        for (uint32_t i = tid; i < H * 9; i += NT) s_beam[i] = lut.beam_tab[i];
     if (!fast) __syncthreads();
 
     // ---- phase 1: stage the tile's columns in LDS, column j at byte j*col_size
@@ -354,8 +357,8 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     // ---- phase 2b: pixels
     const uint32_t q = tid % (TILE / 4);
     const uint32_t vq = (uint32_t)(validmask >> (q * 4)) & 0xfu;
-    decode_rows<S, TILE / 4, XYZM>(a, s_tile, a.g.col_header_size >> 2, col_size >> 2, s_off, s_xyz, lut, f, c0,
-                                   0u, H, vq);
+    decode_rows<S, TILE / 4, XYZM>(a, s_tile, a.g.col_header_size >> 2, col_size >> 2, s_off, s_xyz,
+                                   ((XYZM == 1 || XYZM == 2) && a.beam_lds) ? s_beam : nullptr, lut, f, c0, 0u, H, vq);
 }
 
 // one workgroup per (frame, tile): the optimistic pass (MODE_FAST) or every frame through the
@@ -453,7 +456,8 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     uint32_t* s_valid = s_colofs + TW;                        // [TW] 1 = received, valid, at home
     uint32_t* s_acc = s_valid + TW;                           // [0] valid columns, [1] strays (+2 pad)
     int32_t* s_off = (int32_t*)(s_acc + 4);                   // [TR] destagger offsets of my rows
-    float4* s_xyz = (float4*)(s_off + ((TR + 3) & ~3u));      // [4 waves][192]
+    double* s_beam = (double*)(s_off + ((TR + 3) & ~3u));     // [TR][9] per-beam xyz constants of my rows
+    float4* s_xyz = (float4*)(s_beam + TR * 9 + (TR & 1));    // [4 waves][192] (OUSTER_XYZ_PERMUTE=0 builds)
 
     const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
     uint32_t count = a.slots_per_frame;
@@ -496,6 +500,8 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     if (a.any_destagger)
         for (uint32_t r = tid; r < nrows; r += NT) s_off[r] = a.dst_offsets[r0 + r];
     const LutDev lut = (XYZM != 0) ? a.luts[f % a.n_luts] : LutDev{};
+    if (XYZM == 1 || XYZM == 2)
+        for (uint32_t i = tid; i < nrows * 9; i += NT) s_beam[i] = lut.beam_tab[(size_t)r0 * 9 + i];
     __syncthreads();
 
     // ---- phase 1: stage my TR-row piece of every column, dword granular (packets are 4 B granular)
@@ -601,7 +607,8 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     uint32_t vq = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_valid[jq + c]) ? (1u << c) : 0u;
-    decode_rows<S, TW / 4, XYZM>(a, s_tile, 0u, slot, s_off, s_xyz, lut, f, c0, r0, nrows, vq);
+    decode_rows<S, TW / 4, XYZM>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr, lut, f,
+                                 c0, r0, nrows, vq);
 }
 
 // ------------------------------------------------------------------------------------
@@ -665,7 +672,7 @@ hipError_t OUSTER_SPEC_FN(launch_decode)(const DecodeArgs& a_in, int tile, int x
     const uint32_t tpf = a_in.tiles_per_frame;
     if (a_in.mode == MODE_FIXUP) {
         DecodeArgs a = a_in;
-        const size_t body = decode_lds_bytes(a.g, tile, true);
+        const size_t body = decode_lds_bytes(a.g, tile, true, a.beam_lds != 0);
         a.rows_per_tile = (uint32_t)body;  // where the frame list starts
         const size_t lds = body + FIXUP_CHUNK * 2;
         const uint64_t items = (uint64_t)a.n_frames * tpf;
@@ -680,7 +687,7 @@ hipError_t OUSTER_SPEC_FN(launch_decode)(const DecodeArgs& a_in, int tile, int x
     const DecodeArgs& a = a_in;
     const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * tpf : a.n_frames * tpf;
     const dim3 grid(nblocks);
-    const size_t lds = decode_lds_bytes(a.g, tile, a.mode != MODE_FAST);
+    const size_t lds = decode_lds_bytes(a.g, tile, a.mode != MODE_FAST, a.beam_lds != 0);
     switch (tile) {
         case 64: return launch_decode_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
         case 32: return launch_decode_t<SpecT, 32>(a, xyzm, grid, lds, device, st);

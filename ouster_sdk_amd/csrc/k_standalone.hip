@@ -927,10 +927,11 @@ __global__ __launch_bounds__(256) void k_osf_unpack(OsfUnpackArgs a) {
 // ------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------
-size_t decode_lds_bytes(const Geometry& g, int tile, bool general) {
+size_t decode_lds_bytes(const Geometry& g, int tile, bool general, bool beam_lds) {
     size_t tile_bytes = ((size_t)tile * g.col_size + 16 + 15) & ~(size_t)15;
     size_t h4 = (g.pixels_per_column + 3) & ~3u;
     size_t n = tile_bytes + (size_t)tile * 4 + 32 + h4 * 4 + XYZ_SCRATCH_BYTES;
+    if (beam_lds) n += ((size_t)g.pixels_per_column * 9 + (g.pixels_per_column & 1)) * 8;
     if (general) {  // tile 0: packet map [W / cpp] + valid-column bitmap [(W + 31) / 32] + its count
         const size_t npo = g.columns_per_frame / g.columns_per_packet;
         n += (npo + (g.columns_per_frame + 31) / 32 + 1) * 4;
@@ -940,7 +941,8 @@ size_t decode_lds_bytes(const Geometry& g, int tile, bool general) {
 }
 
 size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_slot) {
-    return ((size_t)tw * (lds_col_slot >> 2) + 4 + 2 * (size_t)tw + 4 + ((rows_per_tile + 3) & ~3u)) * 4 + XYZ_SCRATCH_BYTES;
+    return ((size_t)tw * (lds_col_slot >> 2) + 4 + 2 * (size_t)tw + 4 + ((rows_per_tile + 3) & ~3u)) * 4 +
+           ((size_t)rows_per_tile * 9 + (rows_per_tile & 1)) * 8 + XYZ_SCRATCH_BYTES;
 }
 
 #define OUSTER_DECL_SPEC(sfx)                                                                             \

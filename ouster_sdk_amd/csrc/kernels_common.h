@@ -424,11 +424,17 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_of(const Geometry& g
 //                  full LUT (XYZM 3); f32 xyz leaves through the wave-private LDS transpose
 // vq: bit c set = my column c holds a received, valid column (else zeros / f16 NaN are written).
 // ------------------------------------------------------------------------------------
+// s_beam: the tile rows' per-beam constants [nrows][9] in LDS, or nullptr to read them from the table in
+// global memory.  LDS matters far beyond the bytes: gfx950 counts loads and stores in ONE counter
+// (vmcnt) and they complete out of order with respect to each other, so a global load inside the row
+// loop makes the compiler wait `vmcnt(0)` -- for the load AND for every store the wave has in flight.
+// With the table in LDS (lgkmcnt) the loop contains no vector load and the stores of successive rows
+// stream without ever being waited for.
 template <class S, int QPR, int XYZM>
 __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t* s_tile,
                                             uint32_t col0_dw, uint32_t colstride_dw, const int32_t* s_off,
-                                            float4* s_xyz, const LutDev& lut, uint32_t f, uint32_t c0,
-                                            uint32_t r0, uint32_t nrows, uint32_t vq) {
+                                            float4* s_xyz, const double* s_beam, const LutDev& lut, uint32_t f,
+                                            uint32_t c0, uint32_t r0, uint32_t nrows, uint32_t vq) {
     constexpr int NT = 256;
     constexpr int LPR = QPR < 64 ? QPR : 64;             // lanes of one wave in a row segment
     constexpr int RPP = NT / QPR > 0 ? NT / QPR : 1;     // rows per pass of the workgroup
@@ -483,7 +489,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     v[c] = ((vq >> c) & 1) ? extract_static<S, K, CW>(w[c])
-                                           : trunc_elem(zero_value(a.f16_nan[di]), S::f[K].elem);
+                                           : trunc_elem(zero_value((a.f16_nan_mask >> di) & 1u), S::f[K].elem);
                 if (K == S::range_idx) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
                 if (K == S::range2_idx) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
                 constexpr uint32_t e = S::f[K].elem;
@@ -519,7 +525,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                     const uint32_t bo = ((col0_dw + (jq + c) * colstride_dw) << 2) + rrel * chan + a.bits[i].offset;
                     v[c] = ((vq >> c) & 1)
                                ? trunc_elem(apply_bits(window_lds(s_tile, bo), a.bits[i].mask, a.bits[i].shift), e)
-                               : trunc_elem(zero_value(a.f16_nan[i]), e);
+                               : trunc_elem(zero_value((a.f16_nan_mask >> i) & 1u), e);
                 }
                 if ((int)i == a.xyz_field[0]) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
                 if ((int)i == a.xyz_field[1]) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
@@ -541,7 +547,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
 
         if constexpr (XYZM == 1 || XYZM == 2) {
             using XT = typename std::conditional<XYZM == 1, float, double>::type;
-            const double* b = lut.beam_tab + (size_t)r * 9;  // 9 KB table, L1/L2 resident
+            const double* b = s_beam ? s_beam + (size_t)rrel * 9 : lut.beam_tab + (size_t)r * 9;
             const double u0 = b[0], u1 = b[1], u2 = b[2], v0 = b[3], v1 = b[4], v2 = b[5],
                          w0 = b[6], w1 = b[7], w2 = b[8];
             double d[4][3];

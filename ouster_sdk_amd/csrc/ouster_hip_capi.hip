@@ -78,6 +78,7 @@ struct Knobs {
     int xcd = 1;              // OUSTER_HIP_XCD: 0 disables the XCD-aware block -> frame mapping
     int fast = 1;             // OUSTER_HIP_FAST: 0 sends every frame through the general mapping
     int dewarp_single_pass = 0;  // OUSTER_HIP_DWF_SINGLE: 1 = k_dwf_single instead of count / scan / emit (slower)
+    int beam_lds = 1;         // OUSTER_HIP_BEAM_LDS: 0 keeps k_decode's per-beam table in global memory (A/B)
     int fixup = 1;            // tests only: 0 skips the fix-up pass (flagged frames are then left undone)
 };
 
@@ -276,6 +277,7 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.tune = env_int("OUSTER_HIP_TUNE", k.tune);
         k.xcd = env_int("OUSTER_HIP_XCD", k.xcd);
         k.fast = env_int("OUSTER_HIP_FAST", k.fast);
+        k.beam_lds = env_int("OUSTER_HIP_BEAM_LDS", k.beam_lds);
         k.dewarp_single_pass = env_int("OUSTER_HIP_DWF_SINGLE", k.dewarp_single_pass);
     }
     if (stream == OUSTER_HIP_STREAM_NULL) {
@@ -337,6 +339,7 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "xcd") k.xcd = value;
     else if (n == "fast") k.fast = value;
     else if (n == "fixup") k.fixup = value;
+    else if (n == "beam_lds") k.beam_lds = value;
     else if (n == "dewarp_single_pass") k.dewarp_single_pass = value;
     else return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unknown knob '%s'", name);
     return OUSTER_HIP_OK;
@@ -733,7 +736,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         da.destaggered[i] = out->destaggered[i];
         da.bits[i] = fmt->desc.fields[i].bits;
         da.elem[i] = (uint8_t)fmt->desc.fields[i].dst_elem_size;
-        da.f16_nan[i] = fmt->desc.fields[i].f16_nan_fill ? 1 : 0;
+        da.f16_nan_mask |= fmt->desc.fields[i].f16_nan_fill ? (1u << i) : 0u;
         const size_t fstride = npx * da.elem[i];
         if (out->planes[i]) vec_ok &= al16(out->planes[i]) && (fstride % 16 == 0);
         // destaggered stores are unaligned-capable; only 4-byte stores of sub-dword
@@ -760,16 +763,22 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // tile width: widest tile that still lets two workgroups share a CU's 160 KiB LDS
     int tile = 0;
     for (int t : {64, 32, 16})
-        if (decode_lds_bytes(g, t, true) <= 80 * 1024) { tile = t; break; }
+        if (decode_lds_bytes(g, t, true, false) <= 80 * 1024) { tile = t; break; }
     if (!tile)
         for (int t : {64, 32, 16})
-            if (decode_lds_bytes(g, t, true) <= 160 * 1024) { tile = t; break; }
+            if (decode_lds_bytes(g, t, true, false) <= 160 * 1024) { tile = t; break; }
     if (!tile) return fail(OUSTER_HIP_ERR_UNSUPPORTED, "column of %u bytes does not fit in LDS", g.col_size);
     // small batches: prefer narrower tiles so that at least ~2 workgroups per CU exist
     // (one 128x2048 frame is only 32 tiles of 64 columns -- latency, not bandwidth, bound)
     while (tile > 16 && (size_t)n_frames * ((W + tile - 1) / tile) < 512) tile /= 2;
-    if ((kn.tile == 64 || kn.tile == 32 || kn.tile == 16) && decode_lds_bytes(g, kn.tile, true) <= 160 * 1024)
+    if ((kn.tile == 64 || kn.tile == 32 || kn.tile == 16) && decode_lds_bytes(g, kn.tile, true, false) <= 160 * 1024)
         tile = kn.tile;
+    // the per-beam xyz table goes to LDS (no vector load left in the row loop: stores are never waited
+    // for) whenever that does not cost k_decode a workgroup per CU
+    if (xyzm == 1 || xyzm == 2) {
+        const size_t without = decode_lds_bytes(g, tile, true, false), with = decode_lds_bytes(g, tile, true, true);
+        da.beam_lds = (kn.beam_lds && with <= 160 * 1024 && (160 * 1024) / with == (160 * 1024) / without) ? 1u : 0u;
+    }
     // wide, short tiles (k_decode_wide): TW columns x TR rows with TW*TR*chan <= ~64 KB, TR chosen so that
     // the row chunks are equal.  Needs a batch large enough to fill the chip; fast mode only.
     const uint32_t narrow_tiles = (W + tile - 1) / tile;

@@ -54,6 +54,7 @@ struct DecodeArgs {
     uint32_t row_chunks;      //   bytes of one column's LDS slot (tiles_per_frame = column tiles)
     uint32_t lds_col_slot;
     uint32_t mode;            // DecodeMode
+    uint32_t beam_lds;        // k_decode: the per-beam xyz table is staged in LDS (it fits without costing a workgroup per CU)
     uint32_t n_packets_out;   // W / cpp: length of the packet-level outputs
     const uint32_t* packet_counts;    // device [n_frames], nullable (= slots_per_frame)
     const uint64_t* host_timestamps;  // device [n_frames][slots_per_frame], nullable
@@ -67,7 +68,7 @@ struct DecodeArgs {
     void* destaggered[OUSTER_HIP_MAX_FIELDS];
     ouster_hip_bits bits[OUSTER_HIP_MAX_FIELDS];
     uint8_t elem[OUSTER_HIP_MAX_FIELDS];
-    uint8_t f16_nan[OUSTER_HIP_MAX_FIELDS];
+    uint32_t f16_nan_mask;    // bit i: plane i's "zero" is the f16 NaN pattern (a register operand, never a memory read in the row loop)
     int8_t desc_of_spec[16];  // static spec field k -> index into planes[] (-1: not requested)
     uint64_t* timestamp;
     uint16_t* measurement_id;
@@ -144,7 +145,7 @@ struct FieldC {
 const FieldC* spec_fields(int spec_id, int* nf, uint32_t* chan, int* r1, int* r2);
 
 // LDS of one k_decode workgroup (the general modes add the per-frame packet map and valid bitmap)
-size_t decode_lds_bytes(const Geometry& g, int tile, bool general);
+size_t decode_lds_bytes(const Geometry& g, int tile, bool general, bool beam_lds);
 size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_slot);
 // device: HIP device ordinal of the stream (per-device cache of the one-off kernel attributes)
 hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, int device, hipStream_t st);
