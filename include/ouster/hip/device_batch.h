@@ -34,6 +34,10 @@ struct BatchOptions {
     /// columns are invalid by their status word) instead of uploading per-frame packet counts:
     /// keeps decode() free of host synchronisation, for the streaming pipeline (FrameStream).
     bool all_slots = false;
+    /// Range gate of the dewarp() that will follow decode(): when set (max >= min), decode() also counts
+    /// the gated RANGE pixels per column (they are in registers there) and dewarp(min, max) with the same
+    /// gate skips its counting pass over the RANGE planes.
+    double gate_min_range = 0.0, gate_max_range = -1.0;
     int device = -1;                      ///< GPU to work on (-1: hip::current_device() of the constructing thread)
     std::shared_ptr<Context> context;     ///< share this context (stream + scratch) instead of owning one
 };
@@ -120,6 +124,8 @@ class DeviceFrameBatch {
     std::map<std::string, DeviceBuffer> d_planes_, d_dst_;
     DeviceBuffer d_xyz_[2];
     int xyz_field_[2] = {-1, -1};
+    DeviceBuffer d_gate_;   // u16 [n_frames][8][w] kept counts per column (gate by-product of decode)
+    bool gate_valid_ = false;
     DeviceBuffer d_poses_, d_dw_pts_, d_dw_fi_, d_dw_ci_, d_dw_ts_, d_dw_off_;
     std::vector<uint64_t> dw_offsets_;
     bool dw_prov_ = false;

@@ -148,7 +148,18 @@ typedef struct ouster_hip_frame_out {
     int32_t xyz_field[2];       /* index into fields[]; -1 = unused */
     int32_t xyz_dtype;          /* OUSTER_HIP_F32 or OUSTER_HIP_F64 */
     int32_t reserved;
+    /* Optional by-product for a range-gated dewarp that follows (ouster_hip_dewarp_frames_counted): how
+     * many pixels of every column have gate_min_r <= value <= gate_max_r in the plane of field
+     * gate_field (raw range units, like the u32 min_r / max_r of impl/dewarp_impl.h:33-34).  The decode
+     * kernel has those values in registers, so the dewarp's counting pass over the RANGE plane
+     * disappears.  Layout: u16 [n_frames][OUSTER_HIP_GATE_CHUNKS][W] partial counts (a column's count is
+     * the sum over the chunk axis; unused chunks are written as zero).  NULL: not produced. */
+    uint16_t* gate_counts;
+    uint32_t gate_min_r, gate_max_r;
+    int32_t gate_field;         /* index into fields[] of a 32-bit range field */
+    int32_t reserved2;
 } ouster_hip_frame_out;
+#define OUSTER_HIP_GATE_CHUNKS 8
 
 /* ---- context ------------------------------------------------------------ */
 /* stream: an existing hipStream_t to order on (e.g. torch's current stream),
@@ -290,6 +301,19 @@ int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* l
                              double min_range, double max_range, int dtype, void* points,
                              uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
                              uint64_t capacity, uint64_t* frame_offsets);
+
+/* The same with the per-column kept counts already known: `gate_counts` as written by an
+ * ouster_hip_decode of the same frames with the same gate (ceil(min_range*1e3) / floor(max_range*1e3) on
+ * RANGE); the counting kernel is skipped.  gate_counts == NULL is ouster_hip_dewarp_frames. */
+int ouster_hip_dewarp_frames_counted(ouster_hip_ctx* ctx, const ouster_hip_lut* const* luts, uint32_t n_luts,
+                                     const uint32_t* range, const uint32_t* status,
+                                     const uint64_t* timestamp, const double* poses, uint32_t n_frames,
+                                     double min_range, double max_range, int dtype, void* points,
+                                     uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
+                                     uint64_t capacity, uint64_t* frame_offsets, const uint16_t* gate_counts);
+/* The raw gate ouster_hip_dewarp_frames derives from metres: min_r = ceil(min_range*1e3), max_r =
+ * floor(max_range*1e3), clamped to u32; returns 0 and sets *empty when nothing can pass. */
+int ouster_hip_range_gate(double min_range, double max_range, uint32_t* min_r, uint32_t* max_r, int* empty);
 
 /* ---- OSF field planes -------------------------------------------------------- */
 /* The device half of decode_field (ouster_osf/src/png_tools.cpp:664-745) for a batch of encoded

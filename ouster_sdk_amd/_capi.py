@@ -64,7 +64,14 @@ class FrameOut(C.Structure):
                 ("timestamp", C.c_void_p), ("measurement_id", C.c_void_p), ("status", C.c_void_p),
                 ("packet_timestamp", C.c_void_p), ("alert_flags", C.c_void_p),
                 ("frame_meta", C.c_void_p), ("xyz", C.c_void_p * 2), ("xyz_field", C.c_int32 * 2),
-                ("xyz_dtype", C.c_int32), ("reserved", C.c_int32)]
+                ("xyz_dtype", C.c_int32), ("reserved", C.c_int32),
+                ("gate_counts", C.c_void_p), ("gate_min_r", C.c_uint32), ("gate_max_r", C.c_uint32),
+                ("gate_field", C.c_int32), ("reserved2", C.c_int32)]
+
+
+class OsfPlane(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("encoding", C.c_uint32), ("src_pixel_bytes", C.c_uint32),
+                ("dst_elem_size", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # every symbol include/ouster_hip.h declares (checked by tests/test_abi.py)
@@ -74,7 +81,7 @@ ABI_SYMBOLS = [
     "ouster_hip_last_error", "ouster_hip_version", "ouster_hip_format_create",
     "ouster_hip_format_destroy", "ouster_hip_lut_create", "ouster_hip_lut_create_from_arrays",
     "ouster_hip_lut_export", "ouster_hip_lut_destroy", "ouster_hip_decode", "ouster_hip_destagger",
-    "ouster_hip_cartesian", "ouster_hip_osf_unpack", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_timing_enable", "ouster_hip_timing_read", "ouster_hip_last_decode_tile",
+    "ouster_hip_cartesian", "ouster_hip_osf_unpack", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_dewarp_frames_counted", "ouster_hip_range_gate", "ouster_hip_timing_enable", "ouster_hip_timing_read", "ouster_hip_last_decode_tile",
 ]
 
 _hip = None
@@ -124,6 +131,11 @@ def load_hip():
     L.ouster_hip_dewarp.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
     L.ouster_hip_dewarp_frames.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, C.c_double,
                                            C.c_double, C.c_int, vp, vp, vp, vp, C.c_uint64, vp]
+    if hasattr(L, "ouster_hip_dewarp_frames_counted"):
+        L.ouster_hip_dewarp_frames_counted.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, C.c_double,
+                                                       C.c_double, C.c_int, vp, vp, vp, vp, C.c_uint64, vp, vp]
+        L.ouster_hip_range_gate.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                            C.POINTER(C.c_int)]
     L.ouster_hip_timing_enable.argtypes = [vp, C.c_int]
     L.ouster_hip_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.ouster_hip_last_decode_tile.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]

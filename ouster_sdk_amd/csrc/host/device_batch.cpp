@@ -126,6 +126,20 @@ void DeviceFrameBatch::decode() {
         out.xyz[k] = xyz_field_[k] >= 0 ? d_xyz_[k].data() : nullptr;
     }
     for (const auto& l : luts_) luts.push_back(l.device().handle);
+    gate_valid_ = false;
+    if (opt_.gate_max_range >= opt_.gate_min_range) {
+        int gf = -1;
+        for (size_t i = 0; i < fields_.size(); ++i)
+            if (fields_[i].first == ChanField::RANGE) gf = static_cast<int>(i);
+        int empty = 0;
+        check(ouster_hip_range_gate(opt_.gate_min_range, opt_.gate_max_range, &out.gate_min_r, &out.gate_max_r, &empty));
+        if (gf >= 0 && !empty) {
+            d_gate_.resize(static_cast<size_t>(n_frames_) * OUSTER_HIP_GATE_CHUNKS * w_ * 2);
+            out.gate_counts = static_cast<uint16_t*>(d_gate_.data());
+            out.gate_field = gf;
+            gate_valid_ = true;
+        }
+    }
     check(ouster_hip_decode(default_ctx(), fmt_, static_cast<const uint8_t*>(d_packets_.data()), stride_,
                             slots_, opt_.all_slots ? nullptr : counts_.data(), n_frames_, nullptr, &out,
                             d_dst_.empty() ? nullptr : shifts_.data(), luts.empty() ? nullptr : luts.data(),
@@ -195,7 +209,9 @@ uint64_t DeviceFrameBatch::dewarp(double min_range, double max_range, bool prove
     }
     std::vector<const ouster_hip_lut*> luts;
     for (const auto& l : luts_) luts.push_back(l.device().handle);
-    check(ouster_hip_dewarp_frames(
+    // decode() already counted the gated pixels per column when it ran with this very gate
+    const bool counted = gate_valid_ && min_range == opt_.gate_min_range && max_range == opt_.gate_max_range;
+    check(ouster_hip_dewarp_frames_counted(
         default_ctx(), luts.data(), static_cast<uint32_t>(luts.size()),
         static_cast<const uint32_t*>(rp->second.data()), static_cast<const uint32_t*>(d_status_.data()),
         static_cast<const uint64_t*>(d_ts_.data()), static_cast<const double*>(d_poses_.data()), n_frames_,
@@ -203,7 +219,7 @@ uint64_t DeviceFrameBatch::dewarp(double min_range, double max_range, bool prove
         provenance ? static_cast<uint32_t*>(d_dw_fi_.data()) : nullptr,
         provenance ? static_cast<uint32_t*>(d_dw_ci_.data()) : nullptr,
         provenance ? static_cast<uint64_t*>(d_dw_ts_.data()) : nullptr, cap,
-        static_cast<uint64_t*>(d_dw_off_.data())));
+        static_cast<uint64_t*>(d_dw_off_.data()), counted ? static_cast<const uint16_t*>(d_gate_.data()) : nullptr));
     dw_offsets_.resize(static_cast<size_t>(n_frames_) + 1);
     d_dw_off_.download(dw_offsets_.data(), dw_offsets_.size() * 8);  // synchronous
     return dw_offsets_.back();

@@ -305,6 +305,11 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     }
     if (tid < 4) s_tile[(TILE * col_size >> 2) + tid] = 0;  // slack read by 64-bit windows
     __syncthreads();
+    uint32_t* s_gate = a.gate_counts ? (uint32_t*)s_src : nullptr;  // the slot map is dead after staging
+    if (s_gate) {
+        if (tid < TILE) s_gate[tid] = 0;
+        __syncthreads();
+    }
 
     if (fast) {
         // ---- the check that makes the optimism safe: classify my slots from the staged headers
@@ -358,7 +363,8 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     const uint32_t q = tid % (TILE / 4);
     const uint32_t vq = (uint32_t)(validmask >> (q * 4)) & 0xfu;
     decode_rows<S, TILE / 4, XYZM>(a, s_tile, a.g.col_header_size >> 2, col_size >> 2, s_off, s_xyz,
-                                   ((XYZM == 1 || XYZM == 2) && a.beam_lds) ? s_beam : nullptr, lut, f, c0, 0u, H, vq);
+                                   ((XYZM == 1 || XYZM == 2) && a.beam_lds) ? s_beam : nullptr, s_gate, lut, f, c0, 0u, H,
+                                   vq, 0u, 1u);
 }
 
 // one workgroup per (frame, tile): the optimistic pass (MODE_FAST) or every frame through the
@@ -456,7 +462,8 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     uint32_t* s_valid = s_colofs + TW;                        // [TW] 1 = received, valid, at home
     uint32_t* s_acc = s_valid + TW;                           // [0] valid columns, [1] strays (+2 pad)
     int32_t* s_off = (int32_t*)(s_acc + 4);                   // [TR] destagger offsets of my rows
-    double* s_beam = (double*)(s_off + ((TR + 3) & ~3u));     // [TR][9] per-beam xyz constants of my rows
+    uint32_t* s_gate = (uint32_t*)(s_off + ((TR + 3) & ~3u)); // [TW] range-gate counters
+    double* s_beam = (double*)(s_gate + TW);                  // [TR][9] per-beam xyz constants of my rows
     float4* s_xyz = (float4*)(s_beam + TR * 9 + (TR & 1));    // [4 waves][192] (OUSTER_XYZ_PERMUTE=0 builds)
 
     const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
@@ -496,6 +503,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
         s_colofs[j] = ofs;
     }
     if (tid < 4) s_acc[tid] = 0;
+    for (uint32_t j = tid; j < (uint32_t)TW; j += NT) s_gate[j] = 0;
     if (rc == 0 && tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_of(a.g, fbase, count > 0);
     if (a.any_destagger)
         for (uint32_t r = tid; r < nrows; r += NT) s_off[r] = a.dst_offsets[r0 + r];
@@ -607,8 +615,8 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     uint32_t vq = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_valid[jq + c]) ? (1u << c) : 0u;
-    decode_rows<S, TW / 4, XYZM>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr, lut, f,
-                                 c0, r0, nrows, vq);
+    decode_rows<S, TW / 4, XYZM>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
+                                 a.gate_counts ? s_gate : nullptr, lut, f, c0, r0, nrows, vq, rc, nch);
 }
 
 // ------------------------------------------------------------------------------------

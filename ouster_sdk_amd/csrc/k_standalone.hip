@@ -437,16 +437,26 @@ __global__ __launch_bounds__(256) void k_dwf_scan(DewarpFramesArgs a) {
     // contiguous segment per thread
     const uint32_t seg = (W + 255) / 256;
     const uint32_t x0 = tid * seg, x1 = min(W, x0 + seg);
+    // kept points per column: k_dwf_count's, or the decode kernel's range-gate by-product (partial counts
+    // per row chunk, summed here)
+    const uint16_t* ext = a.gate_counts ? a.gate_counts + (size_t)f * OUSTER_HIP_GATE_CHUNKS * W : nullptr;
+    auto kept = [&](uint32_t x) -> uint32_t {
+        if (!ext) return off[x];
+        uint32_t n = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < OUSTER_HIP_GATE_CHUNKS; ++k) n += ext[(size_t)k * W + x];
+        return n;
+    };
     uint32_t sum = 0;
     for (uint32_t x = x0; x < x1; ++x) {
         const bool keep = (int)x >= lo && (int)x <= hi && st[x] != 0;
-        sum += keep ? off[x] : 0u;
+        sum += keep ? kept(x) : 0u;
     }
     uint32_t total;
     uint32_t run = block_exscan_256(sum, s_wave, &total);
     for (uint32_t x = x0; x < x1; ++x) {
         const bool keep = (int)x >= lo && (int)x <= hi && st[x] != 0;
-        const uint32_t c = keep ? off[x] : 0u;
+        const uint32_t c = keep ? kept(x) : 0u;
         off[x] = run;
         run += c;
     }
@@ -941,7 +951,7 @@ size_t decode_lds_bytes(const Geometry& g, int tile, bool general, bool beam_lds
 }
 
 size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_slot) {
-    return ((size_t)tw * (lds_col_slot >> 2) + 4 + 2 * (size_t)tw + 4 + ((rows_per_tile + 3) & ~3u)) * 4 +
+    return ((size_t)tw * (lds_col_slot >> 2) + 4 + 3 * (size_t)tw + 4 + ((rows_per_tile + 3) & ~3u)) * 4 +
            ((size_t)rows_per_tile * 9 + (rows_per_tile & 1)) * 8 + XYZ_SCRATCH_BYTES;
 }
 
@@ -1080,7 +1090,7 @@ hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipSt
             return separable ? go(k_dwf_single<float, true, DWF_NT>) : go(k_dwf_single<float, false, DWF_NT>);
         return separable ? go(k_dwf_single<double, true, DWF_NT>) : go(k_dwf_single<double, false, DWF_NT>);
     }
-    hipLaunchKernelGGL(k_dwf_count, dim3(tiles, a.n_frames), dim3(256), 0, st, a);
+    if (!a.gate_counts) hipLaunchKernelGGL(k_dwf_count, dim3(tiles, a.n_frames), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dwf_scan, dim3(a.n_frames), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dwf_frame_scan, dim3(1), dim3(256), 0, st, a);
     const dim3 grid(tiles, a.n_frames);  // 64 x 64 emit tiles (32 x 128 measured 15 % slower)

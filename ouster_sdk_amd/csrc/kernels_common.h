@@ -430,11 +430,18 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_of(const Geometry& g
 // loop makes the compiler wait `vmcnt(0)` -- for the load AND for every store the wave has in flight.
 // With the table in LDS (lgkmcnt) the loop contains no vector load and the stores of successive rows
 // stream without ever being waited for.
+// s_gate: [QPR*4] LDS counters, zeroed by the caller before a barrier, or nullptr.  When set, the lanes
+// count the pixels of their columns that pass the range gate (a.gate_*), the counts are reduced in LDS
+// and the tile's partial counts go to a.gate_counts[f][gate_chunk][c0..] -- the dewarp that follows
+// skips its counting pass.  Every thread of the workgroup must call decode_rows (it ends in a barrier
+// when s_gate is set).
 template <class S, int QPR, int XYZM>
 __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t* s_tile,
                                             uint32_t col0_dw, uint32_t colstride_dw, const int32_t* s_off,
-                                            float4* s_xyz, const double* s_beam, const LutDev& lut, uint32_t f,
-                                            uint32_t c0, uint32_t r0, uint32_t nrows, uint32_t vq) {
+                                            float4* s_xyz, const double* s_beam, uint32_t* s_gate,
+                                            const LutDev& lut, uint32_t f, uint32_t c0, uint32_t r0,
+                                            uint32_t nrows, uint32_t vq, uint32_t gate_chunk,
+                                            uint32_t gate_nchunks) {
     constexpr int NT = 256;
     constexpr int LPR = QPR < 64 ? QPR : 64;             // lanes of one wave in a row segment
     constexpr int RPP = NT / QPR > 0 ? NT / QPR : 1;     // rows per pass of the workgroup
@@ -442,7 +449,9 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
     const uint32_t W = a.g.columns_per_frame, H = a.g.pixels_per_column;
     const uint32_t q = tid % QPR, ty = tid / QPR;
     const uint32_t jq = q * 4, col = c0 + jq;
-    if (col >= W) return;
+    const bool live = col < W;
+    if (!live && !s_gate) return;
+    uint32_t gcnt[4] = {0, 0, 0, 0};
     const bool vec = a.vec_ok && (col + 3 < W);
     const uint32_t ncol = (W - col) < 4 ? (W - col) : 4;  // < 4 only when W % 4 != 0
     const size_t plane_px = (size_t)H * W;
@@ -460,7 +469,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
         }
     }
 
-    for (uint32_t rrel = ty; rrel < nrows; rrel += RPP) {
+    for (uint32_t rrel = ty; live && rrel < nrows; rrel += RPP) {
         const uint32_t r = r0 + rrel;
         const size_t rowpix = (size_t)r * W + col;  // pixel index of my first column
         uint32_t doff = 0;                          // destaggered column of my first column
@@ -492,6 +501,11 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                                            : trunc_elem(zero_value((a.f16_nan_mask >> di) & 1u), S::f[K].elem);
                 if (K == S::range_idx) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
                 if (K == S::range2_idx) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
+                if (s_gate && di == a.gate_field) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        gcnt[c] += ((uint32_t)v[c] >= a.gate_min && (uint32_t)v[c] <= a.gate_max) ? 1u : 0u;
+                }
                 constexpr uint32_t e = S::f[K].elem;
                 uint8_t* pl = (uint8_t*)a.planes[di];
                 if (pl) {
@@ -515,9 +529,10 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
         } else {
             for (uint32_t i = 0; i < a.n_fields; ++i) {
                 const bool want_xyz = (XYZM != 0) && ((int)i == a.xyz_field[0] || (int)i == a.xyz_field[1]);
+                const bool want_gate = s_gate && (int)i == a.gate_field;
                 uint8_t* pl = (uint8_t*)a.planes[i];
                 uint8_t* dp = (uint8_t*)a.destaggered[i];
-                if (!pl && !dp && !want_xyz) continue;
+                if (!pl && !dp && !want_xyz && !want_gate) continue;
                 const uint32_t e = a.elem[i];
                 uint64_t v[4];
 #pragma unroll
@@ -529,6 +544,11 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                 }
                 if ((int)i == a.xyz_field[0]) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
                 if ((int)i == a.xyz_field[1]) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
+                if (want_gate) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        gcnt[c] += ((uint32_t)v[c] >= a.gate_min && (uint32_t)v[c] <= a.gate_max) ? 1u : 0u;
+                }
                 if (pl) {
                     uint8_t* d = pl + ((size_t)f * plane_px + rowpix) * e;
                     if (vec) store4(d, v, e);
@@ -606,6 +626,20 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                     else for (uint32_t c = 0; c < ncol; ++c) store_xyz1<double>(dst + c * 3, p[c]);
                 }
             }
+        }
+    }
+    if (s_gate) {   // uniform over the workgroup
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (gcnt[c] && col + c < W) atomicAdd(&s_gate[jq + c], gcnt[c]);
+        }
+        __syncthreads();
+        uint16_t* dst = a.gate_counts + ((size_t)f * OUSTER_HIP_GATE_CHUNKS + gate_chunk) * W;
+        for (uint32_t j = tid; j < (uint32_t)QPR * 4 && c0 + j < W; j += NT) {
+            dst[c0 + j] = (uint16_t)s_gate[j];
+            if (gate_chunk == 0)   // the chunk slots this launch does not use read as zero
+                for (uint32_t k = gate_nchunks; k < OUSTER_HIP_GATE_CHUNKS; ++k) dst[(size_t)k * W + c0 + j] = 0;
         }
     }
 }

@@ -636,6 +636,12 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     for (uint32_t i = 0; i < nf; ++i) any_dst |= out->destaggered[i] != nullptr;
     if (any_dst && !pixel_shift_by_row)
         return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "image height does not match shifts size");
+    if (out->gate_counts) {
+        const int gf = out->gate_field;
+        if (gf < 0 || (uint32_t)gf >= nf || fmt->desc.fields[gf].dst_elem_size != 4)
+            return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "gate_field must name a 32-bit range field");
+        if (H > 65535) return fail(OUSTER_HIP_ERR_UNSUPPORTED, "gate counts are 16-bit: more than 65535 rows");
+    }
     if (any_xyz) {
         if (!luts || n_luts == 0) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "xyz output needs a LUT");
         if (out->xyz_dtype != OUSTER_HIP_F32 && out->xyz_dtype != OUSTER_HIP_F64)
@@ -712,6 +718,10 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     da.packet_counts = d_counts;
     da.host_timestamps = host_timestamps;
     da.frame_state = (uint64_t*)ctx->state.p;
+    da.gate_counts = out->gate_counts;
+    da.gate_min = out->gate_min_r;
+    da.gate_max = out->gate_max_r;
+    da.gate_field = out->gate_counts ? out->gate_field : -1;
     da.tile_valid = (uint16_t*)ctx->tile_valid.p;
     da.dst_offsets = (const int32_t*)ctx->offsets.p;
     da.luts = (const LutDev*)ctx->luts.p;
@@ -799,6 +809,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         }
         if (kn.wide_rows > 0) tr = std::min((uint32_t)kn.wide_rows, H);
         nch = (H + tr - 1) / tr;
+        if (out->gate_counts && nch > OUSTER_HIP_GATE_CHUNKS) return false;  // one count slot per row chunk
         const uint32_t tiles = (W + want - 1) / want;
         if ((size_t)n_frames * tiles * nch < (size_t)std::max(kn.wide_min_blocks, 0)) return false;
         da.rows_per_tile = tr;
@@ -827,7 +838,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
                 pm |= da.planes[i] ? (1ull << i) : 0;
                 dm |= da.destaggered[i] ? (1ull << i) : 0;
             }
-            mix(pm); mix(dm); mix((da.xyz[0] ? 1u : 0u) | (da.xyz[1] ? 2u : 0u));
+            mix(pm); mix(dm); mix((da.xyz[0] ? 1u : 0u) | (da.xyz[1] ? 2u : 0u) | (da.gate_counts ? 4u : 0u));
             if (ctx->tune.size() > 64 && !ctx->tune.count(key)) {  // bounded: forget everything, re-learn
                 for (auto& kv : ctx->tune)
                     for (auto& pr : kv.second.ev)
@@ -990,12 +1001,33 @@ int ouster_hip_dewarp(ouster_hip_ctx* ctx, const void* points, const double* pos
 }
 
 // ---- range-gated, compacting frame dewarp ------------------------------------------------------
+int ouster_hip_range_gate(double min_range, double max_range, uint32_t* min_r, uint32_t* max_r, int* empty) {
+    // uint32_t min_r = ceil(min_range * 1e3), max_r = floor(max_range * 1e3): dewarp_impl.h:33-34
+    const double lo = std::ceil(min_range * 1e3), hi = std::floor(max_range * 1e3);
+    const bool none = !(hi >= 0) || !(lo <= 4294967295.0) || hi < lo;
+    if (empty) *empty = none ? 1 : 0;
+    if (min_r) *min_r = (none || lo <= 0) ? 0u : (uint32_t)lo;
+    if (max_r) *max_r = none ? 0u : (hi >= 4294967295.0 ? 0xffffffffu : (uint32_t)hi);
+    return OUSTER_HIP_OK;
+}
+
 int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* luts, uint32_t n_luts,
                              const uint32_t* range, const uint32_t* status,
                              const uint64_t* timestamp, const double* poses, uint32_t n_frames,
                              double min_range, double max_range, int dtype, void* points,
                              uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
                              uint64_t capacity, uint64_t* frame_offsets) {
+    return ouster_hip_dewarp_frames_counted(ctx, luts, n_luts, range, status, timestamp, poses, n_frames, min_range,
+                                            max_range, dtype, points, frame_idxs, col_idxs, timestamps_ns, capacity,
+                                            frame_offsets, nullptr);
+}
+
+int ouster_hip_dewarp_frames_counted(ouster_hip_ctx* ctx, const ouster_hip_lut* const* luts, uint32_t n_luts,
+                                     const uint32_t* range, const uint32_t* status,
+                                     const uint64_t* timestamp, const double* poses, uint32_t n_frames,
+                                     double min_range, double max_range, int dtype, void* points,
+                                     uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
+                                     uint64_t capacity, uint64_t* frame_offsets, const uint16_t* gate_counts) {
     if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (dtype != OUSTER_HIP_F32 && dtype != OUSTER_HIP_F64)
         return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "dtype must be F32 or F64");
@@ -1046,7 +1078,8 @@ int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* l
     a.max_r = hi >= 4294967295.0 ? 0xffffffffu : (uint32_t)hi;
     a.dtype = dtype;
     a.col_off = (uint32_t*)ctx->scratch.p;
-    a.tile_state = ctx->knobs.dewarp_single_pass ? (uint64_t*)((uint8_t*)ctx->scratch.p + col_off_bytes) : nullptr;
+    a.gate_counts = gate_counts;
+    a.tile_state = (ctx->knobs.dewarp_single_pass && !gate_counts) ? (uint64_t*)((uint8_t*)ctx->scratch.p + col_off_bytes) : nullptr;
     a.frame_off = frame_offsets;
     a.points = points;
     a.frame_idxs = frame_idxs;

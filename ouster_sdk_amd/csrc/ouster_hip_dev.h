@@ -59,6 +59,9 @@ struct DecodeArgs {
     const uint32_t* packet_counts;    // device [n_frames], nullable (= slots_per_frame)
     const uint64_t* host_timestamps;  // device [n_frames][slots_per_frame], nullable
     uint64_t* frame_state;            // device [2 + n_frames] scratch, see FS_* in kernels_common.h
+    uint16_t* gate_counts;            // device [n_frames][OUSTER_HIP_GATE_CHUNKS][W] or nullptr (range gate by-product)
+    uint32_t gate_min, gate_max;
+    int32_t gate_field;               // desc index of the gated range field
     uint16_t* tile_valid;             // device [n_frames][column tiles]: valid columns per tile (fast pass)
     const int32_t* dst_offsets;  // [H] destination column offset per row (device)
     const LutDev* luts;          // [n_luts] (device)
@@ -119,6 +122,7 @@ struct DewarpFramesArgs {
     uint32_t min_r, max_r;      // raw range units (mm), inclusive
     int32_t dtype;              // element type of points
     uint32_t* col_off;          // scratch [n_frames][w + 1] (three-kernel path)
+    const uint16_t* gate_counts; // [n_frames][OUSTER_HIP_GATE_CHUNKS][w] from the decode kernel, or nullptr (k_dwf_count runs)
     uint64_t* tile_state;       // scratch [128 + n_frames * tiles] (single-pass path; nullptr: three kernels)
     uint64_t* frame_off;        // out [n_frames + 1]: exclusive prefix of points per frame
     void* points;               // [capacity][3]

@@ -96,10 +96,20 @@ class HotPath:
         return out
 
     # -- the three operations --------------------------------------------------------------
+    def range_gate(self, min_range: float, max_range: float) -> Tuple[int, int, bool]:
+        """(min_r, max_r, empty): the raw gate ouster_hip_dewarp_frames derives from metres."""
+        lo, hi, e = C.c_uint32(), C.c_uint32(), C.c_int()
+        capi.check(self.ctx.L.ouster_hip_range_gate(float(min_range), float(max_range), C.byref(lo), C.byref(hi),
+                                                    C.byref(e)))
+        return lo.value, hi.value, bool(e.value)
+
     def decode(self, packets: torch.Tensor, out: Dict[str, torch.Tensor],
                packet_counts=None,
-               host_timestamps: Optional[torch.Tensor] = None):
-        """packets: uint8 CUDA tensor [n_frames, slots, packet_stride]."""
+               host_timestamps: Optional[torch.Tensor] = None,
+               gate: Optional[Tuple[float, float]] = None, gate_field: str = "RANGE"):
+        """packets: uint8 CUDA tensor [n_frames, slots, packet_stride].
+        gate = (min_range, max_range) in metres: also produce out["gate_counts"] (u16 [n, 8, W]), the
+        per-column kept counts a following dewarp_frames(..., gate_counts=...) with the same gate needs."""
         assert packets.is_cuda and packets.dtype == torch.uint8 and packets.is_contiguous()
         n_frames, slots, stride = packets.shape
         fo = capi.FrameOut()
@@ -122,6 +132,15 @@ class HotPath:
                      "alert_flags"):
             if name in out:
                 setattr(fo, name, out[name].data_ptr())
+        if gate is not None:
+            lo, hi, empty = self.range_gate(*gate)
+            if empty:
+                lo, hi = 1, 0   # nothing passes
+            if "gate_counts" not in out:
+                out["gate_counts"] = torch.empty((n_frames, 8, self.w), dtype=torch.uint16, device="cuda")
+            fo.gate_counts = out["gate_counts"].data_ptr()
+            fo.gate_min_r, fo.gate_max_r = lo, hi
+            fo.gate_field = self.field_index(gate_field)
         shifts_p = None
         if any_dst:
             if self.shifts is None:
@@ -190,7 +209,8 @@ class HotPath:
     def dewarp_frames(self, rng: torch.Tensor, status: torch.Tensor, poses: torch.Tensor,
                       min_range: float, max_range: float, timestamp: Optional[torch.Tensor] = None,
                       luts=None, dtype=torch.float32, provenance: bool = True,
-                      capacity: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                      capacity: Optional[int] = None,
+                      gate_counts: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Range-gated, compacting dewarp of a batch of frames (impl/dewarp_impl.h:23-115).
         rng [n, h, w] u32, status [n, w] u32, poses [n, w, 4, 4] f64, timestamp [n, w] u64.
         Returns {"points" [cap, 3], "frame_offsets" [n + 1] u64, and with provenance
@@ -215,12 +235,16 @@ class HotPath:
                 out["timestamps_ns"] = torch.empty(cap, dtype=torch.uint64, device="cuda")
         luts_arr = (C.c_void_p * max(len(luts), 1))(*[l.h for l in luts])
         ptr = lambda k: out[k].data_ptr() if k in out else None
-        capi.check(self.ctx.L.ouster_hip_dewarp_frames(
+        if gate_counts is not None:
+            assert gate_counts.is_cuda and gate_counts.dtype == torch.uint16 and gate_counts.is_contiguous()
+            assert tuple(gate_counts.shape) == (n, 8, self.w)
+        capi.check(self.ctx.L.ouster_hip_dewarp_frames_counted(
             self.ctx.h, luts_arr, len(luts), rng.data_ptr(), status.data_ptr(),
             timestamp.data_ptr() if timestamp is not None else None, poses.data_ptr(), n,
             float(min_range), float(max_range), capi.F32 if dtype == torch.float32 else capi.F64,
             out["points"].data_ptr(), ptr("frame_idxs"), ptr("col_idxs"), ptr("timestamps_ns"),
-            cap, out["frame_offsets"].data_ptr()))
+            cap, out["frame_offsets"].data_ptr(),
+            gate_counts.data_ptr() if gate_counts is not None else None))
         return out
 
     def sync(self):

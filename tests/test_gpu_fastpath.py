@@ -315,3 +315,39 @@ def test_bench_size_fused4_w2048(oracle):
                                          n_luts=4)
         assert tc == want_tc
         assert worst <= 4e-5
+
+
+@pytest.mark.parametrize("label,wide", VARIANTS)
+def test_range_gate_counts_feed_the_dewarp(oracle, label, wide):
+    """The decode kernels count, per column, the RANGE pixels inside a dewarp's range gate (by-product
+    `gate_counts`); a dewarp_frames with those counts skips its counting pass and must give exactly the
+    bytes of the stand-alone three-kernel dewarp -- on clean frames, frames with holes and frames that
+    went through the fix-up pass."""
+    O = oracle
+    cal = O.synthetic_calib(h=64, w=1024, profile="RNG15_RFL8_NIR8_DUAL")
+    pf = cal.packet_format()
+    n = 6
+    packets, src = O.synth_packets(cal, n, with_window=True)
+    host = packets.copy()
+    host[1, [3, 4]] = 0                                        # holes
+    sw = host[2].copy(); sw[[10, 11]] = sw[[11, 10]]; host[2] = sw   # strays -> fix-up pass
+    hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL", wide=wide, use_extrinsics=True)
+    out = hp.alloc_outputs(n, xyz=["RANGE"])
+    gate = (2.0, 90.0)
+    hp.decode(torch.from_numpy(host).cuda(), out, gate=gate)
+    hp.sync()
+    lo, hi, empty = hp.range_gate(*gate)
+    assert (lo, hi, empty) == (2000, 90000, False)
+    rng = out["RANGE"]
+    want = ((rng.to(torch.int64) >= lo) & (rng.to(torch.int64) <= hi)).sum(dim=1)          # [n, W]
+    got = out["gate_counts"].to(torch.int64).sum(dim=1)
+    assert torch.equal(got, want)
+    poses = torch.eye(4, dtype=torch.float64, device="cuda").repeat(n, cal.w, 1, 1).contiguous()
+    poses[:, :, 0, 3] = torch.arange(cal.w, device="cuda", dtype=torch.float64) * 0.01
+    a = hp.dewarp_frames(rng, out["status"], poses, *gate, timestamp=out["timestamp"])
+    b = hp.dewarp_frames(rng, out["status"], poses, *gate, timestamp=out["timestamp"], gate_counts=out["gate_counts"])
+    assert torch.equal(a["frame_offsets"], b["frame_offsets"])
+    tot = int(a["frame_offsets"][-1].item())
+    assert tot > 1000
+    for k in ("points", "frame_idxs", "col_idxs", "timestamps_ns"):
+        assert torch.equal(a[k][:tot].view(torch.uint8), b[k][:tot].view(torch.uint8)), k
