@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "ouster/core/lidar_frame.h"
+#include "ouster/core/xyzlut.h"
 #include "ouster/hip/context.h"
 
 namespace ouster {
@@ -98,6 +99,45 @@ struct StagedField {
  *  @throw std::runtime_error("decodeField: could not decode field") like the reference */
 StagedField stage_field(const EncodedField& f, size_t h, size_t w);
 
+/** A batch of OSF frames whose planes stay in HBM: plane `name` is [n_frames][H][W] elements, the layout
+ *  ouster_hip_decode produces, so ouster_hip_destagger / ouster_hip_cartesian / ouster_hip_dewarp_frames (or
+ *  their C++ faces below) run on it unchanged and nothing crosses PCIe but the inflated pixel bytes. */
+class OsfDeviceBatch {
+   public:
+    uint32_t n_frames() const { return n_; }
+    size_t h() const { return h_; }
+    size_t w() const { return w_; }
+    const std::vector<std::pair<std::string, core::ChanFieldType>>& fields() const { return fields_; }
+    /** device pointer of plane `name`, [n_frames][h][w].  @throw std::out_of_range */
+    void* plane_device(const std::string& name) const;
+    /** host copies of the per-frame headers (they come straight from the flatbuffer) */
+    const std::vector<int32_t>& frame_ids() const { return frame_ids_; }
+    const std::vector<uint64_t>& timestamps() const { return ts_; }            ///< [n_frames][w]
+    const std::vector<uint32_t>& status() const { return status_; }            ///< [n_frames][w]
+    /** destagger<T>() of plane `name` for every frame, on the device; returns the device pointer of
+     *  the result (owned by the batch, valid until the next call for the same name). */
+    void* destagger_device(const std::string& name);
+    /** XYZLutT<float|double>::operator() of plane `range_field` for every frame, on the device:
+     *  [n_frames][h*w][3]; owned by the batch. */
+    void* cartesian_device(const core::XYZLut& lut, bool f64 = false, const std::string& range_field = core::ChanField::RANGE);
+    void download(const void* device_ptr, void* host, size_t bytes) const;
+    const std::shared_ptr<hip::Context>& context() const { return ctx_; }
+
+   private:
+    friend class OsfFrameDecoder;
+    std::shared_ptr<hip::Context> ctx_;
+    core::SensorInfo info_;
+    uint32_t n_ = 0;
+    size_t h_ = 0, w_ = 0;
+    std::vector<std::pair<std::string, core::ChanFieldType>> fields_;
+    std::shared_ptr<void> planes_;               // one HBM allocation, planes at plane_off_
+    std::map<std::string, size_t> plane_off_;
+    std::map<std::string, std::shared_ptr<void>> derived_;
+    std::vector<int32_t> frame_ids_;
+    std::vector<uint64_t> ts_;
+    std::vector<uint32_t> status_;
+};
+
 /** Decodes LidarScan messages of one sensor into LidarFrames, the pixel work on the GPU. */
 class OsfFrameDecoder {
    public:
@@ -108,6 +148,9 @@ class OsfFrameDecoder {
      *  @throw std::runtime_error / std::invalid_argument like the reference's reader */
     std::vector<core::LidarFrame> decode(const std::vector<OsfFile::Message>& msgs);
     core::LidarFrame decode(const OsfFile::Message& msg) { return std::move(decode(std::vector<OsfFile::Message>{msg})[0]); }
+    /** The same decode, results left in HBM (all messages must carry the same fields).
+     *  @throw std::invalid_argument when the messages' field lists differ */
+    OsfDeviceBatch decode_device(const std::vector<OsfFile::Message>& msgs);
 
    private:
     struct Impl;

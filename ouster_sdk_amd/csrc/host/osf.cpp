@@ -479,6 +479,130 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
     return frames;
 }
 
+// ---------------------------------------------------------------------------------------
+// device-resident batches
+// ---------------------------------------------------------------------------------------
+namespace {
+std::shared_ptr<void> device_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) throw std::runtime_error("ouster_hip: hipMalloc failed");
+    return std::shared_ptr<void>(p, [](void* q) { (void)hipFree(q); });
+}
+}  // namespace
+
+OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message>& msgs) {
+    Impl& s = *impl_;
+    OsfDeviceBatch b;
+    b.info_ = s.info;
+    b.h_ = s.info.format.pixels_per_column;
+    b.w_ = s.info.format.columns_per_frame;
+    b.n_ = static_cast<uint32_t>(msgs.size());
+    if (msgs.empty()) return b;
+    const size_t h = b.h_, w = b.w_, n = msgs.size();
+    auto al = [](size_t x) { return (x + 255) & ~size_t{255}; };
+    struct Job { size_t frame, field; StagedField st; size_t src_off; };
+    std::vector<Job> jobs;
+    size_t src_total = 0;
+    for (size_t m = 0; m < n; ++m) {
+        const LidarScanMsgView v = LidarScanMsgView::parse(msgs[m]);
+        if (m == 0) {
+            for (const auto& f : v.fields) b.fields_.emplace_back(f.name, f.type);
+        } else {
+            bool same = v.fields.size() == b.fields_.size();
+            for (size_t i = 0; same && i < v.fields.size(); ++i)
+                same = v.fields[i].name == b.fields_[i].first && v.fields[i].type == b.fields_[i].second;
+            if (!same) throw std::invalid_argument("OsfFrameDecoder::decode_device: messages carry different fields");
+        }
+        b.frame_ids_.push_back(v.frame_id);
+        b.ts_.resize((m + 1) * w, 0);
+        b.status_.resize((m + 1) * w, 0);
+        if (v.n_timestamp == w) std::memcpy(b.ts_.data() + m * w, v.timestamp, w * 8);
+        if (v.n_status == w) std::memcpy(b.status_.data() + m * w, v.status, w * 4);
+        for (size_t i = 0; i < v.fields.size(); ++i) {
+            if (v.fields[i].size == 0) continue;
+            Job j{m, i, stage_field(v.fields[i], h, w), src_total};
+            src_total += al(j.st.bytes.size());
+            jobs.push_back(std::move(j));
+        }
+    }
+    hip::ScopedContext on_my_context(s.context());
+    b.ctx_ = s.ctx;
+    size_t dst_total = 0;
+    for (const auto& f : b.fields_) {
+        b.plane_off_[f.first] = dst_total;
+        dst_total += al(n * h * w * field_type_size(f.second));
+    }
+    b.planes_ = device_alloc(dst_total);
+    auto st = static_cast<hipStream_t>(s.ctx->stream());
+    if (hipMemsetAsync(b.planes_.get(), 0, dst_total, st) != hipSuccess) throw std::runtime_error("ouster_hip: memset failed");
+    if (jobs.empty()) return b;
+    s.d_src.resize(src_total);
+    std::vector<uint8_t> staging(src_total);
+    for (const auto& j : jobs) std::memcpy(staging.data() + j.src_off, j.st.bytes.data(), j.st.bytes.size());
+    s.d_src.upload(staging.data(), src_total);
+    std::vector<ouster_hip_osf_plane> planes(jobs.size());
+    bool any_png = false;
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        const auto& f = b.fields_[jobs[i].field];
+        const size_t esz = field_type_size(f.second);
+        planes[i].src = static_cast<const uint8_t*>(s.d_src.data()) + jobs[i].src_off;
+        planes[i].dst = static_cast<uint8_t*>(b.planes_.get()) + b.plane_off_[f.first] + jobs[i].frame * h * w * esz;
+        planes[i].encoding = jobs[i].st.encoding;
+        planes[i].src_pixel_bytes = jobs[i].st.src_pixel_bytes;
+        planes[i].dst_elem_size = static_cast<uint32_t>(esz);
+        planes[i].reserved = 0;
+        any_png |= jobs[i].st.encoding != OUSTER_HIP_OSF_ZPNG;
+    }
+    std::vector<int32_t> shifts(s.info.format.pixel_shift_by_row.begin(), s.info.format.pixel_shift_by_row.end());
+    if (any_png && !shifts.empty() && shifts.size() != h)
+        throw std::invalid_argument("image height does not match shifts size");
+    hip::check(ouster_hip_osf_unpack(s.ctx->handle(), planes.data(), static_cast<uint32_t>(planes.size()),
+                                     static_cast<uint32_t>(h), static_cast<uint32_t>(w),
+                                     shifts.empty() ? nullptr : shifts.data()));
+    return b;
+}
+
+void* OsfDeviceBatch::plane_device(const std::string& name) const {
+    return static_cast<uint8_t*>(planes_.get()) + plane_off_.at(name);
+}
+
+void* OsfDeviceBatch::destagger_device(const std::string& name) {
+    hip::ScopedContext on_my_context(ctx_);
+    size_t esz = 0;
+    for (const auto& f : fields_)
+        if (f.first == name) esz = field_type_size(f.second);
+    if (!esz) throw std::out_of_range("OsfDeviceBatch: no plane '" + name + "'");
+    auto out = device_alloc(static_cast<size_t>(n_) * h_ * w_ * esz);
+    std::vector<int32_t> sh(info_.format.pixel_shift_by_row.begin(), info_.format.pixel_shift_by_row.end());
+    hip::check(ouster_hip_destagger(ctx_->handle(), plane_device(name), out.get(), static_cast<uint32_t>(h_),
+                                    static_cast<uint32_t>(w_), static_cast<uint32_t>(esz), sh.data(),
+                                    static_cast<uint32_t>(sh.size()), 0, n_));
+    derived_["destaggered:" + name] = out;
+    return out.get();
+}
+
+void* OsfDeviceBatch::cartesian_device(const XYZLut& lut, bool f64, const std::string& range_field) {
+    hip::ScopedContext on_my_context(ctx_);
+    bool ok = false;
+    for (const auto& f : fields_) ok |= f.first == range_field && f.second == ChanFieldType::UINT32;
+    if (!ok) throw std::invalid_argument("OsfDeviceBatch::cartesian_device needs a uint32 plane '" + range_field + "'");
+    if (lut.h != h_ || lut.w != w_) throw std::invalid_argument("unexpected image dimensions");
+    auto out = device_alloc(static_cast<size_t>(n_) * h_ * w_ * 3 * (f64 ? 8 : 4));
+    hip::check(ouster_hip_cartesian(ctx_->handle(), lut.device().handle,
+                                    static_cast<const uint32_t*>(plane_device(range_field)), out.get(),
+                                    f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32, n_));
+    derived_[std::string("xyz:") + range_field] = out;
+    return out.get();
+}
+
+void OsfDeviceBatch::download(const void* device_ptr, void* host, size_t bytes) const {
+    hip::ScopedContext on_my_context(ctx_);
+    auto st = static_cast<hipStream_t>(ctx_->stream());
+    if (hipMemcpyAsync(host, device_ptr, bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        throw std::runtime_error("ouster_hip: download failed");
+}
+
 }  // namespace osf
 }  // namespace sdk
 }  // namespace ouster

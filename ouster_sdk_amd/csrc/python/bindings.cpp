@@ -490,6 +490,40 @@ PYBIND11_MODULE(core, m) {
                     mm[i].size = keep[i].size();
                 }
                 return d.decode(mm);
+            })
+            .def("decode_device", [](oo::OsfFrameDecoder& d, const std::vector<py::bytes>& msgs) {
+                std::vector<std::string> keep(msgs.begin(), msgs.end());
+                std::vector<oo::OsfFile::Message> mm(keep.size());
+                for (size_t i = 0; i < keep.size(); ++i) {
+                    mm[i].buffer = reinterpret_cast<const uint8_t*>(keep[i].data());
+                    mm[i].size = keep[i].size();
+                }
+                return d.decode_device(mm);
+            });
+        // planes that stay in HBM: pointers are plain integers, downloads go through numpy arrays
+        py::class_<oo::OsfDeviceBatch>(m, "OsfDeviceBatch")
+            .def_property_readonly("n_frames", &oo::OsfDeviceBatch::n_frames)
+            .def_property_readonly("h", &oo::OsfDeviceBatch::h)
+            .def_property_readonly("w", &oo::OsfDeviceBatch::w)
+            .def_property_readonly("frame_ids", &oo::OsfDeviceBatch::frame_ids)
+            .def("fields", [](const oo::OsfDeviceBatch& b) {
+                py::dict out;
+                for (const auto& f : b.fields()) out[py::str(f.first)] = static_cast<int>(f.second);
+                return out;
+            })
+            .def("plane_ptr", [](const oo::OsfDeviceBatch& b, const std::string& n) {
+                return reinterpret_cast<uintptr_t>(b.plane_device(n));
+            })
+            .def("destagger_ptr", [](oo::OsfDeviceBatch& b, const std::string& n) {
+                return reinterpret_cast<uintptr_t>(b.destagger_device(n));
+            })
+            .def("cartesian_ptr", [](oo::OsfDeviceBatch& b, const XYZLut& lut, bool f64, const std::string& n) {
+                return reinterpret_cast<uintptr_t>(b.cartesian_device(lut, f64, n));
+            }, py::arg("lut"), py::arg("f64") = false, py::arg("range_field") = std::string(ChanField::RANGE))
+            .def("download", [](const oo::OsfDeviceBatch& b, uintptr_t ptr, py::array out) {
+                if (!(out.flags() & py::array::c_style) || !out.writeable())
+                    throw std::invalid_argument("download needs a writeable C-contiguous array");
+                b.download(reinterpret_cast<const void*>(ptr), out.mutable_data(), static_cast<size_t>(out.nbytes()));
             });
     }
 

@@ -76,3 +76,45 @@ def test_osf_frames_match_oracle(oracle, path):
                             np.asarray(info.beam_azimuth_angles), np.asarray(info.beam_altitude_angles))
     want = O.cartesian(rng, d_, o_)
     assert np.abs(np.asarray(xyz).reshape(-1, 3) - want).max() <= 1e-9
+
+
+@pytest.mark.parametrize("path", [LB, ZPNG])
+def test_osf_device_batch_stays_in_hbm(oracle, path):
+    """decode_device leaves [n][H][W] planes in HBM; destagger / cartesian run on them there and only the
+    results are downloaded -- identical to the host-returning decode and to the oracle."""
+    from oracle import osf_oracle as Z
+    from ouster_sdk_amd import core
+    O = oracle
+    zf = Z.OsfFile(path)
+    meta = list(zf.sensor_metadata().values())[0]
+    h, w, shifts = _geometry(meta)
+    pf = core.OsfFile(path)
+    streams = pf.lidar_scan_streams()
+    msgs = [m for (_, sid, m) in pf.messages() if sid in streams]
+    info = _sensor_info(core, meta)
+    dec = core.OsfFrameDecoder(info)
+    frames = dec.decode(msgs)
+    b = dec.decode_device(msgs)
+    assert (b.n_frames, b.h, b.w) == (len(msgs), h, w)
+    assert list(b.frame_ids) == [f.frame_id for f in frames]
+    for name in b.fields():
+        want = np.stack([f.field(name) for f in frames])
+        got = np.empty_like(want)
+        b.download(b.plane_ptr(name), got)
+        assert np.array_equal(got, want), name
+    rng = np.stack([f.field("RANGE") for f in frames])
+    ds = np.empty_like(rng)
+    b.download(b.destagger_ptr("RANGE"), ds)
+    sh = np.array(shifts, np.int32)
+    for i in range(len(frames)):
+        assert np.array_equal(ds[i], O.destagger(rng[i], sh))
+    lut = core.XYZLut(info, False)
+    d_, o_ = O.make_xyz_lut(w, h, 0.001, np.asarray(info.beam_to_lidar_transform), np.asarray(info.lidar_to_sensor_transform),
+                            np.asarray(info.beam_azimuth_angles), np.asarray(info.beam_altitude_angles))
+    for f64, tol in ((True, 1e-9), (False, 1e-4)):
+        xyz = np.empty((len(frames), h * w, 3), np.float64 if f64 else np.float32)
+        b.download(b.cartesian_ptr(lut, f64), xyz)
+        for i in range(len(frames)):
+            assert np.abs(xyz[i].astype(np.float64) - O.cartesian(rng[i], d_, o_)).max() <= tol
+    with pytest.raises(IndexError):
+        b.plane_ptr("NOPE")
