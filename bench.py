@@ -273,9 +273,9 @@ def main():
             dist.barrier()
 
     # setup, like building the LUT: let the library's per-workload kernel-variant tuner finish
-    # (it times three tile shapes twice on the first six calls), so the W
+    # (it times three tile shapes four times on the first twelve calls), so the W
     # warm-up steps and the K timed steps all run the variant it settled on
-    for _ in range(7):
+    for _ in range(14):
         hp.decode(packets, out)
     torch.cuda.synchronize()
     for _ in range(args.warmup):

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
 
     // ---- classify my columns (every row chunk needs the validity; the first one also publishes)
     {
-        uint32_t n_valid = 0, n_stray = 0;
+        uint32_t n_valid = 0, n_stray = 0, n_dead = 0;
 #pragma unroll
         for (int k = 0; k < NJ; ++k) {
             const uint32_t j = tid + (uint32_t)k * NT, c = c0 + j;
@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             bool stray = live && m_id != c;
             const bool v = live && !stray;
             s_valid[j] = v ? 1u : 0u;
+            n_dead += (!v && c < W) ? 1u : 0u;
             if (rc != 0 || c >= W) continue;
             if (c == p * cpp) {  // batch_lidar_packet, lidar_frame.cpp:1534-1539
                 const bool want_pk = a.packet_timestamp || a.alert_flags;
@@ -604,10 +605,20 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             if (n_valid) atomicAdd(&s_acc[0], n_valid);
             if (n_stray) atomicAdd(&s_acc[1], n_stray);
         }
+        if (n_dead) atomicAdd(&s_acc[2], n_dead);
     }
     __syncthreads();
     if (rc == 0 && tid == 0) {
         fast_publish(a, f, tile, s_acc[0], s_acc[1] != 0);
+    }
+    // Columns that were not received (or are invalid / not at home) decode as zeros: blank their
+    // slots once, here, so that the row loop needs no per-pixel select.  Rare, hence the uniform test.
+    if (s_acc[2] != 0) {
+        const uint32_t piece = ((nrows * chan) >> 2) + 1;   // + the pad dword 64-bit windows may touch
+        for (uint32_t j = tid >> 2; j < (uint32_t)TW; j += NT / 4)
+            if (!s_valid[j])
+                for (uint32_t i = tid & 3u; i < piece && i < slot; i += 4) s_tile[j * slot + i] = 0;
+        __syncthreads();
     }
 
     // ---- pixels.  lane = (row within pass, quad of 4 consecutive columns)
@@ -615,7 +626,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     uint32_t vq = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_valid[jq + c]) ? (1u << c) : 0u;
-    decode_rows<S, TW / 4, XYZM>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
+    decode_rows<S, TW / 4, XYZM, S::is_static>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
                                  a.gate_counts ? s_gate : nullptr, lut, f, c0, r0, nrows, vq, rc, nch);
 }
 

@@ -237,25 +237,23 @@ __device__ __forceinline__ uint64_t extract_static(const uint32_t (&w)[CW]) {
 //   full LUT (user arrays / per-pixel angle sensors): xyz = r*dir + ofs in the
 //   LUT's own precision, as cartesianT<T> does (cartesian.h:53-65).
 // ------------------------------------------------------------------------------------
-template <class T>
-__device__ __forceinline__ void store_xyz4(T* dst, const double (&p)[4][3]);
-
-template <>
-__device__ __forceinline__ void store_xyz4<float>(float* dst, const double (&p)[4][3]) {
-    float4* d = (float4*)dst;  // 48 B, 16 B aligned (pixel index multiple of 4)
-    d[0] = make_float4((float)p[0][0], (float)p[0][1], (float)p[0][2], (float)p[1][0]);
-    d[1] = make_float4((float)p[1][1], (float)p[1][2], (float)p[2][0], (float)p[2][1]);
-    d[2] = make_float4((float)p[2][2], (float)p[3][0], (float)p[3][1], (float)p[3][2]);
-}
-template <>
-__device__ __forceinline__ void store_xyz4<double>(double* dst, const double (&p)[4][3]) {
-    double2* d = (double2*)dst;
-    d[0] = make_double2(p[0][0], p[0][1]);
-    d[1] = make_double2(p[0][2], p[1][0]);
-    d[2] = make_double2(p[1][1], p[1][2]);
-    d[3] = make_double2(p[2][0], p[2][1]);
-    d[4] = make_double2(p[2][2], p[3][0]);
-    d[5] = make_double2(p[3][1], p[3][2]);
+// P = precision the points are held in (double, or already rounded to the output type)
+template <class T, class P>
+__device__ __forceinline__ void store_xyz4(T* dst, const P (&p)[4][3]) {
+    if constexpr (sizeof(T) == 4) {
+        float4* d = (float4*)dst;  // 48 B, 16 B aligned (pixel index multiple of 4)
+        d[0] = make_float4((float)p[0][0], (float)p[0][1], (float)p[0][2], (float)p[1][0]);
+        d[1] = make_float4((float)p[1][1], (float)p[1][2], (float)p[2][0], (float)p[2][1]);
+        d[2] = make_float4((float)p[2][2], (float)p[3][0], (float)p[3][1], (float)p[3][2]);
+    } else {
+        double2* d = (double2*)dst;
+        d[0] = make_double2(p[0][0], p[0][1]);
+        d[1] = make_double2(p[0][2], p[1][0]);
+        d[2] = make_double2(p[1][1], p[1][2]);
+        d[3] = make_double2(p[2][0], p[2][1]);
+        d[4] = make_double2(p[2][2], p[3][0]);
+        d[5] = make_double2(p[3][1], p[3][2]);
+    }
 }
 
 // f32 xyz of 4 consecutive pixels per lane = 48 contiguous bytes per lane.  Stored directly,
@@ -263,9 +261,9 @@ __device__ __forceinline__ void store_xyz4<double>(double* dst, const double (&p
 // segment.  Instead the wave transposes through a private LDS scratch so that instruction k
 // writes chunks [k*LPR, (k+1)*LPR) of the row segment: LPR x 16 B contiguous per row.
 //   row_base: xyz address of the first pixel of this lane's row segment (tile column 0)
-template <int LPR>
+template <int LPR, class P>
 __device__ __forceinline__ void store_xyz4_coalesced(float4* s_xyz, uint32_t tid, float* row_base,
-                                                     uint32_t q, const double (&p)[4][3]) {
+                                                     uint32_t q, const P (&p)[4][3]) {
     const uint32_t wave = tid >> 6, lane = tid & 63u, rho = lane / LPR;
     float4* sc = s_xyz + wave * 192 + rho * (3 * LPR);
     sc[3 * q + 0] = make_float4((float)p[0][0], (float)p[0][1], (float)p[0][2], (float)p[1][0]);
@@ -291,8 +289,8 @@ __device__ __forceinline__ void store_xyz4_coalesced(float4* s_xyz, uint32_t tid
 // 3s + j == d (mod LPR) from lane s = (d - j) * 3^-1 mod LPR -- a bijection because LPR is a power
 // of two -- and files it under k = (3s + j) / LPR.  Frees the 12 KB scratch (one more 12 B/px
 // workgroup per CU).
-template <int LPR>
-__device__ __forceinline__ void store_xyz4_permuted(float* row_base, uint32_t q, const double (&p)[4][3]) {
+template <int LPR, class P>
+__device__ __forceinline__ void store_xyz4_permuted(float* row_base, uint32_t q, const P (&p)[4][3]) {
     static_assert(LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32 || LPR == 64, "row segment lanes");
     constexpr uint32_t INV3 = LPR == 64 ? 43u : (LPR >= 16 ? 11u : 3u);  // 3 * INV3 == 1 (mod LPR)
     const uint32_t lane = threadIdx.x & 63u, seg = lane - q;             // first lane of my row segment
@@ -345,8 +343,8 @@ __device__ __forceinline__ void load_quad_coalesced(float4* sc, const float4* ro
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <class T>
-__device__ __forceinline__ void store_xyz1(T* dst, const double (&p)[3]) {
+template <class T, class P>
+__device__ __forceinline__ void store_xyz1(T* dst, const P (&p)[3]) {
     dst[0] = (T)p[0]; dst[1] = (T)p[1]; dst[2] = (T)p[2];
 }
 
@@ -435,7 +433,7 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_of(const Geometry& g
 // and the tile's partial counts go to a.gate_counts[f][gate_chunk][c0..] -- the dewarp that follows
 // skips its counting pass.  Every thread of the workgroup must call decode_rows (it ends in a barrier
 // when s_gate is set).
-template <class S, int QPR, int XYZM>
+template <class S, int QPR, int XYZM, bool DEADZ = false>
 __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t* s_tile,
                                             uint32_t col0_dw, uint32_t colstride_dw, const int32_t* s_off,
                                             float4* s_xyz, const double* s_beam, uint32_t* s_gate,
@@ -488,7 +486,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
             for (int c = 0; c < 4; ++c) {
                 const uint32_t* px = s_tile + col0_dw + (jq + c) * colstride_dw + rrel * CW;
 #pragma unroll
-                for (int k = 0; k < CW; ++k) w[c][k] = px[k];
+                for (int k = 0; k < CW; ++k) w[c][k] = (DEADZ || ((vq >> c) & 1)) ? px[k] : 0u;
             }
             auto do_field = [&](auto kc_) {
                 constexpr int K = decltype(kc_)::value;
@@ -496,9 +494,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                 if (di < 0) return;
                 uint64_t v[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    v[c] = ((vq >> c) & 1) ? extract_static<S, K, CW>(w[c])
-                                           : trunc_elem(zero_value((a.f16_nan_mask >> di) & 1u), S::f[K].elem);
+                for (int c = 0; c < 4; ++c) v[c] = extract_static<S, K, CW>(w[c]);
                 if (K == S::range_idx) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
                 if (K == S::range2_idx) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
                 if (s_gate && di == a.gate_field) {
@@ -581,13 +577,16 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
             for (int ret = 0; ret < 2; ++ret) {
                 XT* out = (XT*)a.xyz[ret];
                 if (!out) continue;
-                double p[4][3];
+                XT p[4][3];   // rounded to the output type before the zero-range select (same value, half the selects)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const uint32_t rr = rng[ret][c];
                     const double rm = (double)rr - lut.n;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) p[c][k] = rr ? fma(rm, d[c][k], kc[c][k]) : 0.0;
+                    for (int k = 0; k < 3; ++k) {
+                        const XT t = (XT)fma(rm, d[c][k], kc[c][k]);
+                        p[c][k] = rr ? t : (XT)0;
+                    }
                 }
                 XT* dst = out + ((size_t)f * plane_px + rowpix) * 3;
                 if constexpr (XYZM == 1) {

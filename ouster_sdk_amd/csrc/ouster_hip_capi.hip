@@ -108,8 +108,9 @@ struct ouster_hip_ctx {
     struct Tune {
         int best = -2;  // -2: still measuring; 0: narrow; 128 / 256: wide
         int calls = 0;
-        hipEvent_t ev[6][2] = {};  // two rounds x three candidates
-        float ms[3] = {0, 0, 0};   // fastest sample of each candidate
+        static constexpr int ROUNDS = 4, SAMPLES = 3 * ROUNDS;
+        hipEvent_t ev[SAMPLES][2] = {};  // three candidates x ROUNDS consecutive launches
+        float ms[3] = {0, 0, 0};         // fastest warm sample of each candidate
     };
     std::map<uint64_t, Tune> tune;
     int last_tile_cols = 0, last_tile_rows = 0;  // tile of the last k_decode launch
@@ -848,20 +849,29 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             }
             ouster_hip_ctx::Tune& t = ctx->tune[key];
             static const int cand[3] = {256, 128, 0};
-            // two rounds over the candidates (single launches vary by ~10 %, mostly upwards: each
-            // candidate's faster sample counts).  The clocks are polled, never waited for: until all
-            // six samples have landed the default variant runs.
-            if (t.best == -2 && t.calls >= 6) {
+            // Four launches of each candidate, back to back (a launch that follows a different variant
+            // is not representative of the steady state: alternating the candidates made the 64-column
+            // kernel look 8 % faster than it then ran).  Single launches vary by ~10 %, mostly upwards,
+            // and the candidates can be within 1-5 % of each other: each candidate's fastest sample
+            // counts, its first one (cold code, cold TLB, another variant's write-backs still draining)
+            // only when nothing else landed.  The clocks are polled, never waited for: until all samples
+            // have landed the default variant runs.
+            constexpr int NS = ouster_hip_ctx::Tune::SAMPLES;
+            if (t.best == -2 && t.calls >= NS) {
                 bool all = true;
-                for (int i = 0; i < 6 && all; ++i) all = hipEventQuery(t.ev[i][1]) == hipSuccess;
+                for (int i = 0; i < NS && all; ++i) all = hipEventQuery(t.ev[i][1]) == hipSuccess;
                 if (!all) (void)hipGetLastError();
                 else {
-                    for (int i = 0; i < 6; ++i) {
+                    float cold[3] = {0, 0, 0};
+                    for (int i = 0; i < NS; ++i) {
                         float ms = 0;
-                        if (hipEventElapsedTime(&ms, t.ev[i][0], t.ev[i][1]) == hipSuccess && ms > 0 &&
-                            (t.ms[i % 3] == 0 || ms < t.ms[i % 3]))
-                            t.ms[i % 3] = ms;
+                        if (hipEventElapsedTime(&ms, t.ev[i][0], t.ev[i][1]) != hipSuccess || ms <= 0) continue;
+                        constexpr int R = ouster_hip_ctx::Tune::ROUNDS;
+                        float& slot = (i % R == 0) ? cold[i / R] : t.ms[i / R];
+                        if (slot == 0 || ms < slot) slot = ms;
                     }
+                    for (int c = 0; c < 3; ++c)
+                        if (t.ms[c] == 0) t.ms[c] = cold[c];
                     t.best = 256;
                     float best_ms = 0;
                     for (int c = 0; c < 3; ++c)
@@ -870,9 +880,9 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             }
             if (t.best != -2) {
                 wide = t.best;
-            } else if (t.calls < 6) {
+            } else if (t.calls < NS) {
                 tune_slot = t.calls;
-                wide = cand[tune_slot % 3];
+                wide = cand[tune_slot / ouster_hip_ctx::Tune::ROUNDS];
                 tuning = &t;
                 ++t.calls;
             }

@@ -573,7 +573,7 @@ def test_wide_tiles_match_oracle(oracle, monkeypatch, tw, profile, h, w, hdr):
 
 def test_variant_tuner_is_transparent(oracle):
     """A batch large enough for the per-workload tuner (>= 512 workgroups): the first calls run the
-    256-wide, 128-wide and 64-column kernels in turn (two rounds), then the fastest; every call must produce the
+    256-wide, 128-wide and 64-column kernels (four launches each), then the fastest; every call must produce the
     same bytes, and they must match the oracle."""
     O = oracle
     cal = O.synthetic_calib(h=128, w=2048, profile="RNG15_RFL8_NIR8_DUAL")
@@ -585,7 +585,7 @@ def test_variant_tuner_is_transparent(oracle):
     d_pk = torch.from_numpy(packets).cuda().repeat(n // 4, 1, 1).contiguous()
     dst = ["RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"]
     seen, first = [], None
-    for call in range(9):
+    for call in range(15):
         out = hp.alloc_outputs(n, destagger=dst, xyz=["RANGE", "RANGE2"])
         for t in out.values():
             t.view(torch.uint8).fill_(0xA5)
@@ -598,8 +598,8 @@ def test_variant_tuner_is_transparent(oracle):
         else:
             for k in first:
                 assert torch.equal(first[k].view(torch.uint8), snap[k].view(torch.uint8)), (call, k, seen)
-    assert {s[0] for s in seen[:3]} == {256, 128, 64} == {s[0] for s in seen[3:6]}, seen  # two rounds
-    assert seen[6] == seen[7] == seen[8], seen                     # then the winner, every time
+    assert [s[0] for s in seen[:12]] == [256] * 4 + [128] * 4 + [64] * 4, seen      # four launches each
+    assert seen[12] == seen[13] == seen[14], seen                  # then the winner, every time
     ldir, lofs = cal.xyz_lut(True)
     for f in (0, 5, 31):
         fr = src[f % 4]
