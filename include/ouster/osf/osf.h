@@ -148,6 +148,10 @@ class OsfFrameDecoder {
      *  @throw std::runtime_error / std::invalid_argument like the reference's reader */
     std::vector<core::LidarFrame> decode(const std::vector<OsfFile::Message>& msgs);
     core::LidarFrame decode(const OsfFile::Message& msg) { return std::move(decode(std::vector<OsfFile::Message>{msg})[0]); }
+    /** decode_field() of png_tools.cpp:664-745 for standalone encoded fields (each an H x W image of its
+     *  type), all in one launch: returns the staggered planes as raw little-endian bytes, one per field.
+     *  @throw std::runtime_error("decodeField: could not decode field") */
+    std::vector<std::vector<uint8_t>> decode_fields(const std::vector<EncodedField>& fields);
     /** The same decode, results left in HBM (all messages must carry the same fields).
      *  @throw std::invalid_argument when the messages' field lists differ */
     OsfDeviceBatch decode_device(const std::vector<OsfFile::Message>& msgs);

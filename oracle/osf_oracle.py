@@ -16,7 +16,9 @@ Restates, in plain Python / numpy (zlib from the standard library, libzstd.so.1 
                        GB-RG transform
 Pinned: tests/test_oracle_osf.py decodes the reference's own tests/osfs/OS-1-128_v2.3.0_1024x10_lb_n3.osf and
 compares every plane and header with the frames the (golden-pinned) packet oracle batches from the pcap
-the reference wrote that file from (tests/pcaps/OS-1-128_v2.3.0_1024x10_lb_n3.pcap).
+the reference wrote that file from (tests/pcaps/OS-1-128_v2.3.0_1024x10_lb_n3.pcap); the ZPNG codec against the
+reference's own zpng.cpp compiled into oracle/_ref/libzpng_ref.so (oracle/Makefile) and the vectors it produced
+(tests/golden/osf/zpng_ref_vectors.json).
 """
 from __future__ import annotations
 

@@ -479,6 +479,57 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
     return frames;
 }
 
+std::vector<std::vector<uint8_t>> OsfFrameDecoder::decode_fields(const std::vector<EncodedField>& fields) {
+    Impl& s = *impl_;
+    const size_t h = s.info.format.pixels_per_column, w = s.info.format.columns_per_frame;
+    auto al = [](size_t x) { return (x + 255) & ~size_t{255}; };
+    std::vector<std::vector<uint8_t>> out(fields.size());
+    std::vector<StagedField> staged(fields.size());
+    std::vector<size_t> src_off(fields.size()), dst_off(fields.size());
+    std::vector<ouster_hip_osf_plane> planes;
+    size_t src_total = 0, dst_total = 0;
+    for (size_t i = 0; i < fields.size(); ++i) {
+        const size_t esz = field_type_size(fields[i].type);
+        out[i].assign(h * w * esz, 0);
+        if (fields[i].size == 0) continue;
+        staged[i] = stage_field(fields[i], h, w);
+        src_off[i] = src_total;
+        dst_off[i] = dst_total;
+        src_total += al(staged[i].bytes.size());
+        dst_total += al(h * w * esz);
+    }
+    if (!src_total) return out;
+    hip::ScopedContext on_my_context(s.context());
+    s.d_src.resize(src_total);
+    s.d_dst.resize(dst_total);
+    std::vector<uint8_t> staging(src_total);
+    bool any_png = false;
+    for (size_t i = 0; i < fields.size(); ++i) {
+        if (fields[i].size == 0) continue;
+        std::memcpy(staging.data() + src_off[i], staged[i].bytes.data(), staged[i].bytes.size());
+        ouster_hip_osf_plane pl{};
+        pl.src = static_cast<const uint8_t*>(s.d_src.data()) + src_off[i];
+        pl.dst = static_cast<uint8_t*>(s.d_dst.data()) + dst_off[i];
+        pl.encoding = staged[i].encoding;
+        pl.src_pixel_bytes = staged[i].src_pixel_bytes;
+        pl.dst_elem_size = static_cast<uint32_t>(field_type_size(fields[i].type));
+        planes.push_back(pl);
+        any_png |= staged[i].encoding != OUSTER_HIP_OSF_ZPNG;
+    }
+    s.d_src.upload(staging.data(), src_total);
+    std::vector<int32_t> shifts(s.info.format.pixel_shift_by_row.begin(), s.info.format.pixel_shift_by_row.end());
+    if (any_png && !shifts.empty() && shifts.size() != h)
+        throw std::invalid_argument("image height does not match shifts size");
+    hip::check(ouster_hip_osf_unpack(s.ctx->handle(), planes.data(), static_cast<uint32_t>(planes.size()),
+                                     static_cast<uint32_t>(h), static_cast<uint32_t>(w),
+                                     shifts.empty() ? nullptr : shifts.data()));
+    std::vector<uint8_t> host(dst_total);
+    s.d_dst.download(host.data(), dst_total);
+    for (size_t i = 0; i < fields.size(); ++i)
+        if (fields[i].size) std::memcpy(out[i].data(), host.data() + dst_off[i], out[i].size());
+    return out;
+}
+
 // ---------------------------------------------------------------------------------------
 // device-resident batches
 // ---------------------------------------------------------------------------------------

@@ -74,6 +74,7 @@ __device__ __forceinline__ uint64_t trunc_elem(uint64_t v, uint32_t elem) {
 // unaligned-capable vector stores (gfx950 global stores only need the HW
 // "unaligned access mode", which amdhsa enables; the compiler emits single
 // global_store_dword{,x2,x4} for these packed types)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(1))) pk4 { uint32_t a; };
 struct __attribute__((packed, aligned(1))) pk8 { uint32_t a, b; };
 struct __attribute__((packed, aligned(1))) pk16 { uint32_t a, b, c, d; };
@@ -130,6 +131,19 @@ __device__ __forceinline__ void store1(uint8_t* p, uint64_t v, uint32_t elem) {
             *(uint16_t*)(p + 4) = (uint16_t)(v >> 32);
             break;
         default: *(uint64_t*)p = v;
+    }
+}
+
+// the same for values of at most 4 bytes held as one register quad (the static profiles): a u32 plane's
+// four elements ARE the 16 B store operand, nothing is moved
+__device__ __forceinline__ void store4v(uint8_t* p, const u32x4_t& v, uint32_t elem) {
+    switch (elem) {
+        case 1: st4(p, v.x | (v.y << 8) | (v.z << 16) | (v.w << 24)); break;
+        case 2: st8(p, v.x | (v.y << 16), v.z | (v.w << 16)); break;
+        default: {
+            struct __attribute__((packed, aligned(1))) pkv { u32x4_t v; };
+            ((pkv*)p)->v = v;
+        }
     }
 }
 
@@ -492,27 +506,28 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                 constexpr int K = decltype(kc_)::value;
                 const int di = a.desc_of_spec[K];
                 if (di < 0) return;
-                uint64_t v[4];
+                constexpr uint32_t e = S::f[K].elem;
+                static_assert(e <= 4, "static profiles carry fields of at most 4 bytes");
+                u32x4_t v;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = extract_static<S, K, CW>(w[c]);
+                for (int c = 0; c < 4; ++c) v[c] = (uint32_t)extract_static<S, K, CW>(w[c]);
                 if (K == S::range_idx) { rng[0][0] = v[0]; rng[0][1] = v[1]; rng[0][2] = v[2]; rng[0][3] = v[3]; }
                 if (K == S::range2_idx) { rng[1][0] = v[0]; rng[1][1] = v[1]; rng[1][2] = v[2]; rng[1][3] = v[3]; }
                 if (s_gate && di == a.gate_field) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        gcnt[c] += ((uint32_t)v[c] >= a.gate_min && (uint32_t)v[c] <= a.gate_max) ? 1u : 0u;
+                        gcnt[c] += (v[c] >= a.gate_min && v[c] <= a.gate_max) ? 1u : 0u;
                 }
-                constexpr uint32_t e = S::f[K].elem;
                 uint8_t* pl = (uint8_t*)a.planes[di];
                 if (pl) {
                     uint8_t* d = pl + ((size_t)f * plane_px + rowpix) * e;
-                    if (vec) store4(d, v, e);
+                    if (vec) store4v(d, v, e);
                     else for (uint32_t c = 0; c < ncol; ++c) store1(d + c * e, v[c], e);
                 }
                 uint8_t* dp = (uint8_t*)a.destaggered[di];
                 if (dp) {
                     uint8_t* drow = dp + ((size_t)f * plane_px + (size_t)r * W) * e;
-                    if (dvec) store4(drow + (size_t)doff * e, v, e);
+                    if (dvec) store4v(drow + (size_t)doff * e, v, e);
                     else for (uint32_t c = 0; c < ncol; ++c) {
                         uint32_t dc = doff + c; if (dc >= W) dc -= W;
                         store1(drow + (size_t)dc * e, v[c], e);

@@ -491,6 +491,20 @@ PYBIND11_MODULE(core, m) {
                 }
                 return d.decode(mm);
             })
+            .def("decode_fields", [](oo::OsfFrameDecoder& d, const std::vector<std::pair<py::bytes, int>>& blobs) {
+                // [(encoded bytes, ChanFieldType value)] -> [bytes of the H x W plane]
+                std::vector<std::string> keep;
+                for (const auto& b : blobs) keep.emplace_back(b.first);
+                std::vector<oo::EncodedField> ff(keep.size());
+                for (size_t i = 0; i < keep.size(); ++i) {
+                    ff[i].type = static_cast<ChanFieldType>(blobs[i].second);
+                    ff[i].data = reinterpret_cast<const uint8_t*>(keep[i].data());
+                    ff[i].size = keep[i].size();
+                }
+                std::vector<py::bytes> out;
+                for (const auto& v : d.decode_fields(ff)) out.emplace_back(reinterpret_cast<const char*>(v.data()), v.size());
+                return out;
+            })
             .def("decode_device", [](oo::OsfFrameDecoder& d, const std::vector<py::bytes>& msgs) {
                 std::vector<std::string> keep(msgs.begin(), msgs.end());
                 std::vector<oo::OsfFile::Message> mm(keep.size());

@@ -118,3 +118,41 @@ def test_osf_device_batch_stays_in_hbm(oracle, path):
             assert np.abs(xyz[i].astype(np.float64) - O.cartesian(rng[i], d_, o_)).max() <= tol
     with pytest.raises(IndexError):
         b.plane_ptr("NOPE")
+
+
+def test_zpng_fields_of_the_reference_codec(oracle):
+    """ouster_hip_osf_unpack's ZPNG path (zstd on the host, prefix sums + colour transform on the GPU)
+    against planes the REFERENCE's ZPNG_Compress produced: the committed vectors, and -- where
+    oracle/_ref/libzpng_ref.so travelled with the snapshot -- freshly compressed full-size planes."""
+    import zpng_ref
+    from ouster_sdk_amd import core
+    from test_oracle_osf import _zpng_vectors, _sha
+    h, w, vec = _zpng_vectors()
+    tag = {1: 1, 2: 2, 4: 3, 8: 4}   # itemsize -> ChanFieldType UINT8 / 16 / 32 / 64 (chanfield.h)
+
+    def decoder(hh, ww):
+        info = core.SensorInfo()
+        fmt = core.DataFormat()
+        fmt.pixels_per_column, fmt.columns_per_frame, fmt.columns_per_packet = hh, ww, 16
+        fmt.pixel_shift_by_row = [0] * hh
+        fmt.udp_profile_lidar = core.UDPProfileLidar.from_string("RNG19_RFL8_SIG16_NIR16")
+        info.format = fmt
+        return core.OsfFrameDecoder(info)
+
+    names = list(vec)
+    planes = decoder(h, w).decode_fields([(vec[n][1], int(tag[vec[n][0].itemsize])) for n in names])   # one launch
+    for n, raw in zip(names, planes):
+        dt, _, sha = vec[n]
+        assert len(raw) == h * w * dt.itemsize and _sha(np.frombuffer(raw, dt)) == sha, n
+    if not zpng_ref.available():
+        return
+    rng = np.random.default_rng(11)
+    hh, ww = 128, 1024
+    want, blobs = [], []
+    for dt in (np.uint8, np.uint16, np.uint32, np.uint64):
+        p = rng.integers(0, np.iinfo(dt).max, (hh, ww), dtype=np.uint64, endpoint=True).astype(dt)
+        p[:, 1::2] = p[:, ::2] + 3                         # compressible: neighbouring columns correlate
+        want.append(p)
+        blobs.append((zpng_ref.compress(p), int(tag[np.dtype(dt).itemsize])))
+    for p, raw in zip(want, decoder(hh, ww).decode_fields(blobs)):
+        assert np.array_equal(np.frombuffer(raw, p.dtype).reshape(hh, ww), p), p.dtype

@@ -8,8 +8,11 @@
     PNG filters, zstd) equals the oracle's, block for block and byte for byte, on the PNG and the ZPNG
     fixtures -- no GPU involved;
   * corrupted files fail loudly like the reference's reader.
-ZPNG: the reference holds no golden for a ZPNG plane; the oracle restates thirdparty/zpng/zpng.cpp and is
-checked for self-consistency only (parity unpinned for that codec).
+ZPNG: the reference's tests hold no golden for a ZPNG plane, but its codec is one self-contained file:
+oracle/Makefile compiles /root/reference/thirdparty/zpng/zpng.cpp into oracle/_ref/libzpng_ref.so, and the
+restatement in osf_oracle.py is pinned on it three ways -- the reference decoder on the reference's own
+ZPNG fixture, reference-compressed random planes of every layout, and the committed vectors of
+tests/golden/osf/zpng_ref_vectors.json (made by tests/golden/make_zpng_golden.py) where the library is absent.
 """
 import hashlib
 import json
@@ -93,7 +96,7 @@ def test_host_half_matches_the_oracle(path):
 
 
 def test_zpng_oracle_self_consistency():
-    """No reference golden exists for ZPNG planes: check the restated codec against its own inverse
+    """Independent of the reference library: check the restated codec against its own inverse
     (left-delta + GB-RG filter of zpng.cpp:69-100, 243-297 re-applied to the decoded plane reproduces the
     residuals) and the decoded values against the masks the wire format allows."""
     from oracle import osf_oracle as Z
@@ -148,3 +151,55 @@ def test_corrupted_files_fail_loudly(tmp_path):
         core.osf_stage_fields(broken, h, w)
     with pytest.raises(RuntimeError, match="Invalid allocation"):   # ZPNG image of another size
         core.osf_stage_fields(good, h, w // 2)
+
+
+def _zpng_vectors():
+    import base64
+    d = json.load(open(os.path.join(OSF_DIR, "zpng_ref_vectors.json")))
+    return d["h"], d["w"], {k: (np.dtype(v["dtype"]), base64.b64decode(v["zpng"]), v["sha256"])
+                            for k, v in d["vectors"].items()}
+
+
+def test_zpng_oracle_decodes_the_reference_codecs_vectors():
+    """Committed vectors: planes compressed by the reference's ZPNG_Compress in the layouts its OSF writer
+    uses (u8: 1x1 B, u16: 1x2 B, u32: 4x1 B with the colour transform, u64: 4x2 B)."""
+    from oracle import osf_oracle as Z
+    h, w, vec = _zpng_vectors()
+    assert len(vec) >= 10
+    for name, (dt, blob, sha) in vec.items():
+        got = Z.decode_zpng_field(blob, dt, h, w)
+        assert got is not None and got.dtype == dt and _sha(got) == sha, name
+
+
+def test_zpng_oracle_matches_the_reference_decoder():
+    """oracle/_ref (the reference's zpng.cpp compiled as it lies): its decoder and the restatement agree on
+    every ZPNG field of the reference's own fixture, and on reference-compressed random planes."""
+    import zpng_ref
+    if not zpng_ref.available():
+        pytest.skip("oracle/_ref/libzpng_ref.so not built (no /root/reference at build time)")
+    from oracle import osf_oracle as Z
+    f = Z.OsfFile(ZPNG)
+    h, w, shifts = _geometry(list(f.sensor_metadata().values())[0])
+    n = 0
+    for ts, sid, m in f.messages():
+        if sid not in f.lidar_streams():
+            continue
+        d = Z.decode_lidar_scan_msg(m, h, w, shifts)
+        t, _ = Z.size_prefixed_root(m, 0)
+        for ch, name in zip(t.table_vector(0), d["fields"]):
+            raw = bytes(ch.vector(0, np.uint8))
+            if raw[:2] != b"\xf8\xfb":
+                continue
+            px, zw, zh, c, bpc = zpng_ref.decompress(raw)
+            plane = d["fields"][name]
+            assert (zw, zh) == (w, h) and c * bpc == plane.dtype.itemsize
+            assert px == plane.tobytes(), name            # ZPNG planes are stored staggered, as they are
+            n += 1
+    assert n >= 4
+    rng = np.random.default_rng(7)
+    for dt in (np.uint8, np.uint16, np.uint32, np.uint64):
+        for hh, ww in ((16, 48), (5, 7), (64, 128)):
+            p = rng.integers(0, np.iinfo(dt).max, (hh, ww), dtype=np.uint64, endpoint=True).astype(dt)
+            p[:, ::3] >>= 3                                   # mixed entropy
+            blob = zpng_ref.compress(p)
+            assert np.array_equal(Z.decode_zpng_field(blob, np.dtype(dt), hh, ww), p), (dt, hh, ww)
