@@ -495,17 +495,27 @@ __device__ __forceinline__ double bcast(double v, uint32_t src) {
 }
 template <class T> struct __attribute__((packed, aligned(4))) Pt3 { T x, y, z; };
 
-template <class T, bool SEP, int TILE>
+// column metadata of an emit tile, staged once in LDS and read back as wave-uniform broadcasts
+template <class T>
+struct __attribute__((aligned(16))) DwfColMeta {
+    T pose[12];      // rows 0..2 of the column's 4x4 pose, cast to the output type
+    double col[5];   // separable LUT: cos, sin of the encoder angle and the column constant
+    uint32_t base, cnt;
+    uint64_t ts;
+};
+
+template <class T, bool SEP, int TILE, int ROWS>
 __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
-    // tile = TILE columns, rows in chunks of ROWS = 4096 / TILE (64 x 64 or 32 x 128).  A wave owns
-    // CPW columns; lane l < CPW keeps the metadata of column l (output base, pose cast to T, table
-    // row, timestamp) in registers and each column iteration broadcasts it with v_readlane -- no
-    // dependent global loads and no LDS traffic in the column loop apart from the transposed
-    // range read.  Lane = row (NR rows per lane): the kept rows are ranked with ballots and every
-    // lane stores its own 12 / 24 B point, so one store instruction writes one dense run.
-    constexpr int LPR = TILE / 4, ROWS = 4096 / TILE, PITCH = TILE + 1, CPW = TILE / 4, NR = ROWS / 64;
+    // tile = TILE columns x ROWS rows (64 x 128: a 128-beam sensor's whole columns).  A wave owns CPW
+    // columns and walks them one at a time, lane = row (NR rows per lane): the kept rows are ranked
+    // with ballots and every lane stores its own 12 / 24 B point, so one store instruction writes one
+    // dense run.  The column's metadata (output base, pose cast to T, table row, timestamp) sits in
+    // LDS and comes back as broadcast reads -- no dependent global loads in the column loop.
+    constexpr int LPR = TILE / 4, PITCH = TILE + 1, CPW = TILE / 4, NR = ROWS / 64;
     constexpr int RPP = 256 / LPR;  // rows staged per pass
+    static_assert(ROWS % 64 == 0 && TILE % 4 == 0 && TILE <= 256, "emit tile");
     __shared__ uint32_t s_rng[ROWS * PITCH];
+    __shared__ DwfColMeta<T> s_meta[TILE];
     const uint32_t W = a.w, H = a.h, f = blockIdx.y, tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t q = tid % LPR, ty = tid / LPR;
@@ -518,32 +528,35 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
     const uint64_t fbase = a.frame_off[f];
     const LutDev lut = a.luts[f % a.n_luts];
     const bool vec = (W % 4 == 0) && ((((uintptr_t)a.range) & 15) == 0);
-    // column metadata: lane l of the wave holds column wave*CPW + l % CPW
-    const uint32_t ml = lane % CPW, mj = wave * CPW + ml, mx = c0 + mj;
-    uint32_t m_base = 0, m_cnt = 0;
-    uint64_t m_ts = 0;
-    T m_pose[12];
-    double m_col[5] = {0, 0, 0, 0, 0};
+    if (tid < (uint32_t)TILE) {
+        DwfColMeta<T> m;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) m_pose[k] = (T)0;
-    if (mj < ncol) {
-        m_base = off[mx];
-        m_cnt = off[mx + 1] - m_base;
-        if (m_cnt) {
-            const double* pm = a.poses + ((size_t)f * W + mx) * 16;
+        for (int k = 0; k < 12; ++k) m.pose[k] = (T)0;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) m_pose[k] = (T)pm[k];
-            if constexpr (SEP) {
+        for (int k = 0; k < 5; ++k) m.col[k] = 0.0;
+        m.base = m.cnt = 0;
+        m.ts = 0;
+        const uint32_t mx = c0 + tid;
+        if (tid < ncol) {
+            m.base = off[mx];
+            m.cnt = off[mx + 1] - m.base;
+            if (m.cnt) {
+                const double* pm = a.poses + ((size_t)f * W + mx) * 16;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) m_col[k] = lut.col_tab[(size_t)mx * 5 + k];
+                for (int k = 0; k < 12; ++k) m.pose[k] = (T)pm[k];
+                if constexpr (SEP) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) m.col[k] = lut.col_tab[(size_t)mx * 5 + k];
+                }
+                if (a.timestamps_ns) m.ts = a.timestamp[(size_t)f * W + mx];
             }
-            if (a.timestamps_ns) m_ts = a.timestamp[(size_t)f * W + mx];
         }
+        s_meta[tid] = m;
     }
-    uint32_t m_run = 0;  // points of column l already written (previous row chunks)
+    uint32_t m_run = 0;  // lane jj of the wave: points of its jj-th column already written (previous row chunks)
     for (uint32_t r0 = 0; r0 < H; r0 += ROWS) {
-        __syncthreads();  // previous chunk consumed
-#pragma unroll
+        __syncthreads();  // previous chunk consumed (and, first time, the metadata published)
+#pragma unroll 4
         for (uint32_t rr = ty; rr < (uint32_t)ROWS; rr += RPP) {
             const uint32_t r = r0 + rr, col = c0 + 4 * q;
             uint32_t v[4] = {0, 0, 0, 0};
@@ -572,7 +585,8 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
         for (uint32_t jj = 0; jj < (uint32_t)CPW; ++jj) {
             const uint32_t j = wave * CPW + jj, x = c0 + j;  // wave-uniform
             if (j >= ncol) break;
-            if (bcast_u32(m_cnt, jj) == 0) continue;  // masked out or empty column
+            const DwfColMeta<T>& m = s_meta[j];
+            if (__builtin_amdgcn_readfirstlane(m.cnt) == 0) continue;  // masked out or empty column
             uint32_t r[NR], rank[NR];
             bool keep[NR];
             uint32_t n_keep = 0;
@@ -585,45 +599,54 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
                 n_keep += (uint32_t)__popcll(mask);
             }
             if (n_keep == 0) continue;
-            const uint64_t g0 = fbase + bcast_u32(m_base, jj) + bcast_u32(m_run, jj);  // first point of this run
+            const uint64_t g0 = fbase + __builtin_amdgcn_readfirstlane(m.base) + bcast_u32(m_run, jj);  // first point of this run
             const uint64_t room = g0 < a.capacity ? a.capacity - g0 : 0;
+            T ps[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) ps[k] = m.pose[k];
+            double cx = 0, sx = 0, kc[3] = {0, 0, 0};
+            if constexpr (SEP) {
+                cx = m.col[0]; sx = m.col[1];
+                kc[0] = m.col[2]; kc[1] = m.col[3]; kc[2] = m.col[4];
+            }
 #pragma unroll
             for (int hh = 0; hh < NR; ++hh) {
                 if (!(keep[hh] && rank[hh] < room)) continue;
-                double p[3];
+                T pt[3];
                 if constexpr (SEP) {
-                    const double cx = bcast(m_col[0], jj), sx = bcast(m_col[1], jj);
                     const double rm = (double)r[hh] - lut.n;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const double d = fma(cx, bt[hh][k], fma(sx, bt[hh][3 + k], bt[hh][6 + k]));
-                        p[k] = r[hh] ? fma(rm, d, bcast(m_col[2 + k], jj)) : 0.0;
+                        const T t = (T)fma(rm, d, kc[k]);
+                        pt[k] = r[hh] ? t : (T)0;
                     }
                 } else {
+                    double p[3];
                     const size_t pix = (size_t)row[hh] * W + x;
                     if (lut.full_dtype == OUSTER_HIP_F32)
                         project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs, pix, r[hh], p);
                     else
                         project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs, pix, r[hh], p);
+                    pt[0] = (T)p[0]; pt[1] = (T)p[1]; pt[2] = (T)p[2];
                 }
-                const T px = (T)p[0], py = (T)p[1], pz = (T)p[2];
+                const T px = pt[0], py = pt[1], pz = pt[2];
                 Pt3<T> o;
-                o.x = bcast(m_pose[0], jj) * px + bcast(m_pose[1], jj) * py + bcast(m_pose[2], jj) * pz + bcast(m_pose[3], jj);
-                o.y = bcast(m_pose[4], jj) * px + bcast(m_pose[5], jj) * py + bcast(m_pose[6], jj) * pz + bcast(m_pose[7], jj);
-                o.z = bcast(m_pose[8], jj) * px + bcast(m_pose[9], jj) * py + bcast(m_pose[10], jj) * pz + bcast(m_pose[11], jj);
+                o.x = ps[0] * px + ps[1] * py + ps[2] * pz + ps[3];
+                o.y = ps[4] * px + ps[5] * py + ps[6] * pz + ps[7];
+                o.z = ps[8] * px + ps[9] * py + ps[10] * pz + ps[11];
                 ((Pt3<T>*)a.points)[g0 + rank[hh]] = o;
             }
             // every point of the run carries the same provenance: dense lanes 0..n_keep-1
             if (a.col_idxs || a.frame_idxs || a.timestamps_ns) {
-                const uint64_t ts = (uint64_t)bcast_u32((uint32_t)m_ts, jj) |
-                                    ((uint64_t)bcast_u32((uint32_t)(m_ts >> 32), jj) << 32);
+                const uint64_t ts = m.ts;
                 for (uint32_t i = lane; i < n_keep && i < room; i += 64) {
                     if (a.col_idxs) a.col_idxs[g0 + i] = x;
                     if (a.frame_idxs) a.frame_idxs[g0 + i] = f;
                     if (a.timestamps_ns) a.timestamps_ns[g0 + i] = ts;
                 }
             }
-            if (ml == jj) m_run += n_keep;
+            if (lane == jj) m_run += n_keep;
         }
     }
 }
@@ -1093,14 +1116,21 @@ hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipSt
     if (!a.gate_counts) hipLaunchKernelGGL(k_dwf_count, dim3(tiles, a.n_frames), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dwf_scan, dim3(a.n_frames), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dwf_frame_scan, dim3(1), dim3(256), 0, st, a);
-    const dim3 grid(tiles, a.n_frames);  // 64 x 64 emit tiles (32 x 128 measured 15 % slower)
-    if (a.dtype == OUSTER_HIP_F32) {
-        if (separable) hipLaunchKernelGGL((k_dwf_emit<float, true, 64>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_dwf_emit<float, false, 64>), grid, dim3(256), 0, st, a);
-    } else {
-        if (separable) hipLaunchKernelGGL((k_dwf_emit<double, true, 64>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_dwf_emit<double, false, 64>), grid, dim3(256), 0, st, a);
-    }
+    // 64-column emit tiles (32-column ones measured 15 % slower); 128 rows per pass when the sensor has
+    // more than 64 beams: the per-column overhead is paid once per column instead of once per 64 rows
+    const dim3 grid(tiles, a.n_frames);
+    auto emit = [&](auto rows) {
+        constexpr int R = decltype(rows)::value;
+        if (a.dtype == OUSTER_HIP_F32) {
+            if (separable) hipLaunchKernelGGL((k_dwf_emit<float, true, 64, R>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_dwf_emit<float, false, 64, R>), grid, dim3(256), 0, st, a);
+        } else {
+            if (separable) hipLaunchKernelGGL((k_dwf_emit<double, true, 64, R>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_dwf_emit<double, false, 64, R>), grid, dim3(256), 0, st, a);
+        }
+    };
+    if (a.h > 64) emit(std::integral_constant<int, 128>{});
+    else emit(std::integral_constant<int, 64>{});
     return hipGetLastError();
 }
 

@@ -386,9 +386,9 @@ def test_dense_dewarp_matches_oracle(oracle):
     assert torch.equal(hp.dewarp(p32, ident), p32)
 
 
-@pytest.mark.parametrize("single_pass", [0, 1])
-@pytest.mark.parametrize("h,w,n", [(128, 1024, 3), (32, 512, 2), (9, 100, 2), (70, 130, 2), (130, 64, 1)])
-def test_dewarp_frames_matches_oracle(oracle, h, w, n, single_pass):
+@pytest.mark.parametrize("path", ["runs", "single"])
+@pytest.mark.parametrize("h,w,n", [(128, 1024, 3), (32, 512, 2), (9, 100, 2), (70, 130, 2), (130, 64, 1), (260, 72, 2)])
+def test_dewarp_frames_matches_oracle(oracle, h, w, n, path):
     """dewarp(LidarFrame / FrameSet, XYZLut, min_range, max_range) with provenance
     (impl/dewarp_impl.h:23-115): order, counts, col/frame indices and timestamps bit-exact;
     points within the XYZ bar."""
@@ -397,7 +397,8 @@ def test_dewarp_frames_matches_oracle(oracle, h, w, n, single_pass):
     cal = O.synthetic_calib(h=h, w=w, b2l_x=15.806)
     ldir, lofs = cal.xyz_lut(True)
     hp = HotPath("RNG15_RFL8_NIR8", h, w, 4 if w % 4 == 0 else 1)
-    hp.ctx.set_knob("dewarp_single_pass", single_pass)   # 1: k_dwf_single (decoupled look-back), 0: count/scan/emit
+    # count / scan / emit (the default) or k_dwf_single (one pass, decoupled look-back)
+    hp.ctx.set_knob("dewarp_single_pass", 1 if path == "single" else 0)
     hp.add_lut(cal.beam_to_lidar, cal.lut_transform(True), cal.beam_azimuth_angles,
                cal.beam_altitude_angles)
     r = rng.integers(0, 2 ** 17, size=(n, h, w)).astype(np.uint32)
