@@ -14,7 +14,7 @@ SPEC_IDS := 0 1 2 3 4 5
 HIP_OBJS := $(foreach i,$(SPEC_IDS),$(OBJ)/k_decode_$(i).o) $(OBJ)/k_standalone.o $(OBJ)/ouster_hip_capi.o
 HIP_HDRS := $(CSRC)/ouster_hip_dev.h $(CSRC)/kernels_common.h include/ouster_hip.h
 ROCM ?= /opt/rocm
-CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude -I$(CSRC)/host -I$(ROCM)/include -D__HIP_PLATFORM_AMD__
+CXXFLAGS := -O2 -std=c++17 -fPIC -pthread -Wall -Wextra -Iinclude -I$(CSRC)/host -I$(ROCM)/include -D__HIP_PLATFORM_AMD__
 
 PYEXT := ouster_sdk_amd/core$(shell python3-config --extension-suffix)
 PYINC := $(shell python3 -m pybind11 --includes)

@@ -9,7 +9,11 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <atomic>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 #include "host_internal.h"
 #include "ouster/hip/device_buffer.h"
@@ -377,6 +381,38 @@ StagedField stage_field(const EncodedField& f, size_t h, size_t w) {
     return out;
 }
 
+// Entropy decoding is the host's share of the work and every field is independent: stage a batch of
+// fields on up to 32 threads (zlib and zstd are re-entrant; the first exception wins and is rethrown).
+static std::vector<StagedField> stage_fields_parallel(const std::vector<EncodedField>& fields, size_t h, size_t w) {
+    std::vector<StagedField> out(fields.size());
+    const size_t n = fields.size();
+    const size_t nt = std::min<size_t>({n, std::max(1u, std::thread::hardware_concurrency()), size_t{32}});
+    if (nt <= 1) {
+        for (size_t i = 0; i < n; ++i) out[i] = stage_field(fields[i], h, w);
+        return out;
+    }
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex mu;
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nt; ++t)
+        pool.emplace_back([&] {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n) return;
+                try {
+                    out[i] = stage_field(fields[i], h, w);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (!err) err = std::current_exception();
+                }
+            }
+        });
+    for (auto& th : pool) th.join();
+    if (err) std::rethrow_exception(err);
+    return out;
+}
+
 // ---------------------------------------------------------------------------------------
 // OsfFrameDecoder
 // ---------------------------------------------------------------------------------------
@@ -403,6 +439,7 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
     std::vector<LidarFrame> frames;
     struct Job { size_t frame; std::string name; size_t esz; StagedField st; size_t src_off, dst_off; };
     std::vector<Job> jobs;
+    std::vector<EncodedField> encoded;   // parallel to jobs
     size_t src_total = 0, dst_total = 0;
     auto al = [](size_t x) { return (x + 255) & ~size_t{255}; };
     for (const auto& m : msgs) {
@@ -437,16 +474,22 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
             j.name = f.name;
             j.esz = field_type_size(f.type);
             if (f.size == 0) continue;  // empty field: stays zero
-            j.st = stage_field(f, h, w);
-            j.src_off = src_total;
-            j.dst_off = dst_total;
-            src_total += al(j.st.bytes.size());
-            dst_total += al(h * w * j.esz);
+            encoded.push_back(f);
             jobs.push_back(std::move(j));
         }
         frames.push_back(std::move(fr));
     }
     if (jobs.empty()) return frames;
+    {
+        std::vector<StagedField> staged = stage_fields_parallel(encoded, h, w);
+        for (size_t i = 0; i < jobs.size(); ++i) {
+            jobs[i].st = std::move(staged[i]);
+            jobs[i].src_off = src_total;
+            jobs[i].dst_off = dst_total;
+            src_total += al(jobs[i].st.bytes.size());
+            dst_total += al(h * w * jobs[i].esz);
+        }
+    }
 
     hip::ScopedContext on_my_context(s.context());
     s.d_src.resize(src_total);
@@ -488,11 +531,18 @@ std::vector<std::vector<uint8_t>> OsfFrameDecoder::decode_fields(const std::vect
     std::vector<size_t> src_off(fields.size()), dst_off(fields.size());
     std::vector<ouster_hip_osf_plane> planes;
     size_t src_total = 0, dst_total = 0;
+    {
+        std::vector<EncodedField> present;
+        std::vector<size_t> idx;
+        for (size_t i = 0; i < fields.size(); ++i)
+            if (fields[i].size) { present.push_back(fields[i]); idx.push_back(i); }
+        std::vector<StagedField> st = stage_fields_parallel(present, h, w);
+        for (size_t k = 0; k < idx.size(); ++k) staged[idx[k]] = std::move(st[k]);
+    }
     for (size_t i = 0; i < fields.size(); ++i) {
         const size_t esz = field_type_size(fields[i].type);
         out[i].assign(h * w * esz, 0);
         if (fields[i].size == 0) continue;
-        staged[i] = stage_field(fields[i], h, w);
         src_off[i] = src_total;
         dst_off[i] = dst_total;
         src_total += al(staged[i].bytes.size());
@@ -553,6 +603,7 @@ OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message
     auto al = [](size_t x) { return (x + 255) & ~size_t{255}; };
     struct Job { size_t frame, field; StagedField st; size_t src_off; };
     std::vector<Job> jobs;
+    std::vector<EncodedField> encoded;   // parallel to jobs
     size_t src_total = 0;
     for (size_t m = 0; m < n; ++m) {
         const LidarScanMsgView v = LidarScanMsgView::parse(msgs[m]);
@@ -571,9 +622,16 @@ OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message
         if (v.n_status == w) std::memcpy(b.status_.data() + m * w, v.status, w * 4);
         for (size_t i = 0; i < v.fields.size(); ++i) {
             if (v.fields[i].size == 0) continue;
-            Job j{m, i, stage_field(v.fields[i], h, w), src_total};
-            src_total += al(j.st.bytes.size());
-            jobs.push_back(std::move(j));
+            encoded.push_back(v.fields[i]);
+            jobs.push_back(Job{m, i, StagedField{}, 0});
+        }
+    }
+    {
+        std::vector<StagedField> staged = stage_fields_parallel(encoded, h, w);
+        for (size_t i = 0; i < jobs.size(); ++i) {
+            jobs[i].st = std::move(staged[i]);
+            jobs[i].src_off = src_total;
+            src_total += al(jobs[i].st.bytes.size());
         }
     }
     hip::ScopedContext on_my_context(s.context());

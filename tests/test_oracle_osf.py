@@ -203,3 +203,84 @@ def test_zpng_oracle_matches_the_reference_decoder():
             p[:, ::3] >>= 3                                   # mixed entropy
             blob = zpng_ref.compress(p)
             assert np.array_equal(Z.decode_zpng_field(blob, np.dtype(dt), hh, ww), p), (dt, hh, ww)
+
+
+_FUZZ = r"""
+import os, sys, random
+sys.path.insert(0, sys.argv[1])
+from ouster_sdk_amd import core
+src, tmp, seed, n = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+data = open(src, "rb").read()
+rnd = random.Random(seed)
+ok = bad = 0
+for it in range(n):
+    b = bytearray(data)
+    kind = rnd.randrange(4)
+    if kind == 0:                                   # flip a few bytes anywhere
+        for _ in range(rnd.randrange(1, 8)):
+            b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+    elif kind == 1:                                 # overwrite a dword with an extreme value
+        p = rnd.randrange(len(b) - 4)
+        b[p:p + 4] = rnd.choice([b"\xff\xff\xff\xff", b"\x00\x00\x00\x00", b"\xff\xff\xff\x7f", b"\x00\x00\x00\x80"])
+    elif kind == 2:                                 # truncate
+        del b[rnd.randrange(16, len(b)):]
+    else:                                           # garbage run
+        p = rnd.randrange(len(b) - 64)
+        b[p:p + 64] = bytes(rnd.randrange(256) for _ in range(64))
+    path = os.path.join(tmp, "f.osf")
+    open(path, "wb").write(bytes(b))
+    try:
+        f = core.OsfFile(path)
+        streams = f.lidar_scan_streams()
+        f.sensor_metadata_json()
+        for ts, sid, m in f.messages():
+            if sid in streams:
+                core.osf_stage_fields(m, int(sys.argv[6]), int(sys.argv[7]))
+        ok += 1
+    except (RuntimeError, ValueError, IndexError, OverflowError, MemoryError):
+        bad += 1
+# the same on single messages, behind the CRCs: flatbuffer offsets, vector lengths, PNG chunks, zlib and
+# zstd streams are all reachable here
+f = core.OsfFile(src)
+streams = f.lidar_scan_streams()
+msgs = [m for ts, sid, m in f.messages() if sid in streams]
+mok = mbad = 0
+for it in range(n * 4):
+    b = bytearray(msgs[it % len(msgs)])
+    kind = rnd.randrange(4)
+    if kind == 0:
+        for _ in range(rnd.randrange(1, 6)):
+            b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+    elif kind == 1:
+        p = rnd.randrange(min(len(b) - 4, 4096) if rnd.random() < 0.7 else len(b) - 4)   # mostly the tables up front
+        b[p:p + 4] = rnd.choice([b"\xff\xff\xff\xff", b"\x00\x00\x00\x00", b"\xff\xff\xff\x7f", b"\x00\x00\x00\x80", b"\x10\x00\x00\x00"])
+    elif kind == 2:
+        del b[rnd.randrange(8, len(b)):]
+    else:
+        p = rnd.randrange(len(b) - 32)
+        b[p:p + 32] = bytes(rnd.randrange(256) for _ in range(32))
+    try:
+        core.osf_stage_fields(bytes(b), int(sys.argv[6]), int(sys.argv[7]))
+        mok += 1
+    except (RuntimeError, ValueError, IndexError, OverflowError, MemoryError):
+        mbad += 1
+print("FUZZ_DONE", ok, bad, mok, mbad)
+"""
+
+
+@pytest.mark.parametrize("path", [LB, ZPNG])
+def test_host_half_survives_corrupted_files(path, tmp_path):
+    """Bit flips, extreme length words, truncation and garbage runs anywhere in a file: the container walk,
+    the flatbuffer reads, CRC checks, zlib / PNG unfilter and zstd either succeed or raise -- the process
+    must not crash (run in a child so that a segfault is a test failure, not a dead test run)."""
+    import subprocess
+    import sys
+    from oracle import osf_oracle as Z
+    h, w, _ = _geometry(list(Z.OsfFile(path).sensor_metadata().values())[0])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FUZZ, root, path, str(tmp_path), "1234", "150", str(h), str(w)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FUZZ_DONE" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    ok, bad, mok, mbad = map(int, r.stdout.split("FUZZ_DONE")[1].split()[:4])
+    assert ok + bad == 150 and bad > 20      # the CRCs catch most corruptions; a few land in slack bytes
+    assert mok + mbad == 600 and mbad > 50   # behind the CRCs: decoders and bounds checks do the rejecting
