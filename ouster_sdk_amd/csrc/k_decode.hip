@@ -469,48 +469,73 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
     uint32_t count = a.slots_per_frame;
     if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
+#ifdef OUSTER_PHASE_TIMING
+    uint64_t* pt_ = a.phase_times ? a.phase_times + (size_t)blockIdx.x * 8 : nullptr;
+#define PHASE_STAMP(i) do { if (pt_ && tid == 0) pt_[i] = __builtin_readcyclecounter(); } while (0)
+    if (pt_ && tid == 0) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); pt_[7] = xcc; }
+#else
+#define PHASE_STAMP(i) do {} while (0)
+#endif
+    PHASE_STAMP(0);
 
-    // ---- phase 0: where my columns live (slot c holds column c), their header words in flight
-    uint64_t w_mid[NJ], w_st[NJ], w_ts[NJ], pk_ts[NJ];
-    uint32_t pk_alert[NJ];
+    // ---- phase 0: where my columns live (slot c holds column c): arithmetic only, nothing is loaded
 #pragma unroll
     for (int k = 0; k < NJ; ++k) {
         const uint32_t j = tid + (uint32_t)k * NT, c = c0 + j;
-        w_mid[k] = w_st[k] = w_ts[k] = pk_ts[k] = 0;
-        pk_alert[k] = 0;
         if (j >= (uint32_t)TW) continue;
         uint32_t ofs = 0xffffffffu;
         if (c < W) {
             const uint32_t p = c / cpp, ic = c - p * cpp;
             ofs = p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
-            if (p < count) {
-                const uint8_t* colp = fbase + ofs;
-                w_mid[k] = window_global_masked(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask);
-                w_st[k] = window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask);
-                if (rc == 0) {
-                    if (a.timestamp) w_ts[k] = window_global_masked(colp + a.g.col_timestamp.offset, a.g.col_timestamp.mask);
-                    if (ic == 0) {
-                        if (a.packet_timestamp && a.host_timestamps)
-                            pk_ts[k] = a.host_timestamps[(size_t)f * a.slots_per_frame + p];
-                        if (a.alert_flags)
-                            pk_alert[k] = (uint32_t)apply_bits(
-                                window_global(fbase + (size_t)p * a.packet_stride + a.g.alert_flags.offset),
-                                a.g.alert_flags.mask, a.g.alert_flags.shift);
-                    }
-                }
-            }
         }
         s_colofs[j] = ofs;
     }
     if (tid < 4) s_acc[tid] = 0;
     for (uint32_t j = tid; j < (uint32_t)TW; j += NT) s_gate[j] = 0;
-    if (rc == 0 && tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_of(a.g, fbase, count > 0);
-    if (a.any_destagger)
-        for (uint32_t r = tid; r < nrows; r += NT) s_off[r] = a.dst_offsets[r0 + r];
     const LutDev lut = (XYZM != 0) ? a.luts[f % a.n_luts] : LutDev{};
-    if (XYZM == 1 || XYZM == 2)
-        for (uint32_t i = tid; i < nrows * 9; i += NT) s_beam[i] = lut.beam_tab[(size_t)r0 * 9 + i];
+    // Everything this workgroup needs from memory besides its tile -- the (measurement_id, status,
+    // timestamp) words of its columns, the destagger offsets and the per-beam table rows -- is put in
+    // flight BEHIND the tile's loads (issue_small, called from the staging loop) and used after the tile
+    // has been written to LDS: a consumer right behind one of these loads would cost the workgroup a
+    // full memory latency before its tile is even requested (18 % of its life, tools/ab/phase_timing.sh).
+    RawWin w_mid[NJ], w_st[NJ], w_ts[NJ], w_alert[NJ];
+    uint64_t pk_ts[NJ];
+    constexpr int NBT = 3;   // at most 84 rows per tile (setup_wide): three table doubles per thread
+    int32_t r_off = 0;
+    double r_beam[NBT];
+    auto issue_small = [&]() {
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const uint32_t j = tid + (uint32_t)k * NT, c = c0 + j;
+            w_mid[k] = w_st[k] = w_ts[k] = w_alert[k] = RawWin{{0u, 0u, 0u}, 0};
+            pk_ts[k] = 0;
+            if (j >= (uint32_t)TW || c >= W) continue;
+            const uint32_t p = c / cpp, ic = c - p * cpp;
+            if (p >= count) continue;
+            const uint8_t* colp = fbase + p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
+            w_mid[k] = window_global_masked_issue(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask);
+            w_st[k] = window_global_masked_issue(colp + a.g.col_status.offset, a.g.col_status.mask);
+            if (rc == 0) {
+                if (a.timestamp) w_ts[k] = window_global_masked_issue(colp + a.g.col_timestamp.offset, a.g.col_timestamp.mask);
+                if (ic == 0) {
+                    if (a.packet_timestamp && a.host_timestamps)
+                        pk_ts[k] = a.host_timestamps[(size_t)f * a.slots_per_frame + p];
+                    if (a.alert_flags)
+                        w_alert[k] = window_global_issue(fbase + (size_t)p * a.packet_stride + a.g.alert_flags.offset);
+                }
+            }
+        }
+        if (a.any_destagger && tid < nrows) r_off = a.dst_offsets[r0 + tid];
+        if (XYZM == 1 || XYZM == 2) {
+#pragma unroll
+            for (int k = 0; k < NBT; ++k) {
+                const uint32_t i = tid + (uint32_t)k * NT;
+                r_beam[k] = i < nrows * 9 ? lut.beam_tab[(size_t)r0 * 9 + i] : 0.0;
+            }
+        }
+    };
     __syncthreads();
+    PHASE_STAMP(1);
 
     // ---- phase 1: stage my TR-row piece of every column, dword granular (packets are 4 B granular)
     {
@@ -528,12 +553,13 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
         constexpr int DEPTH = 18;  // 256 columns x 17 chunks = 17 per thread for 256 B pieces
         for (uint32_t base = 0; base < total; base += NT * DEPTH) {
             u32x4 t[DEPTH];
-            int32_t p0[DEPTH];   // piece-relative dword index of t[k].x, or a value that drops all four
-            uint32_t sj[DEPTH];
+            // (column j << 16) | (piece-relative dword index of t[k].x as int16; -32768 drops all four):
+            // one register per chunk -- the loads of a whole tile are in flight together and the kernel
+            // must stay under 168 VGPRs for three waves per SIMD
+            uint32_t pj[DEPTH];
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
-                p0[k] = -1000000;
-                sj[k] = 0;
+                pj[k] = 0x8000u;
                 t[k] = u32x4{0, 0, 0, 0};
                 if (base + k * NT + tid < total) {
                     const uint32_t ofs = s_colofs[j];
@@ -548,27 +574,40 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
                                 for (int w = 0; w < 4; ++w)
                                     if ((const uint8_t*)(qd + w + 1) <= fend) t[k][w] = qd[w];
                             }
-                            p0[k] = (int32_t)(ch * 4u) - (int32_t)(delta >> 2);
-                            sj[k] = j * slot;
+                            pj[k] = (j << 16) | (uint32_t)(((int32_t)(ch * 4u) - (int32_t)(delta >> 2)) & 0xffff);
                         }
                     }
                 }
                 j += dj; ch += dc;
                 if (ch >= NCH) { ch -= NCH; ++j; }
             }
+            if (base == 0) issue_small();   // behind the tile's loads, ahead of the wait for them
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
+                const int32_t p0 = (int32_t)(int16_t)(pj[k] & 0xffffu);
+                const uint32_t sj = (pj[k] >> 16) * slot;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const int32_t pp = p0[k] + w;
-                    if (pp >= 0 && pp < (int32_t)piece) s_tile[sj[k] + (uint32_t)pp] = t[k][w];
+                    const int32_t pp = p0 + w;
+                    if (pp >= 0 && pp < (int32_t)piece) s_tile[sj + (uint32_t)pp] = t[k][w];
                 }
             }
         }
         // dead columns and the rows past H keep whatever the LDS held: nothing reads them (vq / nrows)
         if (tid < 4) s_tile[TW * slot + tid] = 0;  // slack read by 64-bit windows
     }
+    // the small tables that were in flight behind the tile
+    if (a.any_destagger && tid < nrows) s_off[tid] = r_off;
+    if (XYZM == 1 || XYZM == 2) {
+#pragma unroll
+        for (int k = 0; k < NBT; ++k) {
+            const uint32_t i = tid + (uint32_t)k * NT;
+            if (i < nrows * 9) s_beam[i] = r_beam[k];
+        }
+    }
+    if (rc == 0 && tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_of(a.g, fbase, count > 0);
 
+    PHASE_STAMP(2);
     // ---- classify my columns (every row chunk needs the validity; the first one also publishes)
     {
         uint32_t n_valid = 0, n_stray = 0, n_dead = 0;
@@ -578,8 +617,8 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             if (j >= (uint32_t)TW) continue;
             const uint32_t p = c / cpp;
             const bool present = c < W && p < count;
-            const uint32_t m_id = (uint16_t)apply_bits(w_mid[k], a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
-            const uint32_t st = (uint32_t)apply_bits(w_st[k], a.g.col_status.mask, a.g.col_status.shift);
+            const uint32_t m_id = (uint16_t)apply_bits(window_compose(w_mid[k]), a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
+            const uint32_t st = (uint32_t)apply_bits(window_compose(w_st[k]), a.g.col_status.mask, a.g.col_status.shift);
             const bool live = present && (st & 1u) && m_id < W;
             bool stray = live && m_id != c;
             const bool v = live && !stray;
@@ -592,12 +631,14 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
                 if (present && !home && want_pk && m_id / cpp < npo) stray = true;
                 if (a.packet_timestamp && a.host_timestamps)
                     a.packet_timestamp[(size_t)f * npo + p] = home ? pk_ts[k] : 0ull;
-                if (a.alert_flags && home) a.alert_flags[(size_t)f * npo + p] = (uint8_t)pk_alert[k];
+                if (a.alert_flags && home)
+                    a.alert_flags[(size_t)f * npo + p] =
+                        (uint8_t)apply_bits(window_compose(w_alert[k]), a.g.alert_flags.mask, a.g.alert_flags.shift);
             }
             n_valid += v ? 1u : 0u;
             n_stray += stray ? 1u : 0u;
             if (a.timestamp)
-                a.timestamp[(size_t)f * W + c] = v ? apply_bits(w_ts[k], a.g.col_timestamp.mask, a.g.col_timestamp.shift) : 0ull;
+                a.timestamp[(size_t)f * W + c] = v ? apply_bits(window_compose(w_ts[k]), a.g.col_timestamp.mask, a.g.col_timestamp.shift) : 0ull;
             if (a.measurement_id) a.measurement_id[(size_t)f * W + c] = v ? (uint16_t)c : (uint16_t)0;
             if (a.status) a.status[(size_t)f * W + c] = v ? st : 0u;
         }
@@ -621,6 +662,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
         __syncthreads();
     }
 
+    PHASE_STAMP(3);
     // ---- pixels.  lane = (row within pass, quad of 4 consecutive columns)
     const uint32_t jq = (tid % (TW / 4)) * 4;
     uint32_t vq = 0;
@@ -628,6 +670,13 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_valid[jq + c]) ? (1u << c) : 0u;
     decode_rows<S, TW / 4, XYZM, S::is_static>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
                                  a.gate_counts ? s_gate : nullptr, lut, f, c0, r0, nrows, vq, rc, nch);
+    PHASE_STAMP(4);
+#ifdef OUSTER_PHASE_TIMING
+    if (pt_ && tid == 0) {   // the stores of this wave have been issued; when are they done?
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pt_[5] = __builtin_readcyclecounter();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------

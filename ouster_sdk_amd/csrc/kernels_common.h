@@ -60,6 +60,46 @@ __device__ __forceinline__ uint64_t window_global_masked(const uint8_t* p, uint6
     return v;
 }
 
+// The same two reads split into "issue the loads" and "use them": a consumer right behind a global load
+// makes the wave sit out a full memory latency, and the wide decode kernel has better things to put in
+// flight first (its tile).  RawWin keeps the dwords as they arrive; window_compose is the old arithmetic.
+struct RawWin {
+    uint32_t d[3];
+    int32_t sh0;   // bit position of d[0] inside the 64-bit window at p (negative: d[0] starts before p)
+};
+__device__ __forceinline__ RawWin window_global_issue(const uint8_t* p) {
+    const uintptr_t a = (uintptr_t)p;
+    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+    RawWin w;
+    w.sh0 = -(int32_t)(a & 3) * 8;
+    w.d[0] = q[0]; w.d[1] = q[1];
+    w.d[2] = (a & 3) ? q[2] : 0u;
+    return w;
+}
+__device__ __forceinline__ RawWin window_global_masked_issue(const uint8_t* p, uint64_t mask) {
+    RawWin w{{0u, 0u, 0u}, 0};
+    if (mask == 0) return w;
+    const uint32_t lo = (uint32_t)__builtin_ctzll(mask) >> 3, hi = (63u - (uint32_t)__builtin_clzll(mask)) >> 3;
+    const uintptr_t a = (uintptr_t)p;
+    const uintptr_t first = (a + lo) & ~(uintptr_t)3, last = (a + hi) & ~(uintptr_t)3;
+    w.sh0 = (int32_t)((long)(first - a) * 8);
+    const uint32_t* q = (const uint32_t*)first;
+    w.d[0] = q[0];
+    if (first + 4 <= last) w.d[1] = q[1];
+    if (first + 8 <= last) w.d[2] = q[2];
+    return w;
+}
+__device__ __forceinline__ uint64_t window_compose(const RawWin& w) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int32_t sh = w.sh0 + 32 * k;
+        const uint64_t d = w.d[k];
+        v |= sh >= 0 ? (sh < 64 ? d << sh : 0ull) : (sh > -32 ? d >> (-sh) : 0ull);
+    }
+    return v;
+}
+
 // same, from the LDS tile (byte offset into the tile)
 __device__ __forceinline__ uint64_t window_lds(const uint32_t* tile, uint32_t byte_off) {
     const uint32_t* q = tile + (byte_off >> 2);

@@ -724,6 +724,12 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     da.gate_max = out->gate_max_r;
     da.gate_field = out->gate_counts ? out->gate_field : -1;
     da.tile_valid = (uint16_t*)ctx->tile_valid.p;
+#ifdef OUSTER_PHASE_TIMING
+    {   // experiment builds only: the tool passes a device buffer's address through the environment
+        const char* e = getenv("OUSTER_HIP_PHASE_BUF");
+        da.phase_times = e ? (uint64_t*)strtoull(e, nullptr, 0) : nullptr;
+    }
+#endif
     da.dst_offsets = (const int32_t*)ctx->offsets.p;
     da.luts = (const LutDev*)ctx->luts.p;
     da.n_luts = n_luts ? n_luts : 1;
@@ -809,6 +815,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             if (t2 <= tr_max && t2 * n2 == H) { nch = n2; tr = t2; break; }
         }
         if (kn.wide_rows > 0) tr = std::min((uint32_t)kn.wide_rows, H);
+        if (tr > 84) return false;   // k_decode_wide keeps a row chunk's table rows in registers (3 doubles per thread) while its tile loads
         nch = (H + tr - 1) / tr;
         if (out->gate_counts && nch > OUSTER_HIP_GATE_CHUNKS) return false;  // one count slot per row chunk
         const uint32_t tiles = (W + want - 1) / want;

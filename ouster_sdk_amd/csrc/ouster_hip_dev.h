@@ -82,6 +82,9 @@ struct DecodeArgs {
     void* xyz[2];
     int32_t xyz_field[2];
     int32_t xyz_dtype;
+#ifdef OUSTER_PHASE_TIMING
+    uint64_t* phase_times;   // experiment builds only (tools/ab/phase_timing.sh): [workgroup][8] s_memtime stamps of k_decode_wide
+#endif
 };
 
 struct DestaggerArgs {
