@@ -92,19 +92,26 @@ class OusterHipError(RuntimeError):
     pass
 
 
-def load_hip():
-    """Load libouster_hip.so (after torch, so both share one HIP runtime)."""
+def load_hip(private_path: Optional[str] = None):
+    """Load libouster_hip.so (after torch, so both share one HIP runtime).
+    private_path: an A/B build to load NEXT TO the product library in the same process (tools/ab/ab_inproc.py:
+    same buffers, same physical placement for every variant); bound with RTLD_LOCAL | RTLD_DEEPBIND so that
+    its internal calls stay inside it, not cached."""
     global _hip
-    if _hip is not None:
+    if private_path is None and _hip is not None:
         return _hip
-    if not os.path.exists(HIP_SO):
-        raise OusterHipError(f"{HIP_SO} is missing: run `make` (or __graft_entry__.build()) first; "
+    path = private_path or HIP_SO
+    if not os.path.exists(path):
+        raise OusterHipError(f"{path} is missing: run `make` (or __graft_entry__.build()) first; "
                              "there is no CPU fallback for the hot path")
     try:
         import torch  # noqa: F401  -- its bundled libamdhip64.so.7 must be the one in the process
     except Exception:
         pass
-    L = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
+    if private_path is not None:
+        L = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND | os.RTLD_NOW)
+    else:
+        L = C.CDLL(path, mode=C.RTLD_GLOBAL)
     vp = C.c_void_p
     L.ouster_hip_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     L.ouster_hip_ctx_destroy.argtypes = [vp]
@@ -139,7 +146,8 @@ def load_hip():
     L.ouster_hip_timing_enable.argtypes = [vp, C.c_int]
     L.ouster_hip_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.ouster_hip_last_decode_tile.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    _hip = L
+    if private_path is None:
+        _hip = L
     return L
 
 
@@ -200,8 +208,8 @@ class Context:
 
     STREAM_NULL = C.c_void_p(-1)  # OUSTER_HIP_STREAM_NULL
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None):
-        self.L = load_hip()
+    def __init__(self, device: int = 0, stream: Optional[int] = None, lib=None):
+        self.L = lib if lib is not None else load_hip()
         h = C.c_void_p()
         if stream is None:
             sp = None

@@ -568,7 +568,11 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
                         const uint32_t delta = (uint32_t)((uintptr_t)src & 15u);
                         const u32x4* q = (const u32x4*)(src - delta) + ch;
                         if (ch * 16u < delta + piece * 4u) {
+#if OUSTER_NT_LOADS
+                            if ((const uint8_t*)(q + 1) <= fend) t[k] = __builtin_nontemporal_load(q);
+#else
                             if ((const uint8_t*)(q + 1) <= fend) t[k] = *q;
+#endif
                             else {  // last chunk of the frame buffer: stay inside it
                                 const uint32_t* qd = (const uint32_t*)q;
                                 for (int w = 0; w < 4; ++w)

@@ -119,14 +119,39 @@ struct __attribute__((packed, aligned(1))) pk4 { uint32_t a; };
 struct __attribute__((packed, aligned(1))) pk8 { uint32_t a, b; };
 struct __attribute__((packed, aligned(1))) pk16 { uint32_t a, b, c, d; };
 
-__device__ __forceinline__ void st4(void* p, uint32_t a) { ((pk4*)p)->a = a; }
+#ifndef OUSTER_NT_STORES
+#define OUSTER_NT_STORES 0   // experiment switch (tools/ab/nt_variants.sh): non-temporal hint on the plane / xyz stores
+#endif
+#ifndef OUSTER_NT_LOADS
+#define OUSTER_NT_LOADS 0    // experiment switch: non-temporal hint on the tile staging loads
+#endif
+typedef uint32_t u32x1_u __attribute__((aligned(1)));
+typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+__device__ __forceinline__ void st4(void* p, uint32_t a) {
+#if OUSTER_NT_STORES
+    __builtin_nontemporal_store(a, (u32x1_u*)p);
+#else
+    ((pk4*)p)->a = a;
+#endif
+}
 __device__ __forceinline__ void st8(void* p, uint32_t a, uint32_t b) {
+#if OUSTER_NT_STORES
+    typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(v2{a, b}, (u32x2_u*)p);
+#else
     pk8 v{a, b};
     *((pk8*)p) = v;
+#endif
 }
 __device__ __forceinline__ void st16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+#if OUSTER_NT_STORES
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(v4{a, b, c, d}, (u32x4_u*)p);
+#else
     pk16 v{a, b, c, d};
     *((pk16*)p) = v;
+#endif
 }
 
 // store 4 consecutive elements of `elem` bytes each starting at byte pointer p
@@ -181,8 +206,12 @@ __device__ __forceinline__ void store4v(uint8_t* p, const u32x4_t& v, uint32_t e
         case 1: st4(p, v.x | (v.y << 8) | (v.z << 16) | (v.w << 24)); break;
         case 2: st8(p, v.x | (v.y << 16), v.z | (v.w << 16)); break;
         default: {
+#if OUSTER_NT_STORES
+            __builtin_nontemporal_store(v, (u32x4_u*)p);
+#else
             struct __attribute__((packed, aligned(1))) pkv { u32x4_t v; };
             ((pkv*)p)->v = v;
+#endif
         }
     }
 }
@@ -370,7 +399,14 @@ __device__ __forceinline__ void store_xyz4_permuted(float* row_base, uint32_t q,
     }
     float4* d = (float4*)row_base;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) d[k * LPR + q] = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+    for (int k = 0; k < 3; ++k) {
+#if OUSTER_NT_STORES
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f4{o[k][0], o[k][1], o[k][2], o[k][3]}, (f4*)(d + k * LPR + q));
+#else
+        d[k * LPR + q] = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+#endif
+    }
 }
 
 // Generic forms of the same transpose for a "lane owns 4 consecutive pixels x NV 16 B chunks"

@@ -31,7 +31,7 @@ def _u8(n):
 class HotPath:
     def __init__(self, profile: str, h: int, w: int, cpp: int = 16, header_type: int = 0,
                  fields: Optional[Sequence[Tuple[str, int]]] = None, with_window: bool = True,
-                 device: Optional[int] = None, use_torch_stream: bool = True):
+                 device: Optional[int] = None, use_torch_stream: bool = True, lib=None):
         if not torch.cuda.is_available():
             raise capi.OusterHipError("no MI355X visible: the hot path has no CPU fallback")
         self.device = torch.cuda.current_device() if device is None else device
@@ -39,7 +39,7 @@ class HotPath:
         if os.environ.get("OUSTER_HIP_OWN_STREAM"):  # experiment knob
             use_torch_stream = False
         stream = torch.cuda.current_stream().cuda_stream if use_torch_stream else None
-        self.ctx = capi.Context(self.device, stream)
+        self.ctx = capi.Context(self.device, stream, lib=lib)   # lib: a privately loaded A/B build (capi.load_hip(path))
         self.profile, self.h, self.w, self.cpp = profile, h, w, cpp
         self.fields: List[Tuple[str, int]] = list(fields) if fields is not None else \
             capi.default_planes(profile, with_window)
