@@ -73,6 +73,15 @@ class DeviceFrameBatch {
     /** Copy one frame's packets (host, each lidar_packet_size bytes) into its slots. */
     void upload_frame_packets(uint32_t frame, const std::vector<const uint8_t*>& packets);
 
+    /** Setup-time choice of WHERE the batch's buffers live.  The physical placement of a device allocation
+     *  is drawn when it is made and the decode's achieved write rate differs by 10 - 20 % between draws of
+     *  the same size (tools/ab/alloc_lottery.py).  A batch allocates once and is reused for
+     *  the life of a pipeline, so it can afford to draw: this re-allocates the output buffers `tries` times
+     *  (and the packet buffer, contents preserved, up to 6 times), times decode() into each draw and keeps
+     *  the fastest.  Output contents are undefined afterwards (decode() again).  Returns the seconds per
+     *  decode() of the kept draw; `all_ms` (optional) receives every draw's time in ms, outputs first. */
+    double tune_placement(int tries = 12, std::vector<double>* all_ms = nullptr);
+
     /** Run the fused kernels on everything uploaded so far (asynchronous; sync() to wait). */
     void decode();
     void sync();

@@ -95,6 +95,60 @@ class HotPath:
             out["frame_meta"] = torch.empty((n_frames, 24), dtype=torch.uint8, device="cuda")
         return out
 
+    def pick_placement(self, packets: torch.Tensor, make_outputs, tries: int = 12, launches: int = 12):
+        """Output buffers that live for the life of a pipeline are worth choosing: on MI355X the achieved
+        write rate of the decode differs by 10 - 20 % between allocations of the SAME size made by the SAME
+        process (tools/ab/alloc_lottery.py: the physical placement of an allocation is drawn when it is made
+        and never changes), in two modes -- most draws land near the slow one.  This helper draws `tries`
+        candidate output sets with make_outputs() (each one slab, one draw), times the decode into each and
+        keeps the fastest; then does the same for copies of the packet buffer.  Returns
+        (packets, outputs, report).  Everything but the winners is freed."""
+        def slab_set():
+            tmpl = make_outputs()
+            names = list(tmpl)
+            sizes = [tmpl[n].numel() * tmpl[n].element_size() for n in names]
+            meta = {n: (tmpl[n].dtype, tuple(tmpl[n].shape)) for n in names}
+            del tmpl
+            al = 2 << 20
+            slab = torch.empty(sum((x + al - 1) // al * al for x in sizes) + al, dtype=torch.uint8, device="cuda")
+            off = (-slab.data_ptr()) % al
+            out = {}
+            for n, nb in zip(names, sizes):
+                out[n] = slab[off:off + nb].view(meta[n][0]).view(meta[n][1])
+                off += (nb + al - 1) // al * al
+            return out
+
+        def clock(pk, out):
+            for _ in range(2):
+                self.decode(pk, out)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(launches):
+                self.decode(pk, out)
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / launches
+
+        best_out, best_ms, out_ms = None, None, []
+        for _ in range(max(1, tries)):
+            cand = slab_set()
+            ms = clock(packets, cand)
+            out_ms.append(round(ms, 4))
+            if best_ms is None or ms < best_ms:
+                best_out, best_ms = cand, ms
+            del cand
+            torch.cuda.empty_cache()
+        best_pk, pk_best_ms, pk_ms = packets, best_ms, [round(best_ms, 4)]
+        for _ in range(max(0, min(tries, 6) - 1)):
+            cand = packets.clone()
+            ms = clock(cand, best_out)
+            pk_ms.append(round(ms, 4))
+            if ms < pk_best_ms:
+                best_pk, pk_best_ms = cand, ms
+            del cand
+        torch.cuda.empty_cache()
+        return best_pk, best_out, {"tries": tries, "output_sets_ms": out_ms, "packet_buffers_ms": pk_ms}
+
     # -- the three operations --------------------------------------------------------------
     def range_gate(self, min_range: float, max_range: float) -> Tuple[int, int, bool]:
         """(min_r, max_r, empty): the raw gate ouster_hip_dewarp_frames derives from metres."""

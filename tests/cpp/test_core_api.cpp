@@ -864,6 +864,11 @@ static void test_device_batch() {
             if (!(f == 2 && i == 5)) ptrs.push_back(packets[i].buf.data());  // frame 2 loses a packet
         batch.upload_frame_packets(f, ptrs);
     }
+    // setup-time buffer placement: three draws of the output buffers, two more of the packet buffer (contents
+    // preserved); whatever is kept, the results below must not change
+    std::vector<double> draws;
+    const double kept = batch.tune_placement(3, &draws);
+    CHECK(draws.size() == 5 && kept > 0 && kept * 1e3 <= *std::min_element(draws.begin(), draws.end()) + 1e-9);
     batch.decode();
     XYZLut luts[2] = {XYZLut(a, true), XYZLut(b, true)};
     bool planes_ok = true, dst_ok = true;

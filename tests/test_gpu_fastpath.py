@@ -351,3 +351,30 @@ def test_range_gate_counts_feed_the_dewarp(oracle, label, wide):
     assert tot > 1000
     for k in ("points", "frame_idxs", "col_idxs", "timestamps_ns"):
         assert torch.equal(a[k][:tot].view(torch.uint8), b[k][:tot].view(torch.uint8)), k
+
+
+def test_pick_placement_returns_equivalent_buffers(oracle):
+    """HotPath.pick_placement draws candidate allocations, times the decode into each and keeps the fastest:
+    the winners are ordinary buffers -- same names, dtypes and shapes as alloc_outputs, same decoded bytes."""
+    O = oracle
+    cal = O.synthetic_calib(h=64, w=1024, profile="RNG15_RFL8_NIR8_DUAL")
+    packets, src = O.synth_packets(cal, 4, with_window=True)
+    hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL")
+    d_pk = torch.from_numpy(packets).cuda().repeat(8, 1, 1).contiguous()
+    make = lambda: hp.alloc_outputs(32, destagger=["RANGE", "REFLECTIVITY2"], xyz=["RANGE", "RANGE2"])  # noqa: E731
+    plain = make()
+    hp.decode(d_pk, plain)
+    pk2, out, rep = hp.pick_placement(d_pk, make, tries=3, launches=2)
+    assert rep["tries"] == 3 and len(rep["output_sets_ms"]) == 3 and len(rep["packet_buffers_ms"]) == 3
+    assert torch.equal(pk2, d_pk)
+    assert list(out) == list(plain)
+    for k in plain:
+        assert out[k].dtype == plain[k].dtype and out[k].shape == plain[k].shape and out[k].is_contiguous(), k
+        assert out[k].data_ptr() % 256 == 0, k
+    for t in out.values():
+        t.view(torch.uint8).fill_(0x3C)
+    hp.decode(pk2, out)
+    hp.sync()
+    for k in plain:
+        assert torch.equal(out[k].view(torch.uint8), plain[k].view(torch.uint8)), k
+    _compare(O, cal, hp, out, [src[f % 4] for f in range(32)], ["RANGE", "REFLECTIVITY2"], ["RANGE", "RANGE2"])
