@@ -24,6 +24,25 @@ for r in rows(os.path.join(d, "trace", "bench_kernel_stats.csv"))[:8]:
     name = r["Name"].split("(")[0][-70:]
     print(f"| `{name}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
           f"{float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
+# the timed region alone: bench.py's setup (variant tuner, placement draws) launches the decode kernels many
+# times before the K timed steps, so the per-kernel average above covers all of it; the last K dispatches of
+# the dominant kernel are the timed steps and must agree with the HIP-event average bench.py prints
+tr = rows(os.path.join(d, "trace", "bench_kernel_trace.csv"))
+try:
+    steps = json.loads(open(os.path.join(d, "bench_under_rocprof.json")).read().strip().splitlines()[-1])["steps"]
+except Exception:
+    steps = 20
+dec = [r for r in tr if "k_decode" in r["Kernel_Name"] and "fixup" not in r["Kernel_Name"]]
+dec.sort(key=lambda r: int(r["Start_Timestamp"]))
+if len(dec) >= steps:
+    last = dec[-steps:]
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in last]
+    names = sorted({r["Kernel_Name"].split("(")[0][-70:] for r in last})
+    print(f"\n**Timed region (the last {steps} decode dispatches of the trace):** `{'`, `'.join(names)}` "
+          f"avg {sum(durs)/len(durs):.1f} us, min {min(durs):.1f}, max {max(durs):.1f} "
+          f"(all {len(dec)} decode dispatches of the process: avg "
+          f"{sum((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in dec)/len(dec):.1f} us -- "
+          "setup draws several buffer placements and kernel variants, DESIGN.md 3.2b / 3.2c)")
 print("\n## HBM traffic per launch (separate --pmc passes)\n")
 agg = {}
 for c in ("pmc_fetch", "pmc_write"):
