@@ -176,7 +176,8 @@ int ouster_hip_ctx_device(ouster_hip_ctx* ctx); /* the HIP device ordinal the co
  *   "wide"  -1 auto | 0 k_decode only | 64/128/256/512 force that k_decode_wide tile width
  *   "tile"  force k_decode's tile width (64/32/16)      "wide_kb"  LDS budget of a wide tile
  *   "wide_min_blocks"  smallest launch that may use wide tiles   "tune"  0: no variant timing
- *   "xcd"   0: plain block -> frame mapping   "fast"  0: every frame through the general mapping */
+ *   "xcd"   0: plain block -> frame mapping   "fast"  0: every frame through the general mapping
+ *   "retune" 1: forget the variant tuner's verdicts (a caller that re-allocated its buffers re-learns) */
 int ouster_hip_ctx_set_knob(ouster_hip_ctx* ctx, const char* name, int value);
 int ouster_hip_sync(ouster_hip_ctx* ctx);
 const char* ouster_hip_last_error(void);

@@ -337,6 +337,16 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "wide_rows") k.wide_rows = value;
     else if (n == "wide_min_blocks") k.wide_min_blocks = value;
     else if (n == "tune") k.tune = value;
+    else if (n == "retune") {   // forget what the variant tuner learnt (the caller moved its buffers: pick_placement)
+        if (value) {
+            (void)hipStreamSynchronize(c->stream);
+            for (auto& kv : c->tune)
+                for (auto& pr : kv.second.ev)
+                    for (hipEvent_t e : pr)
+                        if (e) (void)hipEventDestroy(e);
+            c->tune.clear();
+        }
+    }
     else if (n == "xcd") k.xcd = value;
     else if (n == "fast") k.fast = value;
     else if (n == "fixup") k.fixup = value;

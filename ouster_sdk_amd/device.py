@@ -129,24 +129,34 @@ class HotPath:
             torch.cuda.synchronize()
             return a.elapsed_time(b) / launches
 
-        best_out, best_ms, out_ms = None, None, []
+        # the rejected draws stay allocated until the search is over: memory that has just been freed is what
+        # the next allocation of the same size gets back, and it would be the same draw again
+        best_out, best_ms, out_ms, held = None, None, [], []
         for _ in range(max(1, tries)):
             cand = slab_set()
+            held.append(cand)
             ms = clock(packets, cand)
             out_ms.append(round(ms, 4))
             if best_ms is None or ms < best_ms:
                 best_out, best_ms = cand, ms
-            del cand
-            torch.cuda.empty_cache()
         best_pk, pk_best_ms, pk_ms = packets, best_ms, [round(best_ms, 4)]
         for _ in range(max(0, min(tries, 6) - 1)):
             cand = packets.clone()
+            held.append(cand)
             ms = clock(cand, best_out)
             pk_ms.append(round(ms, 4))
             if ms < pk_best_ms:
                 best_pk, pk_best_ms = cand, ms
-            del cand
+        del held, cand
         torch.cuda.empty_cache()
+        # the kernel variant was chosen on the buffers the caller had before: let the tuner look again
+        try:
+            self.ctx.set_knob("retune", 1)
+            for _ in range(14):
+                self.decode(best_pk, best_out)
+            torch.cuda.synchronize()
+        except Exception:
+            pass
         return best_pk, best_out, {"tries": tries, "output_sets_ms": out_ms, "packet_buffers_ms": pk_ms}
 
     # -- the three operations --------------------------------------------------------------
