@@ -35,6 +35,12 @@ def t(pkb, o):
 res = {"workload": wl, "wide": wide, "output_sets_ms": [], "input_copies_ms": []}
 for i, o in enumerate(sets):
     res["output_sets_ms"].append(round(float(np.median([t(pk, o) for _ in range(4)])), 4))
+# optional: the same sets under another knob setting (argv[4] = knob:value), e.g. xcd:2
+if len(sys.argv) > 4:
+    k, v = sys.argv[4].split(":")
+    hp.ctx.set_knob(k, int(v))
+    res["output_sets_ms_" + sys.argv[4]] = [round(float(np.median([t(pk, o) for _ in range(4)])), 4) for o in sets]
+    hp.ctx.set_knob(k, 1)
 for pkb in pks:
     res["input_copies_ms"].append(round(float(np.median([t(pkb, sets[0]) for _ in range(4)])), 4))
 print(json.dumps(res))
