@@ -37,6 +37,7 @@ struct FragBuf {
     std::vector<bool> have;          // per 8-byte block
     size_t total = 0;                // known once the last fragment arrived
     int count = 0;
+    uint64_t first_seen = 0;         // IP packet number of its first fragment (incomplete ones expire)
 };
 }  // namespace
 
@@ -48,6 +49,7 @@ struct PcapReader::Impl {
     std::vector<uint8_t> rec, payload;
     PacketInfo info;
     std::map<FragKey, FragBuf> frags;
+    uint64_t n_ipv4 = 0;
 
     uint32_t u32(const uint8_t* p) const {
         uint32_t v;
@@ -86,7 +88,14 @@ struct PcapReader::Impl {
         FragKey key{0, 0, be16(ip + 4)};
         std::memcpy(&key.src, ip + 12, 4);
         std::memcpy(&key.dst, ip + 16, 4);
+        // a datagram that lost a fragment never completes: forget what has been waiting for more than 4096
+        // IPv4 packets once a few hundred are pending (lossy captures would otherwise grow without bound)
+        ++n_ipv4;
+        if (frags.size() > 256)
+            for (auto it = frags.begin(); it != frags.end();)
+                it = (n_ipv4 - it->second.first_seen > 4096) ? frags.erase(it) : std::next(it);
         FragBuf& fb = frags[key];
+        if (fb.count == 0) fb.first_seen = n_ipv4;
         const size_t plen = tot - ihl;
         if (fb.data.size() < frag_off + plen) {
             fb.data.resize(frag_off + plen);

@@ -104,3 +104,25 @@ def test_vlan_sll_nanos_and_fragment_reassembly(tmp_path):
         bad = tmp_path / "bad.pcap"
         bad.write_bytes(b"\x0a\x0d\x0d\x0a" + bytes(40))
         _read(str(bad))
+
+
+def test_incomplete_fragments_expire(tmp_path):
+    """A lossy capture: thousands of datagrams that each lost their last fragment.  Their buffers are forgotten
+    after a while (the reader's memory stays bounded), complete datagrams keep flowing, and an IP id that comes
+    round again long after its first, incomplete use does not inherit the stale fragment."""
+    eth = bytes(12) + b"\x08\x00"
+    first = _udp(bytes(2000))[:1480]
+    recs = []
+    for i in range(6000):                                   # never completed: MF set, nothing follows
+        recs.append(eth + _ipv4(first, ident=i % 65536, flags_frag=0x2000))
+        if i % 1000 == 999:
+            recs.append(eth + _ipv4(_udp(b"alive-%d" % i)))
+    # IP id 5 again, 6000 packets later: a different datagram whose SECOND fragment arrives first
+    b = bytes([7]) * 3000
+    whole = _udp(b)
+    recs.append(eth + _ipv4(whole[1480:], ident=5, flags_frag=(1480 // 8)))
+    recs.append(eth + _ipv4(whole[:1480], ident=5, flags_frag=0x2000))
+    p = tmp_path / "lossy.pcap"
+    p.write_bytes(_pcap(recs))
+    got, _ = _read(str(p))
+    assert [bytes(g) for g in got] == [b"alive-%d" % i for i in range(999, 6000, 1000)] + [b]
