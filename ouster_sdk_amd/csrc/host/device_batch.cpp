@@ -203,7 +203,12 @@ double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms) 
     std::vector<Outputs> rejected;
     std::vector<DeviceBuffer> rejected_packets;
     for (int t = 1; t < tries; ++t) {
-        Outputs cand = fresh();
+        Outputs cand;
+        try {
+            cand = fresh();
+        } catch (const std::exception&) {   // out of device memory: choose among the draws made so far
+            break;
+        }
         exchange(cand);                  // members = candidate, cand = incumbent
         const double ms = clock();
         if (all_ms) all_ms->push_back(ms);
@@ -212,7 +217,12 @@ double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms) 
         rejected.push_back(std::move(cand));
     }
     for (int t = 1; t < std::min(tries, 6); ++t) {
-        DeviceBuffer cand(d_packets_.size());
+        DeviceBuffer cand;
+        try {
+            cand.resize(d_packets_.size());
+        } catch (const std::exception&) {
+            break;
+        }
         if (hipMemcpyAsync(cand.data(), d_packets_.data(), d_packets_.size(), hipMemcpyDeviceToDevice, st) != hipSuccess)
             throw std::runtime_error("ouster_hip: packet buffer copy failed");
         std::swap(cand, d_packets_);

@@ -133,15 +133,24 @@ class HotPath:
         # the next allocation of the same size gets back, and it would be the same draw again
         best_out, best_ms, out_ms, held = None, None, [], []
         for _ in range(max(1, tries)):
-            cand = slab_set()
+            try:
+                cand = slab_set()
+            except RuntimeError:        # out of device memory: choose among the draws made so far
+                if best_out is None:
+                    raise
+                break
             held.append(cand)
             ms = clock(packets, cand)
             out_ms.append(round(ms, 4))
             if best_ms is None or ms < best_ms:
                 best_out, best_ms = cand, ms
         best_pk, pk_best_ms, pk_ms = packets, best_ms, [round(best_ms, 4)]
+        cand = None
         for _ in range(max(0, min(tries, 6) - 1)):
-            cand = packets.clone()
+            try:
+                cand = packets.clone()
+            except RuntimeError:
+                break
             held.append(cand)
             ms = clock(cand, best_out)
             pk_ms.append(round(ms, 4))
