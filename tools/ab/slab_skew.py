@@ -24,7 +24,7 @@ names = list(tmpl)
 MB2 = 2 << 20
 def carve(skew_of):
     sizes = [tmpl[n].numel() * tmpl[n].element_size() for n in names]
-    total = sum((s + MB2 - 1) // MB2 * MB2 + MB2 for s in sizes)
+    total = sum((s + MB2 - 1) // MB2 * MB2 + MB2 for s in sizes) + (200 << 20)
     slab = torch.empty(total, dtype=torch.uint8, device="cuda")
     base = (-slab.data_ptr()) % MB2
     out, off = {}, base
@@ -37,6 +37,10 @@ def carve(skew_of):
     return out
 layouts = {
     "aligned_2MB": lambda k: 0,
+    "skew_2MB": lambda k: (2 << 20) * k,
+    "skew_6MB": lambda k: (6 << 20) * k,
+    "skew_2MB_mod8": lambda k: (2 << 20) * ((k * 3) % 8),
+    "skew_1MB+4KB": lambda k: ((1 << 20) + 4096) * k,
     "skew_256B": lambda k: 256 * k,
     "skew_4352B": lambda k: 4352 * k,
     "skew_64KB+256": lambda k: (65536 + 256) * k,
