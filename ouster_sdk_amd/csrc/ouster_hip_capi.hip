@@ -817,6 +817,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         const uint32_t rpp = 1024u / (uint32_t)want;  // rows per pass of the 256-thread workgroup
         const uint32_t budget = (uint32_t)(kn.wide_kb > 0 ? kn.wide_kb : 64) * 1024u;
         uint32_t tr_max = budget / ((uint32_t)want * chan) / rpp * rpp;
+        tr_max = std::min(tr_max, 84u / rpp * rpp);   // k_decode_wide keeps a row chunk's table rows in registers (84 rows at most)
         if (tr_max < rpp) return false;
         auto up = [&](uint32_t v) { return (v + rpp - 1) / rpp * rpp; };
         uint32_t nch = (H + tr_max - 1) / tr_max, tr = std::min(up((H + nch - 1) / nch), tr_max);
