@@ -249,7 +249,7 @@ static void fill_geometry(const ouster_hip_format_desc& d, Geometry& g) {
 extern "C" {
 
 const char* ouster_hip_last_error(void) { return g_err.c_str(); }
-const char* ouster_hip_version(void) { return "ouster_hip 0.1 (gfx950)"; }
+const char* ouster_hip_version(void) { return "ouster_hip 0.2 (gfx950)"; }
 
 int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
     if (!out) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "out is NULL");
