@@ -24,14 +24,15 @@ for name, path in variants:
     knob = path[1:].split(":") if path.startswith("@") else None
     lib = _capi.load_hip(os.path.join(ROOT, path)) if path and not knob else None
     hp = HotPath(prof, H, W, 16, lib=lib)
-    if knob:
-        hp.ctx.set_knob(knob[0], int(knob[1]))
+
     hp.set_pixel_shift_by_row(shifts)
     hp.add_lut(b2l, l2s, az, alt)
     try:
         hp.ctx.set_knob("wide", wide)
     except Exception:          # the round-1 library has no knobs: it reads OUSTER_HIP_WIDE from the environment
         pass
+    if knob:
+        hp.ctx.set_knob(knob[0], int(knob[1]))
     if out is None:
         out = hp.alloc_outputs(N, destagger=dst, xyz=xyz)
     hps[name] = hp
@@ -53,6 +54,6 @@ for rnd in range(6):
         for k, v in ref.items():
             if k in ("frame_meta", "gate_counts"): continue
             assert torch.equal(v.view(torch.uint8), out[k].view(torch.uint8)), (name, k)
-print(json.dumps({"workload": wl, "wide": wide, "tile": list(hps[variants[0][0]].ctx.last_decode_tile()),
+print(json.dumps({"workload": wl, "wide": wide, "tiles": {n: list(h.ctx.last_decode_tile()) for n, h in hps.items()},
                   "ms_per_call_median": {n: round(float(np.median(t)), 4) for n, t in times.items()},
                   "ms_per_call_min": {n: round(float(np.min(t)), 4) for n, t in times.items()}}))
