@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--placement-tries", type=int, default=12,
+    ap.add_argument("--placement-tries", type=int, default=16,
                     help="candidate allocations of the output set to draw during setup (1 = take the first)")
     ap.add_argument("--workload", default="dual", choices=sorted(WORKLOADS),
                     help="'dual' is the metric (configs[2]); the others are extra report rows")

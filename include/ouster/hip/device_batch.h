@@ -80,7 +80,7 @@ class DeviceFrameBatch {
      *  (and the packet buffer, contents preserved, up to 6 times), times decode() into each draw and keeps
      *  the fastest.  Output contents are undefined afterwards (decode() again).  Returns the seconds per
      *  decode() of the kept draw; `all_ms` (optional) receives every draw's time in ms, outputs first. */
-    double tune_placement(int tries = 12, std::vector<double>* all_ms = nullptr);
+    double tune_placement(int tries = 16, std::vector<double>* all_ms = nullptr);
 
     /** Run the fused kernels on everything uploaded so far (asynchronous; sync() to wait). */
     void decode();

@@ -95,7 +95,7 @@ class HotPath:
             out["frame_meta"] = torch.empty((n_frames, 24), dtype=torch.uint8, device="cuda")
         return out
 
-    def pick_placement(self, packets: torch.Tensor, make_outputs, tries: int = 12, launches: int = 12):
+    def pick_placement(self, packets: torch.Tensor, make_outputs, tries: int = 16, launches: int = 12):
         """Output buffers that live for the life of a pipeline are worth choosing: on MI355X the achieved
         write rate of the decode differs by 10 - 20 % between allocations of the SAME size made by the SAME
         process (tools/ab/alloc_lottery.py: the physical placement of an allocation is drawn when it is made
