@@ -205,7 +205,9 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--placement-tries", type=int, default=16,
+    ap.add_argument("--placement-stride-gb", type=float, default=4.0,
+                    help="ballast held between two placement draws: the draws scan the device memory")
+    ap.add_argument("--placement-tries", type=int, default=24,
                     help="candidate allocations of the output set to draw during setup (1 = take the first)")
     ap.add_argument("--workload", default="dual", choices=sorted(WORKLOADS),
                     help="'dual' is the metric (configs[2]); the others are extra report rows")
@@ -289,7 +291,8 @@ def main():
     if args.placement_tries > 1:
         del out
         torch.cuda.empty_cache()
-        packets, out, placement = hp.pick_placement(packets, make_outputs, tries=args.placement_tries)
+        packets, out, placement = hp.pick_placement(packets, make_outputs, tries=args.placement_tries,
+                                                    stride_gb=args.placement_stride_gb)
     for _ in range(args.warmup):
         hp.decode(packets, out)
     torch.cuda.synchronize()
@@ -439,9 +442,10 @@ def main():
                        "outputs": "8 planes + 4 destaggered planes + 2x XYZ f32 + column headers"
                        if args.outputs == "full" else "ABLATION:" + args.outputs,
                        "sharding": f"frames x{world}, no data-path collective",
-                       "buffer_placement": ("best of %d allocations of the output set and of up to 6 of the packet "
+                       "buffer_placement": ("best of %d allocations of the output set (%.0f GB of ballast between "
+                                            "two draws: they scan the device memory) and of up to 6 of the packet "
                                             "buffer, drawn and timed during setup (HotPath.pick_placement)"
-                                            % args.placement_tries) if placement else "first allocation"},
+                                            % (args.placement_tries, args.placement_stride_gb)) if placement else "first allocation"},
             "placement": placement,
             "roofline": {"bound": "hbm",
                          "kernel": kernel_name,

@@ -79,8 +79,11 @@ class DeviceFrameBatch {
      *  the life of a pipeline, so it can afford to draw: this re-allocates the output buffers `tries` times
      *  (and the packet buffer, contents preserved, up to 6 times), times decode() into each draw and keeps
      *  the fastest.  Output contents are undefined afterwards (decode() again).  Returns the seconds per
-     *  decode() of the kept draw; `all_ms` (optional) receives every draw's time in ms, outputs first. */
-    double tune_placement(int tries = 16, std::vector<double>* all_ms = nullptr);
+     *  decode() of the kept draw; `all_ms` (optional) receives every draw's time in ms, outputs first.
+     *  `ballast_bytes_between_draws` of device memory are held between two draws so that the draws scan the
+     *  memory instead of its first few GB: which mode a draw gets follows where it lands (tools/ab/ballast.py). */
+    double tune_placement(int tries = 16, std::vector<double>* all_ms = nullptr,
+                          size_t ballast_bytes_between_draws = size_t{4} << 30);
 
     /** Run the fused kernels on everything uploaded so far (asynchronous; sync() to wait). */
     void decode();

@@ -152,7 +152,7 @@ void DeviceFrameBatch::decode() {
 
 void DeviceFrameBatch::sync() { ctx_->sync(); }
 
-double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms) {
+double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms, size_t ballast_bytes) {
     ScopedContext on_my_context(ctx_);
     auto st = static_cast<hipStream_t>(ctx_->stream());
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -215,7 +215,16 @@ double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms) 
         if (ms < best) best = ms;        // keep the candidate
         else exchange(cand);             // put the incumbent back
         rejected.push_back(std::move(cand));
+        if (ballast_bytes) {
+            try {
+                rejected_packets.emplace_back(ballast_bytes);
+            } catch (const std::exception&) {
+                break;
+            }
+        }
     }
+    ctx_->sync();
+    rejected_packets.clear();            // the packet buffer looks for its place in what the ballast occupied
     for (int t = 1; t < std::min(tries, 6); ++t) {
         DeviceBuffer cand;
         try {

@@ -95,14 +95,18 @@ class HotPath:
             out["frame_meta"] = torch.empty((n_frames, 24), dtype=torch.uint8, device="cuda")
         return out
 
-    def pick_placement(self, packets: torch.Tensor, make_outputs, tries: int = 16, launches: int = 12):
+    def pick_placement(self, packets: torch.Tensor, make_outputs, tries: int = 16, launches: int = 12,
+                       stride_gb: float = 0.0):
         """Output buffers that live for the life of a pipeline are worth choosing: on MI355X the achieved
         write rate of the decode differs by 10 - 20 % between allocations of the SAME size made by the SAME
         process (tools/ab/alloc_lottery.py: the physical placement of an allocation is drawn when it is made
         and never changes), in two modes -- most draws land near the slow one.  This helper draws `tries`
         candidate output sets with make_outputs() (each one slab, one draw), times the decode into each and
         keeps the fastest; then does the same for copies of the packet buffer.  Returns
-        (packets, outputs, report).  Everything but the winners is freed."""
+        (packets, outputs, report).  Everything but the winners is freed.
+        stride_gb > 0: hold that much ballast between two draws, so that `tries` draws scan the device memory
+        instead of its first tries x (set size) -- which mode a draw gets follows where it lands
+        (tools/ab/ballast.py), and the fast regions can be tens of GB apart."""
         def slab_set():
             tmpl = make_outputs()
             names = list(tmpl)
@@ -144,6 +148,15 @@ class HotPath:
             out_ms.append(round(ms, 4))
             if best_ms is None or ms < best_ms:
                 best_out, best_ms = cand, ms
+            if stride_gb > 0:
+                try:
+                    held.append(torch.empty(int(stride_gb * (1 << 30)), dtype=torch.uint8, device="cuda"))
+                except RuntimeError:
+                    break
+        # the packet buffer is small: look for its place in the memory the ballast occupied
+        held_outputs = [h for h in held if isinstance(h, dict)]
+        held = held_outputs
+        torch.cuda.empty_cache()
         best_pk, pk_best_ms, pk_ms = packets, best_ms, [round(best_ms, 4)]
         cand = None
         for _ in range(max(0, min(tries, 6) - 1)):
@@ -166,7 +179,8 @@ class HotPath:
             torch.cuda.synchronize()
         except Exception:
             pass
-        return best_pk, best_out, {"tries": tries, "output_sets_ms": out_ms, "packet_buffers_ms": pk_ms}
+        return best_pk, best_out, {"tries": tries, "stride_gb": stride_gb, "output_sets_ms": out_ms,
+                                   "packet_buffers_ms": pk_ms}
 
     # -- the three operations --------------------------------------------------------------
     def range_gate(self, min_range: float, max_range: float) -> Tuple[int, int, bool]:
