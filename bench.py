@@ -443,7 +443,7 @@ def main():
                        if args.outputs == "full" else "ABLATION:" + args.outputs,
                        "sharding": f"frames x{world}, no data-path collective",
                        "buffer_placement": ("best of %d allocations of the output set (%.0f GB of ballast between "
-                                            "two draws: they scan the device memory) and of up to 6 of the packet "
+                                            "two draws: they scan the device memory) and of up to 10 of the packet "
                                             "buffer, drawn and timed during setup (HotPath.pick_placement)"
                                             % (args.placement_tries, args.placement_stride_gb)) if placement else "first allocation"},
             "placement": placement,
