@@ -39,6 +39,19 @@ for name, path in variants:
     for _ in range(3):
         hp.decode(pk, out)
 torch.cuda.synchronize()
+if os.environ.get("AB_PLACEMENT"):     # first find a fast place for the buffers, then compare there
+    first = hps[variants[0][0]]
+    pk, out, rep = first.pick_placement(pk, lambda: first.alloc_outputs(N, destagger=dst, xyz=xyz),
+                                        tries=int(os.environ["AB_PLACEMENT"]), stride_gb=4.0)
+    print("placement:", min(rep["output_sets_ms"]), max(rep["output_sets_ms"]), file=sys.stderr)
+    for hp in hps.values():
+        try:
+            hp.ctx.set_knob("wide", wide)
+        except Exception:
+            pass
+        for _ in range(3):
+            hp.decode(pk, out)
+    torch.cuda.synchronize()
 ref = {k: v.clone() for k, v in out.items() if k != "frame_meta"}
 times = {n: [] for n in hps}
 for rnd in range(6):
