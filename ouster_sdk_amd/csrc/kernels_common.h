@@ -120,38 +120,42 @@ struct __attribute__((packed, aligned(1))) pk8 { uint32_t a, b; };
 struct __attribute__((packed, aligned(1))) pk16 { uint32_t a, b, c, d; };
 
 #ifndef OUSTER_NT_STORES
-#define OUSTER_NT_STORES 0   // experiment switch (tools/ab/nt_variants.sh): non-temporal hint on the plane / xyz stores
+#define OUSTER_NT_STORES 0   // experiment switch (tools/ab/nt_variants.sh): non-temporal hint on EVERY plane / xyz store
 #endif
 #ifndef OUSTER_NT_LOADS
 #define OUSTER_NT_LOADS 0    // experiment switch: non-temporal hint on the tile staging loads
 #endif
+// NT = non-temporal hint.  Measured in-process (BASELINE section 5): the 12 B/px profile's wide tiles gain 3 - 8 % with
+// it (128 x 32: 4.7 % in a fast region, 3 % in a slow one; 256 x 16: 7.5 %) while its 32-column k_decode loses 18 %; the
+// dual-return 256 x 32 tiles are indifferent and the 128 x 64 tiles lose 6.5 % -- so it is a property of the profile
+// specialisation AND the kernel (Spec::nt_stores, applied by k_decode_wide only), not a global switch.
 typedef uint32_t u32x1_u __attribute__((aligned(1)));
 typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(1)));
 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+template <bool NT = false>
 __device__ __forceinline__ void st4(void* p, uint32_t a) {
-#if OUSTER_NT_STORES
-    __builtin_nontemporal_store(a, (u32x1_u*)p);
-#else
-    ((pk4*)p)->a = a;
-#endif
+    if constexpr (NT || OUSTER_NT_STORES) __builtin_nontemporal_store(a, (u32x1_u*)p);
+    else ((pk4*)p)->a = a;
 }
+template <bool NT = false>
 __device__ __forceinline__ void st8(void* p, uint32_t a, uint32_t b) {
-#if OUSTER_NT_STORES
-    typedef uint32_t v2 __attribute__((ext_vector_type(2)));
-    __builtin_nontemporal_store(v2{a, b}, (u32x2_u*)p);
-#else
-    pk8 v{a, b};
-    *((pk8*)p) = v;
-#endif
+    if constexpr (NT || OUSTER_NT_STORES) {
+        typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(v2{a, b}, (u32x2_u*)p);
+    } else {
+        pk8 v{a, b};
+        *((pk8*)p) = v;
+    }
 }
+template <bool NT = false>
 __device__ __forceinline__ void st16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-#if OUSTER_NT_STORES
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    __builtin_nontemporal_store(v4{a, b, c, d}, (u32x4_u*)p);
-#else
-    pk16 v{a, b, c, d};
-    *((pk16*)p) = v;
-#endif
+    if constexpr (NT || OUSTER_NT_STORES) {
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(v4{a, b, c, d}, (u32x4_u*)p);
+    } else {
+        pk16 v{a, b, c, d};
+        *((pk16*)p) = v;
+    }
 }
 
 // store 4 consecutive elements of `elem` bytes each starting at byte pointer p
@@ -201,17 +205,18 @@ __device__ __forceinline__ void store1(uint8_t* p, uint64_t v, uint32_t elem) {
 
 // the same for values of at most 4 bytes held as one register quad (the static profiles): a u32 plane's
 // four elements ARE the 16 B store operand, nothing is moved
+template <bool NT = false>
 __device__ __forceinline__ void store4v(uint8_t* p, const u32x4_t& v, uint32_t elem) {
     switch (elem) {
-        case 1: st4(p, v.x | (v.y << 8) | (v.z << 16) | (v.w << 24)); break;
-        case 2: st8(p, v.x | (v.y << 16), v.z | (v.w << 16)); break;
+        case 1: st4<NT>(p, v.x | (v.y << 8) | (v.z << 16) | (v.w << 24)); break;
+        case 2: st8<NT>(p, v.x | (v.y << 16), v.z | (v.w << 16)); break;
         default: {
-#if OUSTER_NT_STORES
-            __builtin_nontemporal_store(v, (u32x4_u*)p);
-#else
-            struct __attribute__((packed, aligned(1))) pkv { u32x4_t v; };
-            ((pkv*)p)->v = v;
-#endif
+            if constexpr (NT || OUSTER_NT_STORES) {
+                __builtin_nontemporal_store(v, (u32x4_u*)p);
+            } else {
+                struct __attribute__((packed, aligned(1))) pkv { u32x4_t v; };
+                ((pkv*)p)->v = v;
+            }
         }
     }
 }
@@ -251,6 +256,7 @@ __device__ __forceinline__ void stage_range(uint32_t* lds_tile, uint32_t lds_byt
 // ------------------------------------------------------------------------------------
 struct SpecDualLB {  // RNG15_RFL8_NIR8_DUAL / FUSA_RNG15_RFL8_NIR8_DUAL, 8 B/px
     static constexpr bool is_static = true;
+    static constexpr bool nt_stores = false;
     static constexpr uint32_t chan = 8;
     static constexpr int nf = 8;
     static constexpr int range_idx = 0, range2_idx = 4;
@@ -260,6 +266,7 @@ struct SpecDualLB {  // RNG15_RFL8_NIR8_DUAL / FUSA_RNG15_RFL8_NIR8_DUAL, 8 B/px
 };
 struct SpecLB {  // RNG15_RFL8_NIR8, 4 B/px
     static constexpr bool is_static = true;
+    static constexpr bool nt_stores = false;
     static constexpr uint32_t chan = 4;
     static constexpr int nf = 4;
     static constexpr int range_idx = 0, range2_idx = -1;
@@ -268,6 +275,7 @@ struct SpecLB {  // RNG15_RFL8_NIR8, 4 B/px
 };
 struct SpecSingle {  // RNG19_RFL8_SIG16_NIR16, 12 B/px
     static constexpr bool is_static = true;
+    static constexpr bool nt_stores = true;   // k_decode_wide only; measured +3 ... +8 %
     static constexpr uint32_t chan = 12;
     static constexpr int nf = 6;
     static constexpr int range_idx = 0, range2_idx = -1;
@@ -276,6 +284,7 @@ struct SpecSingle {  // RNG19_RFL8_SIG16_NIR16, 12 B/px
 };
 struct SpecDual {  // RNG19_RFL8_SIG16_NIR16_DUAL, 16 B/px
     static constexpr bool is_static = true;
+    static constexpr bool nt_stores = false;
     static constexpr uint32_t chan = 16;
     static constexpr int nf = 10;
     static constexpr int range_idx = 0, range2_idx = 3;
@@ -286,6 +295,7 @@ struct SpecDual {  // RNG19_RFL8_SIG16_NIR16_DUAL, 16 B/px
 };
 struct SpecLegacy {  // LEGACY, 12 B/px
     static constexpr bool is_static = true;
+    static constexpr bool nt_stores = false;
     static constexpr uint32_t chan = 12;
     static constexpr int nf = 5;
     static constexpr int range_idx = 0, range2_idx = -1;
@@ -294,6 +304,7 @@ struct SpecLegacy {  // LEGACY, 12 B/px
 };
 struct SpecGeneric {  // everything else: descriptors read from the kernel arguments
     static constexpr bool is_static = false;
+    static constexpr bool nt_stores = false;
     static constexpr uint32_t chan = 0;
     static constexpr int nf = 0;
     static constexpr int range_idx = -1, range2_idx = -1;
@@ -372,7 +383,7 @@ __device__ __forceinline__ void store_xyz4_coalesced(float4* s_xyz, uint32_t tid
 // 3s + j == d (mod LPR) from lane s = (d - j) * 3^-1 mod LPR -- a bijection because LPR is a power
 // of two -- and files it under k = (3s + j) / LPR.  Frees the 12 KB scratch (one more 12 B/px
 // workgroup per CU).
-template <int LPR, class P>
+template <int LPR, bool NT = false, class P>
 __device__ __forceinline__ void store_xyz4_permuted(float* row_base, uint32_t q, const P (&p)[4][3]) {
     static_assert(LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32 || LPR == 64, "row segment lanes");
     constexpr uint32_t INV3 = LPR == 64 ? 43u : (LPR >= 16 ? 11u : 3u);  // 3 * INV3 == 1 (mod LPR)
@@ -400,12 +411,12 @@ __device__ __forceinline__ void store_xyz4_permuted(float* row_base, uint32_t q,
     float4* d = (float4*)row_base;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-#if OUSTER_NT_STORES
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(f4{o[k][0], o[k][1], o[k][2], o[k][3]}, (f4*)(d + k * LPR + q));
-#else
-        d[k * LPR + q] = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
-#endif
+        if constexpr (NT || OUSTER_NT_STORES) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(f4{o[k][0], o[k][1], o[k][2], o[k][3]}, (f4*)(d + k * LPR + q));
+        } else {
+            d[k * LPR + q] = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+        }
     }
 }
 
@@ -523,7 +534,7 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_of(const Geometry& g
 // and the tile's partial counts go to a.gate_counts[f][gate_chunk][c0..] -- the dewarp that follows
 // skips its counting pass.  Every thread of the workgroup must call decode_rows (it ends in a barrier
 // when s_gate is set).
-template <class S, int QPR, int XYZM, bool DEADZ = false>
+template <class S, int QPR, int XYZM, bool DEADZ = false, bool NTS = false>
 __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t* s_tile,
                                             uint32_t col0_dw, uint32_t colstride_dw, const int32_t* s_off,
                                             float4* s_xyz, const double* s_beam, uint32_t* s_gate,
@@ -597,13 +608,13 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                 uint8_t* pl = (uint8_t*)a.planes[di];
                 if (pl) {
                     uint8_t* d = pl + ((size_t)f * plane_px + rowpix) * e;
-                    if (vec) store4v(d, v, e);
+                    if (vec) store4v<NTS>(d, v, e);
                     else for (uint32_t c = 0; c < ncol; ++c) store1(d + c * e, v[c], e);
                 }
                 uint8_t* dp = (uint8_t*)a.destaggered[di];
                 if (dp) {
                     uint8_t* drow = dp + ((size_t)f * plane_px + (size_t)r * W) * e;
-                    if (dvec) store4v(drow + (size_t)doff * e, v, e);
+                    if (dvec) store4v<NTS>(drow + (size_t)doff * e, v, e);
                     else for (uint32_t c = 0; c < ncol; ++c) {
                         uint32_t dc = doff + c; if (dc >= W) dc -= W;
                         store1(drow + (size_t)dc * e, v[c], e);
@@ -683,7 +694,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                 if constexpr (XYZM == 1) {
                     if (a.vec_ok && seg0 + 4 * LPR <= W) {  // my wave's whole row segment exists
 #if OUSTER_XYZ_PERMUTE
-                        store_xyz4_permuted<LPR>(dst - (size_t)(4 * ql) * 3, ql, p);
+                        store_xyz4_permuted<LPR, NTS>(dst - (size_t)(4 * ql) * 3, ql, p);
 #else
                         store_xyz4_coalesced<LPR>(s_xyz, tid, dst - (size_t)(4 * ql) * 3, ql, p);
 #endif

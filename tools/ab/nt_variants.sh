@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 O=tools/ab/_nt
 if [ "$1" = build ]; then
   mkdir -p $O
-  for v in "ld:-DOUSTER_NT_LOADS=1" "st:-DOUSTER_NT_STORES=1" "ldst:-DOUSTER_NT_LOADS=1 -DOUSTER_NT_STORES=1"; do
+  for v in ${NT_VARIANTS:-"ld:-DOUSTER_NT_LOADS=1" "st:-DOUSTER_NT_STORES=1" "ldst:-DOUSTER_NT_LOADS=1 -DOUSTER_NT_STORES=1"}; do
     tag=${v%%:*}; defs=${v#*:}
     F="--offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result $defs"
     mkdir -p $O/$tag
