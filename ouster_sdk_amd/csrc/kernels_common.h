@@ -256,7 +256,7 @@ __device__ __forceinline__ void stage_range(uint32_t* lds_tile, uint32_t lds_byt
 // ------------------------------------------------------------------------------------
 struct SpecDualLB {  // RNG15_RFL8_NIR8_DUAL / FUSA_RNG15_RFL8_NIR8_DUAL, 8 B/px
     static constexpr bool is_static = true;
-    static constexpr bool nt_stores = false;
+    static constexpr bool nt_stores = false;  // measured: 256 x 32 tiles +0.4 %, 128 x 64 tiles -6.5 %
     static constexpr uint32_t chan = 8;
     static constexpr int nf = 8;
     static constexpr int range_idx = 0, range2_idx = 4;
@@ -266,7 +266,7 @@ struct SpecDualLB {  // RNG15_RFL8_NIR8_DUAL / FUSA_RNG15_RFL8_NIR8_DUAL, 8 B/px
 };
 struct SpecLB {  // RNG15_RFL8_NIR8, 4 B/px
     static constexpr bool is_static = true;
-    static constexpr bool nt_stores = false;
+    static constexpr bool nt_stores = true;   // k_decode_wide only; measured +2.5 % (128 x 64) ... +7.3 % (256 x 64)
     static constexpr uint32_t chan = 4;
     static constexpr int nf = 4;
     static constexpr int range_idx = 0, range2_idx = -1;
@@ -284,7 +284,7 @@ struct SpecSingle {  // RNG19_RFL8_SIG16_NIR16, 12 B/px
 };
 struct SpecDual {  // RNG19_RFL8_SIG16_NIR16_DUAL, 16 B/px
     static constexpr bool is_static = true;
-    static constexpr bool nt_stores = false;
+    static constexpr bool nt_stores = true;   // k_decode_wide only; measured +2.4 % (128 x 32) ... +4.8 % (256 x 16)
     static constexpr uint32_t chan = 16;
     static constexpr int nf = 10;
     static constexpr int range_idx = 0, range2_idx = 3;
@@ -295,7 +295,7 @@ struct SpecDual {  // RNG19_RFL8_SIG16_NIR16_DUAL, 16 B/px
 };
 struct SpecLegacy {  // LEGACY, 12 B/px
     static constexpr bool is_static = true;
-    static constexpr bool nt_stores = false;
+    static constexpr bool nt_stores = true;   // k_decode_wide only; measured +3.6 % (128 x 32) ... +5.4 % (256 x 16)
     static constexpr uint32_t chan = 12;
     static constexpr int nf = 5;
     static constexpr int range_idx = 0, range2_idx = -1;
