@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     uint32_t vq = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_valid[jq + c]) ? (1u << c) : 0u;
-    decode_rows<S, TW / 4, XYZM, S::is_static, S::nt_stores>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
+    decode_rows<S, TW / 4, XYZM, S::is_static, S::nt_stores, S::nt_xyz>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
                                  a.gate_counts ? s_gate : nullptr, lut, f, c0, r0, nrows, vq, rc, nch);
     PHASE_STAMP(4);
 #ifdef OUSTER_PHASE_TIMING

@@ -122,6 +122,12 @@ struct __attribute__((packed, aligned(1))) pk16 { uint32_t a, b, c, d; };
 #ifndef OUSTER_NT_STORES
 #define OUSTER_NT_STORES 0   // experiment switch (tools/ab/nt_variants.sh): non-temporal hint on EVERY plane / xyz store
 #endif
+#ifndef OUSTER_NT_XYZ
+#define OUSTER_NT_XYZ 0      // experiment switch: the hint on the xyz stores only
+#endif
+#ifndef OUSTER_NT_PLANES
+#define OUSTER_NT_PLANES 0   // experiment switch: the hint on the plane stores only
+#endif
 #ifndef OUSTER_NT_LOADS
 #define OUSTER_NT_LOADS 0    // experiment switch: non-temporal hint on the tile staging loads
 #endif
@@ -256,7 +262,8 @@ __device__ __forceinline__ void stage_range(uint32_t* lds_tile, uint32_t lds_byt
 // ------------------------------------------------------------------------------------
 struct SpecDualLB {  // RNG15_RFL8_NIR8_DUAL / FUSA_RNG15_RFL8_NIR8_DUAL, 8 B/px
     static constexpr bool is_static = true;
-    static constexpr bool nt_stores = false;  // measured: 256 x 32 tiles +0.4 %, 128 x 64 tiles -6.5 %
+    static constexpr bool nt_stores = false;  // measured: 256 x 32 tiles +0.4 %, 128 x 64 tiles -6.5 % (the plane stores: -8.7 %)
+    static constexpr bool nt_xyz = true;      // the xyz stores alone: +0.6 % / +0.9 % (k_decode_wide only)
     static constexpr uint32_t chan = 8;
     static constexpr int nf = 8;
     static constexpr int range_idx = 0, range2_idx = 4;
@@ -267,6 +274,7 @@ struct SpecDualLB {  // RNG15_RFL8_NIR8_DUAL / FUSA_RNG15_RFL8_NIR8_DUAL, 8 B/px
 struct SpecLB {  // RNG15_RFL8_NIR8, 4 B/px
     static constexpr bool is_static = true;
     static constexpr bool nt_stores = true;   // k_decode_wide only; measured +2.5 % (128 x 64) ... +7.3 % (256 x 64)
+    static constexpr bool nt_xyz = nt_stores;
     static constexpr uint32_t chan = 4;
     static constexpr int nf = 4;
     static constexpr int range_idx = 0, range2_idx = -1;
@@ -276,6 +284,7 @@ struct SpecLB {  // RNG15_RFL8_NIR8, 4 B/px
 struct SpecSingle {  // RNG19_RFL8_SIG16_NIR16, 12 B/px
     static constexpr bool is_static = true;
     static constexpr bool nt_stores = true;   // k_decode_wide only; measured +3 ... +8 %
+    static constexpr bool nt_xyz = nt_stores;
     static constexpr uint32_t chan = 12;
     static constexpr int nf = 6;
     static constexpr int range_idx = 0, range2_idx = -1;
@@ -285,6 +294,7 @@ struct SpecSingle {  // RNG19_RFL8_SIG16_NIR16, 12 B/px
 struct SpecDual {  // RNG19_RFL8_SIG16_NIR16_DUAL, 16 B/px
     static constexpr bool is_static = true;
     static constexpr bool nt_stores = true;   // k_decode_wide only; measured +2.4 % (128 x 32) ... +4.8 % (256 x 16)
+    static constexpr bool nt_xyz = nt_stores;
     static constexpr uint32_t chan = 16;
     static constexpr int nf = 10;
     static constexpr int range_idx = 0, range2_idx = 3;
@@ -296,6 +306,7 @@ struct SpecDual {  // RNG19_RFL8_SIG16_NIR16_DUAL, 16 B/px
 struct SpecLegacy {  // LEGACY, 12 B/px
     static constexpr bool is_static = true;
     static constexpr bool nt_stores = true;   // k_decode_wide only; measured +3.6 % (128 x 32) ... +5.4 % (256 x 16)
+    static constexpr bool nt_xyz = nt_stores;
     static constexpr uint32_t chan = 12;
     static constexpr int nf = 5;
     static constexpr int range_idx = 0, range2_idx = -1;
@@ -305,6 +316,7 @@ struct SpecLegacy {  // LEGACY, 12 B/px
 struct SpecGeneric {  // everything else: descriptors read from the kernel arguments
     static constexpr bool is_static = false;
     static constexpr bool nt_stores = false;
+    static constexpr bool nt_xyz = nt_stores;
     static constexpr uint32_t chan = 0;
     static constexpr int nf = 0;
     static constexpr int range_idx = -1, range2_idx = -1;
@@ -534,7 +546,7 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_of(const Geometry& g
 // and the tile's partial counts go to a.gate_counts[f][gate_chunk][c0..] -- the dewarp that follows
 // skips its counting pass.  Every thread of the workgroup must call decode_rows (it ends in a barrier
 // when s_gate is set).
-template <class S, int QPR, int XYZM, bool DEADZ = false, bool NTS = false>
+template <class S, int QPR, int XYZM, bool DEADZ = false, bool NTS = false, bool NTX = NTS>
 __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t* s_tile,
                                             uint32_t col0_dw, uint32_t colstride_dw, const int32_t* s_off,
                                             float4* s_xyz, const double* s_beam, uint32_t* s_gate,
@@ -608,13 +620,13 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                 uint8_t* pl = (uint8_t*)a.planes[di];
                 if (pl) {
                     uint8_t* d = pl + ((size_t)f * plane_px + rowpix) * e;
-                    if (vec) store4v<NTS>(d, v, e);
+                    if (vec) store4v<NTS || OUSTER_NT_PLANES>(d, v, e);
                     else for (uint32_t c = 0; c < ncol; ++c) store1(d + c * e, v[c], e);
                 }
                 uint8_t* dp = (uint8_t*)a.destaggered[di];
                 if (dp) {
                     uint8_t* drow = dp + ((size_t)f * plane_px + (size_t)r * W) * e;
-                    if (dvec) store4v<NTS>(drow + (size_t)doff * e, v, e);
+                    if (dvec) store4v<NTS || OUSTER_NT_PLANES>(drow + (size_t)doff * e, v, e);
                     else for (uint32_t c = 0; c < ncol; ++c) {
                         uint32_t dc = doff + c; if (dc >= W) dc -= W;
                         store1(drow + (size_t)dc * e, v[c], e);
@@ -694,7 +706,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                 if constexpr (XYZM == 1) {
                     if (a.vec_ok && seg0 + 4 * LPR <= W) {  // my wave's whole row segment exists
 #if OUSTER_XYZ_PERMUTE
-                        store_xyz4_permuted<LPR, NTS>(dst - (size_t)(4 * ql) * 3, ql, p);
+                        store_xyz4_permuted<LPR, NTX || OUSTER_NT_XYZ>(dst - (size_t)(4 * ql) * 3, ql, p);
 #else
                         store_xyz4_coalesced<LPR>(s_xyz, tid, dst - (size_t)(4 * ql) * 3, ql, p);
 #endif
