@@ -138,14 +138,17 @@ struct __attribute__((packed, aligned(1))) pk16 { uint32_t a, b, c, d; };
 typedef uint32_t u32x1_u __attribute__((aligned(1)));
 typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(1)));
 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+#ifndef OUSTER_PLAIN_STORES
+#define OUSTER_PLAIN_STORES 0   // experiment switch: ignore every non-temporal request (the A/B partner of Spec::nt_stores)
+#endif
 template <bool NT = false>
 __device__ __forceinline__ void st4(void* p, uint32_t a) {
-    if constexpr (NT || OUSTER_NT_STORES) __builtin_nontemporal_store(a, (u32x1_u*)p);
+    if constexpr ((NT || OUSTER_NT_STORES) && !OUSTER_PLAIN_STORES) __builtin_nontemporal_store(a, (u32x1_u*)p);
     else ((pk4*)p)->a = a;
 }
 template <bool NT = false>
 __device__ __forceinline__ void st8(void* p, uint32_t a, uint32_t b) {
-    if constexpr (NT || OUSTER_NT_STORES) {
+    if constexpr ((NT || OUSTER_NT_STORES) && !OUSTER_PLAIN_STORES) {
         typedef uint32_t v2 __attribute__((ext_vector_type(2)));
         __builtin_nontemporal_store(v2{a, b}, (u32x2_u*)p);
     } else {
@@ -155,7 +158,7 @@ __device__ __forceinline__ void st8(void* p, uint32_t a, uint32_t b) {
 }
 template <bool NT = false>
 __device__ __forceinline__ void st16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    if constexpr (NT || OUSTER_NT_STORES) {
+    if constexpr ((NT || OUSTER_NT_STORES) && !OUSTER_PLAIN_STORES) {
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         __builtin_nontemporal_store(v4{a, b, c, d}, (u32x4_u*)p);
     } else {
@@ -217,7 +220,7 @@ __device__ __forceinline__ void store4v(uint8_t* p, const u32x4_t& v, uint32_t e
         case 1: st4<NT>(p, v.x | (v.y << 8) | (v.z << 16) | (v.w << 24)); break;
         case 2: st8<NT>(p, v.x | (v.y << 16), v.z | (v.w << 16)); break;
         default: {
-            if constexpr (NT || OUSTER_NT_STORES) {
+            if constexpr ((NT || OUSTER_NT_STORES) && !OUSTER_PLAIN_STORES) {
                 __builtin_nontemporal_store(v, (u32x4_u*)p);
             } else {
                 struct __attribute__((packed, aligned(1))) pkv { u32x4_t v; };
@@ -273,7 +276,7 @@ struct SpecDualLB {  // RNG15_RFL8_NIR8_DUAL / FUSA_RNG15_RFL8_NIR8_DUAL, 8 B/px
 };
 struct SpecLB {  // RNG15_RFL8_NIR8, 4 B/px
     static constexpr bool is_static = true;
-    static constexpr bool nt_stores = true;   // k_decode_wide only; measured +2.5 % (128 x 64) ... +7.3 % (256 x 64)
+    static constexpr bool nt_stores = false;  // measured +2.5 ... +7.3 % with the buffers in a fast region but -5.7 % in a slow one: off
     static constexpr bool nt_xyz = nt_stores;
     static constexpr uint32_t chan = 4;
     static constexpr int nf = 4;
@@ -423,7 +426,7 @@ __device__ __forceinline__ void store_xyz4_permuted(float* row_base, uint32_t q,
     float4* d = (float4*)row_base;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if constexpr (NT || OUSTER_NT_STORES) {
+        if constexpr ((NT || OUSTER_NT_STORES) && !OUSTER_PLAIN_STORES) {
             typedef float f4 __attribute__((ext_vector_type(4)));
             __builtin_nontemporal_store(f4{o[k][0], o[k][1], o[k][2], o[k][3]}, (f4*)(d + k * LPR + q));
         } else {
