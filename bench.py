@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--rotate-inputs", type=int, default=1,
+                    help="diagnostic: decode this many copies of the packet batch in turn (cold input every step)")
     ap.add_argument("--placement-stride-gb", type=float, default=4.0,
                     help="ballast held between two placement draws: the draws scan the device memory")
     ap.add_argument("--placement-tries", type=int, default=24,
@@ -297,11 +299,14 @@ def main():
         hp.decode(packets, out)
     torch.cuda.synchronize()
     barrier()
+    # --rotate-inputs R > 1 (a diagnostic, not the metric): R copies of the packet batch are decoded in turn, so that
+    # no step finds its input in the 256 MB Infinity Cache left there by the step before
+    inputs = [packets] + [packets.clone() for _ in range(max(0, args.rotate_inputs - 1))]
     hp.ctx.timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hp.decode(packets, out)
+    for i in range(args.steps):
+        hp.decode(inputs[i % len(inputs)], out)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -442,6 +447,7 @@ def main():
                        "outputs": "8 planes + 4 destaggered planes + 2x XYZ f32 + column headers"
                        if args.outputs == "full" else "ABLATION:" + args.outputs,
                        "sharding": f"frames x{world}, no data-path collective",
+                       "input_batches_rotated": args.rotate_inputs,
                        "buffer_placement": ("best of %d allocations of the output set (%.0f GB of ballast between "
                                             "two draws: they scan the device memory) and of up to 10 of the packet "
                                             "buffer, drawn and timed during setup (HotPath.pick_placement)"

@@ -75,7 +75,14 @@ __global__ __launch_bounds__(256) void k_destagger(DestaggerArgs a) {
                     o[k] = b[4 * k] | (b[4 * k + 1] << 8) | (b[4 * k + 2] << 16) |
                            ((uint32_t)b[4 * k + 3] << 24);
             }
+#if OUSTER_NT_STANDALONE
+            {
+                typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(v4{o[0], o[1], o[2], o[3]}, (v4*)(drow + db));
+            }
+#else
             *(uint4*)(drow + db) = make_uint4(o[0], o[1], o[2], o[3]);
+#endif
         }
     } else {
         for (size_t b = threadIdx.x; b < row_bytes; b += blockDim.x) {
@@ -635,7 +642,16 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
                 o.x = ps[0] * px + ps[1] * py + ps[2] * pz + ps[3];
                 o.y = ps[4] * px + ps[5] * py + ps[6] * pz + ps[7];
                 o.z = ps[8] * px + ps[9] * py + ps[10] * pz + ps[11];
+#if OUSTER_NT_STANDALONE
+                {
+                    T* pd = (T*)a.points + (g0 + rank[hh]) * 3;
+                    __builtin_nontemporal_store(o.x, pd);
+                    __builtin_nontemporal_store(o.y, pd + 1);
+                    __builtin_nontemporal_store(o.z, pd + 2);
+                }
+#else
                 ((Pt3<T>*)a.points)[g0 + rank[hh]] = o;
+#endif
             }
             // every point of the run carries the same provenance: dense lanes 0..n_keep-1
             if (a.col_idxs || a.frame_idxs || a.timestamps_ns) {

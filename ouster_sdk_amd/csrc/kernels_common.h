@@ -122,6 +122,12 @@ struct __attribute__((packed, aligned(1))) pk16 { uint32_t a, b, c, d; };
 #ifndef OUSTER_NT_STORES
 #define OUSTER_NT_STORES 0   // experiment switch (tools/ab/nt_variants.sh): non-temporal hint on EVERY plane / xyz store
 #endif
+#ifndef OUSTER_NT_STANDALONE
+#define OUSTER_NT_STANDALONE 1   // the hint on the stores of the standalone kernels (k_standalone.hip): +1.9 ... +5.7 % in-process on cold inputs
+#endif
+#ifndef OUSTER_NT_U32
+#define OUSTER_NT_U32 0      // experiment switch: the hint on the 4-byte plane stores (and whatever else asks for it)
+#endif
 #ifndef OUSTER_NT_XYZ
 #define OUSTER_NT_XYZ 0      // experiment switch: the hint on the xyz stores only
 #endif
@@ -220,7 +226,7 @@ __device__ __forceinline__ void store4v(uint8_t* p, const u32x4_t& v, uint32_t e
         case 1: st4<NT>(p, v.x | (v.y << 8) | (v.z << 16) | (v.w << 24)); break;
         case 2: st8<NT>(p, v.x | (v.y << 16), v.z | (v.w << 16)); break;
         default: {
-            if constexpr ((NT || OUSTER_NT_STORES) && !OUSTER_PLAIN_STORES) {
+            if constexpr ((NT || OUSTER_NT_STORES || OUSTER_NT_U32) && !OUSTER_PLAIN_STORES) {
                 __builtin_nontemporal_store(v, (u32x4_u*)p);
             } else {
                 struct __attribute__((packed, aligned(1))) pkv { u32x4_t v; };
@@ -445,7 +451,15 @@ __device__ __forceinline__ void store_quad_coalesced(float4* sc, float4* row_bas
     for (int k = 0; k < NV; ++k) sc[NV * q + k] = v[k];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < NV; ++k) row_base[k * LPR + q] = sc[k * LPR + q];
+    for (int k = 0; k < NV; ++k) {
+#if OUSTER_NT_STANDALONE
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const float4 t = sc[k * LPR + q];
+        __builtin_nontemporal_store(f4{t.x, t.y, t.z, t.w}, (f4*)(row_base + k * LPR + q));
+#else
+        row_base[k * LPR + q] = sc[k * LPR + q];
+#endif
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 template <int NV, int LPR>

@@ -18,6 +18,12 @@ __global__ __launch_bounds__(256) void k_write(uint4* dst, size_t per_wg16) {
     const uint4 v = {blockIdx.x, threadIdx.x, 3u, 4u};
     for (size_t i = threadIdx.x; i < per_wg16; i += 256) p[i] = v;
 }
+__global__ __launch_bounds__(256) void k_write_nt(uint4* dst, size_t per_wg16) {
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    v4* p = (v4*)dst + (size_t)blockIdx.x * per_wg16;
+    const v4 v = {blockIdx.x, threadIdx.x, 3u, 4u};
+    for (size_t i = threadIdx.x; i < per_wg16; i += 256) __builtin_nontemporal_store(v, p + i);
+}
 __global__ __launch_bounds__(256) void k_read(const uint4* src, size_t per_wg16, uint32_t* sink) {
     const uint4* p = src + (size_t)blockIdx.x * per_wg16;
     uint32_t acc = 0;
@@ -42,14 +48,15 @@ int main() {
     for (size_t gi = 0; gi < sizeof gs / sizeof gs[0]; ++gi) {
         const int G = gs[gi];
         const size_t per = bytes / 16 / G;
-        float ms[3] = {0, 0, 0};
-        for (int mode = 0; mode < 3; ++mode) {
+        float ms[4] = {0, 0, 0, 0};
+        for (int mode = 0; mode < 4; ++mode) {
             float best = 1e30f;
             for (int rep = 0; rep < 4; ++rep) {
                 CK(hipEventRecord(e0));
                 if (mode == 0) hipLaunchKernelGGL(k_write, dim3(G), dim3(256), 0, 0, a, per);
                 else if (mode == 1) hipLaunchKernelGGL(k_read, dim3(G), dim3(256), 0, 0, (const uint4*)a, per, sink);
-                else hipLaunchKernelGGL(k_copy, dim3(G), dim3(256), 0, 0, b, (const uint4*)a, per);
+                else if (mode == 2) hipLaunchKernelGGL(k_copy, dim3(G), dim3(256), 0, 0, b, (const uint4*)a, per);
+                else hipLaunchKernelGGL(k_write_nt, dim3(G), dim3(256), 0, 0, a, per);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
                 float t; CK(hipEventElapsedTime(&t, e0, e1));
@@ -58,9 +65,9 @@ int main() {
             ms[mode] = best;
         }
         const double gb = bytes / 1e9;
-        printf("  {\"workgroups\": %d, \"write_GBps\": %.0f, \"write_GBps_per_wg\": %.2f, \"read_GBps\": %.0f, \"read_GBps_per_wg\": %.2f, \"copy_GBps\": %.0f}%s\n",
+        printf("  {\"workgroups\": %d, \"write_GBps\": %.0f, \"write_GBps_per_wg\": %.2f, \"read_GBps\": %.0f, \"read_GBps_per_wg\": %.2f, \"copy_GBps\": %.0f, \"write_nt_GBps\": %.0f}%s\n",
                G, gb / (ms[0] * 1e-3), gb / (ms[0] * 1e-3) / G, gb / (ms[1] * 1e-3), gb / (ms[1] * 1e-3) / G,
-               2 * gb / (ms[2] * 1e-3), gi + 1 < sizeof gs / sizeof gs[0] ? "," : "");
+               2 * gb / (ms[2] * 1e-3), gb / (ms[3] * 1e-3), gi + 1 < sizeof gs / sizeof gs[0] ? "," : "");
     }
     printf("]}\n");
     return 0;
