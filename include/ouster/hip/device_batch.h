@@ -30,6 +30,10 @@ struct BatchOptions {
     bool xyz = false;                     ///< project RANGE (and RANGE2 when present)
     bool xyz_f64 = false;                 ///< XYZ element type (default float)
     bool use_extrinsics = true;           ///< fold SensorInfo::sensor_to_body into the LUT
+    /// XYZ in the world frame: decode() applies every column's body_to_world pose (upload_poses(); identity
+    /// until set) to the point while it is in registers -- dewarp<T>(cartesian(range), poses) of
+    /// pose_util.h:38-56 without the separate pass over the cloud.
+    bool xyz_world_frame = false;
     /// Treat every packet slot of every frame as filled (missing packets = zeroed slots, whose
     /// columns are invalid by their status word) instead of uploading per-frame packet counts:
     /// keeps decode() free of host synchronisation, for the streaming pipeline (FrameStream).

@@ -158,6 +158,13 @@ typedef struct ouster_hip_frame_out {
     uint32_t gate_min_r, gate_max_r;
     int32_t gate_field;         /* index into fields[] of a 32-bit range field */
     int32_t reserved2;
+    /* dewarp<T>(points, poses) (ouster_core/include/ouster/core/pose_util.h:38-56) fused behind the
+     * cartesian: device array [n_frames][W][16] of row-major 4x4 per-column poses (the frame's
+     * body_to_world).  When set, xyz[k] receives R_col * lut(r) + t_col computed in the element type of xyz
+     * (the poses are cast to it, as the reference does) while the point is still in registers -- the
+     * separate pass over the cloud (read 12 B + write 12 B per point) disappears.  Needs the separable
+     * LUT tables (ouster_hip_lut_create).  NULL: xyz stays in the sensor / body frame of the LUT. */
+    const double* xyz_poses;
 } ouster_hip_frame_out;
 #define OUSTER_HIP_GATE_CHUNKS 8
 

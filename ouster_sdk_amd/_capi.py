@@ -66,7 +66,7 @@ class FrameOut(C.Structure):
                 ("frame_meta", C.c_void_p), ("xyz", C.c_void_p * 2), ("xyz_field", C.c_int32 * 2),
                 ("xyz_dtype", C.c_int32), ("reserved", C.c_int32),
                 ("gate_counts", C.c_void_p), ("gate_min_r", C.c_uint32), ("gate_max_r", C.c_uint32),
-                ("gate_field", C.c_int32), ("reserved2", C.c_int32)]
+                ("gate_field", C.c_int32), ("reserved2", C.c_int32), ("xyz_poses", C.c_void_p)]
 
 
 class OsfPlane(C.Structure):

@@ -130,6 +130,10 @@ void DeviceFrameBatch::decode() {
         out.xyz[k] = xyz_field_[k] >= 0 ? d_xyz_[k].data() : nullptr;
     }
     for (const auto& l : luts_) luts.push_back(l.device().handle);
+    if (opt_.xyz_world_frame && opt_.xyz) {
+        if (d_poses_.size() == 0) upload_poses(0, nullptr);   // identity, like a fresh LidarFrame
+        out.xyz_poses = static_cast<const double*>(d_poses_.data());
+    }
     gate_valid_ = false;
     if (opt_.gate_max_range >= opt_.gate_min_range) {
         int gf = -1;

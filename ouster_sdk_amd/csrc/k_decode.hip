@@ -362,9 +362,10 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     // ---- phase 2b: pixels
     const uint32_t q = tid % (TILE / 4);
     const uint32_t vq = (uint32_t)(validmask >> (q * 4)) & 0xfu;
+    const void* s_pose = stage_poses<XYZM>(a, smem, f, c0, (uint32_t)TILE);
     decode_rows<S, TILE / 4, XYZM>(a, s_tile, a.g.col_header_size >> 2, col_size >> 2, s_off, s_xyz,
                                    ((XYZM == 1 || XYZM == 2) && a.beam_lds) ? s_beam : nullptr, s_gate, lut, f, c0, 0u, H,
-                                   vq, 0u, 1u);
+                                   vq, 0u, 1u, s_pose);
 }
 
 // one workgroup per (frame, tile): the optimistic pass (MODE_FAST) or every frame through the
@@ -672,8 +673,9 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     uint32_t vq = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_valid[jq + c]) ? (1u << c) : 0u;
+    const void* s_pose = stage_poses<XYZM>(a, smem, f, c0, (uint32_t)TW);
     decode_rows<S, TW / 4, XYZM, S::is_static, S::nt_stores, S::nt_xyz>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
-                                 a.gate_counts ? s_gate : nullptr, lut, f, c0, r0, nrows, vq, rc, nch);
+                                 a.gate_counts ? s_gate : nullptr, lut, f, c0, r0, nrows, vq, rc, nch, s_pose);
     PHASE_STAMP(4);
 #ifdef OUSTER_PHASE_TIMING
     if (pt_ && tid == 0) {   // the stores of this wave have been issued; when are they done?
@@ -740,13 +742,21 @@ static hipError_t launch_fixup_t(const DecodeArgs& a, int xyzm, dim3 grid, size_
     }
 }
 
+// bytes of the tile's pose table (ouster_hip_frame_out::xyz_poses): 12 values of the xyz element type per column
+static size_t pose_lds_bytes(const DecodeArgs& a, int xyzm, int cols) {
+    return (a.xyz_poses && (xyzm == 1 || xyzm == 2)) ? (size_t)cols * 12 * (xyzm == 1 ? 4 : 8) : 0;
+}
+
 hipError_t OUSTER_SPEC_FN(launch_decode)(const DecodeArgs& a_in, int tile, int xyzm, int device, hipStream_t st) {
     const uint32_t tpf = a_in.tiles_per_frame;
     if (a_in.mode == MODE_FIXUP) {
         DecodeArgs a = a_in;
         const size_t body = decode_lds_bytes(a.g, tile, true, a.beam_lds != 0);
         a.rows_per_tile = (uint32_t)body;  // where the frame list starts
-        const size_t lds = body + FIXUP_CHUNK * 2;
+        size_t lds = (body + FIXUP_CHUNK * 2 + 15) & ~(size_t)15;
+        a.pose_lds_off = (uint32_t)lds;
+        lds += pose_lds_bytes(a, xyzm, tile);
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
         const uint64_t items = (uint64_t)a.n_frames * tpf;
         // row_chunks carries the number of workgroups the device keeps resident (2 per CU)
         const dim3 grid((uint32_t)std::min<uint64_t>(items, a.row_chunks ? a.row_chunks : 512u));
@@ -756,10 +766,13 @@ hipError_t OUSTER_SPEC_FN(launch_decode)(const DecodeArgs& a_in, int tile, int x
             default: return launch_fixup_t<SpecT, 16>(a, xyzm, grid, lds, device, st);
         }
     }
-    const DecodeArgs& a = a_in;
+    DecodeArgs a = a_in;
     const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * tpf : a.n_frames * tpf;
     const dim3 grid(nblocks);
-    const size_t lds = decode_lds_bytes(a.g, tile, a.mode != MODE_FAST, a.beam_lds != 0);
+    size_t lds = (decode_lds_bytes(a.g, tile, a.mode != MODE_FAST, a.beam_lds != 0) + 15) & ~(size_t)15;
+    a.pose_lds_off = (uint32_t)lds;
+    lds += pose_lds_bytes(a, xyzm, tile);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     switch (tile) {
         case 64: return launch_decode_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
         case 32: return launch_decode_t<SpecT, 32>(a, xyzm, grid, lds, device, st);
@@ -786,11 +799,15 @@ static hipError_t launch_decode_wide_t(const DecodeArgs& a, int xyzm, dim3 grid,
     }
 }
 
-hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a, int tw, int xyzm, int device, hipStream_t st) {
+hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a_in, int tw, int xyzm, int device, hipStream_t st) {
+    DecodeArgs a = a_in;
     const uint32_t bpf = a.tiles_per_frame * a.row_chunks;
     const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * bpf : a.n_frames * bpf;
     const dim3 grid(nblocks);
-    const size_t lds = decode_wide_lds_bytes(tw, a.rows_per_tile, a.lds_col_slot);
+    size_t lds = (decode_wide_lds_bytes(tw, a.rows_per_tile, a.lds_col_slot) + 15) & ~(size_t)15;
+    a.pose_lds_off = (uint32_t)lds;
+    lds += pose_lds_bytes(a, xyzm, tw);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     switch (tw) {
         case 64: return launch_decode_wide_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
         case 128: return launch_decode_wide_t<SpecT, 128>(a, xyzm, grid, lds, device, st);

@@ -538,6 +538,29 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_of(const Geometry& g
     return m;
 }
 
+// The per-column poses of a tile, cast to the xyz element type, in LDS (12 values per column); all threads of the
+// workgroup call it, a barrier follows.  Returns the table or nullptr when no poses were given.
+template <int XYZM>
+__device__ __forceinline__ const void* stage_poses(const DecodeArgs& a, uint32_t* smem, uint32_t f, uint32_t c0,
+                                                   uint32_t ncols) {
+    if constexpr (XYZM != 1 && XYZM != 2) {
+        return nullptr;
+    } else {
+        if (!a.xyz_poses) return nullptr;
+        using XT = typename std::conditional<XYZM == 1, float, double>::type;
+        XT* s_pose = (XT*)((uint8_t*)smem + a.pose_lds_off);
+        const uint32_t W = a.g.columns_per_frame;
+        // transposed: element k of every column next to each other, so that a lane's four columns are one 16 / 32 B
+        // read and a wave's reads are conflict free (column-major rows of 12 cost 0.4 ms per launch in bank conflicts)
+        for (uint32_t i = threadIdx.x; i < ncols * 12; i += blockDim.x) {
+            const uint32_t j = i / 12, k = i - j * 12, c = c0 + j;
+            s_pose[k * ncols + j] = c < W ? (XT)a.xyz_poses[((size_t)f * W + c) * 16 + k] : (XT)0;
+        }
+        __syncthreads();
+        return s_pose;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // decode_rows: the pixel phase shared by k_decode and k_decode_wide.
 // The workgroup's tile (QPR*4 columns x nrows rows, rows r0.. of frame f, columns c0..) sits in LDS,
@@ -569,7 +592,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                                             float4* s_xyz, const double* s_beam, uint32_t* s_gate,
                                             const LutDev& lut, uint32_t f, uint32_t c0, uint32_t r0,
                                             uint32_t nrows, uint32_t vq, uint32_t gate_chunk,
-                                            uint32_t gate_nchunks) {
+                                            uint32_t gate_nchunks, const void* s_pose = nullptr) {
     constexpr int NT = 256;
     constexpr int LPR = QPR < 64 ? QPR : 64;             // lanes of one wave in a row segment
     constexpr int RPP = NT / QPR > 0 ? NT / QPR : 1;     // rows per pass of the workgroup
@@ -717,6 +740,20 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                     for (int k = 0; k < 3; ++k) {
                         const XT t = (XT)fma(rm, d[c][k], kc[c][k]);
                         p[c][k] = rr ? t : (XT)0;
+                    }
+                }
+                if (s_pose) {   // dewarp<T>(points, poses), pose_util.h:38-56: R_col * p + t_col in T (uniform branch)
+                    XT m[12][4];
+#pragma unroll
+                    for (int k = 0; k < 12; ++k)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) m[k][c] = ((const XT*)s_pose)[(size_t)k * (QPR * 4) + jq + c];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const XT x = p[c][0], y = p[c][1], z = p[c][2];
+                        p[c][0] = m[0][c] * x + m[1][c] * y + m[2][c] * z + m[3][c];
+                        p[c][1] = m[4][c] * x + m[5][c] * y + m[6][c] * z + m[7][c];
+                        p[c][2] = m[8][c] * x + m[9][c] * y + m[10][c] * z + m[11][c];
                     }
                 }
                 XT* dst = out + ((size_t)f * plane_px + rowpix) * 3;

@@ -729,6 +729,10 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     da.packet_counts = d_counts;
     da.host_timestamps = host_timestamps;
     da.frame_state = (uint64_t*)ctx->state.p;
+    if (out->xyz_poses && xyzm == 3)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "xyz_poses need LUTs with separable tables (ouster_hip_lut_create)");
+    da.xyz_poses = xyzm ? out->xyz_poses : nullptr;
+    const size_t pose_per_col = da.xyz_poses ? (size_t)12 * (xyzm == 1 ? 4 : 8) : 0;   // LDS bytes of a column's pose
     da.gate_counts = out->gate_counts;
     da.gate_min = out->gate_min_r;
     da.gate_max = out->gate_max_r;
@@ -790,20 +794,22 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // tile width: widest tile that still lets two workgroups share a CU's 160 KiB LDS
     int tile = 0;
     for (int t : {64, 32, 16})
-        if (decode_lds_bytes(g, t, true, false) <= 80 * 1024) { tile = t; break; }
+        if (decode_lds_bytes(g, t, true, false) + 16 + t * pose_per_col <= 80 * 1024) { tile = t; break; }
     if (!tile)
         for (int t : {64, 32, 16})
-            if (decode_lds_bytes(g, t, true, false) <= 160 * 1024) { tile = t; break; }
+            if (decode_lds_bytes(g, t, true, false) + 2048 + t * pose_per_col <= 160 * 1024) { tile = t; break; }
     if (!tile) return fail(OUSTER_HIP_ERR_UNSUPPORTED, "column of %u bytes does not fit in LDS", g.col_size);
     // small batches: prefer narrower tiles so that at least ~2 workgroups per CU exist
     // (one 128x2048 frame is only 32 tiles of 64 columns -- latency, not bandwidth, bound)
     while (tile > 16 && (size_t)n_frames * ((W + tile - 1) / tile) < 512) tile /= 2;
-    if ((kn.tile == 64 || kn.tile == 32 || kn.tile == 16) && decode_lds_bytes(g, kn.tile, true, false) <= 160 * 1024)
+    if ((kn.tile == 64 || kn.tile == 32 || kn.tile == 16) &&
+        decode_lds_bytes(g, kn.tile, true, false) + 2048 + kn.tile * pose_per_col <= 160 * 1024)
         tile = kn.tile;
     // the per-beam xyz table goes to LDS (no vector load left in the row loop: stores are never waited
     // for) whenever that does not cost k_decode a workgroup per CU
     if (xyzm == 1 || xyzm == 2) {
-        const size_t without = decode_lds_bytes(g, tile, true, false), with = decode_lds_bytes(g, tile, true, true);
+        const size_t extra = 2048 + tile * pose_per_col;   // fix-up frame list + pose table
+        const size_t without = decode_lds_bytes(g, tile, true, false) + extra, with = decode_lds_bytes(g, tile, true, true) + extra;
         da.beam_lds = (kn.beam_lds && with <= 160 * 1024 && (160 * 1024) / with == (160 * 1024) / without) ? 1u : 0u;
     }
     // wide, short tiles (k_decode_wide): TW columns x TR rows with TW*TR*chan <= ~64 KB, TR chosen so that
@@ -835,7 +841,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         da.row_chunks = nch;
         da.lds_col_slot = (tr * chan / 4 + 1) * 4;  // +1 dword: bank spread
         da.tiles_per_frame = tiles;
-        return decode_wide_lds_bytes(want, tr, da.lds_col_slot) <= 160 * 1024;
+        return decode_wide_lds_bytes(want, tr, da.lds_col_slot) + 16 + (size_t)want * pose_per_col <= 160 * 1024;
     };
     int wide = 0;
     ouster_hip_ctx::Tune* tuning = nullptr;
@@ -857,7 +863,8 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
                 pm |= da.planes[i] ? (1ull << i) : 0;
                 dm |= da.destaggered[i] ? (1ull << i) : 0;
             }
-            mix(pm); mix(dm); mix((da.xyz[0] ? 1u : 0u) | (da.xyz[1] ? 2u : 0u) | (da.gate_counts ? 4u : 0u));
+            mix(pm); mix(dm);
+            mix((da.xyz[0] ? 1u : 0u) | (da.xyz[1] ? 2u : 0u) | (da.gate_counts ? 4u : 0u) | (da.xyz_poses ? 8u : 0u));
             if (ctx->tune.size() > 64 && !ctx->tune.count(key)) {  // bounded: forget everything, re-learn
                 for (auto& kv : ctx->tune)
                     for (auto& pr : kv.second.ev)

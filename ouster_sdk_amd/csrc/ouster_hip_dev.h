@@ -82,6 +82,8 @@ struct DecodeArgs {
     void* xyz[2];
     int32_t xyz_field[2];
     int32_t xyz_dtype;
+    const double* xyz_poses;  // device [n_frames][W][16] or nullptr: per-column pose applied to the xyz outputs
+    uint32_t pose_lds_off;    // byte offset of the tile's pose table in dynamic LDS (set by the launchers)
 #ifdef OUSTER_PHASE_TIMING
     uint64_t* phase_times;   // experiment builds only (tools/ab/phase_timing.sh): [workgroup][8] s_memtime stamps of k_decode_wide
 #endif

@@ -199,10 +199,13 @@ class HotPath:
     def decode(self, packets: torch.Tensor, out: Dict[str, torch.Tensor],
                packet_counts=None,
                host_timestamps: Optional[torch.Tensor] = None,
-               gate: Optional[Tuple[float, float]] = None, gate_field: str = "RANGE"):
+               gate: Optional[Tuple[float, float]] = None, gate_field: str = "RANGE",
+               poses: Optional[torch.Tensor] = None):
         """packets: uint8 CUDA tensor [n_frames, slots, packet_stride].
         gate = (min_range, max_range) in metres: also produce out["gate_counts"] (u16 [n, 8, W]), the
-        per-column kept counts a following dewarp_frames(..., gate_counts=...) with the same gate needs."""
+        per-column kept counts a following dewarp_frames(..., gate_counts=...) with the same gate needs.
+        poses: float64 CUDA tensor [n_frames, W, 4, 4] (per-column body_to_world): the xyz outputs become
+        dewarp(cartesian(range), poses), computed while the points are in registers."""
         assert packets.is_cuda and packets.dtype == torch.uint8 and packets.is_contiguous()
         n_frames, slots, stride = packets.shape
         fo = capi.FrameOut()
@@ -234,6 +237,10 @@ class HotPath:
             fo.gate_counts = out["gate_counts"].data_ptr()
             fo.gate_min_r, fo.gate_max_r = lo, hi
             fo.gate_field = self.field_index(gate_field)
+        if poses is not None:
+            assert poses.is_cuda and poses.dtype == torch.float64 and poses.is_contiguous()
+            assert tuple(poses.shape) == (n_frames, self.w, 4, 4), poses.shape
+            fo.xyz_poses = poses.data_ptr()
         shifts_p = None
         if any_dst:
             if self.shifts is None:

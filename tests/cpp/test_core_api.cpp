@@ -910,6 +910,38 @@ static void test_device_batch() {
         std::memcpy(&poses[c * 16], m, sizeof m);
     }
     for (uint32_t f = 0; f < n; ++f) batch.upload_poses(f, poses.data());
+    {   // xyz_world_frame: the same batch with the poses applied inside decode() == dewarp<float>(xyz, poses) of the plain one
+        ouster::sdk::hip::BatchOptions wopt = opt;
+        wopt.xyz_world_frame = true;
+        ouster::sdk::hip::DeviceFrameBatch wbatch(sensors, n, wopt);
+        for (uint32_t f = 0; f < n; ++f) {
+            auto packets = impl::frame_to_packets(src[f], pf, a.init_id, a.sn);
+            std::vector<const uint8_t*> ptrs;
+            for (size_t i = 0; i < packets.size(); ++i)
+                if (!(f == 2 && i == 5)) ptrs.push_back(packets[i].buf.data());
+            wbatch.upload_frame_packets(f, ptrs);
+            wbatch.upload_poses(f, poses.data());
+        }
+        wbatch.decode();
+        float wworst = 0;
+        for (uint32_t f = 0; f < n; f += 2) {
+            PointCloudXYZf body(128 * 1024), world(128 * 1024);
+            batch.download_xyz(0, f, body.data());
+            wbatch.download_xyz(0, f, world.data());
+            for (size_t r = 0; r < 128; ++r)
+                for (size_t c = 0; c < 1024; ++c) {
+                    const double* m = &poses[c * 16];
+                    const float* b = body.data() + (r * 1024 + c) * 3;
+                    const float* w = world.data() + (r * 1024 + c) * 3;
+                    for (int k = 0; k < 3; ++k) {
+                        const float want = static_cast<float>(m[4 * k]) * b[0] + static_cast<float>(m[4 * k + 1]) * b[1] +
+                                           static_cast<float>(m[4 * k + 2]) * b[2] + static_cast<float>(m[4 * k + 3]);
+                        wworst = std::max(wworst, std::abs(w[k] - want));
+                    }
+                }
+        }
+        CHECK(wworst <= 1e-4f);
+    }
     const uint64_t total = batch.dewarp(1.0, 150.0, true);
     CHECK(total > 0 && batch.dewarped_frame_offsets().size() == n + 1 &&
           batch.dewarped_frame_offsets().back() == total);

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.FormatDesc) == 10 * 4 + 9 * 16 + 8 + 32 * 24
     assert C.sizeof(capi.FrameMeta) == 24
     assert C.sizeof(capi.OsfPlane) == 32
-    assert C.sizeof(capi.FrameOut) == 2 * 32 * 8 + 6 * 8 + 2 * 8 + 4 * 4 + 8 + 4 * 4   # + the range-gate by-product
+    assert C.sizeof(capi.FrameOut) == 2 * 32 * 8 + 6 * 8 + 2 * 8 + 4 * 4 + 8 + 4 * 4 + 8   # + the range-gate by-product + xyz_poses
     assert C.sizeof(capi.Calib) == 8 + 8 + 128 + 128 + 8 + 8 + 8
 
 

@@ -378,3 +378,52 @@ def test_pick_placement_returns_equivalent_buffers(oracle):
     for k in plain:
         assert torch.equal(out[k].view(torch.uint8), plain[k].view(torch.uint8)), k
     _compare(O, cal, hp, out, [src[f % 4] for f in range(32)], ["RANGE", "REFLECTIVITY2"], ["RANGE", "RANGE2"])
+
+
+@pytest.mark.parametrize("label,wide", VARIANTS)
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_poses_fused_behind_the_cartesian(oracle, label, wide, dt):
+    """ouster_hip_frame_out::xyz_poses: the xyz outputs are dewarp<T>(cartesian(range), poses)
+    (pose_util.h:38-56) -- per-column pose, cast to T, applied while the point is in registers -- for every
+    kernel variant, on clean frames, frames with holes and frames that go through the fix-up pass; everything
+    else the call produces is untouched."""
+    O = oracle
+    cal = O.synthetic_calib(h=64, w=1024, profile="RNG15_RFL8_NIR8_DUAL")
+    packets, src = O.synth_packets(cal, 4, with_window=True)
+    n = 8
+    pk = np.concatenate([packets, packets])
+    pk[2, 5] = 0                                   # a hole: columns 80..95 of frame 2 are absent
+    pk[5, [3, 9]] = pk[5, [9, 3]]                  # swapped packets: frame 5 needs the fix-up pass
+    hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL", wide=wide)
+    d_pk = torch.from_numpy(pk).cuda()
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    rng = np.random.default_rng(3)
+    poses = np.tile(np.eye(4), (n, cal.w, 1, 1))
+    ang = rng.uniform(-0.4, 0.4, size=(n, cal.w))
+    poses[..., 0, 0] = np.cos(ang); poses[..., 0, 1] = -np.sin(ang)
+    poses[..., 1, 0] = np.sin(ang); poses[..., 1, 1] = np.cos(ang)
+    poses[..., :3, 3] = rng.uniform(-30, 30, size=(n, cal.w, 3))
+    d_poses = torch.from_numpy(poses).cuda()
+    plain = hp.alloc_outputs(n, destagger=["RANGE"], xyz=["RANGE", "RANGE2"], xyz_dtype=tdt)
+    fused = hp.alloc_outputs(n, destagger=["RANGE"], xyz=["RANGE", "RANGE2"], xyz_dtype=tdt)
+    hp.decode(d_pk, plain)
+    hp.decode(d_pk, fused, poses=d_poses)
+    hp.sync()
+    for k in plain:
+        if not k.startswith("xyz:") and k != "frame_meta":
+            assert torch.equal(plain[k].view(torch.uint8), fused[k].view(torch.uint8)), k
+    tol = 1e-4 if dt == "f32" else 1e-9      # f32: fma contraction vs separate mul / add = a few ulp at |x| ~ 300 m (1 ulp = 3e-5)
+    for name in ("RANGE", "RANGE2"):
+        body = _np(plain["xyz:" + name])
+        got = _np(fused["xyz:" + name])
+        for f in range(n):
+            want = O.dewarp(body[f], poses[f], cal.h, cal.w)
+            err = np.abs(got[f].astype(np.float64) - want.astype(np.float64)).max()
+            assert err <= tol, (name, f, err)
+        # the standalone pair gives the same cloud
+        two = _np(hp.dewarp(plain["xyz:" + name], d_poses))
+        assert np.abs(got.astype(np.float64) - two.astype(np.float64)).max() <= tol
+    # a zero range maps to the pose's translation, like dewarp() of the (0, 0, 0) point
+    r0 = _np(plain["RANGE"])
+    f, r, c = np.argwhere(r0 == 0)[0]
+    assert np.allclose(_np(fused["xyz:RANGE"])[f, r * cal.w + c], poses[f, c, :3, 3], atol=1e-6)
