@@ -98,7 +98,7 @@ __device__ __forceinline__ void fast_publish(const DecodeArgs& a, uint32_t f, ui
 // ------------------------------------------------------------------------------------
 // XYZM: 0 no xyz, 1 separable tables -> f32, 2 separable -> f64, 3 full LUT (runtime dtypes)
 // GENERAL_ONLY: the fix-up kernel's instantiation (no fast-mode code in it)
-template <class S, int TILE, int XYZM, bool GENERAL_ONLY>
+template <class S, int TILE, int XYZM, bool GENERAL_ONLY, bool POSES>
 __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem, uint32_t f, uint32_t tile) {
     constexpr int NT = 256;
     const uint32_t tid = threadIdx.x;
@@ -362,20 +362,20 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     // ---- phase 2b: pixels
     const uint32_t q = tid % (TILE / 4);
     const uint32_t vq = (uint32_t)(validmask >> (q * 4)) & 0xfu;
-    const void* s_pose = stage_poses<XYZM>(a, smem, f, c0, (uint32_t)TILE);
-    decode_rows<S, TILE / 4, XYZM>(a, s_tile, a.g.col_header_size >> 2, col_size >> 2, s_off, s_xyz,
+    const void* s_pose = stage_poses<XYZM, POSES>(a, smem, f, c0, (uint32_t)TILE);
+    decode_rows<S, TILE / 4, XYZM, false, false, false, POSES>(a, s_tile, a.g.col_header_size >> 2, col_size >> 2, s_off, s_xyz,
                                    ((XYZM == 1 || XYZM == 2) && a.beam_lds) ? s_beam : nullptr, s_gate, lut, f, c0, 0u, H,
                                    vq, 0u, 1u, s_pose);
 }
 
 // one workgroup per (frame, tile): the optimistic pass (MODE_FAST) or every frame through the
 // general mapping (MODE_GENERAL)
-template <class S, int TILE, int XYZM>
+template <class S, int TILE, int XYZM, bool POSES = false>
 __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
     extern __shared__ __align__(16) uint32_t smem[];
     uint32_t f, tile;
     if (!block_to_frame(a, a.tiles_per_frame, f, tile)) return;
-    decode_tile<S, TILE, XYZM, false>(a, smem, f, tile);
+    decode_tile<S, TILE, XYZM, false, POSES>(a, smem, f, tile);
 }
 
 // The fix-up pass behind an optimistic pass.  A small persistent grid (all workgroups resident at
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
 // Workgroup 0 finally advances the sequence word, which retires every flag of this call: nothing is
 // cleared, nothing is waited for, and a captured graph replays correctly (the tag lives in HBM).
 constexpr uint32_t FIXUP_CHUNK = 512;  // frames listed per round (u16 indices in LDS)
-template <class S, int TILE, int XYZM>
+template <class S, int TILE, int XYZM, bool POSES = false>
 __global__ __launch_bounds__(256) void k_decode_fixup(DecodeArgs a) {
     constexpr int NT = 256;
     extern __shared__ __align__(16) uint32_t smem[];
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_decode_fixup(DecodeArgs a) {
         const uint32_t items = s_n * tpf;
         for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
             const uint32_t f = base + s_list[it / tpf], tile = it % tpf;
-            decode_tile<S, TILE, XYZM, true>(a, smem, f, tile);
+            decode_tile<S, TILE, XYZM, true, POSES>(a, smem, f, tile);
             __syncthreads();  // the tile image is reused
         }
     }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void k_decode_fixup(DecodeArgs a) {
 // status) words of its columns next to its staging loads, the first row chunk of a column tile does
 // the stray check, the column headers and the packet-level outputs.
 // ------------------------------------------------------------------------------------
-template <class S, int TW, int XYZM>
+template <class S, int TW, int XYZM, bool POSES = false>
 __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     constexpr int NT = 256;
     constexpr int NJ = (TW + NT - 1) / NT;        // columns per thread in the per-column phases
@@ -673,8 +673,8 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     uint32_t vq = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_valid[jq + c]) ? (1u << c) : 0u;
-    const void* s_pose = stage_poses<XYZM>(a, smem, f, c0, (uint32_t)TW);
-    decode_rows<S, TW / 4, XYZM, S::is_static, S::nt_stores, S::nt_xyz>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
+    const void* s_pose = stage_poses<XYZM, POSES>(a, smem, f, c0, (uint32_t)TW);
+    decode_rows<S, TW / 4, XYZM, S::is_static, S::nt_stores, S::nt_xyz, POSES>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
                                  a.gate_counts ? s_gate : nullptr, lut, f, c0, r0, nrows, vq, rc, nch, s_pose);
     PHASE_STAMP(4);
 #ifdef OUSTER_PHASE_TIMING
@@ -706,6 +706,15 @@ static hipError_t allow_lds(K kernel, size_t lds, int device, LdsGrant& g) {
 
 template <class S, int TILE, int XYZM>
 static hipError_t launch_decode_x(const DecodeArgs& a, dim3 grid, size_t lds, int device, hipStream_t st) {
+    if constexpr (XYZM == 1 || XYZM == 2) {
+        if (a.xyz_poses) {
+            static LdsGrant done_p;
+            hipError_t e = allow_lds(k_decode<S, TILE, XYZM, true>, lds, device, done_p);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_decode<S, TILE, XYZM, true>), grid, dim3(256), lds, st, a);
+            return hipGetLastError();
+        }
+    }
     static LdsGrant done;
     hipError_t e = allow_lds(k_decode<S, TILE, XYZM>, lds, device, done);
     if (e != hipSuccess) return e;
@@ -725,6 +734,15 @@ static hipError_t launch_decode_t(const DecodeArgs& a, int xyzm, dim3 grid, size
 
 template <class S, int TILE, int XYZM>
 static hipError_t launch_fixup_x(const DecodeArgs& a, dim3 grid, size_t lds, int device, hipStream_t st) {
+    if constexpr (XYZM == 1 || XYZM == 2) {
+        if (a.xyz_poses) {
+            static LdsGrant done_p;
+            hipError_t e = allow_lds(k_decode_fixup<S, TILE, XYZM, true>, lds, device, done_p);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_decode_fixup<S, TILE, XYZM, true>), grid, dim3(256), lds, st, a);
+            return hipGetLastError();
+        }
+    }
     static LdsGrant done;
     hipError_t e = allow_lds(k_decode_fixup<S, TILE, XYZM>, lds, device, done);
     if (e != hipSuccess) return e;
@@ -782,6 +800,15 @@ hipError_t OUSTER_SPEC_FN(launch_decode)(const DecodeArgs& a_in, int tile, int x
 
 template <class S, int TW, int XYZM>
 static hipError_t launch_decode_wide_x(const DecodeArgs& a, dim3 grid, size_t lds, int device, hipStream_t st) {
+    if constexpr (XYZM == 1 || XYZM == 2) {
+        if (a.xyz_poses) {
+            static LdsGrant done_p;
+            hipError_t e = allow_lds(k_decode_wide<S, TW, XYZM, true>, lds, device, done_p);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_decode_wide<S, TW, XYZM, true>), grid, dim3(256), lds, st, a);
+            return hipGetLastError();
+        }
+    }
     static LdsGrant done;
     hipError_t e = allow_lds(k_decode_wide<S, TW, XYZM>, lds, device, done);
     if (e != hipSuccess) return e;

@@ -540,10 +540,12 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_of(const Geometry& g
 
 // The per-column poses of a tile, cast to the xyz element type, in LDS (12 values per column); all threads of the
 // workgroup call it, a barrier follows.  Returns the table or nullptr when no poses were given.
-template <int XYZM>
+// POSES is a template parameter of the kernels: the pose arithmetic keeps 48 more registers alive, and a kernel that
+// merely CONTAINS it is allocated for it (the 12 B/px profile went from 155 to 171 VGPRs = from three waves per SIMD to two).
+template <int XYZM, bool POSES>
 __device__ __forceinline__ const void* stage_poses(const DecodeArgs& a, uint32_t* smem, uint32_t f, uint32_t c0,
                                                    uint32_t ncols) {
-    if constexpr (XYZM != 1 && XYZM != 2) {
+    if constexpr (!POSES || (XYZM != 1 && XYZM != 2)) {
         return nullptr;
     } else {
         if (!a.xyz_poses) return nullptr;
@@ -586,7 +588,7 @@ __device__ __forceinline__ const void* stage_poses(const DecodeArgs& a, uint32_t
 // and the tile's partial counts go to a.gate_counts[f][gate_chunk][c0..] -- the dewarp that follows
 // skips its counting pass.  Every thread of the workgroup must call decode_rows (it ends in a barrier
 // when s_gate is set).
-template <class S, int QPR, int XYZM, bool DEADZ = false, bool NTS = false, bool NTX = NTS>
+template <class S, int QPR, int XYZM, bool DEADZ = false, bool NTS = false, bool NTX = NTS, bool POSES = false>
 __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t* s_tile,
                                             uint32_t col0_dw, uint32_t colstride_dw, const int32_t* s_off,
                                             float4* s_xyz, const double* s_beam, uint32_t* s_gate,
@@ -742,7 +744,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                         p[c][k] = rr ? t : (XT)0;
                     }
                 }
-                if (s_pose) {   // dewarp<T>(points, poses), pose_util.h:38-56: R_col * p + t_col in T (uniform branch)
+                if constexpr (POSES) if (s_pose) {   // dewarp<T>(points, poses), pose_util.h:38-56: R_col * p + t_col in T
                     XT m[12][4];
 #pragma unroll
                     for (int k = 0; k < 12; ++k)
