@@ -159,10 +159,22 @@ void DeviceFrameBatch::sync() { ctx_->sync(); }
 double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms, size_t ballast_bytes) {
     ScopedContext on_my_context(ctx_);
     auto st = static_cast<hipStream_t>(ctx_->stream());
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+    struct Events {   // released on every way out, decode() may throw
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } ev;
+    if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess)
         throw std::runtime_error("ouster_hip: hipEventCreate failed");
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     const std::vector<uint32_t> kept_counts = counts_;
+    struct RestoreCounts {   // the caller's per-frame packet counts come back whatever happens
+        std::vector<uint32_t>& dst;
+        const std::vector<uint32_t>& src;
+        ~RestoreCounts() { dst = src; }
+    } restore{counts_, kept_counts};
     counts_.assign(n_frames_, slots_);   // time the full-frame work whatever has been uploaded so far
     auto clock = [&]() {
         constexpr int launches = 12;
@@ -252,9 +264,6 @@ double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms, 
     check(ouster_hip_ctx_set_knob(default_ctx(), "retune", 1));
     for (int i = 0; i < 14; ++i) decode();
     best = std::min(best, clock());
-    counts_ = kept_counts;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return best * 1e-3;
 }
 
