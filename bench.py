@@ -13,6 +13,15 @@ ranks shard the batch with no data-path collective ("weak": per-GPU work fixed).
 prints ONE JSON line with the whole-job rate, the roofline of the dominant kernel
 (k_decode, timed with HIP events on its stream) and the CPU baseline (the oracle's
 restatement of the reference loops, timed on this box's host cores, rank 0 at N=1 only).
+
+Setup before the W warm-up steps (none of it inside the timed region, all of it reported in the JSON line):
+  * the library's kernel-variant tuner settles (first 12 calls of a workload shape);
+  * buffer placement: `--placement-tries` allocations of the output set (`--placement-stride-gb` of ballast between
+    two draws, so that they scan the device memory) and up to 10 of the packet buffer are drawn and timed, the fastest
+    are kept ("placement": every draw's time; `--placement-tries 1` = first allocation; DESIGN.md 3.2c);
+  * after the K timed steps the outputs are compared with the oracle ("validated", "max_abs_dxyz_m").
+`--rotate-inputs R` is a diagnostic: R copies of the packet batch decoded in turn (no step finds its input in the
+Infinity Cache); `--workload`, `--outputs`, `--exchange`, `--pcie` select other configurations / ablations.
 """
 import argparse
 import json
