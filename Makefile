@@ -11,7 +11,8 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result
 # the fused decode kernels are compiled once per packet-profile specialisation (parallel with -j)
 OBJ := $(CSRC)/_build
 SPEC_IDS := 0 1 2 3 4 5
-HIP_OBJS := $(foreach i,$(SPEC_IDS),$(OBJ)/k_decode_$(i).o) $(OBJ)/k_standalone.o $(OBJ)/ouster_hip_capi.o
+STREAM_IDS := 1 2 3 4 5
+HIP_OBJS := $(foreach i,$(SPEC_IDS),$(OBJ)/k_decode_$(i).o) $(foreach i,$(STREAM_IDS),$(OBJ)/k_decode_stream_$(i).o) $(OBJ)/k_standalone.o $(OBJ)/ouster_hip_capi.o
 HIP_HDRS := $(CSRC)/ouster_hip_dev.h $(CSRC)/kernels_common.h include/ouster_hip.h
 ROCM ?= /opt/rocm
 CXXFLAGS := -O2 -std=c++17 -fPIC -pthread -Wall -Wextra -Iinclude -I$(CSRC)/host -I$(ROCM)/include -D__HIP_PLATFORM_AMD__
@@ -20,6 +21,10 @@ PYEXT := ouster_sdk_amd/core$(shell python3-config --extension-suffix)
 PYINC := $(shell python3 -m pybind11 --includes)
 
 all: $(LIB)/libouster_hip.so $(LIB)/libouster_core_amd.so $(PYEXT) oracle cpptests
+
+$(OBJ)/k_decode_stream_%.o: $(CSRC)/k_decode_stream.hip $(HIP_HDRS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -DOUSTER_SPEC_ID=$* -c -o $@ $<
 
 $(OBJ)/k_decode_%.o: $(CSRC)/k_decode.hip $(HIP_HDRS)
 	@mkdir -p $(OBJ)

@@ -289,9 +289,9 @@ def main():
             dist.barrier()
 
     # setup, like building the LUT: let the library's per-workload kernel-variant tuner finish
-    # (it times three tile shapes four times on the first twelve calls), so the W
+    # (it times up to four kernel variants four times each on the first sixteen calls), so the W
     # warm-up steps and the K timed steps all run the variant it settled on
-    for _ in range(14):
+    for _ in range(20):
         hp.decode(packets, out)
     torch.cuda.synchronize()
     # setup, like sizing a memory pool: the physical placement of a buffer is drawn when it is allocated and

@@ -184,7 +184,10 @@ int ouster_hip_ctx_device(ouster_hip_ctx* ctx); /* the HIP device ordinal the co
  *   "tile"  force k_decode's tile width (64/32/16)      "wide_kb"  LDS budget of a wide tile
  *   "wide_min_blocks"  smallest launch that may use wide tiles   "tune"  0: no variant timing
  *   "xcd"   0: plain block -> frame mapping   "fast"  0: every frame through the general mapping
- *   "retune" 1: forget the variant tuner's verdicts (a caller that re-allocated its buffers re-learns) */
+ *   "retune" 1: forget the variant tuner's verdicts (a caller that re-allocated its buffers re-learns)
+ *   "stream" -1 auto | 0 never | 128/256 force k_decode_stream's tile width   "stream_rows" rows of its tiles
+ *   "stream_wait" 0: trust the in-order vmcnt instead of draining it before a prefetched tile is used
+ *   "stream_min_tiles" tiles per persistent workgroup below which a launch stays on the one-tile kernels */
 int ouster_hip_ctx_set_knob(ouster_hip_ctx* ctx, const char* name, int value);
 int ouster_hip_sync(ouster_hip_ctx* ctx);
 const char* ouster_hip_last_error(void);
@@ -366,6 +369,10 @@ int ouster_hip_timing_read(ouster_hip_ctx* ctx, double* avg_ms, uint32_t* n_laun
  * picked per workload by timing each candidate twice on the first six calls (knob "tune" = 0 disables
  * that, knob "wide" forces one). */
 int ouster_hip_last_decode_tile(ouster_hip_ctx* ctx, int* tile_cols, int* tile_rows);
+/* Name of the optimistic-pass kernel the last ouster_hip_decode launched: "k_decode" (64/32/16-column tiles,
+ * also every general-mapping launch), "k_decode_wide" or "k_decode_stream" (persistent workgroups, tiles
+ * double-buffered through LDS-DMA; knob "stream" = 0 disables it, 128 / 256 force that tile width). */
+const char* ouster_hip_last_decode_kernel(ouster_hip_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "ouster_hip_last_error", "ouster_hip_version", "ouster_hip_format_create",
     "ouster_hip_format_destroy", "ouster_hip_lut_create", "ouster_hip_lut_create_from_arrays",
     "ouster_hip_lut_export", "ouster_hip_lut_destroy", "ouster_hip_decode", "ouster_hip_destagger",
-    "ouster_hip_cartesian", "ouster_hip_osf_unpack", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_dewarp_frames_counted", "ouster_hip_range_gate", "ouster_hip_timing_enable", "ouster_hip_timing_read", "ouster_hip_last_decode_tile",
+    "ouster_hip_cartesian", "ouster_hip_osf_unpack", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_dewarp_frames_counted", "ouster_hip_range_gate", "ouster_hip_timing_enable", "ouster_hip_timing_read", "ouster_hip_last_decode_tile", "ouster_hip_last_decode_kernel",
 ]
 
 _hip = None
@@ -146,6 +146,9 @@ def load_hip(private_path: Optional[str] = None):
     L.ouster_hip_timing_enable.argtypes = [vp, C.c_int]
     L.ouster_hip_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.ouster_hip_last_decode_tile.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    if hasattr(L, "ouster_hip_last_decode_kernel"):   # absent only in older A/B builds loaded via OUSTER_HIP_SO
+        L.ouster_hip_last_decode_kernel.restype = C.c_char_p
+        L.ouster_hip_last_decode_kernel.argtypes = [vp]
     if private_path is None:
         _hip = L
     return L
@@ -249,6 +252,12 @@ class Context:
         c, r = C.c_int(), C.c_int()
         check(self.L.ouster_hip_last_decode_tile(self.h, C.byref(c), C.byref(r)))
         return c.value, r.value
+
+    def last_decode_kernel(self) -> str:
+        """Name of the optimistic-pass kernel the last decode launched (k_decode / k_decode_wide / k_decode_stream)."""
+        if not hasattr(self.L, "ouster_hip_last_decode_kernel"):
+            return ""
+        return (self.L.ouster_hip_last_decode_kernel(self.h) or b"").decode()
 
     def timing_read(self) -> Tuple[float, int]:
         ms = C.c_double()

@@ -262,7 +262,7 @@ double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms, 
     rejected_packets.clear();
     // the kernel variant was chosen on the first draw: let the tuner look again on the buffers that stay
     check(ouster_hip_ctx_set_knob(default_ctx(), "retune", 1));
-    for (int i = 0; i < 14; ++i) decode();
+    for (int i = 0; i < 20; ++i) decode();
     best = std::min(best, clock());
     return best * 1e-3;
 }

@@ -44,7 +44,7 @@ struct Span {
 
 template <typename T>
 T rd(const Span& b, size_t pos) {
-    if (pos + sizeof(T) > b.n) bad("read past the end");
+    if (pos > b.n || b.n - pos < sizeof(T)) bad("read past the end");  // subtraction form: a crafted offset cannot wrap
     T v;
     std::memcpy(&v, b.p + pos, sizeof(T));
     return v;
@@ -58,10 +58,10 @@ struct Table {
     Table(const Span& buf, size_t at) : b(buf), pos(at) {
         const int32_t so = rd<int32_t>(b, pos);
         const int64_t v = static_cast<int64_t>(pos) - so;
-        if (v < 0 || static_cast<size_t>(v) + 4 > b.n) bad("vtable");
+        if (v < 0 || static_cast<size_t>(v) > b.n || b.n - static_cast<size_t>(v) < 4) bad("vtable");
         vt = static_cast<size_t>(v);
         vt_len = rd<uint16_t>(b, vt);
-        if (vt + vt_len > b.n) bad("vtable length");
+        if (b.n - vt < vt_len) bad("vtable length");
     }
     bool valid() const { return b.p != nullptr; }
     size_t field_offset(int field) const {
@@ -88,7 +88,7 @@ struct Table {
         const size_t p = indirect(field);
         if (!p) return {};
         const uint32_t n = rd<uint32_t>(b, p);
-        if (p + 4 + n > b.n) bad("string");
+        if (b.n - p - 4 < n) bad("string");   // rd<> above proved p + 4 <= b.n
         return std::string(reinterpret_cast<const char*>(b.p + p + 4), n);
     }
     /** vector of `elem` byte scalars / structs: pointer + count */
@@ -97,7 +97,7 @@ struct Table {
         const size_t p = indirect(field);
         if (!p) return {};
         const uint32_t n = rd<uint32_t>(b, p);
-        if (p + 4 + static_cast<size_t>(n) * elem > b.n) bad("vector");
+        if ((b.n - p - 4) / elem < n) bad("vector");
         *count = n;
         return Span{b.p + p + 4, static_cast<size_t>(n) * elem};
     }
@@ -106,7 +106,7 @@ struct Table {
         const size_t p = indirect(field);
         if (!p) return out;
         const uint32_t n = rd<uint32_t>(b, p);
-        if (p + 4 + 4ull * n > b.n) bad("table vector");
+        if ((b.n - p - 4) / 4 < n) bad("table vector");
         for (uint32_t i = 0; i < n; ++i) {
             const size_t e = p + 4 + 4ull * i;
             out.emplace_back(b, e + rd<uint32_t>(b, e));
@@ -118,14 +118,15 @@ struct Table {
 // [u32 size][flatbuffer: u32 root offset, 4-byte identifier, ...][u32 crc32] (fb_utils.cpp:60-110)
 Table prefixed_root(const Span& file, size_t pos, size_t* body_size) {
     const uint32_t size = rd<uint32_t>(file, pos);
-    if (pos + 4 + size > file.n) bad("block size");
+    if (file.n - pos - 4 < size) bad("block size");
     if (body_size) *body_size = size;
     return Table(file, pos + 4 + rd<uint32_t>(file, pos + 4));
 }
 
 bool block_crc_ok(const Span& file, size_t pos) {
+    if (pos > file.n || file.n - pos < 8) return false;
     const uint32_t size = rd<uint32_t>(file, pos);
-    if (pos + 8 + size > file.n) return false;
+    if (file.n - pos - 8 < size) return false;
     const uint32_t stored = rd<uint32_t>(file, pos + 4 + size);
     return static_cast<uint32_t>(::crc32(0L, file.p + pos, 4 + size)) == stored;
 }
@@ -173,7 +174,7 @@ OsfFile::OsfFile(const std::string& path) {
     metadata_offset_ = hdr.scalar<uint64_t>(2, 1);
     if (status != 2) throw std::runtime_error("OSF: file was not finished (header status is not VALID)");
     chunks_base_ = 4 + hsize + 4;
-    if (metadata_offset_ + 8 > buf_.size() || !block_crc_ok(file, metadata_offset_))
+    if (metadata_offset_ > buf_.size() || buf_.size() - metadata_offset_ < 8 || !block_crc_ok(file, metadata_offset_))
         throw std::runtime_error("OSF: metadata crc32 mismatch");
     const Table meta = prefixed_root(file, metadata_offset_, nullptr);
     id_ = meta.string(0);
@@ -216,8 +217,9 @@ std::vector<OsfFile::Message> OsfFile::messages() const {
     std::vector<Message> out;
     const Span file{buf_.data(), buf_.size()};
     for (uint64_t off : chunk_offsets_) {
+        if (off > buf_.size() || buf_.size() - off < chunks_base_ + 8) throw std::runtime_error("OSF: chunk offset out of range");
         const size_t pos = chunks_base_ + off;
-        if (pos + 8 > buf_.size() || !block_crc_ok(file, pos)) throw std::runtime_error("OSF: chunk crc32 mismatch");
+        if (!block_crc_ok(file, pos)) throw std::runtime_error("OSF: chunk crc32 mismatch");
         const Table chunk = prefixed_root(file, pos, nullptr);
         for (const Table& m : chunk.tables(0)) {
             Message msg;

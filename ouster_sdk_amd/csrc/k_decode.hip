@@ -363,7 +363,11 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     const uint32_t q = tid % (TILE / 4);
     const uint32_t vq = (uint32_t)(validmask >> (q * 4)) & 0xfu;
     const void* s_pose = stage_poses<XYZM, POSES>(a, smem, f, c0, (uint32_t)TILE);
-    decode_rows<S, TILE / 4, XYZM, false, false, false, POSES>(a, s_tile, a.g.col_header_size >> 2, col_size >> 2, s_off, s_xyz,
+    uint32_t px_dw[4];
+    tile_px_offsets<TILE / 4>(px_dw, a.g.col_header_size >> 2, col_size >> 2);
+    ColConst cc;
+    if (XYZM == 1 || XYZM == 2) load_colconst(cc, lut, c0 + q * 4, W);
+    decode_rows<S, TILE / 4, XYZM, false, false, false, POSES>(a, s_tile, px_dw, cc, s_off, s_xyz,
                                    ((XYZM == 1 || XYZM == 2) && a.beam_lds) ? s_beam : nullptr, s_gate, lut, f, c0, 0u, H,
                                    vq, 0u, 1u, s_pose);
 }
@@ -674,7 +678,11 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_valid[jq + c]) ? (1u << c) : 0u;
     const void* s_pose = stage_poses<XYZM, POSES>(a, smem, f, c0, (uint32_t)TW);
-    decode_rows<S, TW / 4, XYZM, S::is_static, S::nt_stores, S::nt_xyz, POSES>(a, s_tile, 0u, slot, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
+    uint32_t px_dw[4];
+    tile_px_offsets<TW / 4>(px_dw, 0u, slot);
+    ColConst cc;
+    if (XYZM == 1 || XYZM == 2) load_colconst(cc, lut, c0 + jq, W);
+    decode_rows<S, TW / 4, XYZM, S::is_static, S::nt_stores, S::nt_xyz, POSES>(a, s_tile, px_dw, cc, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
                                  a.gate_counts ? s_gate : nullptr, lut, f, c0, r0, nrows, vq, rc, nch, s_pose);
     PHASE_STAMP(4);
 #ifdef OUSTER_PHASE_TIMING

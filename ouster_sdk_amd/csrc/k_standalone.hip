@@ -1027,6 +1027,27 @@ hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm
     }
 }
 
+#define OUSTER_DECL_STREAM(sfx) \
+    hipError_t launch_decode_stream_##sfx(const DecodeArgs& a, const StreamArgs& sp, int tw, int xyzm, int device, hipStream_t st);
+OUSTER_DECL_STREAM(dual_lb)
+OUSTER_DECL_STREAM(lb)
+OUSTER_DECL_STREAM(single)
+OUSTER_DECL_STREAM(dual)
+OUSTER_DECL_STREAM(legacy)
+#undef OUSTER_DECL_STREAM
+
+hipError_t launch_decode_stream(const DecodeArgs& a, const StreamArgs& sp, int spec_id, int tw, int xyzm, int device,
+                                hipStream_t st) {
+    switch (spec_id) {
+        case SPEC_DUAL_LB: return launch_decode_stream_dual_lb(a, sp, tw, xyzm, device, st);
+        case SPEC_LB: return launch_decode_stream_lb(a, sp, tw, xyzm, device, st);
+        case SPEC_SINGLE: return launch_decode_stream_single(a, sp, tw, xyzm, device, st);
+        case SPEC_DUAL: return launch_decode_stream_dual(a, sp, tw, xyzm, device, st);
+        case SPEC_LEGACY: return launch_decode_stream_legacy(a, sp, tw, xyzm, device, st);
+        default: return hipErrorInvalidValue;   // run-time descriptors stay on k_decode / k_decode_wide
+    }
+}
+
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st) {
     dim3 grid(a.h, n_images);
     hipLaunchKernelGGL(k_destagger, grid, dim3(256), 0, st, a);

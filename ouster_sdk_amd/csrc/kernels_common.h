@@ -588,39 +588,57 @@ __device__ __forceinline__ const void* stage_poses(const DecodeArgs& a, uint32_t
 // and the tile's partial counts go to a.gate_counts[f][gate_chunk][c0..] -- the dewarp that follows
 // skips its counting pass.  Every thread of the workgroup must call decode_rows (it ends in a barrier
 // when s_gate is set).
-template <class S, int QPR, int XYZM, bool DEADZ = false, bool NTS = false, bool NTX = NTS, bool POSES = false>
+// The per-column constants of a lane's four columns (separable xyz tables, section 3.3): loaded by decode_rows
+// itself, or once per kernel by a persistent caller (k_decode_stream) and handed in.
+struct ColConst {
+    double cx[4], sx[4], kc[4][3];
+};
+__device__ __forceinline__ void load_colconst(ColConst& cc, const LutDev& lut, uint32_t col, uint32_t W) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t k = (col + c < W) ? col + c : W - 1;
+        const double* t = lut.col_tab + (size_t)k * 5;
+        cc.cx[c] = t[0]; cc.sx[c] = t[1]; cc.kc[c][0] = t[2]; cc.kc[c][1] = t[3]; cc.kc[c][2] = t[4];
+    }
+}
+
+// NT: threads of the workgroup.  px_dw: per-lane dword offsets (into s_tile) of row 0 of the lane's four columns
+// (tile_px_offsets for "column j at col0_dw + j*colstride_dw", k_decode_stream has permuted blocks).  cc: the lane's
+// column constants (load_colconst; XYZM 1 / 2 only) -- a persistent caller loads them once.
+template <int QPR>
+__device__ __forceinline__ void tile_px_offsets(uint32_t (&px_dw)[4], uint32_t col0_dw, uint32_t colstride_dw) {
+    const uint32_t jq = (threadIdx.x % QPR) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) px_dw[c] = col0_dw + (jq + c) * colstride_dw;
+}
+// BEAMLDS: s_beam is known to be an LDS table (no run-time choice between it and lut.beam_tab: a pointer select would
+// turn the table reads into flat loads -- vmcnt AND lgkmcnt -- inside the row loop).
+// VECONLY: the caller guarantees a.vec_ok and whole quads (W % 4 == 0, every lane's four columns exist): the
+// element-wise fallbacks are not compiled in (a destaggered run that wraps round the row end still is).
+template <class S, int QPR, int XYZM, bool DEADZ = false, bool NTS = false, bool NTX = NTS, bool POSES = false, int NT = 256,
+          bool BEAMLDS = false, bool VECONLY = false>
 __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t* s_tile,
-                                            uint32_t col0_dw, uint32_t colstride_dw, const int32_t* s_off,
+                                            const uint32_t (&px_dw)[4], const ColConst& cc, const int32_t* s_off,
                                             float4* s_xyz, const double* s_beam, uint32_t* s_gate,
                                             const LutDev& lut, uint32_t f, uint32_t c0, uint32_t r0,
                                             uint32_t nrows, uint32_t vq, uint32_t gate_chunk,
                                             uint32_t gate_nchunks, const void* s_pose = nullptr) {
-    constexpr int NT = 256;
     constexpr int LPR = QPR < 64 ? QPR : 64;             // lanes of one wave in a row segment
     constexpr int RPP = NT / QPR > 0 ? NT / QPR : 1;     // rows per pass of the workgroup
     const uint32_t tid = threadIdx.x;
     const uint32_t W = a.g.columns_per_frame, H = a.g.pixels_per_column;
     const uint32_t q = tid % QPR, ty = tid / QPR;
     const uint32_t jq = q * 4, col = c0 + jq;
-    const bool live = col < W;
+    const bool live = VECONLY || col < W;
     if (!live && !s_gate) return;
     uint32_t gcnt[4] = {0, 0, 0, 0};
-    const bool vec = a.vec_ok && (col + 3 < W);
-    const uint32_t ncol = (W - col) < 4 ? (W - col) : 4;  // < 4 only when W % 4 != 0
+    const bool vec = VECONLY || (a.vec_ok && (col + 3 < W));
+    const uint32_t ncol = VECONLY ? 4u : ((W - col) < 4 ? (W - col) : 4);  // < 4 only when W % 4 != 0
     const size_t plane_px = (size_t)H * W;
     const uint32_t ql = q % LPR;                 // lane position inside its wave's row segment
     const uint32_t seg0 = c0 + (q - ql) * 4;     // first column of that segment
     const uint32_t chan = S::is_static ? S::chan : a.g.channel_data_size;
 
-    double cx[4], sx[4], kc[4][3];
-    if (XYZM == 1 || XYZM == 2) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t cc = (col + c < W) ? col + c : W - 1;
-            const double* t = lut.col_tab + (size_t)cc * 5;
-            cx[c] = t[0]; sx[c] = t[1]; kc[c][0] = t[2]; kc[c][1] = t[3]; kc[c][2] = t[4];
-        }
-    }
 
     for (uint32_t rrel = ty; live && rrel < nrows; rrel += RPP) {
         const uint32_t r = r0 + rrel;
@@ -639,7 +657,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
             uint32_t w[4][CW];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const uint32_t* px = s_tile + col0_dw + (jq + c) * colstride_dw + rrel * CW;
+                const uint32_t* px = s_tile + px_dw[c] + rrel * CW;
 #pragma unroll
                 for (int k = 0; k < CW; ++k) w[c][k] = (DEADZ || ((vq >> c) & 1)) ? px[k] : 0u;
             }
@@ -689,7 +707,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                 uint64_t v[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const uint32_t bo = ((col0_dw + (jq + c) * colstride_dw) << 2) + rrel * chan + a.bits[i].offset;
+                    const uint32_t bo = (px_dw[c] << 2) + rrel * chan + a.bits[i].offset;
                     v[c] = ((vq >> c) & 1)
                                ? trunc_elem(apply_bits(window_lds(s_tile, bo), a.bits[i].mask, a.bits[i].shift), e)
                                : trunc_elem(zero_value((a.f16_nan_mask >> i) & 1u), e);
@@ -719,15 +737,17 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
 
         if constexpr (XYZM == 1 || XYZM == 2) {
             using XT = typename std::conditional<XYZM == 1, float, double>::type;
-            const double* b = s_beam ? s_beam + (size_t)rrel * 9 : lut.beam_tab + (size_t)r * 9;
+            const double* b;
+            if constexpr (BEAMLDS) b = s_beam + rrel * 9u;
+            else b = s_beam ? s_beam + (size_t)rrel * 9 : lut.beam_tab + (size_t)r * 9;
             const double u0 = b[0], u1 = b[1], u2 = b[2], v0 = b[3], v1 = b[4], v2 = b[5],
                          w0 = b[6], w1 = b[7], w2 = b[8];
             double d[4][3];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                d[c][0] = fma(cx[c], u0, fma(sx[c], v0, w0));
-                d[c][1] = fma(cx[c], u1, fma(sx[c], v1, w1));
-                d[c][2] = fma(cx[c], u2, fma(sx[c], v2, w2));
+                d[c][0] = fma(cc.cx[c], u0, fma(cc.sx[c], v0, w0));
+                d[c][1] = fma(cc.cx[c], u1, fma(cc.sx[c], v1, w1));
+                d[c][2] = fma(cc.cx[c], u2, fma(cc.sx[c], v2, w2));
             }
 #pragma unroll
             for (int ret = 0; ret < 2; ++ret) {
@@ -740,7 +760,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                     const double rm = (double)rr - lut.n;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const XT t = (XT)fma(rm, d[c][k], kc[c][k]);
+                        const XT t = (XT)fma(rm, d[c][k], cc.kc[c][k]);
                         p[c][k] = rr ? t : (XT)0;
                     }
                 }
@@ -760,7 +780,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                 }
                 XT* dst = out + ((size_t)f * plane_px + rowpix) * 3;
                 if constexpr (XYZM == 1) {
-                    if (a.vec_ok && seg0 + 4 * LPR <= W) {  // my wave's whole row segment exists
+                    if (VECONLY || (a.vec_ok && seg0 + 4 * LPR <= W)) {  // my wave's whole row segment exists
 #if OUSTER_XYZ_PERMUTE
                         store_xyz4_permuted<LPR, NTX || OUSTER_NT_XYZ>(dst - (size_t)(4 * ql) * 3, ql, p);
 #else

@@ -80,6 +80,12 @@ struct Knobs {
     int dewarp_single_pass = 0;  // OUSTER_HIP_DWF_SINGLE: 1 = k_dwf_single instead of count / scan / emit (slower)
     int beam_lds = 1;         // OUSTER_HIP_BEAM_LDS: 0 keeps k_decode's per-beam table in global memory (A/B)
     int fixup = 1;            // tests only: 0 skips the fix-up pass (flagged frames are then left undone)
+    int stream = -1;          // OUSTER_HIP_STREAM: -1 auto | 0 never | 128 / 256 force k_decode_stream with that tile width when eligible
+    int stream_rows = 0;      // OUSTER_HIP_STREAM_ROWS: force the rows of a streamed tile (experiments)
+    int stream_wait = 1;      // OUSTER_HIP_STREAM_WAIT: 1 vmcnt(0) before a prefetched tile is used | 0 rely on the in-order counter
+    int stream_min_tiles = 8; // OUSTER_HIP_STREAM_MIN_TILES: tiles per workgroup below which a launch stays on k_decode_wide
+    int stream_order = 0;     // OUSTER_HIP_STREAM_ORDER: item order of k_decode_stream's groups (experiments)
+    int stream_loader = 4;    // OUSTER_HIP_STREAM_LOADER: loader waves of k_decode_stream2 (0 = k_decode_stream: every wave fetches)
 };
 
 struct ouster_hip_ctx {
@@ -88,9 +94,12 @@ struct ouster_hip_ctx {
     bool own_stream = false;
     DevBuf state, tile_valid, offsets, luts, counts, scratch;
     uint32_t resident_wgs = 512;         // 2 workgroups (80 KB LDS each) per CU
+    uint32_t cus = 256;                  // compute units (k_decode_stream: one persistent workgroup each)
+    const char* last_kernel = "";        // name of the decode kernel the last ouster_hip_decode launched
     bool state_dirty = false;            // `state` may hold leftovers (fix-up pass skipped / a failed launch)
     std::vector<int32_t> offsets_host;   // cache key of `offsets`
     std::vector<int32_t> shifts_host;    // pixel_shift_by_row the cached offsets were derived from
+    uint32_t shifts_w = 0;               //   ... and the frame width (the offsets are (W + x % W) % W)
     std::vector<LutDev> luts_host;       // cache key of `luts`
     // pageable host packet_counts go through a small pinned ring (no stream synchronisation)
     static constexpr int RING = 4;
@@ -106,11 +115,11 @@ struct ouster_hip_ctx {
     // timing each candidate on the first calls: which one is faster depends on how the output
     // planes happen to be placed in HBM
     struct Tune {
-        int best = -2;  // -2: still measuring; 0: narrow; 128 / 256: wide
+        int best = -2;  // -2: still measuring; 0: narrow; 128 / 256: wide; 1000 + tile width: the persistent kernel
         int calls = 0;
-        static constexpr int ROUNDS = 4, SAMPLES = 3 * ROUNDS;
-        hipEvent_t ev[SAMPLES][2] = {};  // three candidates x ROUNDS consecutive launches
-        float ms[3] = {0, 0, 0};         // fastest warm sample of each candidate
+        static constexpr int ROUNDS = 4, NCAND = 4, SAMPLES = NCAND * ROUNDS;
+        hipEvent_t ev[SAMPLES][2] = {};  // up to four candidates x ROUNDS consecutive launches
+        float ms[NCAND] = {0, 0, 0, 0};  // fastest warm sample of each candidate
     };
     std::map<uint64_t, Tune> tune;
     int last_tile_cols = 0, last_tile_rows = 0;  // tile of the last k_decode launch
@@ -265,7 +274,7 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
-            c->resident_wgs = 2u * (uint32_t)cus;
+            c->resident_wgs = 2u * (uint32_t)cus, c->cus = (uint32_t)cus;
     }
     {   // the only place the environment is read
         auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
@@ -280,6 +289,12 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.fast = env_int("OUSTER_HIP_FAST", k.fast);
         k.beam_lds = env_int("OUSTER_HIP_BEAM_LDS", k.beam_lds);
         k.dewarp_single_pass = env_int("OUSTER_HIP_DWF_SINGLE", k.dewarp_single_pass);
+        k.stream = env_int("OUSTER_HIP_STREAM", k.stream);
+        k.stream_rows = env_int("OUSTER_HIP_STREAM_ROWS", k.stream_rows);
+        k.stream_wait = env_int("OUSTER_HIP_STREAM_WAIT", k.stream_wait);
+        k.stream_min_tiles = env_int("OUSTER_HIP_STREAM_MIN_TILES", k.stream_min_tiles);
+        k.stream_order = env_int("OUSTER_HIP_STREAM_ORDER", k.stream_order);
+        k.stream_loader = env_int("OUSTER_HIP_STREAM_LOADER", k.stream_loader);
     }
     if (stream == OUSTER_HIP_STREAM_NULL) {
         c->stream = nullptr;  // the null stream
@@ -352,6 +367,12 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "fixup") k.fixup = value;
     else if (n == "beam_lds") k.beam_lds = value;
     else if (n == "dewarp_single_pass") k.dewarp_single_pass = value;
+    else if (n == "stream") k.stream = value;
+    else if (n == "stream_rows") k.stream_rows = value;
+    else if (n == "stream_wait") k.stream_wait = value;
+    else if (n == "stream_min_tiles") k.stream_min_tiles = value;
+    else if (n == "stream_order") k.stream_order = value;
+    else if (n == "stream_loader") k.stream_loader = value;
     else return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unknown knob '%s'", name);
     return OUSTER_HIP_OK;
 }
@@ -690,13 +711,14 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     }
     if (any_dst) {
         // the offsets only change with the sensor: key the cache on the shifts themselves
-        if (!(ctx->offsets.p && ctx->shifts_host.size() == H &&
+        if (!(ctx->offsets.p && ctx->shifts_host.size() == H && ctx->shifts_w == W &&
               memcmp(ctx->shifts_host.data(), pixel_shift_by_row, (size_t)H * 4) == 0 &&
               ctx->offsets_host.size() == H)) {
             std::vector<int32_t> off;
             dest_offsets(pixel_shift_by_row, H, W, 0, off);
             if (ensure_offsets(ctx, off)) return fail(OUSTER_HIP_ERR_RUNTIME, "offset upload failed");
             ctx->shifts_host.assign(pixel_shift_by_row, pixel_shift_by_row + H);
+            ctx->shifts_w = W;
         }
     }
     int xyzm = 0;
@@ -843,13 +865,111 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         da.tiles_per_frame = tiles;
         return decode_wide_lds_bytes(want, tr, da.lds_col_slot) + 16 + (size_t)want * pose_per_col <= 160 * 1024;
     };
-    int wide = 0;
+    // Persistent, double-buffered tiles filled by LDS-DMA (k_decode_stream): the optimistic pass of
+    // the static profiles on large batches whose buffers keep every 16 B cell's phase fixed.
+    StreamArgs sa{};
+    auto plan_field = [&](const ouster_hip_bits& b, uint32_t* dws, uint32_t& n_dw, uint32_t max_dw, FieldPlan& fp) -> bool {
+        fp.slot[0] = fp.slot[1] = fp.slot[2] = -1;
+        fp.sh = (uint8_t)((b.offset & 3u) * 8u);
+        if (b.mask == 0) return true;
+        const uint32_t lo = (uint32_t)__builtin_ctzll(b.mask) >> 3, hi = (63u - (uint32_t)__builtin_clzll(b.mask)) >> 3;
+        const uint32_t d0 = b.offset >> 2, first = (b.offset + lo) >> 2, last = (b.offset + hi) >> 2;
+        for (uint32_t d = first; d <= last; ++d) {
+            if (d - d0 > 2) return false;
+            uint32_t k = 0;
+            while (k < n_dw && dws[k] != d) ++k;
+            if (k == n_dw) {
+                if (n_dw == max_dw) return false;
+                dws[n_dw++] = d;
+            }
+            fp.slot[d - d0] = (int8_t)k;
+        }
+        return true;
+    };
+    auto setup_stream = [&](int tw) -> bool {
+        const uint32_t chan = g.channel_data_size, cpp = g.columns_per_packet;
+        if (!(fast && spec != SPEC_GENERIC && xyzm != 3 && !da.xyz_poses && vec_ok && (tw == 128 || tw == 256 || tw == 512 || tw == 1024))) return false;
+        if (W % (uint32_t)tw || (uint32_t)tw % cpp || (uint32_t)tw / cpp > 64 || chan == 0 || chan % 4) return false;
+        const uint32_t ct = W / (uint32_t)tw, per_xcd = std::max(ctx->cus / 8u, 1u);
+        if (ct > per_xcd) return false;
+        // every 16 B cell keeps its phase from tile to tile: frame bases and the frame stride are multiples of 16
+        if (((uintptr_t)packets & 15) || (((uint64_t)slots_per_frame * packet_stride) & 15)) return false;
+        // the last column's last cell must stay inside its frame's buffer
+        const uint64_t last_end = (uint64_t)(slots_per_frame - 1) * packet_stride + g.packet_header_size +
+                                  (uint64_t)(cpp - 1) * g.col_size + g.col_header_size + (uint64_t)H * chan;
+        if (last_end + 16 > (uint64_t)slots_per_frame * packet_stride) return false;
+        const uint32_t rpp = 2048u / (uint32_t)tw;   // rows per pass of the 512-thread workgroup
+        sa = StreamArgs{};
+        if (!plan_field(g.col_measurement_id, sa.hdr_dw, sa.n_hdr, 8, sa.mid) ||
+            !plan_field(g.col_status, sa.hdr_dw, sa.n_hdr, 8, sa.st) ||
+            !plan_field(g.col_timestamp, sa.hdr_dw, sa.n_hdr, 8, sa.ts) ||
+            !plan_field(g.alert_flags, sa.pkt_dw, sa.n_pkt, 4, sa.alert))
+            return false;
+        auto fits = [&](uint32_t tr) -> bool {
+            if (tr == 0 || tr % rpp || H % tr || (tr * chan) % 16) return false;
+            sa.tr = tr;
+            sa.nch = H / tr;
+            sa.ncell = tr * chan / 16 + 1;
+            sa.npix_instr = ((uint32_t)tw * sa.ncell + 63) / 64;
+            if (sa.npix_instr > 72) return false;
+            uint32_t o = sa.npix_instr * 1024u;
+            sa.hdr_off = o; o += sa.n_hdr * (uint32_t)tw * 4u;
+            sa.pkt_off = o; o += 6u * 256u;
+            sa.off_off = o; o += ((tr + 63) / 64) * 256u;
+            sa.beam_off = o; o += ((tr * 18u + 63) / 64) * 256u;
+            sa.ctx_bytes = (o + 1023u) & ~1023u;
+            sa.fixed_off = 2u * sa.ctx_bytes;
+            sa.lds_bytes = sa.fixed_off + 3u * (uint32_t)tw * 4u + 32u;
+            return sa.lds_bytes <= 160u * 1024u;
+        };
+        bool ok = false;
+        if (kn.stream_rows > 0) ok = fits((uint32_t)kn.stream_rows);
+        else
+            for (uint32_t tr = H / rpp * rpp; tr >= rpp && !ok; tr -= rpp) ok = fits(tr);   // the tallest tile that fits twice
+        if (!ok) return false;
+        if (out->gate_counts && sa.nch > OUSTER_HIP_GATE_CHUNKS) return false;
+        sa.groups = per_xcd / ct;
+        const uint64_t tiles = (uint64_t)n_frames * ct * sa.nch, wgs = 8ull * ct * sa.groups;
+        if (kn.stream_min_tiles > 0 && tiles < wgs * (uint64_t)kn.stream_min_tiles) return false;
+        // stores a wave issues per tile (one per output stream and lane row): with at least 63 of them behind a
+        // prefetch the 6-bit in-order vmcnt itself proves the prefetch has landed
+        uint32_t streams = 0;
+        for (uint32_t i = 0; i < nf; ++i) streams += (da.planes[i] ? 1u : 0u) + (da.destaggered[i] ? 1u : 0u);
+        for (int k = 0; k < 2; ++k)
+            if (da.xyz[k]) streams += xyzm == 1 ? 3u : 6u;
+        const uint32_t stores_per_wave = streams * (sa.tr / rpp);
+        sa.wait0 = (kn.stream_wait == 0 && stores_per_wave >= 64) ? 0u : 1u;
+        sa.order = (uint32_t)kn.stream_order;
+        sa.loader = (kn.stream_loader > 0 && (tw == 128 || tw == 256) && !out->gate_counts && kn.stream_order == 0)
+                        ? (uint32_t)std::min(kn.stream_loader, 4) : 0u;
+        da.rows_per_tile = sa.tr;
+        da.row_chunks = sa.nch;
+        da.lds_col_slot = 0;
+        da.tiles_per_frame = ct;
+        return true;
+    };
+    // Which optimistic-pass kernel?  Forced by a knob, or -- large batches of a static profile -- timed: k_decode_wide
+    // 256 x R, 128 x R, k_decode's 64-column tiles and (where the buffers allow it) the persistent k_decode_stream.
+    // Which one wins depends on how the buffers happen to lie in HBM: the persistent kernel is
+    // 1.5 - 3 % ahead where the memory system is fastest and up to 10 % behind where it is slowest.
+    int stream = 0, wide = 0;
+    int stream_auto = 0;   // tile width of the persistent candidate (0: not eligible)
+    if (kn.stream > 0) {
+        if (setup_stream(kn.stream)) stream = kn.stream;
+    } else if (kn.stream < 0 && kn.wide < 0 && kn.tile == 0) {
+        // column pieces of at least 256 B per tile row chunk: 256 columns for the 8 / 16 / 4 B/px profiles, 128 for 12 B/px
+        if (setup_stream(256) && sa.tr * g.channel_data_size >= 256) stream_auto = 256;
+        else if (setup_stream(128)) stream_auto = 128;
+        else if (setup_stream(256)) stream_auto = 256;
+    }
     ouster_hip_ctx::Tune* tuning = nullptr;
     int tune_slot = -1;
-    if (kn.wide >= 0) {  // forced (experiments, tests)
+    if (stream) {
+        // forced
+    } else if (kn.wide >= 0) {  // forced (experiments, tests)
         if (kn.wide && setup_wide(kn.wide)) wide = kn.wide;
     } else if (setup_wide(256)) {
-        wide = 256;
+        int sel = 256;   // >= 1000: the persistent kernel with tile width sel - 1000
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cap);
         if (kn.tune && cap == hipStreamCaptureStatusNone) {
@@ -865,6 +985,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             }
             mix(pm); mix(dm);
             mix((da.xyz[0] ? 1u : 0u) | (da.xyz[1] ? 2u : 0u) | (da.gate_counts ? 4u : 0u) | (da.xyz_poses ? 8u : 0u));
+            mix((uint64_t)stream_auto);
             if (ctx->tune.size() > 64 && !ctx->tune.count(key)) {  // bounded: forget everything, re-learn
                 for (auto& kv : ctx->tune)
                     for (auto& pr : kv.second.ev)
@@ -873,7 +994,8 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
                 ctx->tune.clear();
             }
             ouster_hip_ctx::Tune& t = ctx->tune[key];
-            static const int cand[3] = {256, 128, 0};
+            const int cand[ouster_hip_ctx::Tune::NCAND] = {256, 128, 0, 1000 + stream_auto};
+            const int nc = stream_auto ? 4 : 3;
             // Four launches of each candidate, back to back (a launch that follows a different variant
             // is not representative of the steady state: alternating the candidates made the 64-column
             // kernel look 8 % faster than it then ran).  Single launches vary by ~10 %, mostly upwards,
@@ -881,40 +1003,42 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             // counts, its first one (cold code, cold TLB, another variant's write-backs still draining)
             // only when nothing else landed.  The clocks are polled, never waited for: until all samples
             // have landed the default variant runs.
-            constexpr int NS = ouster_hip_ctx::Tune::SAMPLES;
+            constexpr int R = ouster_hip_ctx::Tune::ROUNDS;
+            const int NS = nc * R;
             if (t.best == -2 && t.calls >= NS) {
                 bool all = true;
                 for (int i = 0; i < NS && all; ++i) all = hipEventQuery(t.ev[i][1]) == hipSuccess;
                 if (!all) (void)hipGetLastError();
                 else {
-                    float cold[3] = {0, 0, 0};
+                    float cold[ouster_hip_ctx::Tune::NCAND] = {0, 0, 0, 0};
                     for (int i = 0; i < NS; ++i) {
                         float ms = 0;
                         if (hipEventElapsedTime(&ms, t.ev[i][0], t.ev[i][1]) != hipSuccess || ms <= 0) continue;
-                        constexpr int R = ouster_hip_ctx::Tune::ROUNDS;
                         float& slot = (i % R == 0) ? cold[i / R] : t.ms[i / R];
                         if (slot == 0 || ms < slot) slot = ms;
                     }
-                    for (int c = 0; c < 3; ++c)
+                    for (int c = 0; c < nc; ++c)
                         if (t.ms[c] == 0) t.ms[c] = cold[c];
                     t.best = 256;
                     float best_ms = 0;
-                    for (int c = 0; c < 3; ++c)
+                    for (int c = 0; c < nc; ++c)
                         if (t.ms[c] > 0 && (best_ms == 0 || t.ms[c] < best_ms)) { t.best = cand[c]; best_ms = t.ms[c]; }
                 }
             }
             if (t.best != -2) {
-                wide = t.best;
+                sel = t.best;
             } else if (t.calls < NS) {
                 tune_slot = t.calls;
-                wide = cand[tune_slot / ouster_hip_ctx::Tune::ROUNDS];
+                sel = cand[tune_slot / R];
                 tuning = &t;
                 ++t.calls;
             }
-            if (wide && !setup_wide(wide)) wide = (setup_wide(256) ? 256 : 0);
         }
+        if (sel >= 1000 && setup_stream(sel - 1000)) stream = sel - 1000;
+        else if (sel > 0 && sel < 1000 && setup_wide(sel)) wide = sel;
+        else if (sel != 0 && setup_wide(256)) wide = 256;
     }
-    if (!wide) {
+    if (!wide && !stream) {
         da.rows_per_tile = da.row_chunks = da.lds_col_slot = 0;
         da.tiles_per_frame = narrow_tiles;
     }
@@ -939,14 +1063,21 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             if (!tuning->ev[tune_slot][k]) HIP_TRY(hipEventCreate(&tuning->ev[tune_slot][k]));
         HIP_TRY(hipEventRecord(tuning->ev[tune_slot][0], st));
     }
-    if (wide) {
+    if (stream) {
+        HIP_TRY(launch_decode_stream(da, sa, spec, stream, xyzm, ctx->device, st));
+        ctx->last_tile_cols = stream;
+        ctx->last_tile_rows = (int)da.rows_per_tile;
+        ctx->last_kernel = "k_decode_stream";
+    } else if (wide) {
         HIP_TRY(launch_decode_wide(da, spec, wide, xyzm, ctx->device, st));
         ctx->last_tile_cols = wide;
         ctx->last_tile_rows = (int)da.rows_per_tile;
+        ctx->last_kernel = "k_decode_wide";
     } else {
         HIP_TRY(launch_decode(da, spec, tile, xyzm, ctx->device, st));
         ctx->last_tile_cols = tile;
         ctx->last_tile_rows = (int)H;
+        ctx->last_kernel = "k_decode";
     }
     if (tuning) HIP_TRY(hipEventRecord(tuning->ev[tune_slot][1], st));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
@@ -1169,6 +1300,8 @@ int ouster_hip_osf_unpack(ouster_hip_ctx* ctx, const ouster_hip_osf_plane* plane
     HIP_TRY(launch_osf_unpack(a, n_planes, ctx->stream));
     return OUSTER_HIP_OK;
 }
+
+const char* ouster_hip_last_decode_kernel(ouster_hip_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
 
 int ouster_hip_last_decode_tile(ouster_hip_ctx* ctx, int* tile_cols, int* tile_rows) {
     if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");

@@ -89,6 +89,31 @@ struct DecodeArgs {
 #endif
 };
 
+// k_decode_stream (persistent, double-buffered tiles filled by LDS-DMA): what the host works out
+// once per launch.  A tile context in LDS = the pixel image (TW column blocks of `ncell` 16 B cells, block of column j at
+// index j/4 + (TW/4)*(j%4)), then the column-header dwords [n_hdr][TW], the packet-level dwords [n_pkt + 2][64], the
+// destagger offsets of the tile's rows and their per-beam xyz constants.
+struct FieldPlan {   // a 64-bit field window assembled from fetched dwords: window dword k comes from slot[k] (-1: not needed)
+    int8_t slot[3];
+    uint8_t sh;      // bit position of the window inside window dword 0
+};
+struct StreamArgs {
+    uint32_t tr, nch;          // rows per tile, row chunks per frame
+    uint32_t ncell;            // 16 B cells per column block (the piece of tr rows plus its 16 B phase)
+    uint32_t npix_instr;       // 1 KB wave-instructions that fill the pixel image
+    uint32_t hdr_off, pkt_off, off_off, beam_off, ctx_bytes;  // byte offsets inside a tile context / its size
+    uint32_t fixed_off;        // byte offset of the per-workgroup tables behind the two contexts
+    uint32_t n_hdr, n_pkt;     // dwords fetched per column / per packet
+    uint32_t hdr_dw[8];        //   their dword offsets from the column start
+    uint32_t pkt_dw[4];        //   ... from the packet start
+    FieldPlan mid, st, ts, alert;
+    uint32_t groups;           // workgroups per (XCD, column tile)
+    uint32_t wait0;            // 1: vmcnt(0) before a prefetched tile is used; 0: rely on the in-order counter (>= 63 stores since)
+    uint32_t lds_bytes;
+    uint32_t order;            // how a group walks the XCD's (frame, row chunk) items, see the kernel
+    uint32_t loader;           // > 0: k_decode_stream2 with that many loader waves behind the eight decoding ones (1..4)
+};
+
 struct DestaggerArgs {
     const void* src;
     void* dst;
@@ -159,6 +184,7 @@ size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_sl
 // device: HIP device ordinal of the stream (per-device cache of the one-off kernel attributes)
 hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, int device, hipStream_t st);
 hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, int device, hipStream_t st);
+hipError_t launch_decode_stream(const DecodeArgs& a, const StreamArgs& sp, int spec_id, int tw, int xyzm, int device, hipStream_t st);
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st);
 hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
 hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);

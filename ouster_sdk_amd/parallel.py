@@ -82,6 +82,7 @@ def scatter_frames(batch: Optional[torch.Tensor], n_frames: int, frame_shape, dt
     mine = torch.empty((e - b, *frame_shape), dtype=dtype, device=device)
     ops = []
     if rank == src:
+        batch = batch.contiguous()   # RCCL sends need dense memory; a no-op for the usual dense batch
         for r in range(world):
             rb, re = shard_range(n_frames, r, world)
             if r == src:

@@ -25,7 +25,33 @@ if has_gpu():
 
 from test_gpu_parity import _np, _oracle_frames  # noqa: E402
 
-VARIANTS = [("narrow", 0), ("wide64", 64), ("wide128", 128), ("wide256", 256)]
+# "s128" / "s256": the persistent, double-buffered k_decode_stream with that tile width
+VARIANTS = [("narrow", 0), ("wide64", 64), ("wide128", 128), ("wide256", 256), ("stream128", "s128"),
+            ("stream256", "s256")]
+
+
+def _force_variant(hp, wide):
+    """wide: None = the library's choice; 0 = k_decode; 64..512 = k_decode_wide; "s128" / "s256" = k_decode_stream."""
+    if wide is None:
+        return
+    if isinstance(wide, str):
+        hp.ctx.set_knob("stream", int(wide[1:]))
+        hp.ctx.set_knob("stream_min_tiles", 0)
+        return
+    hp.ctx.set_knob("stream", 0)
+    hp.ctx.set_knob("wide", wide)
+    hp.ctx.set_knob("wide_min_blocks", 0)
+
+
+def _assert_variant_ran(hp, wide):
+    tc, _ = hp.ctx.last_decode_tile()
+    kernel = hp.ctx.last_decode_kernel()
+    if isinstance(wide, str):
+        assert kernel == "k_decode_stream" and tc == int(wide[1:]), (kernel, tc, wide)
+    elif wide:
+        assert kernel == "k_decode_wide" and tc == wide, (kernel, tc, wide)
+    elif wide == 0:
+        assert kernel == "k_decode" and tc <= 64, (kernel, tc, wide)
 
 
 def _hotpath(cal, profile, wide=None, fixup=True, use_extrinsics=False, **kw):
@@ -33,9 +59,7 @@ def _hotpath(cal, profile, wide=None, fixup=True, use_extrinsics=False, **kw):
     hp.set_pixel_shift_by_row(cal.pixel_shift_by_row)
     hp.add_lut(cal.beam_to_lidar, cal.lut_transform(use_extrinsics), cal.beam_azimuth_angles,
                cal.beam_altitude_angles)
-    if wide is not None:
-        hp.ctx.set_knob("wide", wide)
-        hp.ctx.set_knob("wide_min_blocks", 0)
+    _force_variant(hp, wide)
     if not fixup:
         hp.ctx.set_knob("fixup", 0)
     return hp
@@ -96,8 +120,7 @@ def test_home_slots_with_holes_stay_on_the_fast_pass(oracle, label, wide):
         t.view(torch.uint8).fill_(0xCD)
     hp.decode(torch.from_numpy(host).cuda(), out)
     hp.sync()
-    tc, _ = hp.ctx.last_decode_tile()
-    assert (tc == wide) if wide else (tc <= 64), (tc, wide)
+    _assert_variant_ran(hp, wide)
     ref = _oracle_frames(O, cal, pf, by_frame, True)
     _compare(O, cal, hp, out, ref, dst, xyz, check_nvalid=False)
     hp.ctx.set_knob("fixup", 1)                               # the normal two-pass call: same bytes + counts
@@ -250,7 +273,10 @@ def _bench_size_case(O, profile, n, dst, xyz, wide, n_luts=1, check=(0, 7, 8, 25
             c.extrinsic = ext
         cals.append(c)
         hp.add_lut(c.beam_to_lidar, c.lut_transform(n_luts > 1), c.beam_azimuth_angles, c.beam_altitude_angles)
-    if wide is not None:
+    if isinstance(wide, str):
+        _force_variant(hp, wide)
+    elif wide is not None:
+        hp.ctx.set_knob("stream", 0)
         hp.ctx.set_knob("wide", wide)
     d_pk = torch.from_numpy(packets).cuda().repeat(n // 8, 1, 1).contiguous()
     out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
@@ -259,6 +285,8 @@ def _bench_size_case(O, profile, n, dst, xyz, wide, n_luts=1, check=(0, 7, 8, 25
     hp.decode(d_pk, out)
     hp.sync()
     tc, tr = hp.ctx.last_decode_tile()
+    if isinstance(wide, str):
+        _assert_variant_ran(hp, wide)
     names = [x for x, _ in hp.fields]
     luts = [c.xyz_lut(n_luts > 1) for c in cals]
     worst = 0.0
@@ -290,7 +318,7 @@ def test_bench_size_dual_256_frames(oracle):
     """configs[2] exactly as bench.py runs it: 256 frames of 128x2048 dual return, all outputs; the
     variant the tuner would pick from (256-wide) and the 64-column kernel."""
     dst = ["RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"]
-    for wide, want_tc in ((256, 256), (0, 64), (128, 128)):
+    for wide, want_tc in ((256, 256), (0, 64), (128, 128), ("s256", 256), ("s128", 128)):
         tc, tr, worst = _bench_size_case(oracle, "RNG15_RFL8_NIR8_DUAL", 256, dst, ["RANGE", "RANGE2"], wide)
         assert tc == want_tc, (tc, tr)
         assert worst <= 4e-5
@@ -299,7 +327,7 @@ def test_bench_size_dual_256_frames(oracle):
 def test_bench_size_single_512_frames(oracle):
     """configs[1] / configs[3]: 512 frames of 128x2048 RNG19_RFL8_SIG16_NIR16 (the XCD-aware block ->
     frame map with 64 frames per XCD), default variant selection and the forced ones."""
-    for wide in (None, 0, 128):
+    for wide in (None, 0, 128, "s128", "s256"):
         tc, tr, worst = _bench_size_case(oracle, "RNG19_RFL8_SIG16_NIR16", 512, ["RANGE", "REFLECTIVITY"],
                                          ["RANGE"], wide)
         assert worst <= 4e-5
@@ -310,7 +338,7 @@ def test_bench_size_fused4_w2048(oracle):
     (frame % 4), each with its own extrinsics folded into its LUT, W = 2048, through the 256-wide
     kernel AND the narrow one."""
     dst = ["RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"]
-    for wide, want_tc in ((256, 256), (0, 64)):
+    for wide, want_tc in ((256, 256), (0, 64), ("s256", 256)):
         tc, tr, worst = _bench_size_case(oracle, "RNG15_RFL8_NIR8_DUAL", 256, dst, ["RANGE", "RANGE2"], wide,
                                          n_luts=4)
         assert tc == want_tc
@@ -427,3 +455,104 @@ def test_poses_fused_behind_the_cartesian(oracle, label, wide, dt):
     r0 = _np(plain["RANGE"])
     f, r, c = np.argwhere(r0 == 0)[0]
     assert np.allclose(_np(fused["xyz:RANGE"])[f, r * cal.w + c], poses[f, c, :3, 3], atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# k_decode_stream: persistent workgroups, tiles double-buffered through LDS-DMA
+# ---------------------------------------------------------------------------------------------
+STATIC_PROFILES = ["RNG15_RFL8_NIR8_DUAL", "RNG19_RFL8_SIG16_NIR16", "RNG15_RFL8_NIR8", "LEGACY",
+                   "RNG19_RFL8_SIG16_NIR16_DUAL"]
+
+
+@pytest.mark.parametrize("loader", [2, 4, 0])
+@pytest.mark.parametrize("rows", [0, 16])
+@pytest.mark.parametrize("tw", [128, 256])
+@pytest.mark.parametrize("profile", STATIC_PROFILES)
+def test_stream_kernel_equals_the_one_tile_kernels(oracle, profile, tw, rows, loader):
+    """Every static profile through k_decode_stream (default tile height and 8-row tiles = long per-workgroup
+    pipelines): all planes, destaggered planes, xyz, column headers, packet-level outputs and the frame meta are
+    byte-identical to k_decode's, on clean frames, holes, invalid columns and frames the fix-up pass redoes;
+    sampled frames against the oracle."""
+    O = oracle
+    cal = O.synthetic_calib(h=128, w=1024, profile=profile)
+    pf = cal.packet_format()
+    n = 20
+    packets, src = O.synth_packets(cal, 4, with_window=True)
+    pad = 16 if profile == "LEGACY" else 0       # LEGACY has no packet footer: the last cell needs 16 B behind the last column
+    slots = cal.w // cal.cpp
+    host = np.zeros((n, slots, pf.lidar_packet_size + pad), np.uint8)
+    for f in range(n):
+        host[f, :, :pf.lidar_packet_size] = packets[f % 4]
+    host[2, [5, 6]] = 0                                           # holes
+    host[7, 0] = 0
+    host[13] = 0                                                  # nothing arrived
+    st_off = pf.packet_header_size + 10 if profile != "LEGACY" else pf.packet_header_size + pf.col_size - 4
+    for c in (1, 7, 15):
+        host[4, 9, st_off + c * pf.col_size] &= 0xFE              # invalid columns
+    sw = host[9].copy(); sw[[10, 11]] = sw[[11, 10]]; host[9] = sw   # strays: the fix-up pass redoes frame 9
+    host[17, 3] = host[17, 40]                                    # a duplicate in a foreign slot
+    dev = torch.from_numpy(host).cuda()
+    hts = torch.from_numpy((np.arange(n * slots, dtype=np.uint64) + 1000).reshape(n, slots)).cuda()
+    results = {}
+    names = None
+    for variant in ("narrow", "stream"):
+        hp = _hotpath(cal, profile, wide=0 if variant == "narrow" else "s%d" % tw, use_extrinsics=True)
+        if variant == "stream":
+            hp.ctx.set_knob("stream_loader", loader)   # 1: k_decode_stream2 (a ninth wave fetches), 0: every wave fetches
+            if rows:
+                hp.ctx.set_knob("stream_rows", rows)
+        names = [x for x, _ in hp.fields]
+        xyz = [x for x in ("RANGE", "RANGE2") if x in names]
+        dst = [x for x in ("RANGE", "REFLECTIVITY", "NEAR_IR") if x in names]
+        out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
+        out["packet_timestamp"] = torch.empty((n, slots), dtype=torch.uint64, device="cuda")
+        out["alert_flags"] = torch.empty((n, slots), dtype=torch.uint8, device="cuda")
+        for t in out.values():
+            t.view(torch.uint8).fill_(0x5C)
+        hp.decode(dev, out, host_timestamps=hts)
+        hp.sync()
+        if variant == "stream":
+            _assert_variant_ran(hp, "s%d" % tw)
+            if rows:
+                assert hp.ctx.last_decode_tile()[1] == rows
+        results[variant] = {k: v.cpu().numpy().copy() for k, v in out.items()}
+    for k, v in results["narrow"].items():
+        if k == "alert_flags":     # not written for packets that did not arrive (lidar_frame.cpp:1534-1539): compare where they did
+            got = results["stream"][k]
+            arrived = results["narrow"]["packet_timestamp"] != 0
+            assert np.array_equal(v[arrived], got[arrived]), (k, profile, tw, rows)
+            continue
+        assert np.array_equal(v.view(np.uint8), results["stream"][k].view(np.uint8)), (k, profile, tw, rows)
+    ldir, lofs = cal.xyz_lut(True)
+    for f in (0, 5, 19):
+        fr = src[f % 4]
+        for name in names:
+            assert np.array_equal(results["stream"][name][f], fr.plane(name)), (f, name)
+        for name in xyz:
+            want = O.cartesian(fr.plane(name), ldir, lofs)
+            assert np.abs(results["stream"]["xyz:" + name][f].astype(np.float64) - want).max() <= 1e-4
+
+
+def test_tuner_times_the_persistent_kernel_too(oracle):
+    """256 frames of the metric configuration with the library's own choice: over the first calls the variant tuner
+    runs every candidate -- the persistent kernel among them -- and every call leaves the same bytes."""
+    O = oracle
+    cal = O.synthetic_calib(h=128, w=2048, profile="RNG15_RFL8_NIR8_DUAL")
+    packets, _ = O.synth_packets(cal, 8, with_window=True)
+    d_pk = torch.from_numpy(packets).cuda().repeat(32, 1, 1).contiguous()
+    hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL", wide=None)
+    out = hp.alloc_outputs(256, destagger=["RANGE", "RANGE2"], xyz=["RANGE", "RANGE2"])
+    seen, first = set(), None
+    for call in range(20):
+        for t in out.values():
+            t.view(torch.uint8).fill_(0x77)
+        hp.decode(d_pk, out)
+        hp.sync()
+        seen.add((hp.ctx.last_decode_kernel(),) + tuple(hp.ctx.last_decode_tile()))
+        snap = {k: v.clone() for k, v in out.items()}
+        if first is None:
+            first = snap
+        for k in first:
+            assert torch.equal(first[k].view(torch.uint8), snap[k].view(torch.uint8)), (call, k, seen)
+    kernels = {k for k, _, _ in seen}
+    assert {"k_decode", "k_decode_wide", "k_decode_stream"} <= kernels, seen
