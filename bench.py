@@ -15,13 +15,19 @@ prints ONE JSON line with the whole-job rate, the roofline of the dominant kerne
 restatement of the reference loops, timed on this box's host cores, rank 0 at N=1 only).
 
 Setup before the W warm-up steps (none of it inside the timed region, all of it reported in the JSON line):
-  * the library's kernel-variant tuner settles (first 12 calls of a workload shape);
-  * buffer placement: `--placement-tries` allocations of the output set (`--placement-stride-gb` of ballast between
-    two draws, so that they scan the device memory) and up to 10 of the packet buffer are drawn and timed, the fastest
-    are kept ("placement": every draw's time; `--placement-tries 1` = first allocation; DESIGN.md 3.2c);
+  * the library's kernel-variant tuner settles (first 16 calls of a workload shape);
+  * buffer placement, `--placement refine` (default): what ouster::sdk::hip::DeviceFrameBatch does by itself when it is
+    constructed -- the output buffers are re-drawn group by group (XYZ pair, 32-bit planes, destaggered planes, narrow
+    planes; 3 fresh allocations each, no ballast, ~0.15 s) and the fastest combination is kept; "placement" reports the
+    first allocation's time next to the kept one.  `--placement first` takes the first allocation as it comes;
+    `--placement draws` is the round-2 diagnostic (whole output sets drawn across the device memory, DESIGN.md 3.2c);
   * after the K timed steps the outputs are compared with the oracle ("validated", "max_abs_dxyz_m").
-`--rotate-inputs R` is a diagnostic: R copies of the packet batch decoded in turn (no step finds its input in the
-Infinity Cache); `--workload`, `--outputs`, `--exchange`, `--pcie` select other configurations / ablations.
+The timed steps rotate over `--rotate-inputs` copies of the packet batch (default 2: no step finds its input in the
+256 MB Infinity Cache).  After the timed region the paths the metric never touches are timed on the same buffers and
+reported under "loss_paths" (never as `value`): `holes` (one lost packet per frame, left as a zeroed slot: optimistic
+pass), `stray10` (10 % of the frames compacted after a drop / shuffled: fix-up pass), `general` (every frame compacted
+into 127 slots with per-frame packet counts: the general mapping for every frame).
+`--workload`, `--outputs`, `--exchange`, `--pcie` select other configurations / ablations.
 """
 import argparse
 import json
@@ -206,6 +212,88 @@ def validate_against_oracle(hp, profile, packets, out, shifts, lut_args, n_luts,
     return ok, worst, list(sample)
 
 
+def kernel_sources_sha256() -> str:
+    """Identity of the kernel sources a committed PMC figure was recorded on (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "ouster_sdk_amd", "csrc")
+    for name in ("kernels_common.h", "k_decode.hip", "k_decode_stream.hip", "ouster_hip_dev.h", "ouster_hip_capi.hip"):
+        with open(os.path.join(base, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def time_loss_paths(hp, packets, out, F, bytes_per_frame, steps=30):
+    """Decode rates of the paths the metric never touches, on the buffers of the timed run:
+      holes    one packet of every frame lost and left as a zeroed slot (how FrameStream / DeviceFrameBatch stage a
+               lossy stream): the optimistic pass alone;
+      stray10  10 % of the frames with live columns outside their home slots (compacted after a drop, or two packets
+               swapped): flagged by the optimistic pass, redone by the persistent fix-up pass;
+      general  every frame compacted into W/cpp - 1 slots + per-frame packet counts: slots * cpp != W, the general
+               mapping (MODE_GENERAL) for every frame -- the reference's parse_by_col fallback, lidar_frame.cpp:1422-1466.
+    Algorithmic bytes: the packets that are present + all outputs (missing columns are written as zeros)."""
+    import torch
+    slots, stride = packets.shape[1], packets.shape[2]
+    res = {}
+    f_idx = torch.arange(F, device="cuda")
+    lost = (f_idx * 7 + 3) % slots                       # the packet every frame loses
+    keep = torch.arange(slots, device="cuda").unsqueeze(0).expand(F, slots)
+    keep = keep[keep != lost.unsqueeze(1)].reshape(F, slots - 1)      # [F, slots-1] surviving packet indices, in order
+
+    def clock(pk, counts):
+        for _ in range(20):                               # variant tuner of this shape + warm-up
+            hp.decode(pk, out, packet_counts=counts)
+        torch.cuda.synchronize()
+        hp.ctx.timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            hp.decode(pk, out, packet_counts=counts)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        kms, _ = hp.ctx.timing_read()
+        hp.ctx.timing(False)
+        return dt, kms
+
+    def report(name, dt, kms, present_packets, what):
+        nbytes = bytes_per_frame * F - (F * slots - present_packets) * (stride)
+        tc, tr = hp.ctx.last_decode_tile()
+        res[name] = {"what": what, "ms_per_step": round(dt * 1e3, 4), "first_pass_kernel_ms": round(kms, 4),
+                     "kernel": f"{hp.ctx.last_decode_kernel()} {tc}x{tr}",
+                     "frac": round(nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if kms > 0 else None,
+                     "frac_step": round(nbytes / dt / 1e9 / HBM_PEAK_GBPS, 4),
+                     "algorithmic_bytes_per_launch": int(nbytes)}
+
+    # holes
+    pk = packets.clone()
+    pk[f_idx, lost] = 0
+    dt, kms = clock(pk, None)
+    report("holes", dt, kms, F * (slots - 1), "one packet per frame lost, left as a zeroed slot: optimistic pass only")
+    # stray10: every 20th frame compacted after its drop (count slots-1), every 20th + 10 has two packets swapped
+    pk = packets.clone()
+    counts = torch.full((F,), slots, dtype=torch.int32, device="cuda")
+    comp = f_idx[f_idx % 20 == 3]
+    if comp.numel():
+        pk[comp, :slots - 1] = packets[comp.unsqueeze(1), keep[comp]]
+        pk[comp, slots - 1] = 0
+        counts[comp] = slots - 1
+    swp = f_idx[f_idx % 20 == 13]
+    if swp.numel():
+        a, b = packets[swp, 10].clone(), packets[swp, 11].clone()
+        pk[swp, 10], pk[swp, 11] = b, a
+    dt, kms = clock(pk, counts)
+    n_fix = int(comp.numel() + swp.numel())
+    report("stray10", dt, kms, F * slots - int(comp.numel()),
+           f"{n_fix} of {F} frames with strays (half compacted after a drop, half with two packets swapped): "
+           "optimistic pass + fix-up pass over those frames")
+    # general: [F, slots-1] buffer, every frame compacted
+    pk = packets[f_idx.unsqueeze(1), keep].contiguous()
+    counts = torch.full((F,), slots - 1, dtype=torch.int32, device="cuda")
+    dt, kms = clock(pk, counts)
+    report("general", dt, kms, F * (slots - 1),
+           f"every frame compacted into {slots - 1} slots with per-frame packet counts: general mapping for every frame")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,12 +302,16 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--rotate-inputs", type=int, default=1,
-                    help="diagnostic: decode this many copies of the packet batch in turn (cold input every step)")
+    ap.add_argument("--rotate-inputs", type=int, default=2,
+                    help="decode this many copies of the packet batch in turn (>= 2: cold input every step)")
+    ap.add_argument("--placement", default="refine", choices=["first", "refine", "draws"],
+                    help="first: buffers as allocated; refine: buffer groups re-drawn (3 draws each, what DeviceFrameBatch "
+                         "does at construction); draws: diagnostic, whole output sets drawn across the device memory")
     ap.add_argument("--placement-stride-gb", type=float, default=4.0,
-                    help="ballast held between two placement draws: the draws scan the device memory")
+                    help="--placement draws: ballast held between two draws (they scan the device memory)")
     ap.add_argument("--placement-tries", type=int, default=24,
-                    help="candidate allocations of the output set to draw during setup (1 = take the first)")
+                    help="--placement draws: candidate allocations of the output set (1 = the same as --placement first)")
+    ap.add_argument("--no-loss-paths", action="store_true", help="skip the loss-path timings after the timed region")
     ap.add_argument("--workload", default="dual", choices=sorted(WORKLOADS),
                     help="'dual' is the metric (configs[2]); the others are extra report rows")
     ap.add_argument("--outputs", default="full", choices=["full", "xyz", "planes", "planes+dst"],
@@ -299,11 +391,17 @@ def main():
     # A pipeline allocates its buffers once, so it can afford to draw a few and keep the best -- that is what
     # HotPath.pick_placement does.  Every draw's time is reported ("placement"); --placement-tries 1 turns it off.
     placement = None
-    if args.placement_tries > 1:
+    if args.placement == "draws" and args.placement_tries > 1:
         del out
         torch.cuda.empty_cache()
         packets, out, placement = hp.pick_placement(packets, make_outputs, tries=args.placement_tries,
                                                     stride_gb=args.placement_stride_gb)
+        placement["mode"] = "draws"
+    elif args.placement == "refine":
+        t_setup = time.perf_counter()
+        out, placement = hp.refine_placement(packets, out, draws=3)
+        placement["mode"] = "refine"
+        placement["setup_s"] = round(time.perf_counter() - t_setup, 3)
     for _ in range(args.warmup):
         hp.decode(packets, out)
     torch.cuda.synchronize()
@@ -322,9 +420,10 @@ def main():
     kern_ms, n_launch = hp.ctx.timing_read()
     tc, tr = hp.ctx.last_decode_tile()
     spec_name = "SpecSingle" if args.workload in ("single", "batch512") else "SpecDualLB"
-    kernel_name = (f"k_decode_wide<{spec_name},{tc},sep-f32> ({tc}x{tr} tiles)" if tr < H
-                   else f"k_decode<{spec_name},{tc},sep-f32> ({tc}x{tr} tiles)")
+    kern = hp.ctx.last_decode_kernel() or ("k_decode_wide" if tr < H else "k_decode")
+    kernel_name = f"{kern}<{spec_name},{tc},sep-f32> ({tc}x{tr} tiles)"
     hp.ctx.timing(False)
+
 
     # context for the roofline: what a plain device-to-device copy reaches on THIS box right now
     # (boxes of the pool differ by up to ~35 % in sustained HBM bandwidth)
@@ -424,6 +523,11 @@ def main():
     if rank == 0 and not args.no_cpu and args.outputs == "full":
         validated, max_dxyz, checked = validate_against_oracle(
             hp, profile, packets, out, shifts, lut_args, len(lut_args), sorted({0, 7 % F, F // 2, F - 1}))
+    # the paths the metric never touches, on the same output buffers, outside the timed region and
+    # after the self-check (they overwrite the outputs)
+    loss_paths = None
+    if rank == 0 and not args.no_loss_paths and args.outputs == "full":
+        loss_paths = time_loss_paths(hp, packets, out, F, algorithmic_bytes_per_frame(args.workload))
     # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot wrap a run from inside):
     # only quoted when the committed profile is of exactly this workload and output set.
     traffic, traffic_src = None, None
@@ -434,11 +538,17 @@ def main():
             try:
                 t = json.load(open(pj))
                 if t.get("workload") == args.workload and t.get("frames_per_launch"):
-                    v = t.get("variants_by_tile_columns", {}).get(str(tc), t)  # the variant that ran here
+                    v = t.get("variants", {}).get(f"{kern}:{tc}") or \
+                        (t.get("variants_by_tile_columns", {}).get(str(tc)) if kern != "k_decode_stream" else None)
+                    if not v:
+                        continue           # no committed counters for the variant that ran here
                     traffic = int(round(v["total_bytes"] * F / t["frames_per_launch"]))
+                    stale = t.get("kernel_sources_sha256") != kernel_sources_sha256()
                     traffic_src = (os.path.relpath(pj, os.path.dirname(os.path.abspath(__file__))) +
                                    f": {v['total_bytes']} B per {t['frames_per_launch']}-frame launch of " +
-                                   f"{v.get('kernel', t.get('kernel'))}; " + t.get("method", ""))
+                                   f"{v.get('kernel', t.get('kernel'))}; " + t.get("method", "") +
+                                   ("; RECORDED ON OTHER KERNEL SOURCES than this tree's (stale)" if stale else
+                                    "; recorded on this tree's kernel sources"))
                     break
             except Exception:
                 pass
@@ -453,14 +563,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl_label,
                        "frames_per_step_per_gpu": F, "points_per_frame": H * W * n_ret,
-                       "outputs": "8 planes + 4 destaggered planes + 2x XYZ f32 + column headers"
+                       "outputs": (f"{len(hp.fields)} planes + {len(dst_names)} destaggered planes + "
+                                   f"{len(xyz_names)}x XYZ f32 + column headers")
                        if args.outputs == "full" else "ABLATION:" + args.outputs,
                        "sharding": f"frames x{world}, no data-path collective",
                        "input_batches_rotated": args.rotate_inputs,
-                       "buffer_placement": ("best of %d allocations of the output set (%.0f GB of ballast between "
-                                            "two draws: they scan the device memory) and of up to 10 of the packet "
-                                            "buffer, drawn and timed during setup (HotPath.pick_placement)"
-                                            % (args.placement_tries, args.placement_stride_gb)) if placement else "first allocation"},
+                       "buffer_placement": ("first allocation" if not placement else
+                                            "buffer groups re-drawn 3 x each, fastest kept (HotPath.refine_placement = "
+                                            "DeviceFrameBatch's construction-time default)" if placement["mode"] == "refine" else
+                                            "DIAGNOSTIC: best of %d allocations of the output set (%.0f GB of ballast between "
+                                            "two draws) and of up to 10 of the packet buffer (HotPath.pick_placement)"
+                                            % (args.placement_tries, args.placement_stride_gb))},
             "placement": placement,
             "roofline": {"bound": "hbm",
                          "kernel": kernel_name,
@@ -473,8 +586,13 @@ def main():
                          "kernel_ms_avg": round(kern_ms, 4), "launches_timed": n_launch,
                          "box_d2d_copy_GBps": round(box_copy_gbps, 1)},
             "validated": validated, "max_abs_dxyz_m": max_dxyz, "validated_frames": checked,
+            "loss_paths": loss_paths,
             "cpu_baseline": None,
         }
+        if placement and "first_allocation_ms" in placement:   # the first allocation's fraction next to the kept draw's
+            line["roofline"]["first_allocation_ms_per_call"] = placement["first_allocation_ms"]
+            line["roofline"]["first_allocation_frac_step"] = round(
+                bytes_per_launch / (placement["first_allocation_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         if exchange:
             line["exchange"] = exchange
         if pcie:

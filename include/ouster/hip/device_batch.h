@@ -42,6 +42,10 @@ struct BatchOptions {
     /// the gated RANGE pixels per column (they are in registers there) and dewarp(min, max) with the same
     /// gate skips its counting pass over the RANGE planes.
     double gate_min_range = 0.0, gate_max_range = -1.0;
+    /// Large batches (>= 64 frames) settle WHERE their output buffers live when they are constructed: one
+    /// DeviceFrameBatch::refine_placement(3) on an all-zero packet buffer (same store pattern), ~0.15 s and a
+    /// transient 3 x the largest buffer group.  Pointers handed out afterwards stay valid for the life of the batch.
+    bool auto_placement = true;
     int device = -1;                      ///< GPU to work on (-1: hip::current_device() of the constructing thread)
     std::shared_ptr<Context> context;     ///< share this context (stream + scratch) instead of owning one
 };
@@ -88,6 +92,15 @@ class DeviceFrameBatch {
      *  memory instead of its first few GB: which mode a draw gets follows where it lands (tools/ab/ballast.py). */
     double tune_placement(int tries = 16, std::vector<double>* all_ms = nullptr,
                           size_t ballast_bytes_between_draws = size_t{4} << 30);
+    /** The cheap form, and what a large batch does by itself when it is constructed (BatchOptions::auto_placement):
+     *  the lottery is mostly an interaction between a few heavy output streams (tools/ab/hybrid_sets.py: exchanging
+     *  the two XYZ buffers of a slow set for those of a fast one recovers 90 % of the difference, one buffer alone
+     *  nothing), so the buffers are re-drawn GROUP BY GROUP -- XYZ clouds, 32-bit planes, destaggered planes, narrow
+     *  planes -- `draws` fresh allocations each, decode() timed into every candidate, the fastest kept; the buffers
+     *  the batch has are a candidate too.  Transient footprint `draws` x the largest group, no ballast.  Output
+     *  contents are undefined afterwards; device pointers obtained BEFORE the call are invalid.  Returns seconds per
+     *  decode() of what is kept; `all_ms`: the first allocation's time, then every candidate's. */
+    double refine_placement(int draws = 3, std::vector<double>* all_ms = nullptr);
 
     /** Run the fused kernels on everything uploaded so far (asynchronous; sync() to wait). */
     void decode();

@@ -90,6 +90,11 @@ DeviceFrameBatch::DeviceFrameBatch(const std::vector<SensorInfo>& sensors, uint3
     d_mid_.resize(static_cast<size_t>(n_frames_) * w_ * 2);
     d_status_.resize(static_cast<size_t>(n_frames_) * w_ * 4);
     counts_.assign(n_frames_, 0);
+    if (opt_.auto_placement && n_frames_ >= 64) {
+        if (hipMemsetAsync(d_packets_.data(), 0, d_packets_.size(), static_cast<hipStream_t>(ctx_->stream())) != hipSuccess)
+            throw std::runtime_error("ouster_hip: hipMemset(packets) failed");
+        refine_placement(3);
+    }
 }
 
 DeviceFrameBatch::~DeviceFrameBatch() {
@@ -264,6 +269,77 @@ double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms, 
     check(ouster_hip_ctx_set_knob(default_ctx(), "retune", 1));
     for (int i = 0; i < 20; ++i) decode();
     best = std::min(best, clock());
+    return best * 1e-3;
+}
+
+double DeviceFrameBatch::refine_placement(int draws, std::vector<double>* all_ms) {
+    ScopedContext on_my_context(ctx_);
+    auto st = static_cast<hipStream_t>(ctx_->stream());
+    struct Events {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } ev;
+    if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess)
+        throw std::runtime_error("ouster_hip: hipEventCreate failed");
+    const std::vector<uint32_t> kept_counts = counts_;
+    struct RestoreCounts {
+        std::vector<uint32_t>& dst;
+        const std::vector<uint32_t>& src;
+        ~RestoreCounts() { dst = src; }
+    } restore{counts_, kept_counts};
+    counts_.assign(n_frames_, slots_);   // the full-frame store pattern whatever has been uploaded so far
+    auto clock = [&]() {
+        constexpr int launches = 10;
+        decode();
+        decode();
+        (void)hipEventRecord(ev.a, st);
+        for (int i = 0; i < launches; ++i) decode();
+        (void)hipEventRecord(ev.b, st);
+        (void)hipEventSynchronize(ev.b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev.a, ev.b);
+        return static_cast<double>(ms) / launches;
+    };
+    for (int i = 0; i < 20; ++i) decode();   // the library's variant tuner settles first
+    double best = clock();
+    if (all_ms) all_ms->push_back(best);
+    // the groups, heaviest first: pointers to the batch's own buffers
+    std::vector<std::vector<DeviceBuffer*>> groups(4);
+    for (int k = 0; k < 2; ++k)
+        if (d_xyz_[k].size()) groups[0].push_back(&d_xyz_[k]);
+    auto elem_of = [&](const std::string& name) {
+        for (const auto& f : fields_)
+            if (f.first == name) return f.second;
+        return 0u;
+    };
+    for (auto& kv : d_planes_) groups[elem_of(kv.first) >= 4 ? 1 : 3].push_back(&kv.second);
+    for (auto& kv : d_dst_) groups[2].push_back(&kv.second);
+    for (auto& grp : groups) {
+        if (grp.empty()) continue;
+        // rejected draws stay allocated until the group is decided: a freed block is what the next allocation gets back
+        std::vector<std::vector<DeviceBuffer>> held;
+        for (int d = 0; d < draws; ++d) {
+            std::vector<DeviceBuffer> cand(grp.size());
+            try {
+                for (size_t i = 0; i < grp.size(); ++i) cand[i].resize(grp[i]->size());
+            } catch (const std::exception&) {
+                break;   // out of device memory: decide among what has been drawn
+            }
+            for (size_t i = 0; i < grp.size(); ++i) std::swap(cand[i], *grp[i]);   // members = candidate
+            const double ms = clock();
+            if (all_ms) all_ms->push_back(ms);
+            if (ms < best) best = ms;                                            // keep the candidate
+            else for (size_t i = 0; i < grp.size(); ++i) std::swap(cand[i], *grp[i]);   // put the incumbent back
+            held.push_back(std::move(cand));
+        }
+        ctx_->sync();
+    }
+    check(ouster_hip_ctx_set_knob(default_ctx(), "retune", 1));
+    for (int i = 0; i < 20; ++i) decode();
+    ctx_->sync();
     return best * 1e-3;
 }
 

@@ -394,16 +394,40 @@ __global__ __launch_bounds__(256) void k_decode_fixup(DecodeArgs a) {
     constexpr int NT = 256;
     extern __shared__ __align__(16) uint32_t smem[];
     __shared__ uint32_t s_n;
+    __shared__ uint32_t s_cnt[FIXUP_CHUNK / 64];   // flagged frames per 64-frame group of the chunk
     const uint32_t tid = threadIdx.x, tpf = a.tiles_per_frame;
     const uint32_t fast_tiles = a.lds_col_slot;  // column tiles of the optimistic pass (slots of tile_valid)
     uint16_t* s_list = (uint16_t*)(smem + (a.rows_per_tile >> 2));  // rows_per_tile: byte offset of the list here
     const uint64_t tag = a.frame_state[FS_TAG];
     for (uint32_t base = 0; base < a.n_frames; base += FIXUP_CHUNK) {
-        if (tid == 0) s_n = 0;
-        __syncthreads();
+        // The list must come out in the SAME order in every workgroup -- item `it` is (s_list[it / tpf], it % tpf) and the
+        // workgroups share the items out by index -- so it is compacted in frame order (ballots + a prefix over the
+        // 64-frame groups), not in the arrival order of an atomic counter (r02: with flagged frames in more than one wave's
+        // share, workgroups disagreed about the order, some tiles were redone twice and others never).
         const uint32_t nfr = min(FIXUP_CHUNK, a.n_frames - base);
-        for (uint32_t i = tid; i < nfr; i += NT)
-            if (a.frame_state[FS_WORDS + base + i] == tag) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)i;
+        constexpr uint32_t ROUNDS = FIXUP_CHUNK / NT;
+        uint64_t mine[ROUNDS];
+        bool flagged[ROUNDS];
+#pragma unroll
+        for (uint32_t r = 0; r < ROUNDS; ++r) {
+            const uint32_t i = r * NT + tid;
+            flagged[r] = i < nfr && a.frame_state[FS_WORDS + base + i] == tag;
+            mine[r] = __ballot(flagged[r]);
+            if ((tid & 63u) == 0) s_cnt[i >> 6] = (uint32_t)__popcll(mine[r]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < ROUNDS; ++r) {
+            const uint32_t i = r * NT + tid, grp = i >> 6;
+            uint32_t before = 0;
+            for (uint32_t k = 0; k < grp; ++k) before += s_cnt[k];
+            if (flagged[r]) s_list[before + (uint32_t)__popcll(mine[r] & ((1ull << (tid & 63u)) - 1ull))] = (uint16_t)i;
+        }
+        if (tid == 0) {
+            uint32_t n = 0;
+            for (uint32_t k = 0; k < FIXUP_CHUNK / 64; ++k) n += s_cnt[k];
+            s_n = n;
+        }
         __syncthreads();
         const uint32_t items = s_n * tpf;
         for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {

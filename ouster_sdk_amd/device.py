@@ -189,6 +189,73 @@ class HotPath:
         return best_pk, best_out, {"tries": tries, "stride_gb": stride_gb, "output_sets_ms": out_ms,
                                    "packet_buffers_ms": pk_ms}
 
+    def refine_placement(self, packets: torch.Tensor, out: Dict[str, torch.Tensor], draws: int = 3, launches: int = 10,
+                         passes: int = 1):
+        """The cheap form of pick_placement: the allocation lottery is mostly an interaction between
+        a few heavy output streams (tools/ab/hybrid_sets.py: exchanging the two XYZ buffers of a slow set for those of
+        a fast one recovers 90 % of the difference, exchanging one buffer alone changes nothing), so instead of
+        re-drawing whole output sets the buffers are re-drawn GROUP BY GROUP -- XYZ clouds, 32-bit planes, destaggered
+        planes, narrow planes -- `draws` fresh allocations each, the decode timed into every candidate, the fastest
+        kept (coordinate descent; the current buffers are a candidate too, so the result is never slower).  Transient
+        footprint: `draws` x the largest group (the XYZ pair: 1.5 GB for 256 frames); a dozen allocations and
+        `groups x draws x launches` decodes of setup.  Returns (out, report); `out` is updated in place."""
+        def clock(o):
+            for _ in range(2):
+                self.decode(packets, o)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(launches):
+                self.decode(packets, o)
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / launches
+
+        def group_of(k, t):
+            if k.startswith("xyz:"):
+                return "xyz"
+            if t.dim() < 3:
+                return None                      # column headers / frame meta: a few KB
+            if k.startswith("destaggered:"):
+                return "destaggered"
+            return "planes32" if t.element_size() >= 4 else "planes8_16"
+
+        groups: Dict[str, List[str]] = {}
+        for k, t in out.items():
+            g = group_of(k, t)
+            if g:
+                groups.setdefault(g, []).append(k)
+        order = [g for g in ("xyz", "planes32", "destaggered", "planes8_16") if g in groups]
+        first_ms = best_ms = clock(out)
+        report = {"first_allocation_ms": round(first_ms, 4), "draws_per_group": draws, "groups": {}}
+        for _ in range(max(1, passes)):
+            for g in order:
+                keys = groups[g]
+                held, times = [], []
+                for _ in range(draws):
+                    try:
+                        cand = {k: torch.empty_like(out[k]) for k in keys}
+                    except RuntimeError:
+                        break
+                    held.append(cand)       # rejected draws stay allocated until the group is decided (a freed block is what the next allocation gets back)
+                    trial = dict(out); trial.update(cand)
+                    times.append(clock(trial))
+                report["groups"].setdefault(g, []).append([round(x, 4) for x in times])
+                if times and min(times) < best_ms:
+                    best_ms = min(times)
+                    out.update(held[int(np.argmin(times))])
+                del held
+                torch.cuda.empty_cache()
+        report["kept_ms"] = round(best_ms, 4)
+        try:
+            self.ctx.set_knob("retune", 1)
+        except (capi.OusterHipError, AttributeError):
+            pass
+        else:
+            for _ in range(20):
+                self.decode(packets, out)
+            torch.cuda.synchronize()
+        return out, report
+
     # -- the three operations --------------------------------------------------------------
     def range_gate(self, min_range: float, max_range: float) -> Tuple[int, int, bool]:
         """(min_r, max_r, empty): the raw gate ouster_hip_dewarp_frames derives from metres."""

@@ -556,3 +556,57 @@ def test_tuner_times_the_persistent_kernel_too(oracle):
             assert torch.equal(first[k].view(torch.uint8), snap[k].view(torch.uint8)), (call, k, seen)
     kernels = {k for k, _, _ in seen}
     assert {"k_decode", "k_decode_wide", "k_decode_stream"} <= kernels, seen
+
+
+# ---------------------------------------------------------------------------------------------
+# the loss paths bench.py times next to the metric ("loss_paths"), at the benchmarked size
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["stray10", "general"])
+def test_bench_size_loss_paths(oracle, path):
+    """256 frames of 128x2048 dual return with bench.py's loss patterns: `stray10` (every 20th frame compacted after a
+    drop, every 20th + 10 with two packets swapped: fix-up pass) and `general` (every frame compacted into 127 slots with
+    per-frame packet counts: MODE_GENERAL for every frame, the reference's parse_by_col fallback,
+    lidar_frame.cpp:1422-1466, packet_format_test.cpp:328-406).  Lossy and clean frames against the oracle, all frames
+    against the period of the inputs."""
+    O = oracle
+    profile = "RNG15_RFL8_NIR8_DUAL"
+    cal = O.synthetic_calib(h=128, w=2048, profile=profile)
+    pf = cal.packet_format()
+    packets, src = O.synth_packets(cal, 8, with_window=True)
+    n, slots = 256, 128
+    hp = _hotpath(cal, profile)
+    dst, xyz = ["RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"], ["RANGE", "RANGE2"]
+    lost = [(f * 7 + 3) % slots for f in range(n)]
+    by_frame = {}
+    if path == "general":
+        host = np.zeros((n, slots - 1, pf.lidar_packet_size), np.uint8)
+        for f in range(n):
+            host[f] = np.delete(packets[f % 8], lost[f], axis=0)
+        counts = np.full(n, slots - 1, np.uint32)
+        check = [0, 7, 100, 255]
+        for f in check:
+            by_frame[f] = host[f]
+    else:
+        host = np.zeros((n, slots, pf.lidar_packet_size), np.uint8)
+        counts = np.full(n, slots, np.uint32)
+        for f in range(n):
+            host[f] = packets[f % 8]
+            if f % 20 == 3:
+                host[f, :slots - 1] = np.delete(packets[f % 8], lost[f], axis=0)
+                host[f, slots - 1] = 0
+                counts[f] = slots - 1
+            elif f % 20 == 13:
+                host[f, [10, 11]] = host[f, [11, 10]]
+        check = [0, 3, 13, 23, 243, 253, 255]
+        for f in check:
+            by_frame[f] = host[f, :counts[f]]
+    out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
+    for t in out.values():
+        t.view(torch.uint8).fill_(0xA5)
+    hp.decode(torch.from_numpy(host).cuda(), out, packet_counts=counts)
+    hp.sync()
+    if path == "general":
+        assert hp.ctx.last_decode_kernel() == "k_decode"
+    ref = _oracle_frames(O, cal, pf, [by_frame[f] for f in check], True)
+    worst = _compare(O, cal, hp, out, ref, dst, xyz, frames=list(zip(check, ref)))
+    assert worst <= 4e-5

@@ -51,7 +51,7 @@ def _two_ranks(script_args):
 
 def test_bench_two_ranks_with_exchange():
     line, backend = _two_ranks(["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--frames", "32",
-                                "--no-cpu", "--exchange", "--placement-tries", "1"])
+                                "--no-cpu", "--exchange", "--placement", "first", "--no-loss-paths"])
     assert line["n_gpus"] == 2 and line["steps"] == 5 and line["value"] > 0
     assert line["config"]["sharding"].startswith("frames x2")
     ex = line["exchange"]

@@ -72,17 +72,23 @@ parts = {}
 for (k, c), v in agg.items():
     if k == dom:
         parts[c] = sum(v) / len(v) * 1024 * (2.0 if c == "FETCH_SIZE" else 1.0)
-variants = {}
+variants, variants_by_kernel = {}, {}
 for (k, c), v in agg.items():
-    m = re.search(r"k_decode(?:_wide)?<[^,]+, (\d+),", k)
+    m = re.search(r"(k_decode(?:_wide|_stream2?)?)<[^,]+, (\d+),", k)
     if m:
-        variants.setdefault(m.group(1), {"kernel": k.strip(), "fetch_bytes": 0, "write_bytes": 0})
+        kern = "k_decode_stream" if m.group(1).startswith("k_decode_stream") else m.group(1)
         key = "fetch_bytes" if c == "FETCH_SIZE" else "write_bytes"
-        variants[m.group(1)][key] = round(sum(v) / len(v) * 1024 * (2.0 if c == "FETCH_SIZE" else 1.0))
-for v in variants.values():
+        val = round(sum(v) / len(v) * 1024 * (2.0 if c == "FETCH_SIZE" else 1.0))
+        variants_by_kernel.setdefault(f"{kern}:{m.group(2)}", {"kernel": k.strip(), "fetch_bytes": 0, "write_bytes": 0})[key] = val
+        if kern != "k_decode_stream":
+            variants.setdefault(m.group(2), {"kernel": k.strip(), "fetch_bytes": 0, "write_bytes": 0})[key] = val
+for v in list(variants.values()) + list(variants_by_kernel.values()):
     v["total_bytes"] = v["fetch_bytes"] + v["write_bytes"]
 if len(parts) == 2:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     json.dump({"kernel": dom.strip(), "workload": workload, "frames_per_launch": 256, "variants_by_tile_columns": variants,
+               "variants": variants_by_kernel, "kernel_sources_sha256": bench.kernel_sources_sha256(),
                "fetch_bytes": round(parts["FETCH_SIZE"]), "write_bytes": round(parts["WRITE_SIZE"]),
                "total_bytes": round(parts["FETCH_SIZE"] + parts["WRITE_SIZE"]),
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of "
