@@ -18,6 +18,7 @@
 #include "ouster/core/lidar_scan.h"
 #include "ouster/hip/frame_stream.h"
 #include "ouster/osf/osf.h"
+#include "ouster/pcap/pcap.h"
 
 namespace py = pybind11;
 using namespace ouster::sdk::core;
@@ -159,6 +160,7 @@ PYBIND11_MODULE(core, m) {
         .def_readwrite("beam_azimuth_angles", &SensorInfo::beam_azimuth_angles)
         .def_readwrite("beam_altitude_angles", &SensorInfo::beam_altitude_angles)
         .def_readwrite("init_id", &SensorInfo::init_id)
+        .def_readwrite("lidar_origin_to_beam_origin_mm", &SensorInfo::lidar_origin_to_beam_origin_mm)
         .def_property("beam_to_lidar_transform", [](const SensorInfo& s) { return mat_to(s.beam_to_lidar_transform); },
                       [](SensorInfo& s, const py::array_t<double, py::array::c_style | py::array::forcecast>& a) {
                           s.beam_to_lidar_transform = mat_from(a);
@@ -541,6 +543,18 @@ PYBIND11_MODULE(core, m) {
             });
     }
 
+    // every UDP datagram of a classic pcap as (payload bytes, destination port, capture time in ns): the Python face of
+    // ouster::sdk::pcap::PcapReader (include/ouster/pcap/pcap.h), enough to feed a FrameBatcher from a capture
+    m.def("read_pcap_udp", [](const std::string& path) {
+        ouster::sdk::pcap::PcapReader rd(path);
+        py::list out;
+        while (size_t n = rd.next_packet()) {
+            const auto& info = rd.current_info();
+            out.append(py::make_tuple(py::bytes(reinterpret_cast<const char*>(rd.current_data()), n), info.dst_port,
+                                      static_cast<uint64_t>(info.timestamp.count()) * 1000ull));
+        }
+        return out;
+    });
     m.def("default_lidar_to_sensor", [] { return mat_to(DEFAULT_LIDAR_TO_SENSOR); });
     m.def("default_beam_to_lidar_transform", [](const std::string& p) { return mat_to(default_beam_to_lidar_transform(p)); });
 }

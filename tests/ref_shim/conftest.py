@@ -1,0 +1,66 @@
+"""Fixtures for the REFERENCE's Python tests run against this repo (tests/test_reference_python_tests.py): the same
+names and meaning as the fixtures of the reference's python/tests/conftest.py:139-220 (test_key, base_name,
+stream_digest, meta, packets, frame), built on this repo's pcap reader and GPU-backed FrameBatcher.  The reference's
+conftest itself cannot be used: it imports the viz, CLI and pcap-indexing packages that are out of scope."""
+import os
+
+import pytest
+
+from ouster.sdk import core
+import ouster.sdk.core._digest as digest
+
+PCAPS_DATA_DIR = os.environ["OUSTER_REF_PCAPS"]
+
+TESTS = {
+    'legacy-2.0': 'OS-2-32-U0_v2.0.0_1024x10',
+    'legacy-2.1': 'OS-1-32-G_v2.1.1_1024x10',
+    'dual-2.2': 'OS-0-32-U1_v2.2.0_1024x10',
+    'single-2.3': 'OS-2-128-U1_v2.3.0_1024x10',
+    'low-data-rate-2.3': 'OS-0-128-U1_v2.3.0_1024x10',
+}
+
+
+@pytest.fixture(scope='module', params=TESTS.keys())
+def test_key(request) -> str:
+    return request.param
+
+
+@pytest.fixture
+def base_name(test_key: str) -> str:
+    return TESTS[test_key]
+
+
+@pytest.fixture
+def stream_digest(base_name: str):
+    with open(os.path.join(PCAPS_DATA_DIR, f"{base_name}_digest.json")) as f:
+        return digest.StreamDigest.from_json(f.read())
+
+
+@pytest.fixture
+def meta(base_name: str):
+    with open(os.path.join(PCAPS_DATA_DIR, f"{base_name}.json")) as f:
+        return core.SensorInfo(f.read())
+
+
+@pytest.fixture
+def packets(base_name: str, meta):
+    from ouster_sdk_amd import core as amd
+    pf = amd.PacketFormat(meta)
+    out = []
+    for payload, port, ts in amd.read_pcap_udp(os.path.join(PCAPS_DATA_DIR, f"{base_name}.pcap")):
+        if len(payload) == pf.lidar_packet_size:
+            p = core.LidarPacket(len(payload))
+            p.buf = payload
+            p.host_timestamp = ts
+            out.append(p)
+    return core.Packets(out, meta)
+
+
+@pytest.fixture
+def frame(packets):
+    batcher = core.FrameBatcher(packets.sensor_info[0])
+    lidar_frame = core.LidarFrame(packets.sensor_info[0])
+    for idx, p in packets:
+        if isinstance(p, core.LidarPacket) and batcher.batch(p, lidar_frame):
+            return lidar_frame
+    return lidar_frame
