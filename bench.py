@@ -343,6 +343,16 @@ def main():
         else:
             dist.init_process_group(backend)
     red_device = "cuda" if backend == "nccl" else "cpu"
+    # how many ranks the collective library really joined (counted BY it: an all-reduce of ones), and which library
+    rccl_ranks, coll = None, None
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int32, device=red_device)
+        dist.all_reduce(ones)
+        if backend == "nccl":
+            rccl_ranks = int(ones.item())
+            coll = "RCCL %s via torch.distributed 'nccl', one rank per GPU" % ".".join(str(x) for x in torch.cuda.nccl.version())
+        else:
+            coll = f"{backend} (test transport, {int(ones.item())} ranks): RCCL was not used"
 
     profile, bits, chan, dst_names, xyz_names, _, _, wl_label = WORKLOADS[args.workload]
     alt, az, shifts, b2l, l2s = synth_calibration()
@@ -593,6 +603,8 @@ def main():
             line["roofline"]["first_allocation_ms_per_call"] = placement["first_allocation_ms"]
             line["roofline"]["first_allocation_frac_step"] = round(
                 bytes_per_launch / (placement["first_allocation_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        line["rccl_ranks"] = rccl_ranks
+        line["collective_backend"] = coll
         if exchange:
             line["exchange"] = exchange
         if pcie:

@@ -80,6 +80,9 @@ class DeviceFrameBatch {
     uint8_t* packets_device() { return static_cast<uint8_t*>(d_packets_.data()); }
     /** Copy one frame's packets (host, each lidar_packet_size bytes) into its slots. */
     void upload_frame_packets(uint32_t frame, const std::vector<const uint8_t*>& packets);
+    /** The packet buffer was filled on the device (packets in their home slots, missing ones zeroed -- e.g. by a peer
+     *  copy, ShardedBatch::scatter): decode() treats every slot of every frame as present. */
+    void assume_all_slots_filled() { counts_.assign(n_frames_, slots_); }
 
     /** Setup-time choice of WHERE the batch's buffers live.  The physical placement of a device allocation
      *  is drawn when it is made and the decode's achieved write rate differs by 10 - 20 % between draws of

@@ -20,6 +20,7 @@
 #include "ouster/core/lidar_scan.h"  // pulls in everything + the legacy aliases
 #include "ouster/hip/context.h"
 #include "ouster/hip/device_batch.h"
+#include "ouster/hip/sharded_batch.h"
 #include "ouster/hip/frame_stream.h"
 
 using namespace ouster::sdk::core;
@@ -975,6 +976,83 @@ static void test_device_batch() {
 }
 
 // host packets in, host results out, batches overlapping on the copy / compute / copy streams
+static void test_sharded_batch() {
+    std::printf("ShardedBatch (frames over the visible GPUs, packets scattered / clouds gathered by peer copies)\n");
+    auto a = make_info(UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, HeaderType::STANDARD, 64, 1024);
+    auto b = a;
+    b.sensor_to_body(1, 3) = -3.0;
+    b.sensor_to_body(0, 0) = 0; b.sensor_to_body(0, 1) = 1; b.sensor_to_body(1, 0) = -1; b.sensor_to_body(1, 1) = 0;
+    auto c = a;
+    c.sensor_to_body(2, 3) = 1.5;
+    std::vector<SensorInfo> sensors = {a, b, c};        // three sensors interleaved: frame f uses sensor f % 3 in every shard
+    const uint32_t n = 64;
+    auto pf = std::make_shared<PacketFormat>(a);
+    std::vector<std::vector<LidarPacket>> frames;
+    for (uint32_t f = 0; f < n; ++f) {
+        LidarFrame src(a);
+        randomize(src, *pf, 900 + f);
+        frames.push_back(impl::frame_to_packets(src, pf, a.init_id, a.sn));
+    }
+    auto ptrs_of = [&](uint32_t f) {
+        std::vector<const uint8_t*> ptrs;
+        for (size_t i = 0; i < frames[f].size(); ++i)
+            if (!(f % 7 == 3 && i == 11)) ptrs.push_back(frames[f][i].buf.data());   // some frames lose a packet
+        return ptrs;
+    };
+    ouster::sdk::hip::BatchOptions opt;
+    opt.planes = {"RANGE"};
+    opt.xyz = true;
+    // the one-device answer
+    ouster::sdk::hip::DeviceFrameBatch one(sensors, n, opt);
+    for (uint32_t f = 0; f < n; ++f) one.upload_frame_packets(f, ptrs_of(f));
+    one.decode();
+    auto checksum = [&](auto&& download) {
+        uint64_t h = 1469598103934665603ull;
+        std::vector<float> xyz(static_cast<size_t>(64) * 1024 * 3);
+        for (uint32_t f = 0; f < n; ++f) {
+            download(f, xyz.data());
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(xyz.data());
+            for (size_t i = 0; i < xyz.size(); ++i) h = (h ^ w[i]) * 1099511628211ull;
+        }
+        return h;
+    };
+    const uint64_t want0 = checksum([&](uint32_t f, float* p) { one.download_xyz(0, f, p); });
+    const uint64_t want1 = checksum([&](uint32_t f, float* p) { one.download_xyz(1, f, p); });
+    // shard_range: contiguous, complete, sizes within one frame of each other
+    for (int world : {1, 2, 3, 7, 8}) {
+        uint32_t at = 0, lo = n, hi = 0;
+        for (int r = 0; r < world; ++r) {
+            auto rg = ouster::sdk::hip::shard_range(n, r, world);
+            CHECK(rg.first == at && rg.second >= rg.first);
+            lo = std::min(lo, rg.second - rg.first);
+            hi = std::max(hi, rg.second - rg.first);
+            at = rg.second;
+        }
+        CHECK(at == n && hi - lo <= 1);
+    }
+    const int ndev = ouster::sdk::hip::device_count();
+    std::vector<std::vector<int>> layouts = {{}};               // one shard per visible GPU
+    layouts.push_back({0, 0, 0});                               // three shards on GPU 0: the exchange path on a one-GPU box
+    if (ndev >= 2) layouts.push_back({1, 0});                   // root on another GPU than shard 0
+    for (const auto& devs : layouts) {
+        ouster::sdk::hip::ShardedBatch sb(sensors, n, opt, devs);
+        CHECK(sb.n_shards() == (devs.empty() ? std::min<int>(ndev, n) : static_cast<int>(devs.size())));
+        for (uint32_t f = 0; f < n; ++f) sb.upload_frame_packets(f, ptrs_of(f));
+        sb.scatter();
+        sb.decode();
+        sb.gather_xyz(0);
+        sb.gather_xyz(1);
+        sb.sync();
+        CHECK(checksum([&](uint32_t f, float* p) { sb.download_xyz_root(0, f, p); }) == want0);
+        CHECK(checksum([&](uint32_t f, float* p) { sb.download_xyz_root(1, f, p); }) == want1);
+        CHECK(sb.last_decode_ms() > 0 && sb.last_scatter_ms() >= 0 && sb.last_gather_ms() >= 0);
+        auto loc = sb.locate(n - 1);
+        CHECK(loc.first == sb.n_shards() - 1 && loc.second + 1 == sb.shard(loc.first).n_frames());
+        std::printf("  %d shard(s) on %d visible GPU(s): scatter %.3f ms, decode %.3f ms, gather %.3f ms\n", sb.n_shards(), ndev,
+                    sb.last_scatter_ms(), sb.last_decode_ms(), sb.last_gather_ms());
+    }
+}
+
 static void test_frame_stream() {
     std::printf("FrameStream (pinned staging, overlapped H2D / decode / D2H)\n");
     auto a = make_info(UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, HeaderType::STANDARD, 64, 512);
@@ -1214,6 +1292,7 @@ int main() {
     test_dewarp();
     test_frame_dewarp();
     test_device_batch();
+    test_sharded_batch();
     test_frame_stream();
     test_legacy_aliases();
     std::printf("%d checks, %d failed\n", g_checks, g_fail);

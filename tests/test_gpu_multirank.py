@@ -23,8 +23,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _torchrun(script_args, nproc, backend):
-    env = dict(os.environ, BENCH_ONE_DEVICE="1", BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _torchrun(script_args, nproc, backend, one_device=True):
+    env = dict(os.environ, BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if one_device:
+        env["BENCH_ONE_DEVICE"] = "1"
+    else:
+        env.pop("BENCH_ONE_DEVICE", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
@@ -40,9 +49,16 @@ def _last_json(stdout):
 
 
 def _two_ranks(script_args):
+    """Two ranks.  With two or more GPUs visible: one rank per GPU over RCCL, and a failure IS a failure (no fallback).
+    On a one-GPU box RCCL refuses two ranks on one device ("Duplicate GPU detected"); only then the same code runs over
+    gloo with both ranks on cuda:0, and the returned backend says so."""
+    if _n_gpus() >= 2:
+        p = _torchrun(script_args, 2, "nccl", one_device=False)
+        assert p.returncode == 0, "RCCL run on %d GPUs failed:\n" % _n_gpus() + p.stdout[-2000:] + p.stderr[-3000:]
+        return _last_json(p.stdout), "nccl"
     p = _torchrun(script_args, 2, "nccl")
     backend = "nccl"
-    if p.returncode != 0:      # two ranks on one GPU: RCCL may refuse ("Duplicate GPU detected")
+    if p.returncode != 0:
         p = _torchrun(script_args, 2, "gloo")
         backend = "gloo"
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
@@ -56,7 +72,22 @@ def test_bench_two_ranks_with_exchange():
     assert line["config"]["sharding"].startswith("frames x2")
     ex = line["exchange"]
     assert ex["frames_total"] == 64 and ex["scatter_packets_ms"] > 0 and ex["gather_xyz_ms"] > 0
-    print("two-rank transport:", backend, ex)
+    if backend == "nccl":
+        assert line["rccl_ranks"] == 2 and "RCCL" in line["collective_backend"], line
+    else:
+        assert line["rccl_ranks"] is None and "RCCL was not used" in line["collective_backend"], line
+    print("two-rank transport:", backend, line["collective_backend"], ex)
+
+
+@pytest.mark.parametrize("workload", ["batch512", "fused4"])
+def test_bench_two_ranks_other_workloads_with_exchange(workload):
+    """configs[3] (a fixed 512-frame batch split over the ranks) and configs[4] (four sensors per tick) through the same
+    two-rank launch + exchange, so that the driver's SCALE run needs no code that has not run before."""
+    line, backend = _two_ranks(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "32", "--workload",
+                                workload, "--no-cpu", "--exchange", "--placement", "first", "--no-loss-paths"])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["exchange"]["gather_xyz_ms"] > 0
+    assert line["scaling"] == ("strong" if workload == "batch512" else "weak")
+    assert (line["rccl_ranks"] == 2) == (backend == "nccl")
 
 
 def test_config4_recorded_frames_same_result_for_1_and_2_ranks():
