@@ -205,7 +205,11 @@ __global__ __launch_bounds__(256) void k_cartesian_tiled(CartesianArgs a) {
     const uint32_t W = a.w, H = a.h;
     const uint32_t tiles = (W + TILE - 1) / TILE;
     const uint32_t tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
-    const uint32_t img = blockIdx.y, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    // full-LUT mode: a workgroup projects its tile for a GROUP of images, so the tile's LUT rows (24 B/px for f32,
+    // 1.5 x everything else the kernel moves) are fetched once per group instead of once per image
+    const uint32_t ipb = a.images_per_block ? a.images_per_block : 1u;
+    const uint32_t img0 = blockIdx.y * ipb, img1 = min(a.n_images, img0 + ipb);
     const uint32_t q = tid % LPR, ty = tid / LPR;
     const uint32_t c0 = tile * TILE, col = c0 + 4 * q;
     const uint32_t r_begin = chunk * a.rows_per_block;
@@ -226,60 +230,7 @@ __global__ __launch_bounds__(256) void k_cartesian_tiled(CartesianArgs a) {
             }
         }
     }
-    for (uint32_t r = r_begin + ty; r < r_end; r += RPP) {
-        const size_t rowpix = (size_t)r * W + col;
-        const size_t rowpix0 = (size_t)r * W + c0;
-        uint32_t rng[4] = {0, 0, 0, 0};
-        if (live) {
-            const uint4 t = *(const uint4*)(a.range + (size_t)img * npix + rowpix);
-            rng[0] = t.x; rng[1] = t.y; rng[2] = t.z; rng[3] = t.w;
-        }
-        double p[4][3];
-        if constexpr (MODE == 1 || MODE == 2) {
-            const double* b = lut.beam_tab + (size_t)r * 9;
-            const double u0 = b[0], u1 = b[1], u2 = b[2], v0 = b[3], v1 = b[4], v2 = b[5],
-                         w0 = b[6], w1 = b[7], w2 = b[8];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const double d0 = fma(cx[c], u0, fma(sx[c], v0, w0));
-                const double d1 = fma(cx[c], u1, fma(sx[c], v1, w1));
-                const double d2 = fma(cx[c], u2, fma(sx[c], v2, w2));
-                const double rm = (double)rng[c] - lut.n;
-                p[c][0] = rng[c] ? fma(rm, d0, kc[c][0]) : 0.0;
-                p[c][1] = rng[c] ? fma(rm, d1, kc[c][1]) : 0.0;
-                p[c][2] = rng[c] ? fma(rm, d2, kc[c][2]) : 0.0;
-            }
-        } else {
-            // the LUT rows are streamed like the output: coalesced row segments, transposed
-            // to "lane owns 4 pixels" through the scratch
-            if (lut.full_dtype == OUSTER_HIP_F32) {
-                union { float4 f4[3]; float t[12]; } d, o;
-                if (full_tile) {
-                    load_quad_coalesced<3, LPR>(sc, (const float4*)((const float*)lut.full_dir + rowpix0 * 3), q, d.f4);
-                    load_quad_coalesced<3, LPR>(sc, (const float4*)((const float*)lut.full_ofs + rowpix0 * 3), q, o.f4);
-                } else if (live) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        d.f4[k] = ((const float4*)((const float*)lut.full_dir + rowpix * 3))[k];
-                        o.f4[k] = ((const float4*)((const float*)lut.full_ofs + rowpix * 3))[k];
-                    }
-                }
-                project_full4<float>(d.t, o.t, rng, p);
-            } else {
-                union { float4 f4[6]; double t[12]; } d, o;
-                if (full_tile) {
-                    load_quad_coalesced<6, LPR>(sc, (const float4*)((const double*)lut.full_dir + rowpix0 * 3), q, d.f4);
-                    load_quad_coalesced<6, LPR>(sc, (const float4*)((const double*)lut.full_ofs + rowpix0 * 3), q, o.f4);
-                } else if (live) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        d.f4[k] = ((const float4*)((const double*)lut.full_dir + rowpix * 3))[k];
-                        o.f4[k] = ((const float4*)((const double*)lut.full_ofs + rowpix * 3))[k];
-                    }
-                }
-                project_full4<double>(d.t, o.t, rng, p);
-            }
-        }
+    auto store = [&](uint32_t img, size_t rowpix, const double (&p)[4][3]) {
         if (a.xyz_dtype == OUSTER_HIP_F32) {
             float* dst = (float*)a.xyz + ((size_t)img * npix + rowpix) * 3;
             if (full_tile) {
@@ -300,6 +251,92 @@ __global__ __launch_bounds__(256) void k_cartesian_tiled(CartesianArgs a) {
                     for (int k = 0; k < 3; ++k) o.t[3 * c + k] = p[c][k];
                 store_quad_coalesced<6, LPR>(sc, (float4*)(dst - (size_t)(4 * q) * 3), q, o.f4);
             } else if (live) store_xyz4<double>(dst, p);
+        }
+    };
+    auto load_range = [&](uint32_t img, size_t rowpix, uint32_t (&rng)[4]) {
+        rng[0] = rng[1] = rng[2] = rng[3] = 0;
+        if (live) {
+            const uint4 t = *(const uint4*)(a.range + (size_t)img * npix + rowpix);
+            rng[0] = t.x; rng[1] = t.y; rng[2] = t.z; rng[3] = t.w;
+        }
+    };
+    for (uint32_t r = r_begin + ty; r < r_end; r += RPP) {
+        const size_t rowpix = (size_t)r * W + col;
+        const size_t rowpix0 = (size_t)r * W + c0;
+        // the images of the group, four at a time: the next four range quads are in flight while these four are
+        // projected and stored (one load per iteration left the full-LUT kernel latency bound: 53 % of the roofline)
+        auto project_group = [&](auto&& project) {
+            constexpr int B = 4;
+            uint32_t cur[B][4], nxt[B][4];
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (img0 + k < img1) load_range(img0 + k, rowpix, cur[k]);
+            for (uint32_t img = img0; img < img1; img += B) {
+#pragma unroll
+                for (int k = 0; k < B; ++k)
+                    if (img + B + k < img1) load_range(img + B + k, rowpix, nxt[k]);
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    if (img + k >= img1) break;
+                    double p[4][3];
+                    project(cur[k], p);
+                    store(img + k, rowpix, p);
+                }
+#pragma unroll
+                for (int k = 0; k < B; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) cur[k][c] = nxt[k][c];
+            }
+        };
+        if constexpr (MODE == 1 || MODE == 2) {
+            const double* b = lut.beam_tab + (size_t)r * 9;
+            const double u0 = b[0], u1 = b[1], u2 = b[2], v0 = b[3], v1 = b[4], v2 = b[5],
+                         w0 = b[6], w1 = b[7], w2 = b[8];
+            double dd[4][3];   // the row's directions for my four columns: the same for every image of the group
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                dd[c][0] = fma(cx[c], u0, fma(sx[c], v0, w0));
+                dd[c][1] = fma(cx[c], u1, fma(sx[c], v1, w1));
+                dd[c][2] = fma(cx[c], u2, fma(sx[c], v2, w2));
+            }
+            project_group([&](const uint32_t (&rng)[4], double (&p)[4][3]) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double rm = (double)rng[c] - lut.n;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) p[c][k] = rng[c] ? fma(rm, dd[c][k], kc[c][k]) : 0.0;
+                }
+            });
+        } else {
+            // the LUT rows are streamed like the output: coalesced row segments, transposed to "lane owns 4 pixels"
+            // through the scratch -- once, then every image of the group is projected from registers
+            if (lut.full_dtype == OUSTER_HIP_F32) {
+                union { float4 f4[3]; float t[12]; } d, o;
+                if (full_tile) {
+                    load_quad_coalesced<3, LPR>(sc, (const float4*)((const float*)lut.full_dir + rowpix0 * 3), q, d.f4);
+                    load_quad_coalesced<3, LPR>(sc, (const float4*)((const float*)lut.full_ofs + rowpix0 * 3), q, o.f4);
+                } else if (live) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        d.f4[k] = ((const float4*)((const float*)lut.full_dir + rowpix * 3))[k];
+                        o.f4[k] = ((const float4*)((const float*)lut.full_ofs + rowpix * 3))[k];
+                    }
+                }
+                project_group([&](const uint32_t (&rng)[4], double (&p)[4][3]) { project_full4<float>(d.t, o.t, rng, p); });
+            } else {
+                union { float4 f4[6]; double t[12]; } d, o;
+                if (full_tile) {
+                    load_quad_coalesced<6, LPR>(sc, (const float4*)((const double*)lut.full_dir + rowpix0 * 3), q, d.f4);
+                    load_quad_coalesced<6, LPR>(sc, (const float4*)((const double*)lut.full_ofs + rowpix0 * 3), q, o.f4);
+                } else if (live) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        d.f4[k] = ((const float4*)((const double*)lut.full_dir + rowpix * 3))[k];
+                        o.f4[k] = ((const float4*)((const double*)lut.full_ofs + rowpix * 3))[k];
+                    }
+                }
+                project_group([&](const uint32_t (&rng)[4], double (&p)[4][3]) { project_full4<double>(d.t, o.t, rng, p); });
+            }
         }
     }
 }
@@ -1073,7 +1110,15 @@ hipError_t launch_cartesian(const CartesianArgs& a_in, int mode, hipStream_t st)
         while (rpb > 16 && (size_t)tiles * a.n_images * ((a.h + rpb - 1) / rpb) < 1024) rpb = (rpb + 1) / 2;
         rpb = (rpb + 15) / 16 * 16;
         a.rows_per_block = rpb;
-        dim3 grid(tiles * ((a.h + rpb - 1) / rpb), a.n_images);
+        // as many images per workgroup as leave >= 2048 workgroups (16 at most): a full LUT's rows / the separable
+        // directions of a row are fetched / computed once per group, and the group's range quads are fetched four deep
+        uint32_t ipb = 1;
+        {
+            const size_t per_image = (size_t)tiles * ((a.h + rpb - 1) / rpb);
+            while (ipb < 16 && ipb * 2 <= a.n_images && per_image * ((a.n_images + ipb * 2 - 1) / (ipb * 2)) >= 2048) ipb *= 2;
+        }
+        a.images_per_block = ipb;
+        dim3 grid(tiles * ((a.h + rpb - 1) / rpb), (a.n_images + ipb - 1) / ipb);
         if (tw == 256) {
             switch (mode) {
                 case 1: hipLaunchKernelGGL((k_cartesian_tiled<1, 256>), grid, dim3(256), 0, st, a); break;

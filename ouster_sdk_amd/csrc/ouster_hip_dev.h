@@ -129,6 +129,7 @@ struct CartesianArgs {
     int32_t xyz_dtype;
     uint32_t vec_ok;
     uint32_t rows_per_block;  // tiled kernels: rows of a 64-column tile handled by one workgroup
+    uint32_t images_per_block;  // full-LUT mode: images that share one fetch of a tile's LUT rows (blockIdx.y = image group)
 };
 
 struct DewarpArgs {
