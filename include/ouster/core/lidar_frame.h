@@ -207,6 +207,10 @@ class LidarFrame {
                size_t columns_per_packet = DEFAULT_COLUMNS_PER_PACKET);
     LidarFrame(size_t h, size_t w, UDPProfileLidar profile,
                size_t columns_per_packet = DEFAULT_COLUMNS_PER_PACKET);
+    /** A frame like `other` with only the indicated fields: copied where the type matches, cast where only the element
+     *  type differs, zero where `other` has no such field (lidar_frame.h:297-308, lidar_frame.cpp:361-401).
+     *  @throw std::invalid_argument if a field's dimensions are incompatible */
+    LidarFrame(const LidarFrame& other, const LidarFrameFieldTypes& fields);
 
     /** @throw std::out_of_range if the field does not exist (lidar_frame.cpp:422-436). */
     Field& field(const std::string& name);
@@ -223,6 +227,8 @@ class LidarFrame {
     std::map<std::string, Field>& fields() { return fields_; }
     const std::map<std::string, Field>& fields() const { return fields_; }
     LidarFrameFieldTypes field_types() const;
+    /** Type of one field (lidar_frame.h:476-484).  @throw std::out_of_range if the field does not exist */
+    FieldType field_type(const std::string& name) const;
 
     HeaderRef<uint64_t> timestamp() { return {timestamp_.get<uint64_t>(), w}; }
     HeaderRef<const uint64_t> timestamp() const { return {timestamp_.get<uint64_t>(), w}; }
@@ -239,6 +245,12 @@ class LidarFrame {
     /** per-column 4x4 poses, identity initialised (lidar_frame.cpp:353-358) */
     Field& body_to_world() { return body_to_world_; }
     const Field& body_to_world() const { return body_to_world_; }
+    /** deprecated spelling of body_to_world() (lidar_frame.h:740-753) */
+    [[deprecated("LidarFrame::body_to_world()")]] Field& pose() { return body_to_world_; }
+    [[deprecated("LidarFrame::body_to_world()")]] const Field& pose() const { return body_to_world_; }
+    /** One column's 4x4 pose (lidar_frame.h:755-773).  @throw std::out_of_range if index is out of bounds */
+    void set_column_pose(int index, const mat4d& pose);
+    mat4d get_column_pose(int index) const;
     size_t packet_count() const { return packet_count_; }
 
     ThermalShutdownStatus thermal_shutdown() const {
@@ -249,6 +261,9 @@ class LidarFrame {
     }
     /** true when every column in `window` has status bit 0 set */
     bool complete(ColumnWindow window) const;
+    /** ... in the column window of the frame's SensorInfo (lidar_frame.h:783-791).
+     *  @throw std::runtime_error if the frame has no sensor_info */
+    bool complete() const;
     /** first / last column with status bit 0 set (lidar_frame.cpp:907-925).
      *  @throw std::runtime_error("No valid columns in LidarFrame") */
     int get_first_valid_column() const;

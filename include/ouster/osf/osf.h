@@ -79,6 +79,19 @@ struct LidarScanMsgView {
     uint64_t frame_status = 0;
     uint8_t shutdown_countdown = 0, shot_limiting_countdown = 0;
     std::vector<EncodedField> fields;
+    /** LidarScanMsg.custom_fields (every field whose name is not in the CHAN_FIELD enum: WINDOW, ZONE_MASK, user-added
+     *  pixel / column / packet / frame fields; stream_lidar_frame.cpp:100-127 writes them, fb_restore_fields :322 reads
+     *  them back): name, element type, full shape, class and the encoded bytes (1-D: raw; otherwise PNG / ZPNG of the
+     *  field collapsed to rows x (size / rows), never staggered). */
+    struct CustomField {
+        std::string name;
+        core::ChanFieldType type = core::ChanFieldType::VOID;
+        std::vector<size_t> shape;
+        core::FieldClass field_class = core::FieldClass::NONE;
+        const uint8_t* data = nullptr;
+        size_t size = 0;
+    };
+    std::vector<CustomField> custom_fields;
     const uint64_t* timestamp = nullptr;      size_t n_timestamp = 0;
     const uint16_t* measurement_id = nullptr; size_t n_measurement_id = 0;
     const uint32_t* status = nullptr;         size_t n_status = 0;

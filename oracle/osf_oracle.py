@@ -109,6 +109,9 @@ CHAN_FIELD = {1: "RANGE", 2: "RANGE2", 3: "SIGNAL", 4: "SIGNAL2", 5: "REFLECTIVI
               47: "RAW32_WORD7", 48: "RAW32_WORD8", 49: "RAW32_WORD9", 60: "RAW32_WORD1", 61: "RAW32_WORD2",
               62: "RAW32_WORD3", 63: "RAW32_WORD4", **{50 + i: f"CUSTOM{i}" for i in range(10)}}
 FIELD_DTYPE = {1: np.uint8, 2: np.uint16, 3: np.uint32, 4: np.uint64}
+# CHAN_FIELD_TYPE of os_sensor/common.fbs:4-19, as far as custom fields can carry them (encoded through uint views of the same size)
+CUSTOM_DTYPE = {1: np.uint8, 2: np.uint16, 3: np.uint32, 4: np.uint64, 5: np.int8, 6: np.int16, 7: np.int32, 8: np.int64,
+                9: np.float32, 10: np.float64}
 
 
 class OsfFile:
@@ -301,4 +304,28 @@ def decode_lidar_scan_msg(msg: bytes, h: int, w: int, px_offset) -> dict:
         name = CHAN_FIELD.get(int(ft["field"]), f"UNKNOWN{int(ft['field'])}")
         out["fields"][name] = decode_field(bytes(data) if data is not None else b"", FIELD_DTYPE[int(ft["type"])],
                                            h, w, px_offset)
+    # custom_fields (fb_restore_fields, ouster_osf/src/fb_common.cpp:250-330; table Field of os_sensor/common.fbs:31-38):
+    # name, tag, shape, class, data.  decode_field without pixel offsets (png_tools.cpp:667-706): a 1-D field is raw
+    # bytes, anything else is an image of shape[0] x (size / shape[0]) -- ZPNG or PNG -- that is NOT staggered.
+    out["custom_fields"] = {}
+    for cf in t.table_vector(8):
+        name = cf.string(0)
+        tag = cf.scalar(1, "B")
+        shape = [int(x) for x in (cf.vector(2, "<u8") if cf.vector(2, "<u8") is not None else [])]
+        data = cf.vector(4, np.uint8)
+        data = bytes(data) if data is not None else b""
+        if tag not in CUSTOM_DTYPE or not shape:
+            continue
+        dt = np.dtype(CUSTOM_DTYPE[tag])
+        if len(shape) == 1:
+            arr = np.zeros(shape[0], dt)
+            raw = np.frombuffer(data, np.uint8)
+            arr.view(np.uint8)[:len(raw)] = raw[:arr.nbytes]
+        else:
+            rows = shape[0]
+            cols = int(np.prod(shape)) // rows if rows else 0
+            udt = np.dtype("<u%d" % dt.itemsize)
+            arr = (decode_field(data, udt, rows, cols, []) if data and rows * cols else np.zeros((rows, cols), udt))
+            arr = arr.view(dt).reshape(shape)
+        out["custom_fields"][name] = {"array": arr, "field_class": int(cf.scalar(3, "q"))}
     return out

@@ -203,6 +203,79 @@ LidarFrameFieldTypes LidarFrame::field_types() const {
     return out;
 }
 
+FieldType LidarFrame::field_type(const std::string& name) const {
+    for (const auto& ft : field_types())
+        if (ft.name == name) return ft;
+    throw std::out_of_range("Field '" + name + "' not found in LidarFrame");
+}
+
+namespace {
+// element-wise static_cast between two fields of the same shape (the reference's impl::copy_and_cast)
+template <typename D>
+void cast_into(D* dst, const Field& src) {
+    const size_t n = src.size();
+    switch (src.tag()) {
+#define OUSTER_CAST_CASE(TAG, S) \
+        case ChanFieldType::TAG: { const S* p = static_cast<const S*>(src.get()); for (size_t i = 0; i < n; ++i) dst[i] = static_cast<D>(p[i]); break; }
+        OUSTER_CAST_CASE(UINT8, uint8_t) OUSTER_CAST_CASE(UINT16, uint16_t) OUSTER_CAST_CASE(UINT32, uint32_t)
+        OUSTER_CAST_CASE(UINT64, uint64_t) OUSTER_CAST_CASE(INT8, int8_t) OUSTER_CAST_CASE(INT16, int16_t)
+        OUSTER_CAST_CASE(INT32, int32_t) OUSTER_CAST_CASE(INT64, int64_t) OUSTER_CAST_CASE(FLOAT32, float)
+        OUSTER_CAST_CASE(FLOAT64, double)
+#undef OUSTER_CAST_CASE
+        default: throw std::invalid_argument("LidarFrame: cannot cast a field of element type " + to_string(src.tag()));
+    }
+}
+void copy_and_cast(Field& dst, const Field& src) {
+    switch (dst.tag()) {
+        case ChanFieldType::UINT8: cast_into(static_cast<uint8_t*>(dst.get()), src); break;
+        case ChanFieldType::UINT16: cast_into(static_cast<uint16_t*>(dst.get()), src); break;
+        case ChanFieldType::UINT32: cast_into(static_cast<uint32_t*>(dst.get()), src); break;
+        case ChanFieldType::UINT64: cast_into(static_cast<uint64_t*>(dst.get()), src); break;
+        case ChanFieldType::INT8: cast_into(static_cast<int8_t*>(dst.get()), src); break;
+        case ChanFieldType::INT16: cast_into(static_cast<int16_t*>(dst.get()), src); break;
+        case ChanFieldType::INT32: cast_into(static_cast<int32_t*>(dst.get()), src); break;
+        case ChanFieldType::INT64: cast_into(static_cast<int64_t*>(dst.get()), src); break;
+        case ChanFieldType::FLOAT32: cast_into(static_cast<float*>(dst.get()), src); break;
+        case ChanFieldType::FLOAT64: cast_into(static_cast<double*>(dst.get()), src); break;
+        default: throw std::invalid_argument("LidarFrame: cannot cast to element type " + to_string(dst.tag()));
+    }
+}
+}  // namespace
+
+// lidar_frame.cpp:361-401
+LidarFrame::LidarFrame(const LidarFrame& other, const LidarFrameFieldTypes& fields)
+    : w(other.w), h(other.h), frame_id(other.frame_id), frame_status(other.frame_status),
+      shutdown_countdown(other.shutdown_countdown), shot_limiting_countdown(other.shot_limiting_countdown),
+      sensor_info(other.sensor_info), timestamp_(other.timestamp_), measurement_id_(other.measurement_id_),
+      status_(other.status_), packet_timestamp_(other.packet_timestamp_), body_to_world_(other.body_to_world_),
+      alert_flags_(other.alert_flags_), packet_count_(other.packet_count_) {
+    for (const auto& ft : fields) {
+        Field& dst = add_field(ft);
+        if (!other.has_field(ft.name)) continue;             // zero padded
+        const Field& src = other.field(ft.name);
+        if (src.shape() != dst.shape())
+            throw std::invalid_argument("Field '" + ft.name +
+                                        "' from source frame has dimensions that don't match desired.");
+        if (src.tag() == dst.tag()) std::memcpy(dst.get(), src.get(), src.bytes());
+        else copy_and_cast(dst, src);
+    }
+}
+
+void LidarFrame::set_column_pose(int index, const mat4d& pose) {
+    if (index < 0 || static_cast<size_t>(index) >= w) throw std::out_of_range("LidarFrame: column index out of bounds");
+    std::memcpy(body_to_world_.get<double>() + static_cast<size_t>(index) * 16, pose.data(), 16 * sizeof(double));
+}
+mat4d LidarFrame::get_column_pose(int index) const {
+    if (index < 0 || static_cast<size_t>(index) >= w) throw std::out_of_range("LidarFrame: column index out of bounds");
+    return mat4d::FromRowMajor(body_to_world_.get<double>() + static_cast<size_t>(index) * 16);
+}
+
+bool LidarFrame::complete() const {
+    if (!sensor_info)
+        throw std::runtime_error("LidarFrame must have a valid SensorInfo in order to compute completeness");
+    return complete(sensor_info->format.column_window);
+}
+
 bool LidarFrame::complete(ColumnWindow window) const {
     const uint32_t* st = status_.get<uint32_t>();
     auto valid = [&](int a, int b) {

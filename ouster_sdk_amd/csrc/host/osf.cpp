@@ -261,6 +261,21 @@ LidarScanMsgView LidarScanMsgView::parse(const OsfFile::Message& msg) {
         f.size = nb;
         v.fields.push_back(std::move(f));
     }
+    for (const Table& cf : t.tables(8)) {   // custom_fields: table Field {name, tag, shape, field_class, data, bytes}
+        LidarScanMsgView::CustomField c;
+        c.name = cf.string(0);
+        c.type = static_cast<ChanFieldType>(cf.scalar<uint8_t>(1, 0));
+        size_t nd = 0;
+        const Span sh = cf.vector(2, 8, &nd);
+        for (size_t i = 0; i < nd; ++i) c.shape.push_back(static_cast<size_t>(rd<uint64_t>(sh, i * 8)));
+        const int64_t cls = cf.scalar<int64_t>(3, 0);
+        c.field_class = cls >= 0 && cls <= 4 ? static_cast<FieldClass>(cls) : FieldClass::NONE;
+        size_t nb = 0;
+        const Span d = cf.vector(4, 1, &nb);
+        c.data = d.p;
+        c.size = nb;
+        v.custom_fields.push_back(std::move(c));
+    }
     size_t n = 0;
     v.timestamp = reinterpret_cast<const uint64_t*>(t.vector(2, 8, &n).p); v.n_timestamp = n;
     v.measurement_id = reinterpret_cast<const uint16_t*>(t.vector(3, 2, &n).p); v.n_measurement_id = n;
@@ -440,7 +455,9 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
     const size_t h = s.info.format.pixels_per_column, w = s.info.format.columns_per_frame;
     std::vector<LidarFrame> frames;
     struct Job { size_t frame; std::string name; size_t esz; StagedField st; size_t src_off, dst_off; };
+    struct CustomJob { size_t frame; std::string name; size_t esz, rows, cols; EncodedField enc; };
     std::vector<Job> jobs;
+    std::vector<CustomJob> custom;
     std::vector<EncodedField> encoded;   // parallel to jobs
     size_t src_total = 0, dst_total = 0;
     auto al = [](size_t x) { return (x + 255) & ~size_t{255}; };
@@ -479,7 +496,82 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
             encoded.push_back(f);
             jobs.push_back(std::move(j));
         }
+        // custom fields (fb_restore_fields, fb_common.cpp:250-330): added with their own shape and class; 1-D fields are
+        // raw bytes, everything else is an image of rows x (size / rows) that was never destaggered
+        for (const auto& c : v.custom_fields) {
+            const size_t esz = field_type_size(c.type);
+            if (esz == 0 || c.shape.empty()) continue;   // unsupported element type (a newer writer): skipped like the reference
+            size_t lead = 0;
+            switch (c.field_class) {
+                case FieldClass::PIXEL_FIELD: lead = 2; break;
+                case FieldClass::COLUMN_FIELD:
+                case FieldClass::PACKET_FIELD: lead = 1; break;
+                default: break;
+            }
+            if (c.shape.size() < lead) throw std::runtime_error("OSF: custom field '" + c.name + "' has too few dimensions for its class");
+            Field& dst = fr.add_field(FieldType(c.name, c.type, std::vector<size_t>(c.shape.begin() + lead, c.shape.end()), c.field_class));
+            if (dst.shape() != c.shape)
+                throw std::runtime_error("OSF: custom field '" + c.name + "' does not have the frame's dimensions");
+            if (c.shape.size() == 1) {
+                if (c.size > dst.bytes()) throw std::runtime_error("OSF: custom field '" + c.name + "' holds more bytes than its shape");
+                std::memcpy(dst.get(), c.data, c.size);
+                continue;
+            }
+            if (dst.bytes() == 0 || c.size == 0) continue;
+            CustomJob cj;
+            cj.frame = frames.size();
+            cj.name = c.name;
+            cj.esz = esz;
+            cj.rows = c.shape[0];
+            cj.cols = dst.size() / c.shape[0];
+            cj.enc.name = c.name;
+            cj.enc.type = c.type;
+            cj.enc.data = c.data;
+            cj.enc.size = c.size;
+            custom.push_back(std::move(cj));
+        }
         frames.push_back(std::move(fr));
+    }
+    if (!custom.empty()) {
+        // one no-stagger unpack launch per distinct image shape (custom fields are few; shapes rarely differ)
+        hip::ScopedContext on_my_context(s.context());
+        std::vector<bool> done(custom.size(), false);
+        for (size_t i0 = 0; i0 < custom.size(); ++i0) {
+            if (done[i0]) continue;
+            std::vector<size_t> grp;
+            for (size_t i = i0; i < custom.size(); ++i)
+                if (!done[i] && custom[i].rows == custom[i0].rows && custom[i].cols == custom[i0].cols) { grp.push_back(i); done[i] = true; }
+            const size_t rows = custom[i0].rows, cols = custom[i0].cols;
+            std::vector<StagedField> st(grp.size());
+            std::vector<size_t> so(grp.size()), dof(grp.size());
+            size_t stot = 0, dtot = 0;
+            for (size_t k = 0; k < grp.size(); ++k) {
+                st[k] = stage_field(custom[grp[k]].enc, rows, cols);
+                so[k] = stot; dof[k] = dtot;
+                stot += al(st[k].bytes.size());
+                dtot += al(rows * cols * custom[grp[k]].esz);
+            }
+            hip::DeviceBuffer dsrc(stot), ddst(dtot);
+            std::vector<uint8_t> stage(stot);
+            std::vector<ouster_hip_osf_plane> pl(grp.size());
+            for (size_t k = 0; k < grp.size(); ++k) {
+                std::memcpy(stage.data() + so[k], st[k].bytes.data(), st[k].bytes.size());
+                pl[k].src = static_cast<const uint8_t*>(dsrc.data()) + so[k];
+                pl[k].dst = static_cast<uint8_t*>(ddst.data()) + dof[k];
+                pl[k].encoding = st[k].encoding;
+                pl[k].src_pixel_bytes = st[k].src_pixel_bytes;
+                pl[k].dst_elem_size = static_cast<uint32_t>(custom[grp[k]].esz);
+                pl[k].reserved = 0;
+            }
+            dsrc.upload(stage.data(), stot);
+            hip::check(ouster_hip_osf_unpack(s.ctx->handle(), pl.data(), static_cast<uint32_t>(pl.size()),
+                                             static_cast<uint32_t>(rows), static_cast<uint32_t>(cols), nullptr));
+            std::vector<uint8_t> back(dtot);
+            ddst.download(back.data(), dtot);
+            for (size_t k = 0; k < grp.size(); ++k)
+                std::memcpy(frames[custom[grp[k]].frame].field(custom[grp[k]].name).get(), back.data() + dof[k],
+                            rows * cols * custom[grp[k]].esz);
+        }
     }
     if (jobs.empty()) return frames;
     {

@@ -142,7 +142,7 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
                         a.g.alert_flags.mask, a.g.alert_flags.shift);
             }
         }
-        if (tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_of(a.g, fbase, count > 0);
+        if (tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_first_present(a.g, fbase, a.packet_stride, count);
     } else {
         // general mapping: scan every received column header of the frame, keep the last slot per
         // destination column of my tile; tile 0 also resolves the packet-level outputs and counts
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             if (i < nrows * 9) s_beam[i] = r_beam[k];
         }
     }
-    if (rc == 0 && tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_of(a.g, fbase, count > 0);
+    if (rc == 0 && tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_first_present(a.g, fbase, a.packet_stride, count);
 
     PHASE_STAMP(2);
     // ---- classify my columns (every row chunk needs the validity; the first one also publishes)

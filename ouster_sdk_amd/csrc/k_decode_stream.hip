@@ -218,7 +218,8 @@ __global__ __launch_bounds__(512) void k_decode_stream(DecodeArgs a, StreamArgs 
             const uint32_t f = xcd + 8u * m;
             uint32_t count = a.slots_per_frame;
             if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
-            a.frame_meta[f] = frame_meta_of(a.g, a.packets + (size_t)f * a.slots_per_frame * a.packet_stride, count > 0);
+            a.frame_meta[f] = frame_meta_first_present(a.g, a.packets + (size_t)f * a.slots_per_frame * a.packet_stride,
+                                                       a.packet_stride, count);
         }
     }
 
@@ -380,7 +381,8 @@ __global__ __launch_bounds__(768) void k_decode_stream2(DecodeArgs a, StreamArgs
             const uint32_t f = xcd + 8u * m;
             uint32_t count = a.slots_per_frame;
             if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
-            a.frame_meta[f] = frame_meta_of(a.g, a.packets + (size_t)f * a.slots_per_frame * a.packet_stride, count > 0);
+            a.frame_meta[f] = frame_meta_first_present(a.g, a.packets + (size_t)f * a.slots_per_frame * a.packet_stride,
+                                                       a.packet_stride, count);
         }
     }
     const uint64_t tag = a.frame_state[FS_SEQ] + 1;

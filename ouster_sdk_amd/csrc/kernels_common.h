@@ -538,6 +538,23 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_of(const Geometry& g
     return m;
 }
 
+// The optimistic pass works on home slots: a lost packet is a zeroed slot, and slot 0 may be one.  The reference latches
+// the frame-level values from the first packet it RECEIVES (start_frame, lidar_frame.cpp:1709-1741), so they come from the
+// first slot that holds a packet -- anything non-zero in its first 16 bytes (packet header, or a LEGACY column header) or
+// in its first column's status word.  Slot 0 almost always does; the scan behind it only runs when it does not.
+__device__ __forceinline__ ouster_hip_frame_meta frame_meta_first_present(const Geometry& g, const uint8_t* fbase,
+                                                                          size_t packet_stride, uint32_t count) {
+    for (uint32_t p = 0; p < count; ++p) {
+        const uint8_t* pkt = fbase + (size_t)p * packet_stride;
+        const uint32_t* q = (const uint32_t*)pkt;
+        uint32_t any = q[0] | q[1] | q[2] | q[3];
+        any |= (uint32_t)window_global_masked(pkt + g.packet_header_size + g.col_status.offset, g.col_status.mask) |
+               (uint32_t)(window_global_masked(pkt + g.packet_header_size + g.col_status.offset, g.col_status.mask) >> 32);
+        if (any) return frame_meta_of(g, pkt, true);
+    }
+    return frame_meta_of(g, fbase, false);
+}
+
 // The per-column poses of a tile, cast to the xyz element type, in LDS (12 values per column); all threads of the
 // workgroup call it, a barrier follows.  Returns the table or nullptr when no poses were given.
 // POSES is a template parameter of the kernels: the pose arithmetic keeps 48 more registers alive, and a kernel that

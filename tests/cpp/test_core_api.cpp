@@ -269,6 +269,34 @@ static void test_lidar_frame_container() {
     LidarFrame g = f;  // deep copy
     g.field<uint32_t>("RANGE")(3, 4) = 7;
     CHECK(f.field<uint32_t>("RANGE")(3, 4) == 0 && !(f == g));
+    {   // lidar_frame.h:297-308, 476-484, 740-791: subset / cast copy, field_type, column poses, complete()
+        g.field<uint8_t>("REFLECTIVITY")(1, 2) = 200;
+        g.frame_id = 77;
+        g.status()[5] = 1;
+        LidarFrameFieldTypes want = {{"RANGE", ChanFieldType::UINT64}, {"REFLECTIVITY", ChanFieldType::UINT8},
+                                     {"NEW_PLANE", ChanFieldType::FLOAT32}};
+        LidarFrame sub(g, want);
+        CHECK(sub.fields().size() == 3 && sub.frame_id == 77 && sub.status()[5] == 1 && sub.w == g.w && sub.h == g.h);
+        CHECK(sub.field("RANGE").tag() == ChanFieldType::UINT64 && sub.field<uint64_t>("RANGE")(3, 4) == 7);   // cast
+        CHECK(sub.field<uint8_t>("REFLECTIVITY")(1, 2) == 200);                                                // copied
+        CHECK(sub.field("NEW_PLANE").bytes() == 128 * 1024 * 4 && sub.field<float>("NEW_PLANE")(0, 0) == 0.0f);  // zero
+        CHECK(throws_with<std::invalid_argument>(
+            [&] { LidarFrame bad(g, {{"RANGE", ChanFieldType::UINT32, {3}}}); }, "dimensions that don't match"));
+        CHECK(g.field_type("RANGE") == FieldType("RANGE", ChanFieldType::UINT32));
+        CHECK(throws_with<std::out_of_range>([&] { g.field_type("NOPE"); }, "NOPE"));
+        mat4d m = mat4d::Identity();
+        m(0, 3) = 1.5; m(1, 0) = -2.0;
+        g.set_column_pose(9, m);
+        CHECK(g.get_column_pose(9)(0, 3) == 1.5 && g.get_column_pose(9)(1, 0) == -2.0 && g.get_column_pose(8)(0, 3) == 0.0);
+        CHECK(g.body_to_world().get<double>()[9 * 16 + 3] == 1.5);
+        CHECK(throws_with<std::out_of_range>([&] { g.set_column_pose(1024, m); }, "out of bounds"));
+        CHECK(throws_with<std::out_of_range>([&] { g.get_column_pose(-1); }, "out of bounds"));
+        CHECK(!g.complete());                      // the frame of a SensorInfo knows its column window
+        for (size_t i = 0; i < g.w; ++i) g.status()[i] = 1;
+        CHECK(g.complete());
+        LidarFrame bare(8, 16, UDPProfileLidar::LEGACY);
+        CHECK(throws_with<std::runtime_error>([&] { bare.complete(); }, "valid SensorInfo"));
+    }
 }
 
 // frame -> packets -> FrameBatcher -> frame identity (packet_format_test.cpp:218-326)

@@ -29,7 +29,8 @@ CAPTURES = [
 
 # OSF fixtures of the reference (tests/osfs/): PNG-encoded (16-bit gray, RGBA), PNG with 8-bit planes,
 # ZPNG-encoded dual-return
-OSFS = ["OS-1-128_v2.3.0_1024x10_lb_n3.osf", "OS-0-128_v3.0.1_1024x10_20241017_141645.osf", "single_scan_016.osf"]
+OSFS = ["OS-1-128_v2.3.0_1024x10_lb_n3.osf", "OS-0-128_v3.0.1_1024x10_20241017_141645.osf", "single_scan_016.osf",
+        "pose_delta_1_128.osf"]   # the last one: dual return 128 x 2048 with 1-D custom fields (IMU_*, POSITION_TIMESTAMP)
 
 
 def osf_goldens():

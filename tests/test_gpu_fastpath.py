@@ -86,6 +86,8 @@ def _compare(O, cal, hp, out, ref_frames, dst_names, xyz_names, use_extrinsics=F
             worst = max(worst, float(err))
             assert err <= 1e-4, (f, n, err)
         meta = _np(out["frame_meta"][f])
+        if (fr.status & 1).any():   # frame-level values come from the first packet RECEIVED, even when slot 0 is a hole
+            assert meta[:8].view(np.int64)[0] == fr.frame_id, ("frame_id", f, meta[:8].view(np.int64)[0], fr.frame_id)
         if not check_nvalid:     # published by the fix-up pass
             continue
         assert meta[20:24].view(np.uint32)[0] == int((fr.status & 1).sum()), ("n_valid_columns", f)

@@ -2,7 +2,7 @@
 /root/reference/python/tests/test_xyzlut.py and test_destagger.py -- staged verbatim by oracle/Makefile into the
 git-ignored oracle/_ref/pytests where the reference checkout exists (it travels to the GPU box with the snapshot) -- are
 collected by a child pytest whose `ouster.sdk.core` is tests/ref_shim (= ouster_sdk_amd.core + the JSON metadata reader
-ouster_sdk_amd/metadata.py) and whose fixtures (tests/ref_shim/conftest.py) mirror the reference's conftest.  Every
+ouster_sdk_amd/metadata.py) and whose fixtures (tests/ref_shim/conftest_for_reference_tests.py) mirror the reference's conftest.  Every
 collected test must pass; the counts are printed."""
 import os
 import re
@@ -26,7 +26,7 @@ SHIM = os.path.join(ROOT, "tests", "ref_shim")
 def test_reference_xyzlut_and_destagger_tests_pass_unmodified(tmp_path):
     for name in ("test_xyzlut.py", "test_destagger.py"):
         shutil.copy(os.path.join(STAGED, name), tmp_path / name)          # byte-identical copies
-    shutil.copy(os.path.join(SHIM, "conftest.py"), tmp_path / "conftest.py")
+    shutil.copy(os.path.join(SHIM, "conftest_for_reference_tests.py"), tmp_path / "conftest.py")
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([SHIM, ROOT, env.get("PYTHONPATH", "")])
     env["OUSTER_REF_PCAPS"] = PCAPS
