@@ -17,9 +17,9 @@ restatement of the reference loops, timed on this box's host cores, rank 0 at N=
 Setup before the W warm-up steps (none of it inside the timed region, all of it reported in the JSON line):
   * the library's kernel-variant tuner settles (first 16 calls of a workload shape);
   * buffer placement, `--placement refine` (default): what ouster::sdk::hip::DeviceFrameBatch does by itself when it is
-    constructed -- the output buffers are re-drawn group by group (XYZ pair, 32-bit planes, destaggered planes, narrow
-    planes; 3 fresh allocations each, no ballast, ~0.15 s) and the fastest combination is kept; "placement" reports the
-    first allocation's time next to the kept one.  `--placement first` takes the first allocation as it comes;
+    constructed -- three further copies of the output set are allocated 8 GB apart and every buffer group (XYZ pair,
+    32-bit planes, destaggered planes, narrow planes) is kept at the fastest of its four locations (~35 GB transient,
+    under a second); "placement" reports the first allocation's time next to the kept one.  `--placement first` takes the first allocation as it comes;
     `--placement draws` is the round-2 diagnostic (whole output sets drawn across the device memory, DESIGN.md 3.2c);
   * after the K timed steps the outputs are compared with the oracle ("validated", "max_abs_dxyz_m").
 The timed steps rotate over `--rotate-inputs` copies of the packet batch (default 2: no step finds its input in the
@@ -307,6 +307,9 @@ def main():
     ap.add_argument("--placement", default="refine", choices=["first", "refine", "draws"],
                     help="first: buffers as allocated; refine: buffer groups re-drawn (3 draws each, what DeviceFrameBatch "
                          "does at construction); draws: diagnostic, whole output sets drawn across the device memory")
+    ap.add_argument("--placement-draws", type=int, default=4, help="--placement refine: locations tried per buffer group")
+    ap.add_argument("--placement-ballast-gb", type=float, default=8.0,
+                    help="--placement refine: device memory held between two locations (0: back-to-back draws)")
     ap.add_argument("--placement-stride-gb", type=float, default=4.0,
                     help="--placement draws: ballast held between two draws (they scan the device memory)")
     ap.add_argument("--placement-tries", type=int, default=24,
@@ -409,7 +412,7 @@ def main():
         placement["mode"] = "draws"
     elif args.placement == "refine":
         t_setup = time.perf_counter()
-        out, placement = hp.refine_placement(packets, out, draws=3)
+        out, placement = hp.refine_placement(packets, out, draws=args.placement_draws, ballast_gb=args.placement_ballast_gb)
         placement["mode"] = "refine"
         placement["setup_s"] = round(time.perf_counter() - t_setup, 3)
     for _ in range(args.warmup):
@@ -579,8 +582,9 @@ def main():
                        "sharding": f"frames x{world}, no data-path collective",
                        "input_batches_rotated": args.rotate_inputs,
                        "buffer_placement": ("first allocation" if not placement else
-                                            "buffer groups re-drawn 3 x each, fastest kept (HotPath.refine_placement = "
-                                            "DeviceFrameBatch's construction-time default)" if placement["mode"] == "refine" else
+                                            ("each buffer group at the fastest of %d locations %g GB apart (HotPath.refine_placement "
+                                             "= DeviceFrameBatch's construction-time default)"
+                                             % (placement["draws_per_group"], args.placement_ballast_gb)) if placement["mode"] == "refine" else
                                             "DIAGNOSTIC: best of %d allocations of the output set (%.0f GB of ballast between "
                                             "two draws) and of up to 10 of the packet buffer (HotPath.pick_placement)"
                                             % (args.placement_tries, args.placement_stride_gb))},

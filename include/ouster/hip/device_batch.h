@@ -43,9 +43,13 @@ struct BatchOptions {
     /// gate skips its counting pass over the RANGE planes.
     double gate_min_range = 0.0, gate_max_range = -1.0;
     /// Large batches (>= 64 frames) settle WHERE their output buffers live when they are constructed: one
-    /// DeviceFrameBatch::refine_placement(3) on an all-zero packet buffer (same store pattern), ~0.15 s and a
-    /// transient 3 x the largest buffer group.  Pointers handed out afterwards stay valid for the life of the batch.
+    /// DeviceFrameBatch::refine_placement(placement_draws, nullptr, placement_ballast_bytes) on an all-zero packet
+    /// buffer (same store pattern): 0.1 - 0.6 s and a transient (draws - 1) x (output set + ballast), about 35 GB for
+    /// 256 dual-return frames.  Pointers handed out afterwards stay valid for the life of the batch.
+    /// placement_ballast_bytes = 0 with 3 draws is the footprint-frugal form (it finds a fast place about every other time).
     bool auto_placement = true;
+    int placement_draws = 4;
+    size_t placement_ballast_bytes = size_t{8} << 30;
     int device = -1;                      ///< GPU to work on (-1: hip::current_device() of the constructing thread)
     std::shared_ptr<Context> context;     ///< share this context (stream + scratch) instead of owning one
 };
@@ -98,12 +102,14 @@ class DeviceFrameBatch {
     /** The cheap form, and what a large batch does by itself when it is constructed (BatchOptions::auto_placement):
      *  the lottery is mostly an interaction between a few heavy output streams (tools/ab/hybrid_sets.py: exchanging
      *  the two XYZ buffers of a slow set for those of a fast one recovers 90 % of the difference, one buffer alone
-     *  nothing), so the buffers are re-drawn GROUP BY GROUP -- XYZ clouds, 32-bit planes, destaggered planes, narrow
-     *  planes -- `draws` fresh allocations each, decode() timed into every candidate, the fastest kept; the buffers
-     *  the batch has are a candidate too.  Transient footprint `draws` x the largest group, no ballast.  Output
-     *  contents are undefined afterwards; device pointers obtained BEFORE the call are invalid.  Returns seconds per
-     *  decode() of what is kept; `all_ms`: the first allocation's time, then every candidate's. */
-    double refine_placement(int draws = 3, std::vector<double>* all_ms = nullptr);
+     *  nothing), and fast / slow regions of the device memory are tens of GB wide: `draws - 1` further copies of the
+     *  output set are allocated `ballast_bytes_between_draws` apart, then GROUP BY GROUP -- XYZ clouds, 32-bit planes,
+     *  destaggered planes, narrow planes -- decode() is timed with that group's buffers at each location and the fastest
+     *  is kept (the buffers the batch has are a candidate too); everything else is freed.  Output contents are undefined
+     *  afterwards; device pointers obtained BEFORE the call are invalid.  Returns seconds per decode() of what is kept;
+     *  `all_ms`: the first allocation's time, then every candidate's (groups x (draws - 1)). */
+    double refine_placement(int draws = 4, std::vector<double>* all_ms = nullptr,
+                            size_t ballast_bytes_between_draws = size_t{8} << 30);
 
     /** Run the fused kernels on everything uploaded so far (asynchronous; sync() to wait). */
     void decode();

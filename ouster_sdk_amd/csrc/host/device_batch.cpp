@@ -93,7 +93,7 @@ DeviceFrameBatch::DeviceFrameBatch(const std::vector<SensorInfo>& sensors, uint3
     if (opt_.auto_placement && n_frames_ >= 64) {
         if (hipMemsetAsync(d_packets_.data(), 0, d_packets_.size(), static_cast<hipStream_t>(ctx_->stream())) != hipSuccess)
             throw std::runtime_error("ouster_hip: hipMemset(packets) failed");
-        refine_placement(3);
+        refine_placement(opt_.placement_draws, nullptr, opt_.placement_ballast_bytes);
     }
 }
 
@@ -272,7 +272,7 @@ double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms, 
     return best * 1e-3;
 }
 
-double DeviceFrameBatch::refine_placement(int draws, std::vector<double>* all_ms) {
+double DeviceFrameBatch::refine_placement(int draws, std::vector<double>* all_ms, size_t ballast_bytes) {
     ScopedContext on_my_context(ctx_);
     auto st = static_cast<hipStream_t>(ctx_->stream());
     struct Events {
@@ -303,9 +303,6 @@ double DeviceFrameBatch::refine_placement(int draws, std::vector<double>* all_ms
         (void)hipEventElapsedTime(&ms, ev.a, ev.b);
         return static_cast<double>(ms) / launches;
     };
-    for (int i = 0; i < 20; ++i) decode();   // the library's variant tuner settles first
-    double best = clock();
-    if (all_ms) all_ms->push_back(best);
     // the groups, heaviest first: pointers to the batch's own buffers
     std::vector<std::vector<DeviceBuffer*>> groups(4);
     for (int k = 0; k < 2; ++k)
@@ -317,26 +314,38 @@ double DeviceFrameBatch::refine_placement(int draws, std::vector<double>* all_ms
     };
     for (auto& kv : d_planes_) groups[elem_of(kv.first) >= 4 ? 1 : 3].push_back(&kv.second);
     for (auto& kv : d_dst_) groups[2].push_back(&kv.second);
-    for (auto& grp : groups) {
-        if (grp.empty()) continue;
-        // rejected draws stay allocated until the group is decided: a freed block is what the next allocation gets back
-        std::vector<std::vector<DeviceBuffer>> held;
-        for (int d = 0; d < draws; ++d) {
-            std::vector<DeviceBuffer> cand(grp.size());
-            try {
-                for (size_t i = 0; i < grp.size(); ++i) cand[i].resize(grp[i]->size());
-            } catch (const std::exception&) {
-                break;   // out of device memory: decide among what has been drawn
+    // draws - 1 further copies of the whole output set, `ballast_bytes` of device memory apart: copies[c][g][i]
+    std::vector<std::vector<std::vector<DeviceBuffer>>> copies;
+    std::vector<DeviceBuffer> ballast;
+    for (int d = 1; d < draws; ++d) {
+        try {
+            if (ballast_bytes) ballast.emplace_back(ballast_bytes);
+            std::vector<std::vector<DeviceBuffer>> set(groups.size());
+            for (size_t g = 0; g < groups.size(); ++g) {
+                set[g].resize(groups[g].size());
+                for (size_t i = 0; i < groups[g].size(); ++i) set[g][i].resize(groups[g][i]->size());
             }
-            for (size_t i = 0; i < grp.size(); ++i) std::swap(cand[i], *grp[i]);   // members = candidate
+            copies.push_back(std::move(set));
+        } catch (const std::exception&) {
+            break;   // out of device memory: decide among what has been drawn
+        }
+    }
+    for (int i = 0; i < 20; ++i) decode();   // the library's variant tuner settles first
+    double best = clock();
+    if (all_ms) all_ms->push_back(best);
+    for (size_t g = 0; g < groups.size(); ++g) {
+        if (groups[g].empty()) continue;
+        for (auto& set : copies) {
+            for (size_t i = 0; i < groups[g].size(); ++i) std::swap(set[g][i], *groups[g][i]);   // members = this location
             const double ms = clock();
             if (all_ms) all_ms->push_back(ms);
-            if (ms < best) best = ms;                                            // keep the candidate
-            else for (size_t i = 0; i < grp.size(); ++i) std::swap(cand[i], *grp[i]);   // put the incumbent back
-            held.push_back(std::move(cand));
+            if (ms < best) best = ms;                                                            // keep it (the incumbent moves into the copy)
+            else for (size_t i = 0; i < groups[g].size(); ++i) std::swap(set[g][i], *groups[g][i]);
         }
-        ctx_->sync();
     }
+    ctx_->sync();
+    copies.clear();
+    ballast.clear();
     check(ouster_hip_ctx_set_knob(default_ctx(), "retune", 1));
     for (int i = 0; i < 20; ++i) decode();
     ctx_->sync();

@@ -189,16 +189,23 @@ class HotPath:
         return best_pk, best_out, {"tries": tries, "stride_gb": stride_gb, "output_sets_ms": out_ms,
                                    "packet_buffers_ms": pk_ms}
 
-    def refine_placement(self, packets: torch.Tensor, out: Dict[str, torch.Tensor], draws: int = 3, launches: int = 10,
-                         passes: int = 1):
-        """The cheap form of pick_placement: the allocation lottery is mostly an interaction between
-        a few heavy output streams (tools/ab/hybrid_sets.py: exchanging the two XYZ buffers of a slow set for those of
-        a fast one recovers 90 % of the difference, exchanging one buffer alone changes nothing), so instead of
-        re-drawing whole output sets the buffers are re-drawn GROUP BY GROUP -- XYZ clouds, 32-bit planes, destaggered
-        planes, narrow planes -- `draws` fresh allocations each, the decode timed into every candidate, the fastest
-        kept (coordinate descent; the current buffers are a candidate too, so the result is never slower).  Transient
-        footprint: `draws` x the largest group (the XYZ pair: 1.5 GB for 256 frames); a dozen allocations and
-        `groups x draws x launches` decodes of setup.  Returns (out, report); `out` is updated in place."""
+    def refine_placement(self, packets: torch.Tensor, out: Dict[str, torch.Tensor], draws: int = 4, launches: int = 10,
+                         ballast_gb: float = 8.0):
+        """Where the output buffers live, settled group by group (the cheap successor of pick_placement; what
+        ouster::sdk::hip::DeviceFrameBatch does by itself when it is constructed).
+
+        The allocation lottery is mostly an interaction between a few heavy output streams
+        (tools/ab/hybrid_sets.py: exchanging the two XYZ buffers of a slow set for those of a fast one recovers 90 % of
+        the difference, exchanging one buffer alone changes nothing), and fast and slow regions of the device memory
+        are tens of GB wide (tools/ab/ballast.py).  So: `draws - 1` further copies of the output set are allocated,
+        `ballast_gb` of device memory held between two of them (they land in different regions); then, group by group
+        -- XYZ clouds, 32-bit planes, destaggered planes, narrow planes -- the decode is timed with that group's
+        buffers taken from each copy in turn and the fastest location is kept (coordinate descent; the buffers the
+        caller came with are a candidate, so the result is never slower).  Everything else is freed.
+        Transient footprint (draws - 1) x (output set + ballast), ~35 GB for 256 dual-return frames with the defaults;
+        setup well under a second of allocations plus groups x draws x launches decodes.  ballast_gb = 0, draws = 3 is
+        the footprint-frugal form (back-to-back draws share a region: it finds a fast place about every other time).
+        Returns (out, report); `out` is updated in place."""
         def clock(o):
             for _ in range(2):
                 self.decode(packets, o)
@@ -225,26 +232,33 @@ class HotPath:
             if g:
                 groups.setdefault(g, []).append(k)
         order = [g for g in ("xyz", "planes32", "destaggered", "planes8_16") if g in groups]
+        keys = [k for g in order for k in groups[g]]
+        t_alloc = __import__("time").perf_counter()
+        copies, ballast = [], []
+        for _ in range(max(0, draws - 1)):
+            try:
+                if ballast_gb > 0:
+                    ballast.append(torch.empty(int(ballast_gb * (1 << 30)), dtype=torch.uint8, device="cuda"))
+                copies.append({k: torch.empty_like(out[k]) for k in keys})
+            except RuntimeError:                 # out of device memory: choose among what has been drawn
+                break
+        torch.cuda.synchronize()
+        alloc_s = __import__("time").perf_counter() - t_alloc
         first_ms = best_ms = clock(out)
-        report = {"first_allocation_ms": round(first_ms, 4), "draws_per_group": draws, "groups": {}}
-        for _ in range(max(1, passes)):
-            for g in order:
-                keys = groups[g]
-                held, times = [], []
-                for _ in range(draws):
-                    try:
-                        cand = {k: torch.empty_like(out[k]) for k in keys}
-                    except RuntimeError:
-                        break
-                    held.append(cand)       # rejected draws stay allocated until the group is decided (a freed block is what the next allocation gets back)
-                    trial = dict(out); trial.update(cand)
-                    times.append(clock(trial))
-                report["groups"].setdefault(g, []).append([round(x, 4) for x in times])
-                if times and min(times) < best_ms:
-                    best_ms = min(times)
-                    out.update(held[int(np.argmin(times))])
-                del held
-                torch.cuda.empty_cache()
+        report = {"first_allocation_ms": round(first_ms, 4), "draws_per_group": 1 + len(copies),
+                  "ballast_gb_between_draws": ballast_gb, "allocation_s": round(alloc_s, 3), "groups": {}}
+        for g in order:
+            times = []
+            for cand in copies:
+                trial = dict(out)
+                trial.update({k: cand[k] for k in groups[g]})
+                times.append(clock(trial))
+            report["groups"][g] = [round(x, 4) for x in times]
+            if times and min(times) < best_ms:
+                best_ms = min(times)
+                out.update({k: copies[int(np.argmin(times))][k] for k in groups[g]})
+        del copies, ballast
+        torch.cuda.empty_cache()
         report["kept_ms"] = round(best_ms, 4)
         try:
             self.ctx.set_knob("retune", 1)

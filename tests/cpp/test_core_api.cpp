@@ -898,10 +898,11 @@ static void test_device_batch() {
     std::vector<double> draws;
     const double kept = batch.tune_placement(3, &draws);
     CHECK(draws.size() == 5 && kept > 0 && kept * 1e3 <= *std::min_element(draws.begin(), draws.end()) + 1e-9);
-    // the cheap form (what batches of 64 frames and more do by themselves when constructed): buffer groups re-drawn one
-    // after the other -- xyz pair, 32-bit planes, destaggered planes, narrow planes: 1 + 4 groups x 2 draws clocks
+    // the cheap form (what batches of 64 frames and more do by themselves when constructed): two further copies of the
+    // output set 64 MB apart, then every buffer group -- xyz pair, 32-bit planes, destaggered planes, narrow planes --
+    // at the fastest of its three locations: 1 + 4 groups x 2 clocks
     std::vector<double> gdraws;
-    const double gkept = batch.refine_placement(2, &gdraws);
+    const double gkept = batch.refine_placement(3, &gdraws, size_t{64} << 20);
     CHECK(gdraws.size() == 9 && gkept > 0 && gkept * 1e3 <= *std::min_element(gdraws.begin(), gdraws.end()) + 1e-9);
     batch.decode();
     XYZLut luts[2] = {XYZLut(a, true), XYZLut(b, true)};

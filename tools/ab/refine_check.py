@@ -10,6 +10,7 @@ from ouster_sdk_amd.device import HotPath
 wl = sys.argv[1]
 draws = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+ballast = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 prof, bits, chan, dst, xyz = bench.WORKLOADS[wl][:5]
 H, W, N = bench.H, bench.W, 256
 alt, az, shifts, b2l, l2s = bench.synth_calibration()
@@ -24,7 +25,7 @@ for _ in range(20):
 torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
-out, rep = hp.refine_placement(pk, out, draws=draws, passes=passes)
+out, rep = hp.refine_placement(pk, out, draws=draws, ballast_gb=ballast)
 rep["setup_s"] = round(time.perf_counter() - t0, 3)
 rep["kernel"] = [hp.ctx.last_decode_kernel()] + list(hp.ctx.last_decode_tile())
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
