@@ -514,11 +514,16 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
         if (j >= (uint32_t)TW) continue;
         uint32_t ofs = 0xffffffffu;
         if (c < W) {
-            const uint32_t p = c / cpp, ic = c - p * cpp;
-            ofs = p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
+            // source slot of destination column c: itself (the optimistic pass), or what k_slotmap found (general mapping)
+            const int32_t sl = a.slot_map ? a.slot_map[(size_t)f * W + c] : (int32_t)c;
+            if (sl >= 0) {
+                const uint32_t p = (uint32_t)sl / cpp, ic = (uint32_t)sl - p * cpp;
+                ofs = p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
+            }
         }
         s_colofs[j] = ofs;
     }
+    const bool mapped = a.slot_map != nullptr;
     if (tid < 4) s_acc[tid] = 0;
     for (uint32_t j = tid; j < (uint32_t)TW; j += NT) s_gate[j] = 0;
     const LutDev lut = (XYZM != 0) ? a.luts[f % a.n_luts] : LutDev{};
@@ -540,13 +545,17 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             pk_ts[k] = 0;
             if (j >= (uint32_t)TW || c >= W) continue;
             const uint32_t p = c / cpp, ic = c - p * cpp;
-            if (p >= count) continue;
-            const uint8_t* colp = fbase + p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
+            uint32_t cofs = p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
+            if (mapped) {
+                cofs = s_colofs[j];   // written before the barrier below, read behind it (the staging loop calls this)
+                if (cofs == 0xffffffffu) continue;
+            } else if (p >= count) continue;
+            const uint8_t* colp = fbase + cofs;
             w_mid[k] = window_global_masked_issue(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask);
             w_st[k] = window_global_masked_issue(colp + a.g.col_status.offset, a.g.col_status.mask);
             if (rc == 0) {
                 if (a.timestamp) w_ts[k] = window_global_masked_issue(colp + a.g.col_timestamp.offset, a.g.col_timestamp.mask);
-                if (ic == 0) {
+                if (ic == 0 && !mapped) {   // packet-level outputs of the general mapping come from k_slotmap
                     if (a.packet_timestamp && a.host_timestamps)
                         pk_ts[k] = a.host_timestamps[(size_t)f * a.slots_per_frame + p];
                     if (a.alert_flags)
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             if (i < nrows * 9) s_beam[i] = r_beam[k];
         }
     }
-    if (rc == 0 && tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_first_present(a.g, fbase, a.packet_stride, count);
+    if (!mapped && rc == 0 && tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_first_present(a.g, fbase, a.packet_stride, count);
 
     PHASE_STAMP(2);
     // ---- classify my columns (every row chunk needs the validity; the first one also publishes)
@@ -649,16 +658,16 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             const uint32_t j = tid + (uint32_t)k * NT, c = c0 + j;
             if (j >= (uint32_t)TW) continue;
             const uint32_t p = c / cpp;
-            const bool present = c < W && p < count;
+            const bool present = c < W && (mapped ? s_colofs[j] != 0xffffffffu : p < count);
             const uint32_t m_id = (uint16_t)apply_bits(window_compose(w_mid[k]), a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
             const uint32_t st = (uint32_t)apply_bits(window_compose(w_st[k]), a.g.col_status.mask, a.g.col_status.shift);
             const bool live = present && (st & 1u) && m_id < W;
-            bool stray = live && m_id != c;
+            bool stray = live && m_id != c;   // never under the general mapping: the map holds slots whose column IS c
             const bool v = live && !stray;
             s_valid[j] = v ? 1u : 0u;
             n_dead += (!v && c < W) ? 1u : 0u;
             if (rc != 0 || c >= W) continue;
-            if (c == p * cpp) {  // batch_lidar_packet, lidar_frame.cpp:1534-1539
+            if (c == p * cpp && !mapped) {  // batch_lidar_packet, lidar_frame.cpp:1534-1539
                 const bool want_pk = a.packet_timestamp || a.alert_flags;
                 const bool home = present && m_id / cpp == p;
                 if (present && !home && want_pk && m_id / cpp < npo) stray = true;
@@ -682,7 +691,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
         if (n_dead) atomicAdd(&s_acc[2], n_dead);
     }
     __syncthreads();
-    if (rc == 0 && tid == 0) {
+    if (rc == 0 && tid == 0 && !mapped) {
         fast_publish(a, f, tile, s_acc[0], s_acc[1] != 0);
     }
     // Columns that were not received (or are invalid / not at home) decode as zeros: blank their

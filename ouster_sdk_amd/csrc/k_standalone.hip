@@ -1085,6 +1085,88 @@ hipError_t launch_decode_stream(const DecodeArgs& a, const StreamArgs& sp, int s
     }
 }
 
+// ------------------------------------------------------------------------------------
+// k_slotmap: the general column mapping of a whole frame, once (one workgroup per frame) -- for buffers that do not have
+// one slot per column of the frame (compacted after drops, any order, duplicates), where round 2 let EVERY 64-column tile
+// of k_decode scan the frame's column headers.  destination column c <- the LAST slot in buffer order whose live column
+// (status & 1, measurement_id < W) carries measurement_id c: what FrameBatcher::parse_by_col leaves behind
+// (ouster_core/src/lidar_frame.cpp:1422-1466, "the packet batched later overwrites").  Also everything the general path's
+// tile 0 used to resolve: packet-level outputs (batch_lidar_packet :1534-1539), the frame-level values (start_frame
+// :1709-1741, from the first packet of the buffer) and the valid-column count.  k_decode_wide then decodes from the map.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_slotmap(DecodeArgs a) {
+    constexpr int NT = 256;
+    extern __shared__ __align__(16) uint32_t smem[];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t W = a.g.columns_per_frame, cpp = a.g.columns_per_packet, npo = a.n_packets_out;
+    int32_t* s_map = (int32_t*)smem;          // [W]
+    int32_t* s_pk = s_map + W;                // [npo]
+    uint32_t* s_n = (uint32_t*)(s_pk + npo);  // [1]
+    const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
+    uint32_t count = a.slots_per_frame;
+    if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
+    for (uint32_t i = tid; i < W; i += NT) s_map[i] = -1;
+    for (uint32_t i = tid; i < npo; i += NT) s_pk[i] = -1;
+    if (tid == 0) *s_n = 0;
+    __syncthreads();
+    const uint32_t nslots = count * cpp;
+    constexpr int U = 4;   // headers per thread per round, all loads in flight before the first use
+    for (uint32_t base = 0; base < nslots; base += NT * U) {
+        uint64_t w_mid[U], w_st[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t s = base + (uint32_t)u * NT + tid;
+            w_mid[u] = w_st[u] = 0;
+            if (s < nslots) {
+                const uint32_t p = s / cpp, ic = s - p * cpp;
+                const uint8_t* colp = fbase + (size_t)p * a.packet_stride + a.g.packet_header_size + (size_t)ic * a.g.col_size;
+                w_mid[u] = window_global_masked(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask);
+                w_st[u] = window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t s = base + (uint32_t)u * NT + tid;
+            if (s >= nslots) continue;
+            const uint32_t m_id = (uint16_t)apply_bits(w_mid[u], a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
+            const uint32_t stv = (uint32_t)apply_bits(w_st[u], a.g.col_status.mask, a.g.col_status.shift);
+            if ((stv & 1u) && m_id < W) atomicMax(&s_map[m_id], (int32_t)s);
+            const uint32_t p = s / cpp;
+            if (s == p * cpp && m_id / cpp < npo) atomicMax(&s_pk[m_id / cpp], (int32_t)p);
+        }
+    }
+    __syncthreads();
+    uint32_t n = 0;
+    for (uint32_t i = tid; i < W; i += NT) {
+        const int32_t v = s_map[i];
+        a.slot_map[(size_t)f * W + i] = v;
+        n += v >= 0 ? 1u : 0u;
+    }
+    if (n) atomicAdd(s_n, n);
+    // packet_timestamp is zeroed at frame start (lidar_frame.cpp:1719), alert_flags is not
+    for (uint32_t i = tid; i < npo; i += NT) {
+        const int32_t p = s_pk[i];
+        if (a.packet_timestamp && a.host_timestamps)
+            a.packet_timestamp[(size_t)f * npo + i] = p >= 0 ? a.host_timestamps[(size_t)f * a.slots_per_frame + p] : 0ull;
+        if (a.alert_flags && p >= 0)
+            a.alert_flags[(size_t)f * npo + i] = (uint8_t)apply_bits(
+                window_global(fbase + (size_t)p * a.packet_stride + a.g.alert_flags.offset), a.g.alert_flags.mask, a.g.alert_flags.shift);
+    }
+    __syncthreads();
+    if (tid == 0 && a.frame_meta) {
+        ouster_hip_frame_meta m = frame_meta_of(a.g, fbase, count > 0);
+        m.n_valid_columns = *s_n;
+        a.frame_meta[f] = m;
+    }
+}
+
+hipError_t launch_slotmap(const DecodeArgs& a, hipStream_t st) {
+    const size_t lds = ((size_t)a.g.columns_per_frame + a.n_packets_out + 4) * 4;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_slotmap, dim3(a.n_frames), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st) {
     dim3 grid(a.h, n_images);
     hipLaunchKernelGGL(k_destagger, grid, dim3(256), 0, st, a);

@@ -85,6 +85,8 @@ struct Knobs {
     int stream_wait = 1;      // OUSTER_HIP_STREAM_WAIT: 1 vmcnt(0) before a prefetched tile is used | 0 rely on the in-order counter
     int stream_min_tiles = 8; // OUSTER_HIP_STREAM_MIN_TILES: tiles per workgroup below which a launch stays on k_decode_wide
     int stream_order = 0;     // OUSTER_HIP_STREAM_ORDER: item order of k_decode_stream's groups (experiments)
+    int slotmap = 1;          // OUSTER_HIP_SLOTMAP: 0 = buffers without one slot per column go through k_decode's general tiles
+                              //   (every tile scans the frame's headers) instead of k_slotmap + k_decode_wide
     int stream_loader = 4;    // OUSTER_HIP_STREAM_LOADER: loader waves of k_decode_stream2 (0 = k_decode_stream: every wave fetches)
 };
 
@@ -92,7 +94,7 @@ struct ouster_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf state, tile_valid, offsets, luts, counts, scratch;
+    DevBuf state, tile_valid, offsets, luts, counts, scratch, slotmap;
     uint32_t resident_wgs = 512;         // 2 workgroups (80 KB LDS each) per CU
     uint32_t cus = 256;                  // compute units (k_decode_stream: one persistent workgroup each)
     const char* last_kernel = "";        // name of the decode kernel the last ouster_hip_decode launched
@@ -295,6 +297,7 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.stream_min_tiles = env_int("OUSTER_HIP_STREAM_MIN_TILES", k.stream_min_tiles);
         k.stream_order = env_int("OUSTER_HIP_STREAM_ORDER", k.stream_order);
         k.stream_loader = env_int("OUSTER_HIP_STREAM_LOADER", k.stream_loader);
+        k.slotmap = env_int("OUSTER_HIP_SLOTMAP", k.slotmap);
     }
     if (stream == OUSTER_HIP_STREAM_NULL) {
         c->stream = nullptr;  // the null stream
@@ -326,6 +329,7 @@ void ouster_hip_ctx_destroy(ouster_hip_ctx* c) {
     c->luts.release();
     c->counts.release();
     c->scratch.release();
+    c->slotmap.release();
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -373,6 +377,7 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "stream_min_tiles") k.stream_min_tiles = value;
     else if (n == "stream_order") k.stream_order = value;
     else if (n == "stream_loader") k.stream_loader = value;
+    else if (n == "slotmap") k.slotmap = value;
     else return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unknown knob '%s'", name);
     return OUSTER_HIP_OK;
 }
@@ -837,9 +842,11 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // wide, short tiles (k_decode_wide): TW columns x TR rows with TW*TR*chan <= ~64 KB, TR chosen so that
     // the row chunks are equal.  Needs a batch large enough to fill the chip; fast mode only.
     const uint32_t narrow_tiles = (W + tile - 1) / tile;
+    // General mapping on wide tiles: the column -> slot map of every frame is resolved once (k_slotmap), not by every tile
+    const bool mapped_ok = !fast && kn.slotmap && kn.tile == 0 && ((size_t)W + da.n_packets_out + 4) * 4 <= 64 * 1024;
     auto setup_wide = [&](int want) -> bool {
         const uint32_t chan = g.channel_data_size;
-        if (!(fast && (want == 64 || want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 &&
+        if (!((fast || mapped_ok) && (want == 64 || want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 &&
               W >= (uint32_t)want))
             return false;
         const uint32_t rpp = 1024u / (uint32_t)want;  // rows per pass of the 256-thread workgroup
@@ -968,6 +975,11 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         // forced
     } else if (kn.wide >= 0) {  // forced (experiments, tests)
         if (kn.wide && setup_wide(kn.wide)) wide = kn.wide;
+    } else if (!fast) {
+        // general mapping on wide tiles (k_slotmap first): column pieces of at least 256 B, like the persistent kernel's choice
+        if (setup_wide(256) && da.rows_per_tile * g.channel_data_size >= 256) wide = 256;
+        else if (setup_wide(128)) wide = 128;
+        else if (setup_wide(256)) wide = 256;
     } else if (setup_wide(256)) {
         int sel = 256;   // >= 1000: the persistent kernel with tile width sel - 1000
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1062,6 +1074,11 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         for (int k = 0; k < 2; ++k)
             if (!tuning->ev[tune_slot][k]) HIP_TRY(hipEventCreate(&tuning->ev[tune_slot][k]));
         HIP_TRY(hipEventRecord(tuning->ev[tune_slot][0], st));
+    }
+    if (wide && !fast) {
+        if (ctx->slotmap.ensure((size_t)n_frames * W * sizeof(int32_t))) return fail(OUSTER_HIP_ERR_RUNTIME, "out of device memory (slot map)");
+        da.slot_map = (int32_t*)ctx->slotmap.p;
+        HIP_TRY(launch_slotmap(da, st));
     }
     if (stream) {
         HIP_TRY(launch_decode_stream(da, sa, spec, stream, xyzm, ctx->device, st));

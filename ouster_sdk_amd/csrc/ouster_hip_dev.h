@@ -82,6 +82,9 @@ struct DecodeArgs {
     void* xyz[2];
     int32_t xyz_field[2];
     int32_t xyz_dtype;
+    int32_t* slot_map;        // device [n_frames][W] or nullptr.  General mapping on wide tiles: k_slotmap writes, per
+                              //   destination column, the LAST buffer slot whose live column carries that measurement_id
+                              //   (-1: none), k_decode_wide takes its source columns from it instead of "slot c holds column c"
     const double* xyz_poses;  // device [n_frames][W][16] or nullptr: per-column pose applied to the xyz outputs
     uint32_t pose_lds_off;    // byte offset of the tile's pose table in dynamic LDS (set by the launchers)
 #ifdef OUSTER_PHASE_TIMING
@@ -186,6 +189,7 @@ size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_sl
 hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, int device, hipStream_t st);
 hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, int device, hipStream_t st);
 hipError_t launch_decode_stream(const DecodeArgs& a, const StreamArgs& sp, int spec_id, int tw, int xyzm, int device, hipStream_t st);
+hipError_t launch_slotmap(const DecodeArgs& a, hipStream_t st);
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st);
 hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
 hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);

@@ -561,9 +561,85 @@ def test_tuner_times_the_persistent_kernel_too(oracle):
 
 
 # ---------------------------------------------------------------------------------------------
+# buffers WITHOUT one slot per column of the frame: the general mapping, resolved once per frame by k_slotmap and
+# decoded on k_decode_wide's tiles (or, slotmap = 0 / narrow forced, by every 64-column tile of k_decode for itself)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wide", [None, 64, 128, 256, 0])
+@pytest.mark.parametrize("profile,slots", [("RNG15_RFL8_NIR8_DUAL", 67), ("RNG19_RFL8_SIG16_NIR16", 61),
+                                           ("RNG15_RFL8_NIR8", 70), ("FUSA_RNG15_RFL8_NIR8_DUAL", 64 + 5)])
+def test_general_mapping_on_wide_tiles(oracle, profile, slots, wide):
+    """parse_by_col semantics (lidar_frame.cpp:1422-1466) for every frame of a batch whose buffer has `slots` != W / cpp
+    packet slots: compacted after drops, any order, a late duplicate that must win, an empty frame, a full frame, packets
+    whose columns lie outside the frame.  Everything -- planes, destaggered planes, XYZ, column headers, packet-level
+    outputs, frame meta -- against the oracle fed the same packets in the same order."""
+    O = oracle
+    cal = O.synthetic_calib(h=32, w=1024, profile=profile)
+    pf = cal.packet_format()
+    n, npk = 12, 64
+    packets, _ = O.synth_packets(cal, n, with_window=True)
+    rng = np.random.default_rng(5)
+    by_frame = [packets[f] for f in range(n)]
+    by_frame[1] = np.delete(by_frame[1], [0, 9, 63], axis=0)
+    by_frame[2] = by_frame[2][rng.permutation(npk)]
+    dup = by_frame[3][30:31].copy()
+    body = pf.packet_header_size + pf.col_header_size
+    dup[0, body:body + 64] ^= 0x15   # the late copy differs: it is the one that must be decoded
+    by_frame[3] = np.concatenate([by_frame[3], dup])[: min(slots, npk + 1)]
+    by_frame[4] = by_frame[4][:0]
+    by_frame[5] = np.delete(by_frame[5], np.arange(1, npk, 2), axis=0)[rng.permutation(npk // 2)]
+    mid_ofs = pf.col_measurement_id_info.offset
+    assert pf.col_measurement_id_info.mask == 0xffff and pf.col_measurement_id_info.shift == 0
+    far = by_frame[6][:2].copy()   # measurement ids beyond the frame: dropped (lidar_frame.cpp:1432-1434)
+    for k in range(2):
+        for ic in range(cal.cpp):
+            o = pf.packet_header_size + ic * pf.col_size + mid_ofs
+            far[k, o:o + 2] = np.frombuffer(np.uint16(cal.w + 16 * k + ic).tobytes(), np.uint8)
+    by_frame[6] = np.concatenate([np.delete(by_frame[6], [5], axis=0), far])[:slots]
+    by_frame[7] = by_frame[7][::-1].copy()
+    by_frame = [b[:slots] for b in by_frame]
+    host = np.zeros((n, slots, pf.lidar_packet_size), np.uint8)
+    counts = np.zeros(n, np.uint32)
+    for f, pk in enumerate(by_frame):
+        host[f, :len(pk)] = pk
+        counts[f] = len(pk)
+    names = [nm for nm, _ in HotPath(profile, cal.h, cal.w, cal.cpp, header_type=cal.header_type).fields]
+    xyz = [nm for nm in ("RANGE", "RANGE2") if nm in names]
+    dst = [nm for nm in ("RANGE", "REFLECTIVITY", "RANGE2") if nm in names]
+    ref = _oracle_frames(O, cal, pf, by_frame, True)
+    hp = _hotpath(cal, profile, wide=wide)
+    if wide is None:
+        hp.ctx.set_knob("wide_min_blocks", 0)
+    out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
+    out["packet_timestamp"] = torch.empty((n, npk), dtype=torch.uint64, device="cuda")
+    out["alert_flags"] = torch.empty((n, npk), dtype=torch.uint8, device="cuda")
+    for t in out.values():
+        t.view(torch.uint8).fill_(0xCD)
+    ts = torch.arange(1, n * slots + 1, dtype=torch.int64).view(n, slots).cuda() * 1000
+    hp.decode(torch.from_numpy(host).cuda(), out, packet_counts=counts, host_timestamps=ts)
+    hp.sync()
+    kernel = hp.ctx.last_decode_kernel()
+    assert kernel == ("k_decode" if wide == 0 else "k_decode_wide"), kernel
+    _compare(O, cal, hp, out, ref, dst, xyz)
+    # packet-level outputs: the LAST buffered packet of each packet index (batch_lidar_packet, lidar_frame.cpp:1534-1539)
+    pts = _np(out["packet_timestamp"])
+    for f, pk in enumerate(by_frame):
+        want = np.zeros(npk, np.uint64)
+        for sl, p in enumerate(pk):
+            o = pf.packet_header_size + mid_ofs
+            idx = int(np.frombuffer(p[o:o + 2].tobytes(), np.uint16)[0]) // cal.cpp
+            if idx < npk:
+                want[idx] = (f * slots + sl + 1) * 1000
+        assert np.array_equal(pts[f], want), f
+    # alert_flags: written for the packets that arrived, untouched elsewhere (not zeroed at frame start, lidar_frame.cpp:1719)
+    al = _np(out["alert_flags"])
+    for f, pk in enumerate(by_frame):
+        assert np.all(al[f][pts[f] == 0] == 0xCD), f
+
+
+# ---------------------------------------------------------------------------------------------
 # the loss paths bench.py times next to the metric ("loss_paths"), at the benchmarked size
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("path", ["stray10", "general"])
+@pytest.mark.parametrize("path", ["stray10", "general", "general_narrow"])
 def test_bench_size_loss_paths(oracle, path):
     """256 frames of 128x2048 dual return with bench.py's loss patterns: `stray10` (every 20th frame compacted after a
     drop, every 20th + 10 with two packets swapped: fix-up pass) and `general` (every frame compacted into 127 slots with
@@ -580,7 +656,9 @@ def test_bench_size_loss_paths(oracle, path):
     dst, xyz = ["RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"], ["RANGE", "RANGE2"]
     lost = [(f * 7 + 3) % slots for f in range(n)]
     by_frame = {}
-    if path == "general":
+    if path == "general_narrow":
+        hp.ctx.set_knob("slotmap", 0)
+    if path.startswith("general"):
         host = np.zeros((n, slots - 1, pf.lidar_packet_size), np.uint8)
         for f in range(n):
             host[f] = np.delete(packets[f % 8], lost[f], axis=0)
@@ -607,8 +685,8 @@ def test_bench_size_loss_paths(oracle, path):
         t.view(torch.uint8).fill_(0xA5)
     hp.decode(torch.from_numpy(host).cuda(), out, packet_counts=counts)
     hp.sync()
-    if path == "general":
-        assert hp.ctx.last_decode_kernel() == "k_decode"
+    if path.startswith("general"):
+        assert hp.ctx.last_decode_kernel() == ("k_decode" if path == "general_narrow" else "k_decode_wide")
     ref = _oracle_frames(O, cal, pf, [by_frame[f] for f in check], True)
     worst = _compare(O, cal, hp, out, ref, dst, xyz, frames=list(zip(check, ref)))
     assert worst <= 4e-5
