@@ -459,7 +459,8 @@ __global__ __launch_bounds__(256) void k_decode_fixup(DecodeArgs a) {
 // (TR*chan bytes, 256 B for dual-LB at TW = 256), staged into per-column LDS slots padded by one dword
 // (bank spread for the 4-columns-per-lane reads).  The column tiles of one row chunk are consecutive
 // blocks of one XCD, so neighbouring workgroups write whole rows together.
-// MODE_FAST only (the fix-up pass always runs k_decode): every row chunk reads the (measurement_id,
+// The optimistic pass (slot c holds column c), or -- a.slot_map set -- the general mapping from k_slotmap's per-frame
+// map (the fix-up pass always runs k_decode).  Every row chunk reads the (measurement_id,
 // status) words of its columns next to its staging loads, the first row chunk of a column tile does
 // the stray check, the column headers and the packet-level outputs.
 // ------------------------------------------------------------------------------------
