@@ -49,6 +49,7 @@ oracle:
 
 cpptests: $(LIB)/libouster_core_amd.so
 	$(MAKE) -C tests/cpp -s
+	$(MAKE) -C oracle -s refcpptests
 
 clean:
 	rm -rf $(LIB) $(OBJ) oracle/_build tests/cpp/_build

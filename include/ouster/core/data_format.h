@@ -8,6 +8,8 @@
 #include <utility>
 #include <vector>
 
+#include "nonstd/optional.hpp"
+
 namespace ouster {
 namespace sdk {
 namespace core {
@@ -65,8 +67,12 @@ bool operator!=(const DataFormat& lhs, const DataFormat& rhs);
 DataFormat default_data_format(uint32_t columns, uint16_t fps = 10);
 
 std::string to_string(UDPProfileLidar profile);
-/** @return UNKNOWN when the name is not registered. */
-UDPProfileLidar udp_profile_lidar_of_string(const std::string& s);
+/** @return nullopt when the name is not registered (data_format.h:179). */
+nonstd::optional<UDPProfileLidar> udp_profile_lidar_of_string(const std::string& s);
+std::string to_string(UDPProfileIMU profile);
+nonstd::optional<UDPProfileIMU> udp_profile_imu_of_string(const std::string& s);
+std::string to_string(HeaderType profile);
+nonstd::optional<HeaderType> udp_profile_type_of_string(const std::string& s);
 
 }  // namespace core
 }  // namespace sdk

@@ -155,31 +155,46 @@ class Field {
     void* ptr_ = nullptr;
 };
 
-/** 1-D header view (stands in for the Eigen headers returned by the reference). */
+/** 1-D header view (stands in for the Eigen headers returned by the reference): a contiguous VecRef. */
 template <typename T>
-class HeaderRef {
+class HeaderRef : public VecRef<T> {
    public:
-    HeaderRef(T* p, size_t n) : p_(p), n_(n) {}
+    HeaderRef(T* p, size_t n) : VecRef<T>(p, n, 1), p_(p) {}
     T* data() const { return p_; }
-    size_t size() const { return n_; }
-    size_t rows() const { return n_; }
-    T& operator[](size_t i) const { return p_[i]; }
-    T& operator()(size_t i) const { return p_[i]; }
-    void setZero() const { for (size_t i = 0; i < n_; ++i) p_[i] = T{}; }
-    size_t count() const {  ///< number of non-zero entries
-        size_t c = 0;
-        for (size_t i = 0; i < n_; ++i) c += p_[i] != T{};
-        return c;
-    }
+    using VecRef<T>::operator=;
+
    private:
     T* p_;
-    size_t n_;
 };
+namespace impl {
+template <typename T> struct is_array_like<HeaderRef<T>> : std::true_type {};
+template <typename T> T& flat_at(const HeaderRef<T>& a, size_t i) { return a(i); }
+}  // namespace impl
+template <typename T>
+BoolMask operator==(const HeaderRef<T>& a, const HeaderRef<T>& b) {
+    return impl::compare_arrays(a, b, [](const auto& x, const auto& y) { return x == y; });
+}
+template <typename T>
+BoolMask operator!=(const HeaderRef<T>& a, const HeaderRef<T>& b) {
+    return impl::compare_arrays(a, b, [](const auto& x, const auto& y) { return x != y; });
+}
 
 /** Default planes of a profile / data format (lidar_frame.cpp:73-259, :1038-1117). */
 LidarFrameFieldTypes get_field_types(UDPProfileLidar profile);
 LidarFrameFieldTypes get_field_types(const DataFormat& format, const Version& fw_version);
 LidarFrameFieldTypes get_field_types(const SensorInfo& info);
+
+class LidarFrame;
+namespace impl {
+/** A FrameBatcher's promise to a frame it is assembling: the packets collected so far are decoded (one GPU launch) the
+ *  first time somebody looks at the frame's planes or column headers -- the reference parses every packet on arrival
+ *  (lidar_frame.cpp:1530-1576), so a partially assembled frame shows what has been received; this mirror defers the
+ *  pixel work to the release of the frame and pays for an early look only when one is taken. */
+struct PendingDecode {
+    virtual ~PendingDecode() = default;
+    virtual void flush(LidarFrame& frame) = 0;
+};
+}  // namespace impl
 
 class LidarFrame {
    public:
@@ -224,18 +239,18 @@ class LidarFrame {
     Field& add_field(const std::string& name, ChanFieldType type, std::vector<size_t> extra_dims = {},
                      FieldClass c = FieldClass::PIXEL_FIELD);
     Field del_field(const std::string& name);
-    std::map<std::string, Field>& fields() { return fields_; }
-    const std::map<std::string, Field>& fields() const { return fields_; }
+    std::map<std::string, Field>& fields() { sync_(); return fields_; }
+    const std::map<std::string, Field>& fields() const { sync_(); return fields_; }
     LidarFrameFieldTypes field_types() const;
     /** Type of one field (lidar_frame.h:476-484).  @throw std::out_of_range if the field does not exist */
     FieldType field_type(const std::string& name) const;
 
-    HeaderRef<uint64_t> timestamp() { return {timestamp_.get<uint64_t>(), w}; }
-    HeaderRef<const uint64_t> timestamp() const { return {timestamp_.get<uint64_t>(), w}; }
-    HeaderRef<uint16_t> measurement_id() { return {measurement_id_.get<uint16_t>(), w}; }
-    HeaderRef<const uint16_t> measurement_id() const { return {measurement_id_.get<uint16_t>(), w}; }
-    HeaderRef<uint32_t> status() { return {status_.get<uint32_t>(), w}; }
-    HeaderRef<const uint32_t> status() const { return {status_.get<uint32_t>(), w}; }
+    HeaderRef<uint64_t> timestamp() { sync_(); return {timestamp_.get<uint64_t>(), w}; }
+    HeaderRef<const uint64_t> timestamp() const { sync_(); return {timestamp_.get<uint64_t>(), w}; }
+    HeaderRef<uint16_t> measurement_id() { sync_(); return {measurement_id_.get<uint16_t>(), w}; }
+    HeaderRef<const uint16_t> measurement_id() const { sync_(); return {measurement_id_.get<uint16_t>(), w}; }
+    HeaderRef<uint32_t> status() { sync_(); return {status_.get<uint32_t>(), w}; }
+    HeaderRef<const uint32_t> status() const { sync_(); return {status_.get<uint32_t>(), w}; }
     HeaderRef<uint64_t> packet_timestamp() { return {packet_timestamp_.get<uint64_t>(), packet_count_}; }
     HeaderRef<const uint64_t> packet_timestamp() const {
         return {packet_timestamp_.get<uint64_t>(), packet_count_};
@@ -281,7 +296,28 @@ class LidarFrame {
 
     bool equals(const LidarFrame& other) const;
 
+    /** Used by FrameBatcher: a field without triggering a pending decode (nullptr: no such field). */
+    Field* peek_field(const std::string& name) const {
+        auto it = fields_.find(name);
+        return it == fields_.end() ? nullptr : const_cast<Field*>(&it->second);
+    }
+    /** Used by FrameBatcher: the decode that the next look at this frame's data triggers (none: empty pointer). */
+    void set_pending_decode(std::weak_ptr<impl::PendingDecode> p) const {
+        pending_ = std::move(p);
+        has_pending_ = true;
+    }
+    void clear_pending_decode() const {
+        pending_.reset();
+        has_pending_ = false;
+    }
+
    private:
+    void sync_() const {
+        if (has_pending_) run_pending_();
+    }
+    void run_pending_() const;
+    mutable std::weak_ptr<impl::PendingDecode> pending_;
+    mutable bool has_pending_ = false;
     Field timestamp_, measurement_id_, status_, packet_timestamp_, body_to_world_, alert_flags_;
     std::map<std::string, Field> fields_;
     size_t packet_count_{0};
@@ -412,6 +448,66 @@ namespace impl {
 std::vector<LidarPacket> frame_to_packets(const LidarFrame& frame,
                                           std::shared_ptr<PacketFormat> packet_format,
                                           uint32_t init_id, uint64_t prod_sn);
+/** RAW_HEADERS present and tall enough for one column's headers and footers (lidar_frame.cpp:260-279). */
+bool raw_headers_enabled(const PacketFormat& pf, const LidarFrame& frame);
+/** The reference's form: the packets go to an STL output iterator over Packet (impl/lidar_frame_impl.h:433-437). */
+template <typename OutputItT>
+void frame_to_packets(const LidarFrame& frame, std::shared_ptr<PacketFormat> packet_format, OutputItT iter,
+                      uint32_t init_id, uint64_t prod_sn) {
+    for (auto& p : frame_to_packets(frame, std::move(packet_format), init_id, prod_sn)) *iter++ = std::move(p);
+}
+
+// ---- visiting fields by their run-time element type (impl/lidar_frame_impl.h:57-375) ----------------------------
+// The operation receives a typed 2-D view of the field: OUSTER_FIELD_REF(T), by default this mirror's ImgRef<T>
+// (the reference hands out Eigen::Ref<img_t<T>>; a build that has an Eigen with that spelling can define the macro to it
+// before including this header).  FLOAT16 / ZONE_STATE / CHAR / VOID fields are skipped, as in the reference.
+#ifndef OUSTER_FIELD_REF
+#define OUSTER_FIELD_REF(T) ::ouster::sdk::core::ImgRef<T>
+#define OUSTER_CONST_FIELD_REF(T) ::ouster::sdk::core::ImgRef<const T>
+#endif
+template <typename FIELD, typename OP, typename... Args>
+void visit_field_2d(FIELD&& field, OP&& op, Args&&... args) {
+    constexpr bool is_const = std::is_const<typename std::remove_reference<FIELD>::type>::value;
+#define OUSTER_VISIT_CASE_(TAG, T)                                                                                  \
+    case ChanFieldType::TAG: {                                                                                      \
+        using E = typename std::conditional<is_const, const T, T>::type;                                            \
+        using R = typename std::conditional<is_const, OUSTER_CONST_FIELD_REF(T), OUSTER_FIELD_REF(T)>::type;        \
+        op(R(static_cast<ImgRef<E>>(field)), std::forward<Args>(args)...);                                          \
+        break;                                                                                                      \
+    }
+    switch (field.tag()) {
+        OUSTER_VISIT_CASE_(UINT8, uint8_t)
+        OUSTER_VISIT_CASE_(UINT16, uint16_t)
+        OUSTER_VISIT_CASE_(UINT32, uint32_t)
+        OUSTER_VISIT_CASE_(UINT64, uint64_t)
+        OUSTER_VISIT_CASE_(INT8, int8_t)
+        OUSTER_VISIT_CASE_(INT16, int16_t)
+        OUSTER_VISIT_CASE_(INT32, int32_t)
+        OUSTER_VISIT_CASE_(INT64, int64_t)
+        OUSTER_VISIT_CASE_(FLOAT32, float)
+        OUSTER_VISIT_CASE_(FLOAT64, double)
+        case ChanFieldType::FLOAT16:
+        case ChanFieldType::ZONE_STATE:
+        case ChanFieldType::CHAR:
+        case ChanFieldType::VOID:
+        case ChanFieldType::UNREGISTERED:
+            break;
+        default:
+            throw std::invalid_argument("Invalid field for LidarFrame");
+    }
+#undef OUSTER_VISIT_CASE_
+}
+template <typename FRAME, typename OP, typename... Args>
+void visit_field(FRAME&& frame, const std::string& name, OP&& op, Args&&... args) {
+    if (!frame.has_field(name)) throw std::invalid_argument("Invalid field for LidarFrame");
+    visit_field_2d(frame.field(name), std::forward<OP>(op), std::forward<Args>(args)...);
+}
+/** op(field view, field name, args...) for every channel field of the packet format the frame has. */
+template <typename FRAME, typename OP, typename... Args>
+void foreach_channel_field(FRAME&& frame, const PacketFormat& pf, OP&& op, Args&&... args) {
+    for (const auto& ft : pf)
+        if (frame.has_field(ft.first)) visit_field(frame, ft.first, std::forward<OP>(op), ft.first, std::forward<Args>(args)...);
+}
 }  // namespace impl
 
 }  // namespace core

@@ -128,6 +128,53 @@ using PointCloudXYZ = ArrayX3R<T>;
 using PointCloudXYZf = PointCloudXYZ<float>;
 using PointCloudXYZd = PointCloudXYZ<double>;
 
+/** Result of an element-wise comparison (`a == b`, `a != 7`): the reductions the reference's callers write on Eigen
+ *  expressions -- `(a == b).all()`, `.any()`, `.count()`. */
+class BoolMask {
+   public:
+    explicit BoolMask(size_t n) : v_(n, 0) {}
+    size_t size() const { return v_.size(); }
+    bool operator()(size_t i) const { return v_[i] != 0; }
+    void set(size_t i, bool b) { v_[i] = b ? 1 : 0; }
+    bool all() const { return std::all_of(v_.begin(), v_.end(), [](uint8_t b) { return b != 0; }); }
+    bool any() const { return std::any_of(v_.begin(), v_.end(), [](uint8_t b) { return b != 0; }); }
+    size_t count() const { return static_cast<size_t>(std::count_if(v_.begin(), v_.end(), [](uint8_t b) { return b != 0; })); }
+
+   private:
+    std::vector<uint8_t> v_;
+};
+
+/** Non-owning strided 1-D view: a column or row of an image, a segment of a header (Eigen's .col() / .row() / .segment()). */
+template <typename T>
+class VecRef {
+   public:
+    VecRef(T* p, size_t n, size_t stride = 1) : p_(p), n_(n), stride_(stride) {}
+    size_t size() const { return n_; }
+    size_t rows() const { return n_; }
+    T& operator()(size_t i) const { return p_[i * stride_]; }
+    T& operator[](size_t i) const { return p_[i * stride_]; }
+    VecRef segment(size_t start, size_t n) const {
+        if (start + n > n_) throw std::out_of_range("segment outside the vector");
+        return VecRef(p_ + start * stride_, n, stride_);
+    }
+    const VecRef& operator=(typename std::remove_const<T>::type v) const {   ///< fill, as assigning a scalar to an Eigen block does
+        for (size_t i = 0; i < n_; ++i) p_[i * stride_] = v;
+        return *this;
+    }
+    void setZero() const { *this = T{}; }
+    size_t count() const {   ///< non-zero entries
+        size_t c = 0;
+        for (size_t i = 0; i < n_; ++i) c += p_[i * stride_] != T{};
+        return c;
+    }
+    bool all() const { return count() == n_; }   ///< every entry non-zero (Eigen's .all() of an integer array)
+    bool any() const { return count() != 0; }
+
+   private:
+    T* p_;
+    size_t n_, stride_;
+};
+
 /** Non-owning row-major 2-D view; stands in for Eigen::Ref<img_t<T>>. */
 template <typename T>
 class ImgRef {
@@ -159,11 +206,69 @@ class ImgRef {
     size_t cols() const { return cols_; }
     size_t size() const { return rows_ * cols_; }
     T& operator()(size_t r, size_t c) const { return p_[r * cols_ + c]; }
+    T& operator()(size_t i) const { return p_[i]; }   ///< flat, row-major
+    VecRef<T> col(size_t c) const { return VecRef<T>(p_ + c, rows_, cols_); }
+    VecRef<T> row(size_t r) const { return VecRef<T>(p_ + r * cols_, cols_, 1); }
+    void setConstant(NC v) const { std::fill(p_, p_ + size(), v); }
+    void setZero() const { setConstant(NC{}); }
+    size_t count() const { return static_cast<size_t>(size() - std::count(p_, p_ + size(), NC{})); }
+    bool all() const { return count() == size(); }
+    bool any() const { return count() != 0; }
 
    private:
     T* p_;
     size_t rows_, cols_;
 };
+
+// ---- element-wise comparisons of the array stand-ins -> BoolMask -------------------------------------------------
+namespace impl {
+template <typename X> struct is_array_like : std::false_type {};
+template <typename T> struct is_array_like<ArrayXXR<T>> : std::true_type {};
+template <typename T> struct is_array_like<ArrayX3R<T>> : std::true_type {};
+template <typename T> struct is_array_like<ImgRef<T>> : std::true_type {};
+template <typename T> struct is_array_like<VecRef<T>> : std::true_type {};
+template <typename T> const T& flat_at(const ArrayXXR<T>& a, size_t i) { return a.data()[i]; }
+template <typename T> T& flat_at(const ImgRef<T>& a, size_t i) { return a.data()[i]; }
+template <typename T> T& flat_at(const VecRef<T>& a, size_t i) { return a(i); }
+template <typename A, typename B, typename F>
+BoolMask compare_arrays(const A& a, const B& b, F f) {
+    if (a.size() != b.size()) throw std::invalid_argument("element-wise comparison of arrays of different size");
+    BoolMask m(a.size());
+    for (size_t i = 0; i < a.size(); ++i) m.set(i, f(flat_at(a, i), flat_at(b, i)));
+    return m;
+}
+template <typename A, typename S, typename F>
+BoolMask compare_scalar(const A& a, S s, F f) {
+    BoolMask m(a.size());
+    for (size_t i = 0; i < a.size(); ++i) m.set(i, f(flat_at(a, i), s));
+    return m;
+}
+}  // namespace impl
+
+#define OUSTER_ARRAY_CMP_(op)                                                                                          \
+    template <typename A, typename B,                                                                                  \
+              typename = typename std::enable_if<impl::is_array_like<A>::value && impl::is_array_like<B>::value &&     \
+                                                 !std::is_same<A, B>::value>::type>                                    \
+    BoolMask operator op(const A& a, const B& b) {                                                                     \
+        return impl::compare_arrays(a, b, [](const auto& x, const auto& y) { return x op y; });                        \
+    }                                                                                                                  \
+    template <typename T>                                                                                              \
+    BoolMask operator op(const ImgRef<T>& a, const ImgRef<T>& b) {                                                     \
+        return impl::compare_arrays(a, b, [](const auto& x, const auto& y) { return x op y; });                        \
+    }                                                                                                                  \
+    template <typename T>                                                                                              \
+    BoolMask operator op(const VecRef<T>& a, const VecRef<T>& b) {                                                     \
+        return impl::compare_arrays(a, b, [](const auto& x, const auto& y) { return x op y; });                        \
+    }                                                                                                                  \
+    template <typename A, typename S,                                                                                  \
+              typename = typename std::enable_if<impl::is_array_like<A>::value && std::is_arithmetic<S>::value>::type, \
+              typename = void>                                                                                         \
+    BoolMask operator op(const A& a, S s) {                                                                            \
+        return impl::compare_scalar(a, s, [](const auto& x, const auto& y) { return x op y; });                        \
+    }
+OUSTER_ARRAY_CMP_(==)
+OUSTER_ARRAY_CMP_(!=)
+#undef OUSTER_ARRAY_CMP_
 
 /** 4x4 double matrix with (row, col) access. */
 struct mat4d {

@@ -16,6 +16,7 @@
 #include <utility>
 #include <vector>
 
+#include "ouster/core/visibility.h"
 #include "ouster/core/chanfield.h"
 #include "ouster/core/data_format.h"
 #include "ouster/core/field_decode_info.h"
@@ -54,9 +55,9 @@ template <typename T> class XYZLutT;
 
 /**
  * Sensor metadata needed by the hot path: data format + calibration.  Field names match
- * ouster_core/include/ouster/core/sensor_info.h:187-211.  Metadata-JSON parsing is out of
- * scope (restated only as a POD "calibration" struct); fill the
- * members directly.
+ * ouster_core/include/ouster/core/sensor_info.h:187-211.  Fill the members directly, or read the
+ * data-format / calibration subset of a metadata JSON (SensorInfo(json_text), metadata_from_json(path),
+ * csrc/host/metadata.cpp); the rest of the reference's metadata handling is out of scope.
  */
 class SensorInfo {
    public:
@@ -74,6 +75,9 @@ class SensorInfo {
     uint32_t init_id{};
 
     SensorInfo() = default;
+    /** From the text of a metadata JSON, either generation (sensor_info.h:229, metadata.cpp:482-842).
+     *  @throw std::runtime_error on malformed JSON or an unknown lidar profile */
+    explicit SensorInfo(const std::string& metadata_json);
     Version get_version() const;  ///< parsed from fw_rev ("v2.3.0" ...)
     uint32_t w() const { return format.columns_per_frame; }
     uint32_t h() const { return format.pixels_per_column; }
@@ -87,6 +91,9 @@ class SensorInfo {
     struct Cache;
     mutable std::shared_ptr<Cache> cache_;
 };
+
+/** Read a metadata JSON file (sensor_info.h:413).  `skip_beam_validation` is accepted and ignored: nothing is validated. */
+SensorInfo metadata_from_json(const std::string& json_file, bool skip_beam_validation = false);
 
 /** sensor_info.cpp:89-105 */
 double default_lidar_origin_to_beam_origin(const std::string& prod_line);
@@ -194,6 +201,12 @@ class PacketFormat {
 
     /** Stored CRC64 of a packet; `has == false` for LEGACY / FUSA (parsing.cpp:1219-1228). */
     bool crc(const uint8_t* buffer, size_t buffer_size, uint64_t& out) const;
+    /** The reference's spelling (types.h:618): nullopt where the format carries no CRC. */
+    nonstd::optional<uint64_t> crc(const uint8_t* buffer, size_t buffer_size) const {
+        uint64_t v = 0;
+        if (!crc(buffer, buffer_size, v)) return nonstd::nullopt;
+        return v;
+    }
     uint64_t calculate_crc(const uint8_t* buffer, size_t buffer_size) const;
 
     int frame_id_difference(uint32_t current, uint32_t other) const;

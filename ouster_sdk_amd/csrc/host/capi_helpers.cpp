@@ -25,7 +25,7 @@ int ouster_core_format_desc(const char* profile_name, int header_type, uint32_t 
         df.pixels_per_column = pixels_per_column;
         df.columns_per_packet = columns_per_packet;
         df.columns_per_frame = columns_per_frame;
-        df.udp_profile_lidar = udp_profile_lidar_of_string(profile_name);
+        df.udp_profile_lidar = udp_profile_lidar_of_string(profile_name).value_or(UDPProfileLidar::UNKNOWN);
         df.header_type = header_type ? HeaderType::FUSA : HeaderType::STANDARD;
         df.column_window = {0, static_cast<int>(columns_per_frame) - 1};
         PacketFormat pf(df);
@@ -62,7 +62,7 @@ int ouster_core_format_desc(const char* profile_name, int header_type, uint32_t 
 int ouster_core_default_planes(const char* profile_name, int with_window, char* names_out,
                                size_t names_len, uint32_t* elem_sizes, uint32_t max_n) {
     try {
-        auto prof = udp_profile_lidar_of_string(profile_name);
+        auto prof = udp_profile_lidar_of_string(profile_name).value_or(UDPProfileLidar::UNKNOWN);
         auto planes = impl::default_planes(prof);
         std::string s;
         uint32_t n = 0;

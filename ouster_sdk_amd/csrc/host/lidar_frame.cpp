@@ -100,11 +100,30 @@ LidarFrameFieldTypes get_field_types(const SensorInfo& info) {
 // LidarFrame
 // ---------------------------------------------------------------------------------------
 LidarFrame::LidarFrame() = default;
-LidarFrame::LidarFrame(const LidarFrame&) = default;
+// a copy is a snapshot: whatever a batcher still owes the source is decoded first, the copy owes nothing
+LidarFrame::LidarFrame(const LidarFrame& o)
+    : w(o.w), h(o.h), frame_id(o.frame_id), frame_status(o.frame_status), shutdown_countdown(o.shutdown_countdown),
+      shot_limiting_countdown(o.shot_limiting_countdown), sensor_info(o.sensor_info),
+      timestamp_((o.sync_(), o.timestamp_)), measurement_id_(o.measurement_id_), status_(o.status_),
+      packet_timestamp_(o.packet_timestamp_), body_to_world_(o.body_to_world_), alert_flags_(o.alert_flags_),
+      fields_(o.fields_), packet_count_(o.packet_count_) {}
 LidarFrame::LidarFrame(LidarFrame&&) noexcept = default;
-LidarFrame& LidarFrame::operator=(const LidarFrame&) = default;
+LidarFrame& LidarFrame::operator=(const LidarFrame& o) {
+    if (this != &o) {
+        LidarFrame tmp(o);
+        *this = std::move(tmp);
+    }
+    return *this;
+}
 LidarFrame& LidarFrame::operator=(LidarFrame&&) noexcept = default;
 LidarFrame::~LidarFrame() = default;
+
+void LidarFrame::run_pending_() const {
+    has_pending_ = false;   // first: the decode itself goes through the accessors
+    std::shared_ptr<impl::PendingDecode> p = pending_.lock();
+    pending_.reset();
+    if (p) p->flush(const_cast<LidarFrame&>(*this));
+}
 
 LidarFrame::LidarFrame(size_t h_, size_t w_, const LidarFrameFieldTypes& field_types,
                        size_t columns_per_packet)
@@ -148,11 +167,13 @@ LidarFrame::LidarFrame(std::shared_ptr<SensorInfo> info, const LidarFrameFieldTy
 }
 
 Field& LidarFrame::field(const std::string& name) {
+    sync_();
     auto it = fields_.find(name);
     if (it == fields_.end()) throw std::out_of_range("Field '" + name + "' not found in LidarFrame");
     return it->second;
 }
 const Field& LidarFrame::field(const std::string& name) const {
+    sync_();
     auto it = fields_.find(name);
     if (it == fields_.end()) throw std::out_of_range("Field '" + name + "' not found in LidarFrame");
     return it->second;
@@ -177,6 +198,7 @@ Field& LidarFrame::add_field(const std::string& name, ChanFieldType type,
     return add_field(FieldType(name, type, std::move(extra_dims), c));
 }
 Field LidarFrame::del_field(const std::string& name) {
+    sync_();
     auto it = fields_.find(name);
     if (it == fields_.end())
         throw std::invalid_argument("Attempted deleting non existing field '" + name + "'");
@@ -367,6 +389,8 @@ uint64_t LidarFrame::get_max_valid_packet_timestamp() const {
 }
 
 bool LidarFrame::equals(const LidarFrame& o) const {
+    sync_();
+    o.sync_();
     return w == o.w && h == o.h && frame_id == o.frame_id && frame_status == o.frame_status &&
            shutdown_countdown == o.shutdown_countdown &&
            shot_limiting_countdown == o.shot_limiting_countdown && fields_ == o.fields_ &&
@@ -418,6 +442,10 @@ struct FrameBatcher::State {
     size_t expected_lidar_packets = 0;
     size_t batched_lidar_packets = 0;
     size_t dropped_packets = 0;
+    // the reference's bookkeeping of what a partially assembled frame holds (lidar_frame.cpp:1455, 1497, 1438): channel
+    // columns below next_valid_m_id are decoded or zeroed, the ones above still carry the frame's previous contents
+    uint32_t next_valid_m_id = 0, next_headers_m_id = 0;
+    std::shared_ptr<impl::PendingDecode> pending;   // what frames being assembled are told to call
 
     // packets of the frame being assembled, in arrival order
     std::vector<uint8_t> staged;
@@ -469,6 +497,7 @@ void FrameBatcher::reset() {
     s_->finished_frame_id = -1;
     s_->batched_lidar_packets = 0;
     s_->staged_count = 0;
+    s_->next_valid_m_id = s_->next_headers_m_id = 0;
     s_->cache.clear();
 }
 void FrameBatcher::set_packet_sink(PacketSink sink) { s_->sink = std::move(sink); }
@@ -487,6 +516,8 @@ struct BatcherOps {
         s.finished_frame_id = -1;
         s.batched_lidar_packets = 0;
         s.staged_count = 0;
+        s.next_valid_m_id = s.next_headers_m_id = 0;
+        frame.clear_pending_decode();   // what an earlier frame still owed this object is void: its packets are gone
         frame.frame_id = f_id;
         frame.timestamp().setZero();
         frame.measurement_id().setZero();
@@ -516,6 +547,58 @@ struct BatcherOps {
         if (len < pf.lidar_packet_size) std::memset(dst + len, 0, pf.lidar_packet_size - len);
         s.staged_count++;
         s.batched_lidar_packets++;
+        track_columns(s, pf, dst, frame);
+        if (!s.sink) frame.set_pending_decode(s.pending);
+    }
+
+    // Which columns of the frame this packet settles, as the reference's two parse paths do it (batch_lidar_packet
+    // :1541-1573 chooses; parse_by_block :1492-1500, parse_by_col :1422-1466), and the RAW_HEADERS plane, which is header
+    // bytes only and is written here, on the host, packet by packet (PackRawHeadersCol :1328-1363).
+    static void track_columns(FrameBatcher::State& s, const PacketFormat& pf, const uint8_t* buf, LidarFrame& frame) {
+        const bool raw = impl::raw_headers_enabled(pf, frame);
+        const uint32_t cpp = pf.columns_per_packet, W = static_cast<uint32_t>(frame.w);
+        uint32_t block = static_cast<uint32_t>(pf.block_parsable());
+        for (uint32_t ic = 0; ic < cpp && block; ++ic) {
+            const uint8_t* col = pf.nth_col(ic, buf);
+            if (!(pf.col_status(col) & 1u) || pf.col_measurement_id(col) >= W) block = 0;
+        }
+        for (uint32_t ic = 0; ic < cpp && block; ic += block)
+            if (pf.col_measurement_id(pf.nth_col(ic, buf)) + block > W) block = 0;
+        if (block && !raw) {
+            const uint32_t first = pf.col_measurement_id(pf.nth_col(0, buf));
+            if (first >= s.next_valid_m_id) s.next_valid_m_id = first + cpp;
+            return;
+        }
+        Field* rh = raw ? frame.peek_field(ChanField::RAW_HEADERS) : nullptr;
+        for (uint32_t ic = 0; ic < cpp; ++ic) {
+            const uint8_t* col = pf.nth_col(ic, buf);
+            const uint32_t m_id = pf.col_measurement_id(col);
+            if (m_id >= W) continue;
+            if (rh) {
+                if (m_id >= s.next_headers_m_id) {
+                    zero_raw_header_cols(*rh, s.next_headers_m_id, m_id);
+                    s.next_headers_m_id = m_id + 1;
+                }
+                // rows of column m_id: column header, column footer, packet header, packet footer, in elements of the field
+                const size_t es = rh->element_size(), Wf = rh->shape()[1];
+                uint8_t* base = static_cast<uint8_t*>(rh->get());
+                size_t row = 0;
+                auto put = [&](const uint8_t* src, size_t bytes) {
+                    for (size_t k = 0; k < bytes / es; ++k, ++row) std::memcpy(base + (row * Wf + m_id) * es, src + k * es, es);
+                };
+                put(col, pf.col_header_size);
+                put(col + pf.col_size - pf.col_footer_size, pf.col_footer_size);
+                put(buf, pf.packet_header_size);
+                put(pf.footer(buf), pf.packet_footer_size);
+            }
+            if ((pf.col_status(col) & 1u) && m_id >= s.next_valid_m_id) s.next_valid_m_id = m_id + 1;
+        }
+    }
+    static void zero_raw_header_cols(Field& rh, size_t from, size_t to) {
+        const size_t es = rh.element_size(), H = rh.shape()[0], Wf = rh.shape()[1];
+        uint8_t* base = static_cast<uint8_t*>(rh.get());
+        if (to > Wf) to = Wf;
+        for (size_t r = 0; r < H && from < to; ++r) std::memset(base + (r * Wf + from) * es, 0, (to - from) * es);
     }
 
     static bool frame_complete(const FrameBatcher::State& s, const PacketFormat& pf,
@@ -532,8 +615,11 @@ struct BatcherOps {
             for (size_t i = 0; i < s.staged_count; ++i) ptrs[i] = s.staged.data() + i * s.stride;
             s.sink(ptrs);
         } else {
-            decode_staged(s, pf, frame);
+            frame.clear_pending_decode();
+            decode_staged(s, pf, frame, frame.w);
         }
+        if (impl::raw_headers_enabled(pf, frame))
+            zero_raw_header_cols(*frame.peek_field(ChanField::RAW_HEADERS), s.next_headers_m_id, frame.w);
         if (frame.sensor_info && frame.sensor_info->init_id == s.last_init_id &&
             frame.frame_id <= s.last_frame_id && pf.header_type == HeaderType::FUSA)
             throw std::runtime_error("32-bit frame id did not increase since the last frame");
@@ -544,7 +630,9 @@ struct BatcherOps {
     }
 
     // one GPU launch: every plane the frame shares with the packet format + column headers
-    static void decode_staged(FrameBatcher::State& s, const PacketFormat& pf, LidarFrame& frame) {
+    // `col_limit` < W: a look at a frame that is still being assembled -- only the channel columns the reference would
+    // have settled by now (below next_valid_m_id) are taken over, the rest of every plane keeps what it held
+    static void decode_staged(FrameBatcher::State& s, const PacketFormat& pf, LidarFrame& frame, size_t col_limit) {
         hip::ScopedContext on_my_context(s.context());
         std::vector<std::pair<std::string, uint32_t>> fields;
         std::vector<bool> nan;
@@ -604,8 +692,18 @@ struct BatcherOps {
         hip::check(ouster_hip_decode(ctx, s.fmt, static_cast<const uint8_t*>(s.d_packets.data()),
                                      s.stride, static_cast<uint32_t>(slots), &count, 1, nullptr, &out,
                                      nullptr, nullptr, 0));
-        for (size_t i = 0; i < dst.size(); ++i)
-            s.d_out.download(dst[i]->get(), H * W * elems[i], off[i]);
+        if (col_limit >= W) {
+            for (size_t i = 0; i < dst.size(); ++i) s.d_out.download(dst[i]->get(), H * W * elems[i], off[i]);
+        } else if (col_limit > 0) {
+            std::vector<uint8_t> tmp;
+            for (size_t i = 0; i < dst.size(); ++i) {
+                tmp.resize(H * W * elems[i]);
+                s.d_out.download(tmp.data(), tmp.size(), off[i]);
+                uint8_t* out_plane = static_cast<uint8_t*>(dst[i]->get());
+                for (size_t r = 0; r < H; ++r)
+                    std::memcpy(out_plane + r * W * elems[i], tmp.data() + r * W * elems[i], col_limit * elems[i]);
+            }
+        }
         s.d_out.download(frame.timestamp().data(), W * 8, off_ts);
         s.d_out.download(frame.status().data(), W * 4, off_st);
         s.d_out.download(frame.measurement_id().data(), W * 2, off_mid);
@@ -622,12 +720,27 @@ struct BatcherOps {
     }
 };
 
-void FrameBatcher::flush(LidarFrame& frame) {
-    if (frame.frame_id != -1 && s_->finished_frame_id < 0) BatcherOps::decode_staged(*s_, pf, frame);
-}
+namespace {
+// what a frame under assembly calls when somebody looks at it (lidar_frame.h: impl::PendingDecode).  It refers to the
+// batcher's heap state, which stays where it is when the FrameBatcher object is moved.
+struct BatcherPending : impl::PendingDecode {
+    FrameBatcher::State* state;
+    PacketFormat pf;
+    BatcherPending(FrameBatcher::State* s, const PacketFormat& f) : state(s), pf(f) {}
+    void flush(LidarFrame& frame) override {
+        if (frame.frame_id != -1 && state->finished_frame_id < 0 && !state->sink && state->staged_count) {
+            frame.clear_pending_decode();
+            BatcherOps::decode_staged(*state, pf, frame, std::min<size_t>(state->next_valid_m_id, frame.w));
+        }
+    }
+};
+}  // namespace
+
+void FrameBatcher::flush(LidarFrame& frame) { BatcherPending(s_.get(), pf).flush(frame); }
 
 bool FrameBatcher::batch(const Packet& packet, LidarFrame& frame) {
     State& s = *s_;
+    if (!s.pending) s.pending = std::make_shared<BatcherPending>(&s, pf);
     if (s.reset_frame) {
         frame.frame_id = -1;
         s.reset_frame = false;
@@ -726,6 +839,15 @@ bool FrameBatcher::batch(const Packet& packet, LidarFrame& frame) {
 // ---------------------------------------------------------------------------------------
 namespace impl {
 
+bool raw_headers_enabled(const PacketFormat& pf, const LidarFrame& frame) {
+    const Field* fp = frame.peek_field(ChanField::RAW_HEADERS);
+    if (!fp) return false;
+    const Field& f = *fp;
+    if (f.shape().size() != 2) return false;
+    return pf.pixels_per_column * f.element_size() >=
+           pf.packet_header_size + pf.col_header_size + pf.col_footer_size + pf.packet_footer_size;
+}
+
 namespace {
 template <typename T>
 void pack_plane(const PacketFormat& pf, const Field& f, const std::string& name, int cols,
@@ -789,7 +911,29 @@ std::vector<LidarPacket> frame_to_packets(const LidarFrame& frame,
                 default: break;
             }
         }
-        if (pf->udp_profile_lidar != UDPProfileLidar::LEGACY &&
+        if (raw_headers_enabled(*pf, frame)) {
+            // the recorded headers and footers replace the ones written above, checksum included
+            // (PacketFormat::unpack_raw_headers, types.h:1122-1164; element types wider than 32 bit are refused there)
+            const Field& rh = frame.field(ChanField::RAW_HEADERS);
+            const size_t es = rh.element_size(), Wf = rh.shape()[1];
+            if (es > 4)
+                throw std::invalid_argument("RAW_HEADERS field should be of typeuint32_t or smaller to work correctly");
+            const uint8_t* base = static_cast<const uint8_t*>(rh.get());
+            const size_t ch = pf->col_header_size / es, cf = pf->col_footer_size / es, ph = pf->packet_header_size / es,
+                         pfo = pf->packet_footer_size / es;
+            auto get = [&](uint8_t* dstp, size_t row0, size_t n, size_t m_id) {
+                for (size_t k = 0; k < n; ++k) std::memcpy(dstp + k * es, base + ((row0 + k) * Wf + m_id) * es, es);
+            };
+            size_t m0 = pf->col_measurement_id(pf->nth_col(0, buf));
+            get(buf, ch + cf, ph, m0);
+            get(pf->footer(buf), ch + cf + ph, pfo, m0);
+            for (uint32_t icol = 0; icol < cpp; ++icol) {
+                uint8_t* col = pf->nth_col(icol, buf);
+                const size_t m_id = pf->col_measurement_id(col);   // read BEFORE the header is replaced
+                get(col, 0, ch, m_id);
+                get(col + pf->col_size - pf->col_footer_size, ch, cf, m_id);
+            }
+        } else if (pf->udp_profile_lidar != UDPProfileLidar::LEGACY &&
             pf->header_type == HeaderType::STANDARD) {
             const uint64_t crc = pf->calculate_crc(buf, pkt.buf.size());
             std::memcpy(buf + pkt.buf.size() - sizeof crc, &crc, sizeof crc);

@@ -19,6 +19,7 @@
 
 #include "host_internal.h"
 #include "ouster/core/profile_extension.h"
+#include "ouster/core/packet.h"
 #include "ouster/core/types.h"
 #include "ouster_hip.h"
 
@@ -324,11 +325,38 @@ std::string to_string(UDPProfileLidar profile) {
     return "UNKNOWN";
 }
 
-UDPProfileLidar udp_profile_lidar_of_string(const std::string& s) {
+nonstd::optional<UDPProfileLidar> udp_profile_lidar_of_string(const std::string& s) {
     std::lock_guard<std::mutex> lk(registry_mutex());
     for (const auto& e : registry())
         if (e.name == s) return static_cast<UDPProfileLidar>(e.profile);
-    return UDPProfileLidar::UNKNOWN;
+    return nonstd::nullopt;
+}
+
+// data_format.cpp:183-230 of the reference: the IMU profile and header type name tables
+std::string to_string(UDPProfileIMU profile) {
+    switch (profile) {
+        case UDPProfileIMU::LEGACY: return "LEGACY";
+        case UDPProfileIMU::ACCEL32_GYRO32_NMEA: return "ACCEL32_GYRO32_NMEA";
+        case UDPProfileIMU::OFF: return "OFF";
+    }
+    return "UNKNOWN";
+}
+nonstd::optional<UDPProfileIMU> udp_profile_imu_of_string(const std::string& s) {
+    for (auto p : {UDPProfileIMU::LEGACY, UDPProfileIMU::ACCEL32_GYRO32_NMEA, UDPProfileIMU::OFF})
+        if (to_string(p) == s) return p;
+    return nonstd::nullopt;
+}
+std::string to_string(HeaderType profile) {
+    switch (profile) {
+        case HeaderType::STANDARD: return "STANDARD";
+        case HeaderType::FUSA: return "FUSA";
+    }
+    return "UNKNOWN";
+}
+nonstd::optional<HeaderType> udp_profile_type_of_string(const std::string& s) {
+    for (auto p : {HeaderType::STANDARD, HeaderType::FUSA})
+        if (to_string(p) == s) return p;
+    return nonstd::nullopt;
 }
 
 void add_custom_profile(int profile_nr, const std::string& name,
@@ -375,6 +403,25 @@ UDPProfileLidar add_custom_profile(
 namespace impl {
 std::vector<std::pair<std::string, ChanFieldType>> default_planes(UDPProfileLidar profile) {
     return lookup(profile).planes;
+}
+
+// The profile table as the reference's tests look at it (tests/packet_format_test.cpp:27-36 declares this function and
+// the entry layout itself; parsing.cpp:365-420 holds the reference's table): MAX_NUM_PROFILES slots, the registered
+// profiles first, the rest zero.  The field pointers stay valid while no profile is added.
+struct ProfileEntry {
+    const std::pair<std::string, FieldDecodeInfo>* fields;
+    size_t n_fields;
+    size_t chan_data_size;
+};
+std::array<std::pair<UDPProfileLidar, ProfileEntry>, MAX_NUM_PROFILES> get_profiles() {
+    std::array<std::pair<UDPProfileLidar, ProfileEntry>, MAX_NUM_PROFILES> out{};
+    std::lock_guard<std::mutex> lk(registry_mutex());
+    size_t i = 0;
+    for (const auto& e : registry()) {
+        if (i == out.size()) break;
+        out[i++] = {static_cast<UDPProfileLidar>(e.profile), ProfileEntry{e.fields.data(), e.fields.size(), e.chan_bytes}};
+    }
+    return out;
 }
 }  // namespace impl
 
@@ -731,6 +778,22 @@ int SensorInfo::num_returns() const {
         default:
             return 1;
     }
+}
+
+// packet.cpp:28-73 of the reference, lidar packets (an IMU / zone sized buffer has no counterpart here: every buffer that
+// is not explicitly of another kind is held against the lidar packet size)
+PacketValidationFailure validate_packet(const SensorInfo& info, const PacketFormat& format, const uint8_t* buf,
+                                        uint64_t buf_size, PacketType type) {
+    if (type == PacketType::Unknown) type = PacketType::Lidar;
+    if (type == PacketType::Lidar && buf_size != format.lidar_packet_size) return PacketValidationFailure::PACKET_SIZE;
+    if (type == PacketType::Imu && format.udp_profile_imu == UDPProfileIMU::LEGACY) return PacketValidationFailure::NONE;
+    const uint32_t init_id = format.init_id(buf);
+    if (info.init_id != 0 && init_id != 0 && init_id != info.init_id) return PacketValidationFailure::ID;
+    if (info.sn != 0) {
+        const uint64_t sn = format.prod_sn(buf);
+        if (sn != 0 && sn != info.sn) return PacketValidationFailure::ID;
+    }
+    return PacketValidationFailure::NONE;
 }
 
 }  // namespace core

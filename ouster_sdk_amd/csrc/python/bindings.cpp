@@ -135,7 +135,7 @@ PYBIND11_MODULE(core, m) {
         .value("RNG19_RFL8_SIG16_NIR16_RGB16", UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_RGB16)
         .value("RNG19_RFL8_SIG16_NIR16_RGB16_DUAL", UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_RGB16_DUAL)
         .value("OFF", UDPProfileLidar::OFF)
-        .def_static("from_string", &udp_profile_lidar_of_string);
+        .def_static("from_string", [](const std::string& s) { return udp_profile_lidar_of_string(s).value_or(UDPProfileLidar::UNKNOWN); });
     py::enum_<HeaderType>(m, "HeaderType").value("STANDARD", HeaderType::STANDARD).value("FUSA", HeaderType::FUSA);
 
     py::class_<DataFormat>(m, "DataFormat")

@@ -35,7 +35,7 @@ static size_t matrix_hash(const Field& f) {
 int main(int argc, char** argv) {
     if (argc < 9) return 2;
     SensorInfo info;
-    info.format.udp_profile_lidar = udp_profile_lidar_of_string(argv[2]);
+    info.format.udp_profile_lidar = udp_profile_lidar_of_string(argv[2]).value_or(UDPProfileLidar::UNKNOWN);
     info.format.header_type = std::atoi(argv[3]) ? HeaderType::FUSA : HeaderType::STANDARD;
     info.format.pixels_per_column = static_cast<uint32_t>(std::atoi(argv[4]));
     info.format.columns_per_frame = static_cast<uint32_t>(std::atoi(argv[5]));
