@@ -344,6 +344,24 @@ inline void destagger_into(const ImgRef<const T>& img, const std::vector<int>& p
                           pixel_shift_by_row, inverse, destaggered.rows(), destaggered.cols());
 }
 
+/** n-d form: the dimensions behind (row, column) travel with the pixel (impl/lidar_frame_impl.h:776-811).
+ *  @throw std::invalid_argument("image height does not match shifts size" / "image and destaggered must have the same shape") */
+template <typename T, int ndim>
+inline void destagger_into(const ConstArrayView<T, static_cast<size_t>(ndim)>& img, const std::vector<int>& pixel_shift_by_row,
+                           bool inverse, ArrayView<T, static_cast<size_t>(ndim)> destaggered) {
+    static_assert(ndim >= 2, "an image has rows and columns");
+    if (pixel_shift_by_row.size() != img.shape[0]) throw std::invalid_argument{"image height does not match shifts size"};
+    size_t extra = 1;
+    for (int d = 0; d < ndim; ++d) {
+        if (img.shape[d] != destaggered.shape[d]) throw std::invalid_argument{"image and destaggered must have the same shape"};
+        if (d >= 2) extra *= img.shape[d];
+    }
+    if (img.sparse() || destaggered.sparse()) throw std::invalid_argument{"destagger needs dense row-major images"};
+    if (extra == 0) return;
+    impl::destagger_bytes(img.data(), destaggered.data(), img.shape[0], img.shape[1], sizeof(T) * extra,
+                          pixel_shift_by_row, inverse, destaggered.shape[0], destaggered.shape[1]);
+}
+
 template <typename T>
 inline img_t<T> destagger(const ImgRef<const T>& img, const std::vector<int>& pixel_shift_by_row,
                           bool inverse = false) {

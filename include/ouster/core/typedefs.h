@@ -20,6 +20,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -43,6 +44,9 @@ using EigenImg = Eigen::Array<T, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor
 template <typename T>
 using EigenX3R = Eigen::Array<T, Eigen::Dynamic, 3, Eigen::RowMajor>;
 #endif
+
+template <typename T> class ImgRef;
+template <typename T> class VecRef;
 
 /** Dense row-major 2-D array owning its storage (zero initialised). */
 template <typename T>
@@ -75,6 +79,56 @@ class ArrayXXR {
         for (size_t i = 0; i < d_.size(); ++i) r.data()[i] = static_cast<U>(d_[i]);
         return r;
     }
+    // ---- the handful of Eigen::Array conveniences the reference's callers lean on -------------------------------
+    static ArrayXXR Zero(size_t rows, size_t cols) { return ArrayXXR(rows, cols); }
+    static ArrayXXR Constant(size_t rows, size_t cols, T v) {
+        ArrayXXR a(rows, cols);
+        a.setConstant(v);
+        return a;
+    }
+    /** Pseudo-random fill: integers over their whole range, floating point in [-1, 1] (as Eigen's Random()). */
+    static ArrayXXR Random(size_t rows, size_t cols) {
+        ArrayXXR a(rows, cols);
+        for (auto& v : a.d_) v = random_value();
+        return a;
+    }
+    /** Equal shapes and element-wise equal (integers) / equal within `prec` relative to the smaller norm (floating point). */
+    template <typename O>
+    bool isApprox(const O& o, double prec = 1e-12) const {
+        if (rows() != o.rows() || cols() != o.cols()) return false;
+        if (std::is_integral<T>::value) {
+            for (size_t i = 0; i < size(); ++i)
+                if (!(d_[i] == o.data()[i])) return false;
+            return true;
+        }
+        if (std::is_same<T, float>::value && prec == 1e-12) prec = 1e-5;
+        double diff = 0, na = 0, nb = 0;
+        for (size_t i = 0; i < size(); ++i) {
+            const double a = static_cast<double>(d_[i]), b = static_cast<double>(o.data()[i]);
+            diff += (a - b) * (a - b);
+            na += a * a;
+            nb += b * b;
+        }
+        return diff <= prec * prec * std::min(na, nb);
+    }
+    /** op(element) for every element, as a new array. */
+    template <typename F>
+    ArrayXXR unaryExpr(F f) const {
+        ArrayXXR r(rows_, cols_);
+        for (size_t i = 0; i < d_.size(); ++i) r.d_[i] = static_cast<T>(f(d_[i]));
+        return r;
+    }
+    VecRef<T> row(size_t r);
+    VecRef<const T> row(size_t r) const;
+    VecRef<T> col(size_t c);
+    VecRef<const T> col(size_t c) const;
+    /** View of `r` whole rows from row `i` on (a block that is not one dense run of memory is refused).
+     *  @throw std::invalid_argument */
+    ImgRef<T> block(size_t i, size_t j, size_t r, size_t c);
+    T& operator()(size_t i) { return d_[i]; }   ///< flat, row-major
+    const T& operator()(size_t i) const { return d_[i]; }
+    T& operator[](size_t i) { return d_[i]; }
+    const T& operator[](size_t i) const { return d_[i]; }
 #ifdef OUSTER_HIP_USE_EIGEN
     /** from any dense Eigen expression (copied element by element: any storage order) */
     template <typename D>
@@ -90,6 +144,15 @@ class ArrayXXR {
 #endif
 
    private:
+    static T random_value() {
+        static uint64_t state = 0x9E3779B97F4A7C15ull;   // splitmix64: deterministic, good enough for test data
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        if (std::is_floating_point<T>::value) return static_cast<T>(static_cast<double>(z >> 11) / 4503599627370496.0 - 1.0);
+        return static_cast<T>(z);
+    }
     size_t rows_ = 0, cols_ = 0;
     std::vector<T> d_;
 };
@@ -112,6 +175,12 @@ class ArrayX3R : public ArrayXXR<T> {
         for (size_t i = 0; i < this->size(); ++i) r.data()[i] = static_cast<U>(this->data()[i]);
         return r;
     }
+    ArrayX3R(const ArrayXXR<T>& a) : ArrayXXR<T>(a) {
+        if (a.cols() != 3) throw std::invalid_argument("ArrayX3R needs 3 columns");
+    }
+    static ArrayX3R Zero(size_t rows, size_t cols = 3) { return ArrayX3R(rows, cols); }
+    static ArrayX3R Constant(size_t rows, size_t cols, T v) { return ArrayX3R(ArrayXXR<T>::Constant(rows, cols, v)); }
+    static ArrayX3R Random(size_t rows, size_t cols = 3) { return ArrayX3R(ArrayXXR<T>::Random(rows, cols)); }
 #ifdef OUSTER_HIP_USE_EIGEN
     template <typename D>
     ArrayX3R(const Eigen::DenseBase<D>& e) : ArrayXXR<T>(e) {
@@ -122,6 +191,9 @@ class ArrayX3R : public ArrayXXR<T> {
     }
 #endif
 };
+
+using ArrayX3dR = ArrayX3R<double>;   ///< typedefs.h of the reference
+using ArrayX3fR = ArrayX3R<float>;
 
 template <typename T>
 using PointCloudXYZ = ArrayX3R<T>;
@@ -161,6 +233,17 @@ class VecRef {
         for (size_t i = 0; i < n_; ++i) p_[i * stride_] = v;
         return *this;
     }
+    /** element-wise copy from a view of the same length (Eigen: block = block).  @throw std::invalid_argument */
+    template <typename U>
+    const VecRef& assign(const VecRef<U>& o) const {
+        if (o.size() != n_) throw std::invalid_argument("assignment between views of different length");
+        for (size_t i = 0; i < n_; ++i) p_[i * stride_] = o(i);
+        return *this;
+    }
+    const VecRef& operator=(const VecRef& o) const { return assign(o); }
+    template <typename U, typename = typename std::enable_if<!std::is_same<U, T>::value>::type>
+    const VecRef& operator=(const VecRef<U>& o) const { return assign(o); }
+    VecRef(const VecRef&) = default;
     void setZero() const { *this = T{}; }
     size_t count() const {   ///< non-zero entries
         size_t c = 0;
@@ -219,6 +302,17 @@ class ImgRef {
     T* p_;
     size_t rows_, cols_;
 };
+
+template <typename T> VecRef<T> ArrayXXR<T>::row(size_t r) { return VecRef<T>(data() + r * cols_, cols_, 1); }
+template <typename T> VecRef<const T> ArrayXXR<T>::row(size_t r) const { return VecRef<const T>(data() + r * cols_, cols_, 1); }
+template <typename T> VecRef<T> ArrayXXR<T>::col(size_t c) { return VecRef<T>(data() + c, rows_, cols_); }
+template <typename T> VecRef<const T> ArrayXXR<T>::col(size_t c) const { return VecRef<const T>(data() + c, rows_, cols_); }
+template <typename T>
+ImgRef<T> ArrayXXR<T>::block(size_t i, size_t j, size_t r, size_t c) {
+    if (i + r > rows_ || j + c > cols_) throw std::out_of_range("block outside the array");
+    if (j != 0 || c != cols_) throw std::invalid_argument("block: only whole rows form one dense run of memory");
+    return ImgRef<T>(data() + i * cols_, r, c);
+}
 
 // ---- element-wise comparisons of the array stand-ins -> BoolMask -------------------------------------------------
 namespace impl {

@@ -51,6 +51,29 @@ struct Version {
     }
 };
 
+/** Output resolution and frame rate of the lidar (sensor_config.h:27-63). */
+struct LidarMode {
+    /** From "COLUMNSxFPS".  @throw std::invalid_argument("Invalid lidar mode string ...") */
+    explicit LidarMode(const std::string& mode);
+    LidarMode(unsigned int cols, unsigned int framerate) : columns(cols), fps(framerate) {}
+    unsigned int columns;
+    unsigned int fps;
+    static const LidarMode _512x10, _512x20, _1024x10, _1024x20, _2048x10, _4096x5;
+};
+inline bool operator==(const LidarMode& a, const LidarMode& b) { return a.columns == b.columns && a.fps == b.fps; }
+inline bool operator!=(const LidarMode& a, const LidarMode& b) { return !(a == b); }
+std::string to_string(LidarMode mode);
+nonstd::optional<LidarMode> lidar_mode_of_string(const std::string& s);
+inline uint32_t n_cols_of_lidar_mode(LidarMode mode) { return mode.columns; }
+inline unsigned int frequency_of_lidar_mode(LidarMode mode) { return mode.fps; }
+
+/** The two entries of the reference's SensorConfig (sensor_config.h:233-420) that describe the data this path decodes;
+ *  the rest of the sensor configuration (ports, sync, NMEA ...) is out of scope. */
+struct SensorConfig {
+    nonstd::optional<LidarMode> lidar_mode;
+    nonstd::optional<UDPProfileLidar> udp_profile_lidar;
+};
+
 template <typename T> class XYZLutT;
 
 /**
@@ -65,6 +88,7 @@ class SensorInfo {
     std::string fw_rev{};
     std::string prod_line{};
     DataFormat format{};
+    SensorConfig config{};
     std::vector<double> beam_azimuth_angles{};
     std::vector<double> beam_altitude_angles{};
     double lidar_origin_to_beam_origin_mm{};

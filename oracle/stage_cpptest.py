@@ -26,11 +26,30 @@ def drop_block(lines, suite, name):
     return lines, False
 
 
+def drop_function(lines, name):
+    """A free function defined at file scope (its signature may span lines): from the line that starts its declaration
+    to the closing brace."""
+    for i, ln in enumerate(lines):
+        if re.search(r"\b%s\s*\(" % re.escape(name), ln) and not ln.startswith((" ", "\t", "//", "TEST")):
+            depth, j, seen = 0, i, False
+            while j < len(lines):
+                depth += lines[j].count("{") - lines[j].count("}")
+                seen = seen or "{" in lines[j]
+                if seen and depth == 0:
+                    break
+                j += 1
+            if j == len(lines):
+                raise SystemExit("unbalanced braces in %s" % name)
+            return lines[:i] + ["// [function %s is not staged: see oracle/Makefile]\n" % name] + lines[j + 1:], True
+    return lines, False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("src")
     ap.add_argument("dst")
     ap.add_argument("--drop", action="append", default=[], help="Suite.name of a TEST to leave out")
+    ap.add_argument("--drop-function", action="append", default=[], help="file-scope helper function to leave out")
     a = ap.parse_args()
     lines = open(a.src).readlines()
     for d in a.drop:
@@ -38,6 +57,10 @@ def main():
         lines, found = drop_block(lines, suite, name)
         if not found:
             sys.exit("%s: no TEST %s" % (a.src, d))
+    for d in a.drop_function:
+        lines, found = drop_function(lines, d)
+        if not found:
+            sys.exit("%s: no function %s" % (a.src, d))
     open(a.dst, "w").writelines(lines)
 
 

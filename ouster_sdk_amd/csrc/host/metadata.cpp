@@ -185,6 +185,35 @@ mat4d mat_from(const Json& j, const mat4d& fallback) {
 
 }  // namespace
 
+LidarMode::LidarMode(const std::string& mode) {
+    const size_t split = mode.find('x');
+    try {
+        if (split == std::string::npos) throw std::invalid_argument("");
+        const int c = std::stoi(mode.substr(0, split)), f = std::stoi(mode.substr(split + 1));
+        if (c < 0 || f < 0) throw std::invalid_argument("");
+        columns = static_cast<unsigned int>(c);
+        fps = static_cast<unsigned int>(f);
+    } catch (const std::invalid_argument&) {
+        throw std::invalid_argument("Invalid lidar mode string \"" + mode + "\".");
+    } catch (const std::out_of_range&) {
+        throw std::invalid_argument("Invalid lidar mode string \"" + mode + "\".");
+    }
+}
+const LidarMode LidarMode::_512x10 = {512, 10};
+const LidarMode LidarMode::_512x20 = {512, 20};
+const LidarMode LidarMode::_1024x10 = {1024, 10};
+const LidarMode LidarMode::_1024x20 = {1024, 20};
+const LidarMode LidarMode::_2048x10 = {2048, 10};
+const LidarMode LidarMode::_4096x5 = {4096, 5};
+std::string to_string(LidarMode mode) { return std::to_string(mode.columns) + "x" + std::to_string(mode.fps); }
+nonstd::optional<LidarMode> lidar_mode_of_string(const std::string& s) {
+    try {
+        return LidarMode(s);
+    } catch (const std::invalid_argument&) {
+        return {};
+    }
+}
+
 SensorInfo::SensorInfo(const std::string& metadata_json) {
     const Json d = Parser(metadata_json).parse();
     if (d.kind != Json::Object) throw std::runtime_error("metadata JSON: not an object");
@@ -205,6 +234,7 @@ SensorInfo::SensorInfo(const std::string& metadata_json) {
         w_mode = static_cast<uint32_t>(std::strtoul(mode.substr(0, x).c_str(), nullptr, 10));
         fps = static_cast<uint16_t>(std::strtoul(mode.substr(x + 1).c_str(), nullptr, 10));
     }
+    config.lidar_mode = lidar_mode_of_string(mode);
     format = default_data_format(w_mode, fps);
     if (!df.at("pixels_per_column").is_null()) format.pixels_per_column = static_cast<uint32_t>(df.at("pixels_per_column").as_u64());
     if (!df.at("columns_per_packet").is_null()) format.columns_per_packet = static_cast<uint32_t>(df.at("columns_per_packet").as_u64());
@@ -231,6 +261,7 @@ SensorInfo::SensorInfo(const std::string& metadata_json) {
         if (!p) throw std::runtime_error("metadata JSON: unknown udp_profile_lidar " + profile);
         format.udp_profile_lidar = *p;
     }
+    if (const auto p = udp_profile_lidar_of_string(cfg.at("udp_profile_lidar").as_string())) config.udp_profile_lidar = *p;
     std::string imu_profile = df.at("udp_profile_imu").as_string();
     if (imu_profile.empty()) imu_profile = cfg.at("udp_profile_imu").as_string();
     if (const auto p = udp_profile_imu_of_string(imu_profile)) format.udp_profile_imu = *p;

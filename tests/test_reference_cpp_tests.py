@@ -1,7 +1,7 @@
 """The REFERENCE's own C++ tests of this path, run against this repo.
 
-`oracle/Makefile` (target refcpptests) compiles tests/packet_format_test.cpp, tests/frame_batcher_test.cpp and
-tests/profile_extension_test.cpp of ouster-sdk from where they lie against the mirror of the ouster_core API under include/
+`oracle/Makefile` (target refcpptests) compiles tests/packet_format_test.cpp, frame_batcher_test.cpp,
+profile_extension_test.cpp, fusa_profile_test.cpp, destagger_test.cpp and cartesian_test.cpp of ouster-sdk from where they lie against the mirror of the ouster_core API under include/
 and links them with ouster_sdk_amd/lib -- the reference's assertions (profile bit tables, header accessors, encode -> decode
 round trips, dropped / reordered / wrapped-around packets, the snapshot hashes of five recorded captures, init-id and serial
 number handling ...) then run on the product, FrameBatcher decoding on the GPU.  Not the reference's: a GoogleTest stand-in
@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 BIN = os.path.join(ROOT, "oracle", "_ref", "cpptests")
 DATA = os.path.join(ROOT, "tests", "golden", "pcaps")
 # test binary -> the least number of test cases it must hold (a staging accident that drops cases must not go unnoticed)
-SUITES = {"packet_format_test": 47, "frame_batcher_test": 49, "profile_extension_test": 1}
+SUITES = {"packet_format_test": 47, "frame_batcher_test": 49, "profile_extension_test": 1, "fusa_profile_test": 2,
+          "destagger_test": 10, "cartesian_test": 2}
 
 
 @pytest.mark.parametrize("name", sorted(SUITES))
@@ -34,8 +35,8 @@ def test_reference_cpp_test_file_passes(name):
     ran = re.search(r"\[==========\] (\d+) tests ran", out)
     passed = re.search(r"\[  PASSED  \] (\d+) tests", out)
     assert ran and passed, out[-3000:] + p.stderr[-2000:]
-    failed = re.findall(r"^\[  FAILED  \] (\S+)$", out, re.M)
-    skipped = re.findall(r"^\[  SKIPPED \] (\S+)", out, re.M)
+    failed = re.findall(r"^\[  FAILED  \] (\S+\.\S+)$", out, re.M)
+    skipped = set(re.findall(r"^\[  SKIPPED \] (\S+\.\S+)", out, re.M))
     print("%s: %s ran, %s passed, %d skipped, %d failed" % (name, ran.group(1), passed.group(1), len(skipped), len(set(failed))))
     assert p.returncode == 0 and not failed, "\n".join(sorted(set(failed))) + "\n" + out[-6000:]
     assert int(ran.group(1)) >= SUITES[name] and int(passed.group(1)) + len(skipped) == int(ran.group(1))
