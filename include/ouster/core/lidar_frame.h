@@ -28,6 +28,36 @@ namespace sdk {
 namespace core {
 
 enum class FieldClass { NONE = 0, PIXEL_FIELD = 1, COLUMN_FIELD = 2, PACKET_FIELD = 3, FRAME_FIELD = 4 };
+std::string to_string(FieldClass c);   ///< field.cpp:81-87
+
+/** Element type and full shape of a field to create (the array part of field.h:116-297). */
+struct FieldDescriptor {
+    ChanFieldType element_type = ChanFieldType::VOID;
+    std::vector<size_t> shape;
+    ChanFieldType tag() const { return element_type; }
+    size_t size() const {
+        size_t n = 1;
+        for (size_t d : shape) n *= d;
+        return n;
+    }
+    size_t bytes() const { return size() * field_type_size(element_type); }
+    template <typename T>
+    static FieldDescriptor array(std::vector<size_t> shape_in) {
+        return FieldDescriptor{FieldTag<T>::tag, std::move(shape_in)};
+    }
+    static FieldDescriptor array(ChanFieldType tag, std::vector<size_t> shape_in) {
+        return FieldDescriptor{tag, std::move(shape_in)};
+    }
+};
+/** fd_array<T>(d0, d1, ...) / fd_array(tag, d0, d1, ...) (field.h:305-316) */
+template <typename T, typename... Args>
+FieldDescriptor fd_array(Args&&... args) {
+    return FieldDescriptor::array<T>({static_cast<size_t>(args)...});
+}
+template <typename... Args>
+FieldDescriptor fd_array(ChanFieldType tag, Args&&... args) {
+    return FieldDescriptor::array(tag, {static_cast<size_t>(args)...});
+}
 
 /** Name, element type and extra dimensions of a LidarFrame field (lidar_frame.h:36-74). */
 struct FieldType {
@@ -46,6 +76,8 @@ struct FieldType {
     bool operator<(const FieldType& o) const { return name < o.name; }
 };
 using LidarFrameFieldTypes = std::vector<FieldType>;
+std::string to_string(const FieldType& field_type);              ///< lidar_frame.cpp:1119-1147
+std::string to_string(const LidarFrameFieldTypes& field_types);
 
 /** Owning, zero-initialised, typed n-d buffer (field.h:828-905, field.cpp:247-296). */
 class Field {
@@ -217,6 +249,8 @@ class LidarFrame {
     explicit LidarFrame(const SensorInfo& info);
     explicit LidarFrame(std::shared_ptr<SensorInfo> info);
     LidarFrame(std::shared_ptr<SensorInfo> info, const LidarFrameFieldTypes& field_types);
+    /** Deprecated in the reference too: the LEGACY profile's fields, 16 columns per packet (lidar_frame.h:229). */
+    LidarFrame(size_t h, size_t w);
     /** @throw std::invalid_argument for zero dims / zero columns_per_packet. */
     LidarFrame(size_t h, size_t w, const LidarFrameFieldTypes& field_types,
                size_t columns_per_packet = DEFAULT_COLUMNS_PER_PACKET);
@@ -236,6 +270,9 @@ class LidarFrame {
     }
     bool has_field(const std::string& name) const;
     Field& add_field(const FieldType& type);
+    /** A field of the descriptor's full shape; pixel / column / packet fields must start with the frame's own extents
+     *  (lidar_frame.cpp:463-510).  @throw std::invalid_argument with the reference's texts */
+    Field& add_field(const std::string& name, const FieldDescriptor& desc, FieldClass field_class = FieldClass::PIXEL_FIELD);
     Field& add_field(const std::string& name, ChanFieldType type, std::vector<size_t> extra_dims = {},
                      FieldClass c = FieldClass::PIXEL_FIELD);
     Field del_field(const std::string& name);
@@ -323,6 +360,9 @@ class LidarFrame {
     size_t packet_count_{0};
 };
 
+/** Human-readable summary: extents, frame id and status, field types, min / mean / max of every numeric field
+ *  (lidar_frame.cpp:1149-1250). */
+std::string to_string(const LidarFrame& lidar_frame);
 bool operator==(const LidarFrame& a, const LidarFrame& b);
 inline bool operator!=(const LidarFrame& a, const LidarFrame& b) { return !(a == b); }
 

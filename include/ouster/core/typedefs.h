@@ -293,6 +293,11 @@ class ImgRef {
     VecRef<T> col(size_t c) const { return VecRef<T>(p_ + c, rows_, cols_); }
     VecRef<T> row(size_t r) const { return VecRef<T>(p_ + r * cols_, cols_, 1); }
     void setConstant(NC v) const { std::fill(p_, p_ + size(), v); }
+    const ImgRef& operator=(NC v) const {   ///< fill, as assigning a scalar to an Eigen::Ref of an array does
+        setConstant(v);
+        return *this;
+    }
+    ImgRef(const ImgRef&) = default;
     void setZero() const { setConstant(NC{}); }
     size_t count() const { return static_cast<size_t>(size() - std::count(p_, p_ + size(), NC{})); }
     bool all() const { return count() == size(); }

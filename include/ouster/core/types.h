@@ -39,6 +39,9 @@ enum class ShotLimitingStatus {
     REDUCTION_60_70 = 0x08, REDUCTION_70_75 = 0x09
 };
 
+std::string to_string(ThermalShutdownStatus status);   ///< sensor_info.cpp:505-514
+std::string to_string(ShotLimitingStatus status);
+
 /** Firmware version triple (lidar_frame.cpp:1097-1110 compares against 3.2.0). */
 struct Version {
     uint16_t major = 0, minor = 0, patch = 0;
@@ -86,6 +89,7 @@ class SensorInfo {
    public:
     uint64_t sn{};
     std::string fw_rev{};
+    std::string image_rev{};   ///< image_rev of the metadata (sensor_info.h:192); the same string as fw_rev on current firmware
     std::string prod_line{};
     DataFormat format{};
     SensorConfig config{};

@@ -353,40 +353,53 @@ int RunAllTests(int argc, char** argv);   // gtest_main.cpp
 #define EXPECT_NEAR(a, b, tol) OUSTER_GTEST_PRED_(::testing::internal::CmpNear(#a, #b, a, b, tol), OUSTER_GTEST_NONFATAL_)
 #define ASSERT_NEAR(a, b, tol) OUSTER_GTEST_PRED_(::testing::internal::CmpNear(#a, #b, a, b, tol), OUSTER_GTEST_FATAL_)
 
-#define OUSTER_GTEST_THROW_(stmt, extype, on_fail)                                                                      \
-    OUSTER_GTEST_PRED_(([&]() -> ::testing::internal::Result {                                                          \
-                           try {                                                                                        \
-                               stmt;                                                                                    \
-                           } catch (const extype&) {                                                                    \
-                               return {true, {}};                                                                       \
-                           } catch (...) {                                                                              \
-                               return {false, "Expected: " #stmt " throws " #extype ".\n  Actual: it throws a different type."}; \
-                           }                                                                                            \
-                           return {false, "Expected: " #stmt " throws " #extype ".\n  Actual: it throws nothing."};     \
-                       })(),                                                                                            \
-                       on_fail)
-#define OUSTER_GTEST_NO_THROW_(stmt, on_fail)                                                                            \
-    OUSTER_GTEST_PRED_(([&]() -> ::testing::internal::Result {                                                          \
-                           try {                                                                                        \
-                               stmt;                                                                                    \
-                           } catch (const std::exception& e) {                                                          \
-                               return {false, std::string("Expected: " #stmt " doesn't throw.\n  Actual: it throws: ") + e.what()}; \
-                           } catch (...) {                                                                              \
-                               return {false, "Expected: " #stmt " doesn't throw.\n  Actual: it throws."};              \
-                           }                                                                                            \
-                           return {true, {}};                                                                           \
-                       })(),                                                                                            \
-                       on_fail)
-#define OUSTER_GTEST_ANY_THROW_(stmt, on_fail)                                                                           \
-    OUSTER_GTEST_PRED_(([&]() -> ::testing::internal::Result {                                                          \
-                           try {                                                                                        \
-                               stmt;                                                                                    \
-                           } catch (...) {                                                                              \
-                               return {true, {}};                                                                       \
-                           }                                                                                            \
-                           return {false, "Expected: " #stmt " throws.\n  Actual: it doesn't."};                        \
-                       })(),                                                                                            \
-                       on_fail)
+// The statement runs in the test body itself (not in a lambda): ASSERT_* inside it may `return` from the test, as with GoogleTest.
+#define OUSTER_GTEST_CAT2_(a, b) a##b
+#define OUSTER_GTEST_CAT_(a, b) OUSTER_GTEST_CAT2_(a, b)
+#define OUSTER_GTEST_THROW_(stmt, extype, on_fail)                                                                   \
+    OUSTER_GTEST_AMBIGUOUS_ELSE_ if (::testing::internal::Result gtest_r_ = ::testing::internal::Result{true, {}}) { \
+        bool gtest_caught_ = false;                                                                                  \
+        try {                                                                                                        \
+            stmt;                                                                                                    \
+        } catch (const extype&) {                                                                                    \
+            gtest_caught_ = true;                                                                                    \
+        } catch (...) {                                                                                              \
+            gtest_r_ = {false, "Expected: " #stmt " throws " #extype ".\n  Actual: it throws a different type."};    \
+            goto OUSTER_GTEST_CAT_(gtest_label_throw_, __LINE__);                                                    \
+        }                                                                                                            \
+        if (!gtest_caught_) {                                                                                        \
+            gtest_r_ = {false, "Expected: " #stmt " throws " #extype ".\n  Actual: it throws nothing."};             \
+            goto OUSTER_GTEST_CAT_(gtest_label_throw_, __LINE__);                                                    \
+        }                                                                                                            \
+    } else                                                                                                           \
+        OUSTER_GTEST_CAT_(gtest_label_throw_, __LINE__) : on_fail(gtest_r_.msg)
+#define OUSTER_GTEST_NO_THROW_(stmt, on_fail)                                                                        \
+    OUSTER_GTEST_AMBIGUOUS_ELSE_ if (::testing::internal::Result gtest_r_ = ::testing::internal::Result{true, {}}) { \
+        try {                                                                                                        \
+            stmt;                                                                                                    \
+        } catch (const std::exception& e) {                                                                          \
+            gtest_r_ = {false, std::string("Expected: " #stmt " doesn't throw.\n  Actual: it throws: ") + e.what()}; \
+            goto OUSTER_GTEST_CAT_(gtest_label_nothrow_, __LINE__);                                                  \
+        } catch (...) {                                                                                              \
+            gtest_r_ = {false, "Expected: " #stmt " doesn't throw.\n  Actual: it throws."};                          \
+            goto OUSTER_GTEST_CAT_(gtest_label_nothrow_, __LINE__);                                                  \
+        }                                                                                                            \
+    } else                                                                                                           \
+        OUSTER_GTEST_CAT_(gtest_label_nothrow_, __LINE__) : on_fail(gtest_r_.msg)
+#define OUSTER_GTEST_ANY_THROW_(stmt, on_fail)                                                                       \
+    OUSTER_GTEST_AMBIGUOUS_ELSE_ if (::testing::internal::Result gtest_r_ = ::testing::internal::Result{true, {}}) { \
+        bool gtest_caught_ = false;                                                                                  \
+        try {                                                                                                        \
+            stmt;                                                                                                    \
+        } catch (...) {                                                                                              \
+            gtest_caught_ = true;                                                                                    \
+        }                                                                                                            \
+        if (!gtest_caught_) {                                                                                        \
+            gtest_r_ = {false, "Expected: " #stmt " throws.\n  Actual: it doesn't."};                                \
+            goto OUSTER_GTEST_CAT_(gtest_label_anythrow_, __LINE__);                                                 \
+        }                                                                                                            \
+    } else                                                                                                           \
+        OUSTER_GTEST_CAT_(gtest_label_anythrow_, __LINE__) : on_fail(gtest_r_.msg)
 #define EXPECT_THROW(stmt, extype) OUSTER_GTEST_THROW_(stmt, extype, OUSTER_GTEST_NONFATAL_)
 #define ASSERT_THROW(stmt, extype) OUSTER_GTEST_THROW_(stmt, extype, OUSTER_GTEST_FATAL_)
 #define EXPECT_NO_THROW(stmt) OUSTER_GTEST_NO_THROW_(stmt, OUSTER_GTEST_NONFATAL_)

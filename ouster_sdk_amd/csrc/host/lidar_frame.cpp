@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstring>
 #include <deque>
+#include <sstream>
 
 #include "host_internal.h"
 #include "ouster/core/lidar_frame.h"
@@ -145,6 +146,9 @@ LidarFrame::LidarFrame(size_t h_, size_t w_, const LidarFrameFieldTypes& field_t
         for (int d = 0; d < 4; ++d) poses[i * 16 + d * 5] = 1.0;
 }
 
+LidarFrame::LidarFrame(size_t h_, size_t w_)
+    : LidarFrame(h_, w_, get_field_types(UDPProfileLidar::LEGACY), DEFAULT_COLUMNS_PER_PACKET) {}
+
 LidarFrame::LidarFrame(size_t h_, size_t w_, UDPProfileLidar profile, size_t columns_per_packet)
     : LidarFrame(h_, w_, get_field_types(profile), columns_per_packet) {}
 
@@ -197,6 +201,28 @@ Field& LidarFrame::add_field(const std::string& name, ChanFieldType type,
                              std::vector<size_t> extra_dims, FieldClass c) {
     return add_field(FieldType(name, type, std::move(extra_dims), c));
 }
+Field& LidarFrame::add_field(const std::string& name, const FieldDescriptor& desc, FieldClass field_class) {
+    if (has_field(name)) throw std::invalid_argument("Duplicated field '" + name + "'");
+    const auto& sh = desc.shape;
+    if (field_class == FieldClass::PIXEL_FIELD) {
+        if (sh.size() < 2) throw std::invalid_argument("Pixel fields must have at least 2 dimensions");
+        if (sh[0] != h || sh[1] != w)
+            throw std::invalid_argument("Pixel field shape must match LidarFrame's width and height. Was " +
+                                        std::to_string(sh[0]) + "x" + std::to_string(sh[1]) + " vs " + std::to_string(h) +
+                                        "x" + std::to_string(w));
+        for (size_t d : sh)
+            if (d == 0) throw std::invalid_argument("Cannot add pixel field with 0 elements.");
+    }
+    if (field_class == FieldClass::COLUMN_FIELD && (sh.empty() || sh[0] != w))
+        throw std::invalid_argument("Column field shape must match LidarFrame's height. Width was " +
+                                    std::to_string(sh.empty() ? 0 : sh[0]) + " vs required width of " + std::to_string(w));
+    if (field_class == FieldClass::PACKET_FIELD && (sh.empty() || sh[0] != packet_count_))
+        throw std::invalid_argument("Packet field shape must match number of packets. Width was " +
+                                    std::to_string(sh.empty() ? 0 : sh[0]) + " vs required width of " +
+                                    std::to_string(packet_count_));
+    return fields_.emplace(name, Field(desc.element_type, sh, field_class)).first->second;
+}
+
 Field LidarFrame::del_field(const std::string& name) {
     sync_();
     auto it = fields_.find(name);
@@ -399,6 +425,75 @@ bool LidarFrame::equals(const LidarFrame& o) const {
            alert_flags_ == o.alert_flags_ && body_to_world_ == o.body_to_world_;
 }
 bool operator==(const LidarFrame& a, const LidarFrame& b) { return a.equals(b); }
+
+std::string to_string(FieldClass c) {
+    switch (c) {
+        case FieldClass::PIXEL_FIELD: return "PIXEL_FIELD";
+        case FieldClass::COLUMN_FIELD: return "COLUMN_FIELD";
+        case FieldClass::PACKET_FIELD: return "PACKET_FIELD";
+        case FieldClass::FRAME_FIELD: return "FRAME_FIELD";
+        default: return "UNKNOWN";
+    }
+}
+std::string to_string(const FieldType& ft) {
+    std::string out = ft.name + ": " + to_string(ft.element_type) + " (";
+    for (size_t i = 0; i < ft.extra_dims.size(); ++i) out += (i ? ", " : "") + std::to_string(ft.extra_dims[i]);
+    return out + ") " + to_string(ft.field_class);
+}
+std::string to_string(const LidarFrameFieldTypes& fts) {
+    std::string out = "(";
+    for (size_t i = 0; i < fts.size(); ++i) out += (i ? ", " : "") + to_string(fts[i]);
+    return out + ")";
+}
+
+namespace {
+template <typename T>
+void min_mean_max(const Field& f, std::ostream& os) {
+    const T* p = static_cast<const T*>(f.get());
+    double lo = static_cast<double>(p[0]), hi = lo, sum = 0;
+    for (size_t i = 0; i < f.size(); ++i) {
+        const double v = static_cast<double>(p[i]);
+        lo = std::min(lo, v);
+        hi = std::max(hi, v);
+        sum += v;
+    }
+    os << "min: " << lo << "; mean: " << sum / static_cast<double>(f.size()) << "; max: " << hi;
+}
+}  // namespace
+
+std::string to_string(const LidarFrame& frame) {
+    std::ostringstream os;
+    os << "LidarFrame: {h = " << frame.h << ", w = " << frame.w << ", packets_per_frame = " << frame.packet_timestamp().size()
+       << ", fid = " << frame.frame_id << "," << std::endl
+       << " frame status = " << std::hex << frame.frame_status << std::dec
+       << ", thermal_shutdown status = " << to_string(frame.thermal_shutdown())
+       << ", shot_limiting status = " << to_string(frame.shot_limiting()) << "," << std::endl
+       << "  field_types = " << to_string(frame.field_types()) << "," << std::endl;
+    for (const auto& kv : frame.fields()) {
+        const Field& f = kv.second;
+        os << "     " << kv.first << " type:" << to_string(f.tag()) << " shape: (";
+        for (size_t i = 0; i < f.shape().size(); ++i) os << (i ? ", " : "") << f.shape()[i];
+        os << ") ";
+        if (f.bytes() > 0) {
+            switch (f.tag()) {
+                case ChanFieldType::UINT8: min_mean_max<uint8_t>(f, os); break;
+                case ChanFieldType::UINT16: min_mean_max<uint16_t>(f, os); break;
+                case ChanFieldType::UINT32: min_mean_max<uint32_t>(f, os); break;
+                case ChanFieldType::UINT64: min_mean_max<uint64_t>(f, os); break;
+                case ChanFieldType::INT8: min_mean_max<int8_t>(f, os); break;
+                case ChanFieldType::INT16: min_mean_max<int16_t>(f, os); break;
+                case ChanFieldType::INT32: min_mean_max<int32_t>(f, os); break;
+                case ChanFieldType::INT64: min_mean_max<int64_t>(f, os); break;
+                case ChanFieldType::FLOAT32: min_mean_max<float>(f, os); break;
+                case ChanFieldType::FLOAT64: min_mean_max<double>(f, os); break;
+                default: break;   // text, half floats and zone states have no summary here
+            }
+        }
+        os << std::endl;
+    }
+    os << "}";
+    return os.str();
+}
 
 uint64_t column_timestamp_at_destaggered_pixel(size_t row, size_t col,
                                                const std::vector<int>& pixel_shift_by_row,

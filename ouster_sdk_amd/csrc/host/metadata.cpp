@@ -214,6 +214,21 @@ nonstd::optional<LidarMode> lidar_mode_of_string(const std::string& s) {
     }
 }
 
+std::string to_string(ThermalShutdownStatus status) {
+    switch (status) {
+        case ThermalShutdownStatus::NORMAL: return "NORMAL";
+        case ThermalShutdownStatus::IMMINENT: return "IMMINENT";
+    }
+    return "UNKNOWN";
+}
+std::string to_string(ShotLimitingStatus status) {
+    static const char* const names[] = {"NORMAL", "IMMINENT", "REDUCTION_0_10", "REDUCTION_10_20", "REDUCTION_20_30",
+                                        "REDUCTION_30_40", "REDUCTION_40_50", "REDUCTION_50_60", "REDUCTION_60_70",
+                                        "REDUCTION_70_75"};
+    const unsigned v = static_cast<unsigned>(status);
+    return v < sizeof names / sizeof names[0] ? names[v] : "UNKNOWN";
+}
+
 SensorInfo::SensorInfo(const std::string& metadata_json) {
     const Json d = Parser(metadata_json).parse();
     if (d.kind != Json::Object) throw std::runtime_error("metadata JSON: not an object");
@@ -273,8 +288,9 @@ SensorInfo::SensorInfo(const std::string& metadata_json) {
     bi.at("beam_altitude_angles").flatten(beam_altitude_angles);
     bi.at("beam_azimuth_angles").flatten(beam_azimuth_angles);
     prod_line = si.at("prod_line").as_string();
+    image_rev = si.at("image_rev").as_string();
     fw_rev = si.at("build_rev").as_string();
-    if (fw_rev.empty()) fw_rev = si.at("image_rev").as_string();
+    if (fw_rev.empty()) fw_rev = image_rev;
     std::vector<double> b2l;
     bi.at("beam_to_lidar_transform").flatten(b2l);
     const Json& origin = bi.at("lidar_origin_to_beam_origin_mm");
