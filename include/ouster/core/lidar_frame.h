@@ -457,22 +457,19 @@ class FrameBatcher {
     ~FrameBatcher();
 
     /**
-     * Add a packet to the frame; returns true when `lidar_frame` is ready.  The frame's
-     * planes and column headers are written when the frame completes (one GPU decode per
-     * frame); packet_timestamp / alert_flags / frame-level values are updated per packet
-     * exactly as the reference does.
+     * Add a packet to the frame; returns true when `lidar_frame` is ready.  packet_timestamp / alert_flags /
+     * frame-level values are updated per packet exactly as the reference does; the frame's planes and column headers
+     * are written by ONE GPU decode when the frame completes -- or earlier, when somebody looks: a frame that is still
+     * being assembled decodes what has arrived the first time its planes or headers are accessed (impl::PendingDecode),
+     * and then shows what the reference's packet-by-packet parse would (columns below the highest settled one decoded
+     * or zeroed, the others unchanged).
      * @throw std::invalid_argument("unexpected frame dimensions") etc. as the reference
      * @throw std::runtime_error for a non-increasing FUSA frame id
      */
     bool batch(const Packet& packet, LidarFrame& lidar_frame);
     bool operator()(const Packet& packet, LidarFrame& lidar_frame) { return batch(packet, lidar_frame); }
     void reset();
-    /**
-     * Extension (not in the reference, whose batcher decodes packet by packet): decode the
-     * packets collected so far into `lidar_frame` without releasing the frame, so a caller can
-     * look at a partially assembled frame.  Columns not received yet read as zero.  Batching
-     * continues normally afterwards.
-     */
+    /** Extension: decode the packets collected so far into `lidar_frame` now (what the first access would do). */
     void flush(LidarFrame& lidar_frame);
     /**
      * Extension: hand every released frame's packets (arrival order, each lidar_packet_size bytes,
