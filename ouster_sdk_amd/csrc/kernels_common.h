@@ -777,7 +777,12 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                     const double rm = (double)rr - lut.n;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
+#ifdef OUSTER_ABLATE_XYZ_MATH   // experiment builds only (tools/ab/ablate.sh): how much of the kernel's time is the arithmetic?
+                        const XT t = (XT)rr;
+                        (void)rm;
+#else
                         const XT t = (XT)fma(rm, d[c][k], cc.kc[c][k]);
+#endif
                         p[c][k] = rr ? t : (XT)0;
                     }
                 }

@@ -65,7 +65,7 @@ for rnd in range(6):
         torch.cuda.synchronize()
         times[name].append(a.elapsed_time(b) / 20)
         for k, v in ref.items():
-            if k in ("frame_meta", "gate_counts"): continue
+            if k in ("frame_meta", "gate_counts") or os.environ.get("AB_NOCHECK"): continue   # ablation builds differ by design
             assert torch.equal(v.view(torch.uint8), out[k].view(torch.uint8)), (name, k)
 print(json.dumps({"workload": wl, "wide": wide, "tiles": {n: list(h.ctx.last_decode_tile()) for n, h in hps.items()},
                   "ms_per_call_median": {n: round(float(np.median(t)), 4) for n, t in times.items()},
