@@ -223,6 +223,9 @@ class VecRef {
     VecRef(T* p, size_t n, size_t stride = 1) : p_(p), n_(n), stride_(stride) {}
     size_t size() const { return n_; }
     size_t rows() const { return n_; }
+    T* data() const { return p_; }           ///< the first element; the next one is stride() elements further on
+    size_t stride() const { return stride_; }
+    size_t innerStride() const { return stride_; }
     T& operator()(size_t i) const { return p_[i * stride_]; }
     T& operator[](size_t i) const { return p_[i * stride_]; }
     VecRef segment(size_t start, size_t n) const {

@@ -35,7 +35,7 @@ OSFS = ["OS-1-128_v2.3.0_1024x10_lb_n3.osf", "OS-0-128_v3.0.1_1024x10_20241017_1
 
 def osf_goldens():
     """Copies the OSF fixtures and pins the first one on the capture the reference wrote it from:
-    tests/pcaps/OS-1-128_v2.3.0_1024x10_lb_n3.pcap (too big to carry along) is decoded here with the
+    tests/pcaps/OS-1-128_v2.3.0_1024x10_lb_n3.pcap is decoded here with the
     packet oracle (itself pinned on the reference's digests / snapshot hashes) and the sha256 of every
     plane and column header of its three frames goes to osf/lb_n3_pcap_planes.json."""
     import ctypes as C
@@ -83,6 +83,11 @@ def main():
             src = os.path.join(REF, "tests", "pcaps", base + ext)
             if os.path.exists(src):
                 shutil.copyfile(src, os.path.join(dst, base + ext))
+
+    # the pair the reference's parsing_benchmark_test.cpp reads besides the captures above (its names do not follow the
+    # <base>.pcap / <base>.json pattern)
+    for name in ("OS-1-128_v2.3.0_1024x10_lb_n3.pcap", "OS-1-128_v2.3.0_1024x10.json"):
+        shutil.copyfile(os.path.join(REF, "tests", "pcaps", name), os.path.join(dst, name))
 
     # snapshot hashes from the C++ test source
     text = open(os.path.join(REF, "tests", "frame_batcher_test.cpp")).read()

@@ -22,7 +22,7 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "cpptests")
 DATA = os.path.join(ROOT, "tests", "golden", "pcaps")
 # test binary -> the least number of test cases it must hold (a staging accident that drops cases must not go unnoticed)
 SUITES = {"packet_format_test": 47, "frame_batcher_test": 49, "profile_extension_test": 1, "fusa_profile_test": 2,
-          "destagger_test": 10, "cartesian_test": 2, "lidar_frame_test": 21}
+          "destagger_test": 10, "cartesian_test": 2, "lidar_frame_test": 21, "parsing_benchmark_test": 10}
 
 
 @pytest.mark.parametrize("name", sorted(SUITES))
