@@ -339,7 +339,7 @@ class LidarFrame {
         return it == fields_.end() ? nullptr : const_cast<Field*>(&it->second);
     }
     /** Used by FrameBatcher: the decode that the next look at this frame's data triggers (none: empty pointer). */
-    void set_pending_decode(std::weak_ptr<impl::PendingDecode> p) const {
+    void set_pending_decode(std::shared_ptr<impl::PendingDecode> p) const {
         pending_ = std::move(p);
         has_pending_ = true;
     }
@@ -353,7 +353,7 @@ class LidarFrame {
         if (has_pending_) run_pending_();
     }
     void run_pending_() const;
-    mutable std::weak_ptr<impl::PendingDecode> pending_;
+    mutable std::shared_ptr<impl::PendingDecode> pending_;   ///< keeps the batcher's staged packets alive, even past the batcher
     mutable bool has_pending_ = false;
     Field timestamp_, measurement_id_, status_, packet_timestamp_, body_to_world_, alert_flags_;
     std::map<std::string, Field> fields_;
@@ -495,7 +495,7 @@ class FrameBatcher {
     struct State;  ///< implementation detail (host state machine + staging + device buffers)
 
    private:
-    std::unique_ptr<State> s_;
+    std::shared_ptr<State> s_;   ///< shared with the frames that still owe a decode of its staged packets
 };
 
 namespace impl {

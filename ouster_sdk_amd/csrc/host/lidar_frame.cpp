@@ -121,7 +121,7 @@ LidarFrame::~LidarFrame() = default;
 
 void LidarFrame::run_pending_() const {
     has_pending_ = false;   // first: the decode itself goes through the accessors
-    std::shared_ptr<impl::PendingDecode> p = pending_.lock();
+    std::shared_ptr<impl::PendingDecode> p = std::move(pending_);
     pending_.reset();
     if (p) p->flush(const_cast<LidarFrame&>(*this));
 }
@@ -525,7 +525,7 @@ struct CachedPacket {
 };
 }  // namespace
 
-struct FrameBatcher::State {
+struct FrameBatcher::State : std::enable_shared_from_this<FrameBatcher::State> {
     std::shared_ptr<SensorInfo> info;
     size_t max_cache_size = 4;
     std::deque<CachedPacket> cache;  // small (<= max_cache_size); searched linearly
@@ -540,7 +540,7 @@ struct FrameBatcher::State {
     // the reference's bookkeeping of what a partially assembled frame holds (lidar_frame.cpp:1455, 1497, 1438): channel
     // columns below next_valid_m_id are decoded or zeroed, the ones above still carry the frame's previous contents
     uint32_t next_valid_m_id = 0, next_headers_m_id = 0;
-    std::shared_ptr<impl::PendingDecode> pending;   // what frames being assembled are told to call
+    std::weak_ptr<impl::PendingDecode> pending;     // what frames being assembled are told to call (they own it, and through it this state)
 
     // packets of the frame being assembled, in arrival order
     std::vector<uint8_t> staged;
@@ -593,6 +593,7 @@ void FrameBatcher::reset() {
     s_->batched_lidar_packets = 0;
     s_->staged_count = 0;
     s_->next_valid_m_id = s_->next_headers_m_id = 0;
+    s_->pending.reset();
     s_->cache.clear();
 }
 void FrameBatcher::set_packet_sink(PacketSink sink) { s_->sink = std::move(sink); }
@@ -612,7 +613,8 @@ struct BatcherOps {
         s.batched_lidar_packets = 0;
         s.staged_count = 0;
         s.next_valid_m_id = s.next_headers_m_id = 0;
-        frame.clear_pending_decode();   // what an earlier frame still owed this object is void: its packets are gone
+        s.pending.reset();              // notes left on frames of an earlier assembly are void: their packets are gone
+        frame.clear_pending_decode();
         frame.frame_id = f_id;
         frame.timestamp().setZero();
         frame.measurement_id().setZero();
@@ -643,8 +645,9 @@ struct BatcherOps {
         s.staged_count++;
         s.batched_lidar_packets++;
         track_columns(s, pf, dst, frame);
-        if (!s.sink) frame.set_pending_decode(s.pending);
+        if (!s.sink) frame.set_pending_decode(pending_note(s, pf));
     }
+    static std::shared_ptr<impl::PendingDecode> pending_note(FrameBatcher::State& s, const PacketFormat& pf);
 
     // Which columns of the frame this packet settles, as the reference's two parse paths do it (batch_lidar_packet
     // :1541-1573 chooses; parse_by_block :1492-1500, parse_by_col :1422-1466), and the RAW_HEADERS plane, which is header
@@ -819,10 +822,14 @@ namespace {
 // what a frame under assembly calls when somebody looks at it (lidar_frame.h: impl::PendingDecode).  It refers to the
 // batcher's heap state, which stays where it is when the FrameBatcher object is moved.
 struct BatcherPending : impl::PendingDecode {
-    FrameBatcher::State* state;
+    std::shared_ptr<FrameBatcher::State> state;   // shared: the frame can still be looked at after the batcher is gone
     PacketFormat pf;
-    BatcherPending(FrameBatcher::State* s, const PacketFormat& f) : state(s), pf(f) {}
+    bool standalone;   // FrameBatcher::flush(): an explicit request, not a note left on a frame
+    BatcherPending(std::shared_ptr<FrameBatcher::State> s, const PacketFormat& f, bool alone = false)
+        : state(std::move(s)), pf(f), standalone(alone) {}
     void flush(LidarFrame& frame) override {
+        // a note is good for the frame the batcher is assembling NOW: start_frame / reset() retire the earlier ones
+        if (!standalone && state->pending.lock().get() != this) return;
         if (frame.frame_id != -1 && state->finished_frame_id < 0 && !state->sink && state->staged_count) {
             frame.clear_pending_decode();
             BatcherOps::decode_staged(*state, pf, frame, std::min<size_t>(state->next_valid_m_id, frame.w));
@@ -831,11 +838,19 @@ struct BatcherPending : impl::PendingDecode {
 };
 }  // namespace
 
-void FrameBatcher::flush(LidarFrame& frame) { BatcherPending(s_.get(), pf).flush(frame); }
+std::shared_ptr<impl::PendingDecode> BatcherOps::pending_note(FrameBatcher::State& s, const PacketFormat& pf) {
+    std::shared_ptr<impl::PendingDecode> p = s.pending.lock();
+    if (!p) {
+        p = std::make_shared<BatcherPending>(s.shared_from_this(), pf);
+        s.pending = p;
+    }
+    return p;
+}
+
+void FrameBatcher::flush(LidarFrame& frame) { BatcherPending(s_, pf, true).flush(frame); }
 
 bool FrameBatcher::batch(const Packet& packet, LidarFrame& frame) {
     State& s = *s_;
-    if (!s.pending) s.pending = std::make_shared<BatcherPending>(&s, pf);
     if (s.reset_frame) {
         frame.frame_id = -1;
         s.reset_frame = false;

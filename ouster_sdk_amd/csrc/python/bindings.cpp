@@ -75,6 +75,24 @@ const uint8_t* buf_ptr(const py::buffer& b, size_t min_size) {
     return static_cast<const uint8_t*>(info.ptr);
 }
 
+// the bytes of a packet argument: a LidarPacket, or anything with the buffer protocol (bytearray, numpy uint8 array)
+const uint8_t* packet_bytes(const py::object& o, size_t min_size) {
+    if (py::isinstance<LidarPacket>(o)) {
+        const LidarPacket& p = o.cast<const LidarPacket&>();
+        if (p.buf.size() < min_size)
+            throw std::invalid_argument("Incompatible argument: expected a packet of size >= " + std::to_string(min_size));
+        return p.buf.data();
+    }
+    return buf_ptr(o.cast<py::buffer>(), min_size);
+}
+uint8_t* packet_bytes_mut(const py::object& o, size_t min_size) {
+    if (py::isinstance<LidarPacket>(o)) return const_cast<uint8_t*>(packet_bytes(o, min_size));
+    py::buffer_info info = o.cast<py::buffer>().request(true);
+    if (static_cast<size_t>(info.size * info.itemsize) < min_size)
+        throw std::invalid_argument("Incompatible argument: expected a bytearray of size >= " + std::to_string(min_size));
+    return static_cast<uint8_t*>(info.ptr);
+}
+
 template <typename T>
 py::array lut_call(const XYZLutT<T>& lut, const py::object& arg) {
     PointCloudXYZ<T> pts;
@@ -137,6 +155,59 @@ PYBIND11_MODULE(core, m) {
         .value("OFF", UDPProfileLidar::OFF)
         .def_static("from_string", [](const std::string& s) { return udp_profile_lidar_of_string(s).value_or(UDPProfileLidar::UNKNOWN); });
     py::enum_<HeaderType>(m, "HeaderType").value("STANDARD", HeaderType::STANDARD).value("FUSA", HeaderType::FUSA);
+    py::enum_<UDPProfileIMU>(m, "UDPProfileIMU")
+        .value("LEGACY", UDPProfileIMU::LEGACY)
+        .value("ACCEL32_GYRO32_NMEA", UDPProfileIMU::ACCEL32_GYRO32_NMEA)
+        .value("OFF", UDPProfileIMU::OFF);
+    py::enum_<ThermalShutdownStatus>(m, "ThermalShutdownStatus")
+        .value("NORMAL", ThermalShutdownStatus::NORMAL)
+        .value("IMMINENT", ThermalShutdownStatus::IMMINENT);
+    py::enum_<ShotLimitingStatus>(m, "ShotLimitingStatus")
+        .value("NORMAL", ShotLimitingStatus::NORMAL)
+        .value("IMMINENT", ShotLimitingStatus::IMMINENT)
+        .value("REDUCTION_0_10", ShotLimitingStatus::REDUCTION_0_10)
+        .value("REDUCTION_10_20", ShotLimitingStatus::REDUCTION_10_20)
+        .value("REDUCTION_20_30", ShotLimitingStatus::REDUCTION_20_30)
+        .value("REDUCTION_30_40", ShotLimitingStatus::REDUCTION_30_40)
+        .value("REDUCTION_40_50", ShotLimitingStatus::REDUCTION_40_50)
+        .value("REDUCTION_50_60", ShotLimitingStatus::REDUCTION_50_60)
+        .value("REDUCTION_60_70", ShotLimitingStatus::REDUCTION_60_70)
+        .value("REDUCTION_70_75", ShotLimitingStatus::REDUCTION_70_75);
+    py::enum_<FieldClass>(m, "FieldClass")
+        .value("PIXEL_FIELD", FieldClass::PIXEL_FIELD)
+        .value("COLUMN_FIELD", FieldClass::COLUMN_FIELD)
+        .value("PACKET_FIELD", FieldClass::PACKET_FIELD)
+        .value("FRAME_FIELD", FieldClass::FRAME_FIELD);
+    py::class_<LidarMode>(m, "LidarMode")
+        .def(py::init<const std::string&>())
+        .def(py::init<unsigned int, unsigned int>())
+        .def_readwrite("columns", &LidarMode::columns)
+        .def_readwrite("fps", &LidarMode::fps)
+        .def("__eq__", [](const LidarMode& a, const LidarMode& b) { return a == b; })
+        .def("__str__", [](const LidarMode& a) { return to_string(a); })
+        .def_readonly_static("_512x10", &LidarMode::_512x10)
+        .def_readonly_static("_512x20", &LidarMode::_512x20)
+        .def_readonly_static("_1024x10", &LidarMode::_1024x10)
+        .def_readonly_static("_1024x20", &LidarMode::_1024x20)
+        .def_readonly_static("_2048x10", &LidarMode::_2048x10)
+        .def_readonly_static("_4096x5", &LidarMode::_4096x5);
+    py::class_<SensorConfig>(m, "SensorConfig")
+        .def(py::init<>())
+        .def_readwrite("lidar_mode", &SensorConfig::lidar_mode)
+        .def_readwrite("udp_profile_lidar", &SensorConfig::udp_profile_lidar);
+    // lidar_frame.h:36-74; the element type travels as a numpy dtype
+    py::class_<FieldType>(m, "FieldType")
+        .def(py::init([](const std::string& name, const py::object& dt, std::vector<size_t> extra, FieldClass c) {
+                 return FieldType(name, tag_of(py::dtype::from_args(dt)), std::move(extra), c);
+             }),
+             py::arg("name"), py::arg("dtype"), py::arg("extra_dims") = std::vector<size_t>{},
+             py::arg("field_class") = FieldClass::PIXEL_FIELD)
+        .def_readwrite("name", &FieldType::name)
+        .def_property_readonly("element_type", [](const FieldType& f) { return dtype_of(f.element_type); })
+        .def_readwrite("extra_dims", &FieldType::extra_dims)
+        .def_readwrite("field_class", &FieldType::field_class)
+        .def("__eq__", [](const FieldType& a, const FieldType& b) { return a == b; })
+        .def("__repr__", [](const FieldType& f) { return to_string(f); });
 
     py::class_<DataFormat>(m, "DataFormat")
         .def(py::init<>())
@@ -148,11 +219,20 @@ PYBIND11_MODULE(core, m) {
         .def_readwrite("udp_profile_lidar", &DataFormat::udp_profile_lidar)
         .def_readwrite("header_type", &DataFormat::header_type)
         .def_readwrite("fps", &DataFormat::fps)
+        .def_readwrite("udp_profile_imu", &DataFormat::udp_profile_imu)
+        .def_readwrite("imu_packets_per_frame", &DataFormat::imu_packets_per_frame)
+        .def_readwrite("imu_measurements_per_packet", &DataFormat::imu_measurements_per_packet)
+        .def_readwrite("zone_monitoring_enabled", &DataFormat::zone_monitoring_enabled)
+        .def("valid_columns_per_frame", &DataFormat::valid_columns_per_frame)
         .def("lidar_packets_per_frame", &DataFormat::lidar_packets_per_frame);
 
-    py::class_<SensorInfo>(m, "SensorInfo")
+    py::class_<SensorInfo, std::shared_ptr<SensorInfo>>(m, "SensorInfo")
         .def(py::init<>())
+        .def(py::init<const std::string&>(), py::arg("metadata_json"))   // sensor_info.h:229
         .def("__copy__", [](const SensorInfo& s) { return SensorInfo(s); })
+        .def("__deepcopy__", [](const SensorInfo& s, const py::dict&) { return SensorInfo(s); })
+        .def_readwrite("config", &SensorInfo::config)
+        .def_readwrite("image_rev", &SensorInfo::image_rev)
         .def_readwrite("sn", &SensorInfo::sn)
         .def_readwrite("fw_rev", &SensorInfo::fw_rev)
         .def_readwrite("prod_line", &SensorInfo::prod_line)
@@ -192,9 +272,68 @@ PYBIND11_MODULE(core, m) {
                                    for (auto it = pf.begin(); it != pf.end(); ++it) names.push_back(it->first);
                                    return names;
                                })
-        .def("frame_id", [](const PacketFormat& pf, const py::buffer& b) { return pf.frame_id(buf_ptr(b, 32)); })
-        .def("init_id", [](const PacketFormat& pf, const py::buffer& b) { return pf.init_id(buf_ptr(b, 32)); })
-        .def("prod_sn", [](const PacketFormat& pf, const py::buffer& b) { return pf.prod_sn(buf_ptr(b, 32)); })
+        .def_readonly("udp_profile_imu", &PacketFormat::udp_profile_imu)
+        .def_readonly("header_type", &PacketFormat::header_type)
+        .def_readonly("max_frame_id", &PacketFormat::max_frame_id)
+        // header getters: a LidarPacket or a buffer (python/src/cpp/client/packet.cpp)
+        .def("packet_type", [](const PacketFormat& pf, const py::object& b) { return pf.packet_type(packet_bytes(b, 32)); })
+        .def("frame_id", [](const PacketFormat& pf, const py::object& b) { return pf.frame_id(packet_bytes(b, 32)); })
+        .def("init_id", [](const PacketFormat& pf, const py::object& b) { return pf.init_id(packet_bytes(b, 32)); })
+        .def("prod_sn", [](const PacketFormat& pf, const py::object& b) { return pf.prod_sn(packet_bytes(b, 32)); })
+        .def("alert_flags", [](const PacketFormat& pf, const py::object& b) { return pf.alert_flags(packet_bytes(b, 32)); })
+        .def("countdown_thermal_shutdown",
+             [](const PacketFormat& pf, const py::object& b) { return pf.countdown_thermal_shutdown(packet_bytes(b, 32)); })
+        .def("countdown_shot_limiting",
+             [](const PacketFormat& pf, const py::object& b) { return pf.countdown_shot_limiting(packet_bytes(b, 32)); })
+        .def("thermal_shutdown",
+             [](const PacketFormat& pf, const py::object& b) { return static_cast<int>(pf.thermal_shutdown(packet_bytes(b, 32))); })
+        .def("shot_limiting",
+             [](const PacketFormat& pf, const py::object& b) { return static_cast<int>(pf.shot_limiting(packet_bytes(b, 32))); })
+        .def("crc", [](const PacketFormat& pf, const py::object& b) -> py::object {
+            py::buffer_info i = py::isinstance<LidarPacket>(b) ? py::buffer_info() : b.cast<py::buffer>().request();
+            const size_t n = py::isinstance<LidarPacket>(b) ? b.cast<const LidarPacket&>().buf.size()
+                                                            : static_cast<size_t>(i.size * i.itemsize);
+            const auto v = pf.crc(packet_bytes(b, 32), n);
+            if (!v) return py::none();
+            return py::int_(*v);
+        })
+        .def("calculate_crc", [](const PacketFormat& pf, const py::object& b) {
+            py::buffer_info i = py::isinstance<LidarPacket>(b) ? py::buffer_info() : b.cast<py::buffer>().request();
+            const size_t n = py::isinstance<LidarPacket>(b) ? b.cast<const LidarPacket&>().buf.size()
+                                                            : static_cast<size_t>(i.size * i.itemsize);
+            return pf.calculate_crc(packet_bytes(b, 32), n);
+        })
+        .def("frame_id_difference", &PacketFormat::frame_id_difference)
+        // column headers by column index
+        .def("col_status", [](const PacketFormat& pf, const py::object& b, size_t col) {
+            return pf.col_status(pf.nth_col(col, packet_bytes(b, pf.lidar_packet_size)));
+        })
+        .def("col_timestamp", [](const PacketFormat& pf, const py::object& b, size_t col) {
+            return pf.col_timestamp(pf.nth_col(col, packet_bytes(b, pf.lidar_packet_size)));
+        })
+        .def("col_measurement_id", [](const PacketFormat& pf, const py::object& b, size_t col) {
+            return pf.col_measurement_id(pf.nth_col(col, packet_bytes(b, pf.lidar_packet_size)));
+        })
+        // setters (parsing.cpp:1007-1090), as the reference's Python module spells them: (packet, [column,] value)
+        .def("set_col_status", [](const PacketFormat& pf, const py::object& b, size_t col, uint32_t v) {
+            pf.set_col_status(pf.nth_col(col, packet_bytes_mut(b, pf.lidar_packet_size)), v);
+        })
+        .def("set_col_timestamp", [](const PacketFormat& pf, const py::object& b, size_t col, uint64_t v) {
+            pf.set_col_timestamp(pf.nth_col(col, packet_bytes_mut(b, pf.lidar_packet_size)), v);
+        })
+        .def("set_col_measurement_id", [](const PacketFormat& pf, const py::object& b, size_t col, uint16_t v) {
+            pf.set_col_measurement_id(pf.nth_col(col, packet_bytes_mut(b, pf.lidar_packet_size)), v);
+        })
+        .def("set_frame_id", [](const PacketFormat& pf, const py::object& b, uint32_t v) { pf.set_frame_id(packet_bytes_mut(b, 32), v); })
+        .def("set_init_id", [](const PacketFormat& pf, const py::object& b, uint32_t v) { pf.set_init_id(packet_bytes_mut(b, 32), v); })
+        .def("set_prod_sn", [](const PacketFormat& pf, const py::object& b, uint64_t v) { pf.set_prod_sn(packet_bytes_mut(b, 32), v); })
+        .def("set_alert_flags", [](const PacketFormat& pf, const py::object& b, uint8_t v) { pf.set_alert_flags(packet_bytes_mut(b, 32), v); })
+        .def("set_shutdown", [](const PacketFormat& pf, const py::object& b, uint8_t v) { pf.set_shutdown(packet_bytes_mut(b, 32), v); })
+        .def("set_shot_limiting", [](const PacketFormat& pf, const py::object& b, uint8_t v) { pf.set_shot_limiting(packet_bytes_mut(b, 32), v); })
+        .def("set_shutdown_countdown",
+             [](const PacketFormat& pf, const py::object& b, uint8_t v) { pf.set_shutdown_countdown(packet_bytes_mut(b, 32), v); })
+        .def("set_shot_limiting_countdown",
+             [](const PacketFormat& pf, const py::object& b, uint8_t v) { pf.set_shot_limiting_countdown(packet_bytes_mut(b, 32), v); })
         .def("field_value_mask", &PacketFormat::field_value_mask)
         .def("field_bitness", &PacketFormat::field_bitness)
         // python/src/cpp/client/packet.cpp:173-210 -- (H, columns_per_packet) array, GPU decode
@@ -223,6 +362,16 @@ PYBIND11_MODULE(core, m) {
 
     py::class_<LidarPacket>(m, "LidarPacket")
         .def(py::init<int>(), py::arg("size") = 65536)
+        .def(py::init([](const PacketFormat& pf) { return LidarPacket(std::make_shared<PacketFormat>(pf)); }), py::arg("format"))
+        .def("__copy__", [](const LidarPacket& p) { return LidarPacket(p); })
+        .def("__deepcopy__", [](const LidarPacket& p, const py::dict&) { return LidarPacket(p); })
+        .def_property_readonly("format", [](const LidarPacket& p) { return p.format; })
+        .def("frame_id", [](const LidarPacket& p) { return p.frame_id(); })
+        .def("init_id", [](const LidarPacket& p) { return p.init_id(); })
+        .def("prod_sn", [](const LidarPacket& p) { return p.prod_sn(); })
+        .def("alert_flags", [](const LidarPacket& p) { return p.alert_flags(); })
+        .def("shot_limiting", [](const LidarPacket& p) { return p.shot_limiting(); })
+        .def("thermal_shutdown", [](const LidarPacket& p) { return p.thermal_shutdown(); })
         .def_readwrite("host_timestamp", &LidarPacket::host_timestamp)
         .def_property("buf",
                       [](py::object self) {
@@ -238,6 +387,27 @@ PYBIND11_MODULE(core, m) {
 
     py::class_<LidarFrame>(m, "LidarFrame")
         .def(py::init<const SensorInfo&>())
+        .def(py::init([](const SensorInfo& info, const std::vector<FieldType>& fields) {
+                 return LidarFrame(std::make_shared<SensorInfo>(info), fields);
+             }),
+             py::arg("info"), py::arg("field_types"))
+        .def(py::init<size_t, size_t, const std::vector<FieldType>&, size_t>(), py::arg("h"), py::arg("w"),
+             py::arg("field_types"), py::arg("columns_per_packet") = DEFAULT_COLUMNS_PER_PACKET)
+        .def("__copy__", [](const LidarFrame& f) { return LidarFrame(f); })
+        .def("__deepcopy__", [](const LidarFrame& f, const py::dict&) { return LidarFrame(f); })
+        .def_readwrite("shutdown_countdown", &LidarFrame::shutdown_countdown)
+        .def_readwrite("shot_limiting_countdown", &LidarFrame::shot_limiting_countdown)
+        .def_readwrite("sensor_info", &LidarFrame::sensor_info)
+        .def("shot_limiting", &LidarFrame::shot_limiting)
+        .def("thermal_shutdown", &LidarFrame::thermal_shutdown)
+        .def("complete", [](const LidarFrame& f, const py::object& window) {
+                 if (window.is_none()) return f.complete();
+                 const auto w = window.cast<std::pair<int, int>>();
+                 return f.complete(ColumnWindow{w.first, w.second});
+             },
+             py::arg("window") = py::none())
+        .def_property_readonly("field_types", &LidarFrame::field_types)
+        .def("__repr__", [](const LidarFrame& f) { return to_string(f); })
         .def(py::init<size_t, size_t, UDPProfileLidar, size_t>(), py::arg("h"), py::arg("w"),
              py::arg("profile"), py::arg("columns_per_packet") = DEFAULT_COLUMNS_PER_PACKET)
         .def_readonly("w", &LidarFrame::w)
@@ -304,6 +474,8 @@ PYBIND11_MODULE(core, m) {
         .def("batch", [](FrameBatcher& b, const LidarPacket& p, LidarFrame& f) { return b.batch(p, f); })
         .def("flush", &FrameBatcher::flush)
         .def("reset", &FrameBatcher::reset)
+        .def("set_max_cache_size", &FrameBatcher::set_max_cache_size)
+        .def("get_max_cache_size", &FrameBatcher::get_max_cache_size)
         .def("batched_packets", &FrameBatcher::batched_packets)
         .def("dropped_packets", &FrameBatcher::dropped_packets);
     m.attr("ScanBatcher") = m.attr("FrameBatcher");

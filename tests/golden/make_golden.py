@@ -86,7 +86,9 @@ def main():
 
     # the pair the reference's parsing_benchmark_test.cpp reads besides the captures above (its names do not follow the
     # <base>.pcap / <base>.json pattern)
-    for name in ("OS-1-128_v2.3.0_1024x10_lb_n3.pcap", "OS-1-128_v2.3.0_1024x10.json"):
+    # ... and the windowed captures of the reference's python/tests/test_batching.py::test_early_release
+    for name in ("OS-1-128_v2.3.0_1024x10_lb_n3.pcap", "OS-1-128_v2.3.0_1024x10.json", "windowed_frame1.pcap",
+                 "windowed_frame1_0.json", "windowed_frame2.pcap", "windowed_frame2_0.json"):
         shutil.copyfile(os.path.join(REF, "tests", "pcaps", name), os.path.join(dst, name))
 
     # snapshot hashes from the C++ test source

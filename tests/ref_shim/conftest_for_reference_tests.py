@@ -43,17 +43,20 @@ def meta(base_name: str):
 
 
 @pytest.fixture
-def packets(base_name: str, meta):
-    from ouster_sdk_amd import core as amd
-    pf = amd.PacketFormat(meta)
-    out = []
-    for payload, port, ts in amd.read_pcap_udp(os.path.join(PCAPS_DATA_DIR, f"{base_name}.pcap")):
-        if len(payload) == pf.lidar_packet_size:
-            p = core.LidarPacket(len(payload))
-            p.buf = payload
-            p.host_timestamp = ts
-            out.append(p)
-    return core.Packets(out, meta)
+def real_pcap_path(base_name: str, meta) -> str:
+    return os.path.join(PCAPS_DATA_DIR, f"{base_name}.pcap")
+
+
+@pytest.fixture
+def packets(real_pcap_path: str, meta):
+    from ouster.sdk import pcap
+    return core.Packets([p for _, p in pcap.PcapPacketSource(real_pcap_path, sensor_info=[meta])], meta)
+
+
+@pytest.fixture(scope="package")
+def test_data_dir():
+    from pathlib import Path
+    return Path(PCAPS_DATA_DIR).parent   # <test_data_dir>/pcaps/<file>, as in the reference's tree
 
 
 @pytest.fixture

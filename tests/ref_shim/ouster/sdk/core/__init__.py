@@ -2,22 +2,9 @@
 plus the three things that are Python-side in the reference too: SensorInfo(json), stagger(), Packets."""
 from ouster_sdk_amd.core import *  # noqa: F401,F403
 from ouster_sdk_amd import core as _core
-from ouster_sdk_amd.metadata import sensor_info_from_json as _from_json
 
 
-class _SensorInfoMeta(type):
-    """core.SensorInfo(json_text) builds one; isinstance(x, core.SensorInfo) keeps working."""
-    def __call__(cls, *args, **kwargs):
-        if len(args) == 1 and isinstance(args[0], str):
-            return _from_json(args[0])
-        return _core.SensorInfo(*args, **kwargs)
-
-    def __instancecheck__(cls, obj):
-        return isinstance(obj, _core.SensorInfo)
-
-
-class SensorInfo(metaclass=_SensorInfoMeta):
-    pass
+SensorInfo = _core.SensorInfo   # SensorInfo(json_text) is a constructor of the C++ class (csrc/host/metadata.cpp)
 
 
 class ChanField:
@@ -32,6 +19,11 @@ class ChanField:
     FLAGS = "FLAGS"
     FLAGS2 = "FLAGS2"
     WINDOW = "WINDOW"
+    RAW_HEADERS = "RAW_HEADERS"
+    RAW32_WORD1 = "RAW32_WORD1"
+    RAW32_WORD2 = "RAW32_WORD2"
+    RAW32_WORD3 = "RAW32_WORD3"
+    RAW32_WORD4 = "RAW32_WORD4"
 
 
 def stagger(info, field):
@@ -40,10 +32,20 @@ def stagger(info, field):
 
 
 class Packets:
-    """A list of packets with its metadata, iterated as (sensor index, packet) like core.Packets."""
+    """Packets with their metadata, iterated as (sensor index, packet) like core.Packets; the iterable is consumed lazily
+    (the reference's tests hand over endless generators)."""
     def __init__(self, packets, info):
-        self._packets = list(packets)
+        self._packets = packets
         self.sensor_info = [info]
 
     def __iter__(self):
-        return iter((0, p) for p in self._packets)
+        return ((0, p) for p in self._packets)
+
+
+PacketSource = Packets
+
+
+class ImuPacket:
+    """IMU packets are out of scope of this repo; the name exists so that test modules import."""
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("IMU packets are out of scope")
