@@ -173,6 +173,15 @@ PYBIND11_MODULE(core, m) {
         .value("REDUCTION_50_60", ShotLimitingStatus::REDUCTION_50_60)
         .value("REDUCTION_60_70", ShotLimitingStatus::REDUCTION_60_70)
         .value("REDUCTION_70_75", ShotLimitingStatus::REDUCTION_70_75);
+    py::enum_<PacketValidationFailure>(m, "PacketValidationFailure")
+        .value("NONE", PacketValidationFailure::NONE)
+        .value("PACKET_SIZE", PacketValidationFailure::PACKET_SIZE)
+        .value("ID", PacketValidationFailure::ID);
+    py::enum_<PacketType>(m, "PacketType")
+        .value("Unknown", PacketType::Unknown)
+        .value("Lidar", PacketType::Lidar)
+        .value("Imu", PacketType::Imu)
+        .value("Zone", PacketType::Zone);
     py::enum_<FieldClass>(m, "FieldClass")
         .value("PIXEL_FIELD", FieldClass::PIXEL_FIELD)
         .value("COLUMN_FIELD", FieldClass::COLUMN_FIELD)
@@ -366,6 +375,10 @@ PYBIND11_MODULE(core, m) {
         .def("__copy__", [](const LidarPacket& p) { return LidarPacket(p); })
         .def("__deepcopy__", [](const LidarPacket& p, const py::dict&) { return LidarPacket(p); })
         .def_property_readonly("format", [](const LidarPacket& p) { return p.format; })
+        .def("validate", [](const LidarPacket& p, const SensorInfo& info) { return p.validate(info); })
+        .def("validate", [](const LidarPacket& p, const SensorInfo& info, const PacketFormat& pf) { return p.validate(info, pf); })
+        .def_property_readonly("type", [](const LidarPacket& p) { return p.type(); })
+        .def("packet_type", [](const LidarPacket& p) { return p.packet_type(); })
         .def("frame_id", [](const LidarPacket& p) { return p.frame_id(); })
         .def("init_id", [](const LidarPacket& p) { return p.init_id(); })
         .def("prod_sn", [](const LidarPacket& p) { return p.prod_sn(); })
