@@ -597,6 +597,12 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
         }
         s_meta[tid] = m;
     }
+    // The common case, decided once per tile: everything this tile emits lies below `capacity`, and no kept range can be
+    // zero (the gate's lower bound is at least 1): then the column loop carries neither the per-point room check nor the
+    // zero-range select.
+    const bool easy = fbase + off[c0 + ncol] <= a.capacity && a.min_r > 0;
+    auto emit_tile = [&](auto easy_c) {
+    constexpr bool roomy = decltype(easy_c)::value, no_zero = decltype(easy_c)::value;
     uint32_t m_run = 0;  // lane jj of the wave: points of its jj-th column already written (previous row chunks)
     for (uint32_t r0 = 0; r0 < H; r0 += ROWS) {
         __syncthreads();  // previous chunk consumed (and, first time, the metadata published)
@@ -638,13 +644,14 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
             for (int hh = 0; hh < NR; ++hh) {
                 r[hh] = s_rng[(lane + 64 * hh) * PITCH + j];
                 keep[hh] = row[hh] < H && r[hh] >= a.min_r && r[hh] <= a.max_r;
-                const uint64_t mask = __ballot(keep[hh]);
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(keep[hh]);
                 rank[hh] = n_keep + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
                 n_keep += (uint32_t)__popcll(mask);
             }
             if (n_keep == 0) continue;
             const uint64_t g0 = fbase + __builtin_amdgcn_readfirstlane(m.base) + bcast_u32(m_run, jj);  // first point of this run
-            const uint64_t room = g0 < a.capacity ? a.capacity - g0 : 0;
+            const uint64_t room = roomy ? ~0ull : (g0 < a.capacity ? a.capacity - g0 : 0);
+            T* const run = (T*)a.points + g0 * 3;   // wave-uniform: the stores take it as a scalar base + a 32-bit lane offset
             T ps[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) ps[k] = m.pose[k];
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
             }
 #pragma unroll
             for (int hh = 0; hh < NR; ++hh) {
-                if (!(keep[hh] && rank[hh] < room)) continue;
+                if (!(keep[hh] && (roomy || rank[hh] < room))) continue;
                 T pt[3];
                 if constexpr (SEP) {
                     const double rm = (double)r[hh] - lut.n;
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
                     for (int k = 0; k < 3; ++k) {
                         const double d = fma(cx, bt[hh][k], fma(sx, bt[hh][3 + k], bt[hh][6 + k]));
                         const T t = (T)fma(rm, d, kc[k]);
-                        pt[k] = r[hh] ? t : (T)0;
+                        pt[k] = (no_zero || r[hh]) ? t : (T)0;
                     }
                 } else {
                     double p[3];
@@ -681,13 +688,13 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
                 o.z = ps[8] * px + ps[9] * py + ps[10] * pz + ps[11];
 #if OUSTER_NT_STANDALONE
                 {
-                    T* pd = (T*)a.points + (g0 + rank[hh]) * 3;
+                    T* pd = run + rank[hh] * 3u;
                     __builtin_nontemporal_store(o.x, pd);
                     __builtin_nontemporal_store(o.y, pd + 1);
                     __builtin_nontemporal_store(o.z, pd + 2);
                 }
 #else
-                ((Pt3<T>*)a.points)[g0 + rank[hh]] = o;
+                ((Pt3<T>*)run)[rank[hh]] = o;
 #endif
             }
             // every point of the run carries the same provenance: dense lanes 0..n_keep-1
@@ -702,6 +709,9 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
             if (lane == jj) m_run += n_keep;
         }
     }
+    };
+    if (easy) emit_tile(std::true_type{});
+    else emit_tile(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------
