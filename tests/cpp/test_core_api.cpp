@@ -1306,7 +1306,76 @@ static void test_field_conversions() {
     CHECK(img.rows() == 8 && img.cols() == 32 && refl.shape[1] == 32);
 }
 
+// A frame that is still being assembled shows what has arrived, as the reference's packet-by-packet parse does
+// (lidar_frame.cpp:1422-1576): columns below the highest settled one decoded or zeroed, the others untouched, headers
+// zeroed at frame start; RAW_HEADERS filled on the host; the view survives the batcher.
+static void test_frame_under_assembly() {
+    std::printf("a frame under assembly shows what has arrived\n");
+    auto info = std::make_shared<SensorInfo>(make_info(UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, HeaderType::STANDARD, 64, 512));
+    auto pf = std::make_shared<PacketFormat>(*info);
+    LidarFrame src(info);
+    randomize(src, *pf, 0x5eed);
+    auto packets = impl::frame_to_packets(src, pf, info->init_id, info->sn);
+    const size_t cpp = 16, n_pk = packets.size();   // 32 packets
+    LidarFrameFieldTypes fts = src.field_types();
+    fts.emplace_back(ChanField::RAW_HEADERS, ChanFieldType::UINT32);
+    LidarFrame ls(info, fts);
+    for (auto& kv : ls.fields()) std::memset(kv.second.get(), 0x11, kv.second.bytes());
+    std::memset(ls.status().data(), 0x11, ls.w * 4);
+    auto batcher = std::make_unique<FrameBatcher>(info);
+    // packets 0, 1, 3 (2 is missing) of the first half
+    for (size_t p : {size_t{0}, size_t{1}, size_t{3}}) CHECK(!(*batcher)(packets[p], ls));
+    {
+        auto rng = ls.field<uint32_t>(ChanField::RANGE);
+        auto want = src.field<uint32_t>(ChanField::RANGE);
+        auto rh = ls.field<uint32_t>(ChanField::RAW_HEADERS);
+        bool ok_rx = true, ok_gap = true, ok_rest = true, ok_rh = true;
+        for (size_t r = 0; r < ls.h; ++r)
+            for (size_t c = 0; c < ls.w; ++c) {
+                const size_t p = c / cpp;
+                const uint32_t v = rng(r, c);
+                if (p == 0 || p == 1 || p == 3) ok_rx &= v == want(r, c);
+                else if (p == 2) ok_gap &= v == 0;              // skipped over: zeroed when packet 3 arrived
+                else ok_rest &= v == 0x11111111u;               // not reached yet: what the frame held before
+            }
+        for (size_t c = 0; c < 4 * cpp; ++c) ok_rh &= (c / cpp == 2) ? rh(0, c) == 0 : rh(0, c) != 0x11111111u;
+        CHECK(ok_rx);
+        CHECK(ok_gap);
+        CHECK(ok_rest);
+        CHECK(ok_rh);
+        CHECK(ls.status()[0] == src.status()[0] && ls.status()[2 * cpp] == 0 && ls.status()[5 * cpp] == 0);
+        CHECK(ls.measurement_id()[3 * cpp + 1] == 3 * cpp + 1);
+    }
+    // more packets, then the batcher goes away before anybody looks: the frame still shows them
+    for (size_t p = 4; p < n_pk / 2; ++p) CHECK(!(*batcher)(packets[p], ls));
+    batcher.reset();
+    {
+        auto rng = ls.field<uint32_t>(ChanField::RANGE);
+        auto want = src.field<uint32_t>(ChanField::RANGE);
+        bool ok = true;
+        for (size_t r = 0; r < ls.h; ++r)
+            for (size_t c = 4 * cpp; c < (n_pk / 2) * cpp; ++c) ok &= rng(r, c) == want(r, c);
+        CHECK(ok);
+        CHECK(rng(0, ls.w - 1) == 0x11111111u);
+    }
+    // a copy is a snapshot of what has arrived
+    {
+        FrameBatcher b2(info);
+        LidarFrame f2(info);
+        for (size_t p = 0; p < 5; ++p) CHECK(!b2(packets[p], f2));
+        LidarFrame snap = f2;
+        CHECK(snap.field<uint32_t>(ChanField::RANGE)(3, 4 * cpp + 2) == src.field<uint32_t>(ChanField::RANGE)(3, 4 * cpp + 2));
+        for (size_t p = 5; p < n_pk; ++p) {
+            const bool done = b2(packets[p], f2);
+            CHECK(done == (p + 1 == n_pk));
+        }
+        CHECK(f2.field<uint32_t>(ChanField::RANGE)(7, ls.w - 3) == src.field<uint32_t>(ChanField::RANGE)(7, ls.w - 3));
+        CHECK(snap.field<uint32_t>(ChanField::RANGE)(7, ls.w - 3) == 0);   // the snapshot did not move on
+    }
+}
+
 int main() {
+    test_frame_under_assembly();
     test_threads_and_contexts();
     test_field_conversions();
     test_packet_format_tables();
