@@ -88,7 +88,14 @@ class Parser {
         }
         return false;
     }
+    struct Depth {   // metadata files nest four or five levels; a crafted one must not be able to exhaust the stack
+        int& d;
+        explicit Depth(int& depth) : d(depth) { ++d; }
+        ~Depth() { --d; }
+    };
     Json value() {
+        Depth guard(depth_);
+        if (depth_ > 64) fail("nesting too deep");
         ws();
         if (i_ >= s_.size()) fail("unexpected end");
         const char c = s_[i_];
@@ -126,7 +133,9 @@ class Parser {
             i_ += 4;
         } else {
             const size_t b = i_;
-            while (i_ < s_.size() && (std::isdigit(static_cast<unsigned char>(s_[i_])) || std::strchr("+-.eE", s_[i_]))) ++i_;
+            while (i_ < s_.size() && s_[i_] != '\0' &&
+                   (std::isdigit(static_cast<unsigned char>(s_[i_])) || std::strchr("+-.eE", s_[i_])))
+                ++i_;
             if (b == i_) fail("unexpected character");
             j.kind = Json::Number;
             j.str = s_.substr(b, i_ - b);
@@ -174,6 +183,7 @@ class Parser {
     }
     const std::string& s_;
     size_t i_ = 0;
+    int depth_ = 0;
 };
 
 mat4d mat_from(const Json& j, const mat4d& fallback) {
