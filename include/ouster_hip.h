@@ -163,7 +163,9 @@ typedef struct ouster_hip_frame_out {
      * body_to_world).  When set, xyz[k] receives R_col * lut(r) + t_col computed in the element type of xyz
      * (the poses are cast to it, as the reference does) while the point is still in registers -- the
      * separate pass over the cloud (read 12 B + write 12 B per point) disappears.  Needs the separable
-     * LUT tables (ouster_hip_lut_create).  NULL: xyz stays in the sensor / body frame of the LUT. */
+     * LUT tables (ouster_hip_lut_create).  NULL: xyz stays in the sensor / body frame of the LUT.
+     * 16-byte aligned arrays take the wide-tile kernels; an array that is only 8-byte aligned is decoded by the
+     * 64-column kernel (same result, slower). */
     const double* xyz_poses;
 } ouster_hip_frame_out;
 #define OUSTER_HIP_GATE_CHUNKS 8

@@ -538,6 +538,12 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     constexpr int NBT = 3;   // at most 84 rows per tile (setup_wide): three table doubles per thread
     int32_t r_off = 0;
     double r_beam[NBT];
+    // the tile's column poses (xyz_poses): 12 of the 16 doubles of each column as 16 B pieces, all in flight together with
+    // the other small tables (a loop of load -> convert -> LDS write would pay one memory latency per piece: 12 in a row
+    // for a 256-column tile, measured at +27 % of the kernel's time)
+    constexpr bool HAS_POSES = POSES && (XYZM == 1 || XYZM == 2);
+    constexpr int NPOSE = HAS_POSES ? (TW * 6 + NT - 1) / NT : 1;
+    double2 r_pose[NPOSE];
     auto issue_small = [&]() {
 #pragma unroll
         for (int k = 0; k < NJ; ++k) {
@@ -570,6 +576,21 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             for (int k = 0; k < NBT; ++k) {
                 const uint32_t i = tid + (uint32_t)k * NT;
                 r_beam[k] = i < nrows * 9 ? lut.beam_tab[(size_t)r0 * 9 + i] : 0.0;
+            }
+        }
+        if constexpr (HAS_POSES) {
+            if (a.xyz_poses) {
+#pragma unroll
+                for (int k = 0; k < NPOSE; ++k) {
+                    const uint32_t i = tid + (uint32_t)k * NT, j = i / 6u, kk = (i - j * 6u) * 2u;
+#ifdef OUSTER_ABLATE_POSE_LOAD   // experiment builds only: no pose is read
+                    r_pose[k] = double2{kk == 0 ? 1.0 : 0.0, 0.0};
+                    (void)j;
+#else
+                    r_pose[k] = (i < (uint32_t)TW * 6u && c0 + j < W)
+                                    ? *(const double2*)(a.xyz_poses + ((size_t)f * W + c0 + j) * 16 + kk) : double2{0.0, 0.0};
+#endif
+                }
             }
         }
     };
@@ -648,6 +669,27 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             if (i < nrows * 9) s_beam[i] = r_beam[k];
         }
     }
+    // pose table, transposed (element k of every column next to each other: a lane's four columns are one 16 / 32 B read,
+    // a wave's reads conflict free) and cast to the xyz element type; published by the barrier behind the classification
+    const void* s_pose = nullptr;
+    if constexpr (HAS_POSES) {
+        if (a.xyz_poses) {
+            using XT = typename std::conditional<XYZM == 1, float, double>::type;
+            XT* sp = (XT*)((uint8_t*)smem + a.pose_lds_off);
+#pragma unroll
+            for (int k = 0; k < NPOSE; ++k) {
+                const uint32_t i = tid + (uint32_t)k * NT, j = i / 6u, kk = (i - j * 6u) * 2u;
+                if (i < (uint32_t)TW * 6u) {
+                    sp[kk * (uint32_t)TW + j] = (XT)r_pose[k].x;
+                    sp[(kk + 1u) * (uint32_t)TW + j] = (XT)r_pose[k].y;
+                }
+            }
+            s_pose = sp;
+#ifdef OUSTER_ABLATE_POSE_ALL   // experiment builds only: the POSES instantiation runs, its pose code does not
+            s_pose = nullptr;
+#endif
+        }
+    }
     if (!mapped && rc == 0 && tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_first_present(a.g, fbase, a.packet_stride, count);
 
     PHASE_STAMP(2);
@@ -711,12 +753,11 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     uint32_t vq = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) vq |= (jq + c < (uint32_t)TW && s_valid[jq + c]) ? (1u << c) : 0u;
-    const void* s_pose = stage_poses<XYZM, POSES>(a, smem, f, c0, (uint32_t)TW);
     uint32_t px_dw[4];
     tile_px_offsets<TW / 4>(px_dw, 0u, slot);
     ColConst cc;
     if (XYZM == 1 || XYZM == 2) load_colconst(cc, lut, c0 + jq, W);
-    decode_rows<S, TW / 4, XYZM, S::is_static, S::nt_stores, S::nt_xyz, POSES>(a, s_tile, px_dw, cc, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
+    decode_rows<S, TW / 4, XYZM, S::is_static, S::nt_stores, S::nt_xyz, POSES, 256, false, false, true>(a, s_tile, px_dw, cc, s_off, s_xyz, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr,
                                  a.gate_counts ? s_gate : nullptr, lut, f, c0, r0, nrows, vq, rc, nch, s_pose);
     PHASE_STAMP(4);
 #ifdef OUSTER_PHASE_TIMING

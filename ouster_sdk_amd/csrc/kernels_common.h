@@ -571,9 +571,14 @@ __device__ __forceinline__ const void* stage_poses(const DecodeArgs& a, uint32_t
         const uint32_t W = a.g.columns_per_frame;
         // transposed: element k of every column next to each other, so that a lane's four columns are one 16 / 32 B
         // read and a wave's reads are conflict free (column-major rows of 12 cost 0.4 ms per launch in bank conflicts)
+        // at most 64 columns here (k_decode's tiles): three values per thread
         for (uint32_t i = threadIdx.x; i < ncols * 12; i += blockDim.x) {
             const uint32_t j = i / 12, k = i - j * 12, c = c0 + j;
+#ifdef OUSTER_ABLATE_POSE_LOAD   // experiment builds only: no pose is read
+            s_pose[k * ncols + j] = (XT)(k % 5 == 0);
+#else
             s_pose[k * ncols + j] = c < W ? (XT)a.xyz_poses[((size_t)f * W + c) * 16 + k] : (XT)0;
+#endif
         }
         __syncthreads();
         return s_pose;
@@ -628,12 +633,14 @@ __device__ __forceinline__ void tile_px_offsets(uint32_t (&px_dw)[4], uint32_t c
 #pragma unroll
     for (int c = 0; c < 4; ++c) px_dw[c] = col0_dw + (jq + c) * colstride_dw;
 }
+// POSEREG: keep the f32 poses of the lane's four columns in registers across the row loop (k_decode_wide; k_decode's
+// 16-lane row segments read them as LDS broadcasts cheaply enough, and its fix-up instantiation has no registers to spare).
 // BEAMLDS: s_beam is known to be an LDS table (no run-time choice between it and lut.beam_tab: a pointer select would
 // turn the table reads into flat loads -- vmcnt AND lgkmcnt -- inside the row loop).
 // VECONLY: the caller guarantees a.vec_ok and whole quads (W % 4 == 0, every lane's four columns exist): the
 // element-wise fallbacks are not compiled in (a destaggered run that wraps round the row end still is).
 template <class S, int QPR, int XYZM, bool DEADZ = false, bool NTS = false, bool NTX = NTS, bool POSES = false, int NT = 256,
-          bool BEAMLDS = false, bool VECONLY = false>
+          bool BEAMLDS = false, bool VECONLY = false, bool POSEREG = false>
 __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t* s_tile,
                                             const uint32_t (&px_dw)[4], const ColConst& cc, const int32_t* s_off,
                                             float4* s_xyz, const double* s_beam, uint32_t* s_gate,
@@ -656,6 +663,23 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
     const uint32_t seg0 = c0 + (q - ql) * 4;     // first column of that segment
     const uint32_t chan = S::is_static ? S::chan : a.g.channel_data_size;
 
+
+    // The poses of my four columns (f32: 12 x 4 values = 48 registers) are read from the LDS table ONCE, before the row
+    // loop: left inside it they are re-read for every row and return -- 384 B per lane and row, 64 different quads per
+    // wave, which cost k_decode_wide 0.19 ms per launch (the 64-column kernel, whose 16-lane row segments read the same
+    // addresses four times over as broadcasts, paid 0.03).  The f64 table (96 registers) stays in LDS and is read once per
+    // row for both returns.
+    using PXT = typename std::conditional<XYZM == 2, double, float>::type;
+    constexpr bool POSE_REGS = POSES && POSEREG && XYZM == 1;
+    PXT m_pose[POSE_REGS ? 12 : 1][4];
+    if constexpr (POSE_REGS) {
+        if (s_pose && live) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m_pose[k][c] = ((const PXT*)s_pose)[(size_t)k * (QPR * 4) + jq + c];
+        }
+    }
 
     for (uint32_t rrel = ty; live && rrel < nrows; rrel += RPP) {
         const uint32_t r = r0 + rrel;
@@ -791,7 +815,16 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
 #pragma unroll
                     for (int k = 0; k < 12; ++k)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) m[k][c] = ((const XT*)s_pose)[(size_t)k * (QPR * 4) + jq + c];
+                        for (int c = 0; c < 4; ++c) {
+                            if constexpr (POSE_REGS) m[k][c] = m_pose[k][c];
+                            else m[k][c] = ((const XT*)s_pose)[(size_t)k * (QPR * 4) + jq + c];
+                        }
+#ifdef OUSTER_ABLATE_POSE_MATH   // experiment builds only: the table stays in registers, the arithmetic goes
+#pragma unroll
+                    for (int k = 0; k < 12; ++k)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(m[k][c]));
+#else
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const XT x = p[c][0], y = p[c][1], z = p[c][2];
@@ -799,6 +832,7 @@ __device__ __forceinline__ void decode_rows(const DecodeArgs& a, const uint32_t*
                         p[c][1] = m[4][c] * x + m[5][c] * y + m[6][c] * z + m[7][c];
                         p[c][2] = m[8][c] * x + m[9][c] * y + m[10][c] * z + m[11][c];
                     }
+#endif
                 }
                 XT* dst = out + ((size_t)f * plane_px + rowpix) * 3;
                 if constexpr (XYZM == 1) {
