@@ -429,11 +429,25 @@ __global__ __launch_bounds__(256) void k_decode_fixup(DecodeArgs a) {
             s_n = n;
         }
         __syncthreads();
-        const uint32_t items = s_n * tpf;
-        for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
-            const uint32_t f = base + s_list[it / tpf], tile = it % tpf;
-            decode_tile<S, TILE, XYZM, true, POSES>(a, smem, f, tile);
-            __syncthreads();  // the tile image is reused
+        // A flagged frame stays on ONE XCD (workgroup b runs on XCD b % 8): its 64-column tiles write 64 - 256 B row segments,
+        // and neighbouring tiles' halves of a cache line must meet in the same L2 (the reason for xcd_map in the one-tile
+        // kernels; spread over all eight XCDs the same tiles cost 5.5 us per frame instead of 3.6).  The k-th flagged frame
+        // goes to XCD k % 8, whose workgroups share its tiles out by index.
+        const uint32_t n_flagged = s_n;
+        if (gridDim.x >= 16 && (gridDim.x & 7u) == 0) {
+            const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+            const uint32_t mine = n_flagged > xcd ? (n_flagged - xcd + 7u) / 8u : 0u;   // flagged frames of my XCD
+            for (uint32_t it = slot; it < mine * tpf; it += per_xcd) {
+                const uint32_t f = base + s_list[(it / tpf) * 8u + xcd], tile = it % tpf;
+                decode_tile<S, TILE, XYZM, true, POSES>(a, smem, f, tile);
+                __syncthreads();  // the tile image is reused
+            }
+        } else {
+            for (uint32_t it = blockIdx.x; it < n_flagged * tpf; it += gridDim.x) {
+                const uint32_t f = base + s_list[it / tpf], tile = it % tpf;
+                decode_tile<S, TILE, XYZM, true, POSES>(a, smem, f, tile);
+                __syncthreads();  // the tile image is reused
+            }
         }
     }
     // valid-column counts of the clean frames (flagged ones got theirs from the general path)
