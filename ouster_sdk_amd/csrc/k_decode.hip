@@ -258,12 +258,13 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
             u32x4 t[DEPTH];
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
-                const uint32_t idx = base + k * NT + tid;
-                if (idx < total) {
-                    const uint32_t g = (idx >= n16) + (idx >= 2 * n16) + (idx >= 3 * n16);
-                    const u32x4* sp = g == 0 ? src[0] : g == 1 ? src[1] : g == 2 ? src[2] : src[3];
-                    t[k] = __builtin_nontemporal_load(sp + (idx - g * n16));
-                }
+                // every lane loads (the ones past the end re-read the last piece): a guarded load and its guarded LDS
+                // write further down were merged into one block per piece in the fix-up instantiation -- a full memory
+                // latency per 16 B piece, fifteen in a row per tile
+                const uint32_t idx = min(base + k * NT + tid, total - 1u);
+                const uint32_t g = (idx >= n16) + (idx >= 2 * n16) + (idx >= 3 * n16);
+                const u32x4* sp = g == 0 ? src[0] : g == 1 ? src[1] : g == 2 ? src[2] : src[3];
+                t[k] = __builtin_nontemporal_load(sp + (idx - g * n16));
             }
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
