@@ -546,8 +546,15 @@ def main():
     traffic, traffic_src = None, None
     if args.outputs == "full":
         import glob
+        cands = []
         for pj in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                 "profiles", "*", "pmc_traffic.json")), reverse=True):
+            try:
+                cands.append((json.load(open(pj)).get("kernel_sources_sha256") != kernel_sources_sha256(), pj))
+            except Exception:
+                pass
+        # counters recorded on THIS tree's kernel sources first, then the most recent directory name
+        for _, pj in sorted(cands, key=lambda c: c[0]):
             try:
                 t = json.load(open(pj))
                 if t.get("workload") == args.workload and t.get("frames_per_launch"):
