@@ -85,6 +85,11 @@ const uint8_t* packet_bytes(const py::object& o, size_t min_size) {
     }
     return buf_ptr(o.cast<py::buffer>(), min_size);
 }
+size_t packet_size(const py::object& o) {
+    if (py::isinstance<LidarPacket>(o)) return o.cast<const LidarPacket&>().buf.size();
+    const py::buffer_info info = o.cast<py::buffer>().request();
+    return static_cast<size_t>(info.size * info.itemsize);
+}
 uint8_t* packet_bytes_mut(const py::object& o, size_t min_size) {
     if (py::isinstance<LidarPacket>(o)) return const_cast<uint8_t*>(packet_bytes(o, min_size));
     py::buffer_info info = o.cast<py::buffer>().request(true);
@@ -299,18 +304,12 @@ PYBIND11_MODULE(core, m) {
         .def("shot_limiting",
              [](const PacketFormat& pf, const py::object& b) { return static_cast<int>(pf.shot_limiting(packet_bytes(b, 32))); })
         .def("crc", [](const PacketFormat& pf, const py::object& b) -> py::object {
-            py::buffer_info i = py::isinstance<LidarPacket>(b) ? py::buffer_info() : b.cast<py::buffer>().request();
-            const size_t n = py::isinstance<LidarPacket>(b) ? b.cast<const LidarPacket&>().buf.size()
-                                                            : static_cast<size_t>(i.size * i.itemsize);
-            const auto v = pf.crc(packet_bytes(b, 32), n);
+            const auto v = pf.crc(packet_bytes(b, 32), packet_size(b));
             if (!v) return py::none();
             return py::int_(*v);
         })
         .def("calculate_crc", [](const PacketFormat& pf, const py::object& b) {
-            py::buffer_info i = py::isinstance<LidarPacket>(b) ? py::buffer_info() : b.cast<py::buffer>().request();
-            const size_t n = py::isinstance<LidarPacket>(b) ? b.cast<const LidarPacket&>().buf.size()
-                                                            : static_cast<size_t>(i.size * i.itemsize);
-            return pf.calculate_crc(packet_bytes(b, 32), n);
+            return pf.calculate_crc(packet_bytes(b, 32), packet_size(b));
         })
         .def("frame_id_difference", &PacketFormat::frame_id_difference)
         // column headers by column index
