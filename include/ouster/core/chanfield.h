@@ -64,6 +64,7 @@ inline size_t field_type_size(ChanFieldType t) {
     switch (t) {
         case ChanFieldType::INT8:
         case ChanFieldType::UINT8:
+        case ChanFieldType::CHAR:
             return 1;
         case ChanFieldType::INT16:
         case ChanFieldType::UINT16:

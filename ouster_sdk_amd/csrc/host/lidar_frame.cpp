@@ -185,8 +185,6 @@ const Field& LidarFrame::field(const std::string& name) const {
 bool LidarFrame::has_field(const std::string& name) const { return fields_.count(name) > 0; }
 
 Field& LidarFrame::add_field(const FieldType& type) {
-    if (has_field(type.name))
-        throw std::invalid_argument("Duplicated field '" + type.name + "'");
     std::vector<size_t> dims;
     switch (type.field_class) {
         case FieldClass::PIXEL_FIELD: dims = {h, w}; break;
@@ -195,7 +193,7 @@ Field& LidarFrame::add_field(const FieldType& type) {
         default: break;
     }
     dims.insert(dims.end(), type.extra_dims.begin(), type.extra_dims.end());
-    return fields_.emplace(type.name, Field(type.element_type, dims, type.field_class)).first->second;
+    return add_field(type.name, FieldDescriptor::array(type.element_type, dims), type.field_class);   // same checks
 }
 Field& LidarFrame::add_field(const std::string& name, ChanFieldType type,
                              std::vector<size_t> extra_dims, FieldClass c) {
@@ -393,24 +391,52 @@ uint64_t LidarFrame::get_last_valid_packet_timestamp() const {
     for_valid_packets(*this, [&](size_t i) { found = true; v = packet_timestamp()[i]; });
     return ts_or_throw(found, v);
 }
+namespace {
+// The other packet streams a frame may carry stamps of, as plain fields (lidar_frame.cpp:839-891): IMU_PACKET_TIMESTAMP is
+// valid where any of its packet's IMU_STATUS entries has bit 0 set, ZONE_PACKET_TIMESTAMP[0] where it is non-zero.
+template <class F>
+void for_other_stream_stamps(const LidarFrame& f, F&& fn) {
+    if (f.has_field("IMU_PACKET_TIMESTAMP") && f.has_field("IMU_STATUS")) {
+        const Field& ts = f.field("IMU_PACKET_TIMESTAMP");
+        const Field& st = f.field("IMU_STATUS");
+        if (ts.tag() == ChanFieldType::UINT64 && st.tag() == ChanFieldType::UINT16 && ts.size() > 0) {
+            const size_t per = st.size() / ts.size();
+            const uint64_t* t = ts.get<uint64_t>();
+            const uint16_t* s = st.get<uint16_t>();
+            for (size_t i = 0; i < ts.size(); ++i) {
+                bool any = false;
+                for (size_t k = i * per; k < (i + 1) * per; ++k) any |= (s[k] & 1u) != 0;
+                if (any) fn(t[i]);
+            }
+        }
+    }
+    if (f.has_field("ZONE_PACKET_TIMESTAMP")) {
+        const Field& z = f.field("ZONE_PACKET_TIMESTAMP");
+        if (z.tag() == ChanFieldType::UINT64 && z.size() > 0 && z.get<uint64_t>()[0] != 0) fn(z.get<uint64_t>()[0]);
+    }
+}
+}  // namespace
+
 uint64_t LidarFrame::get_min_valid_packet_timestamp() const {
     bool found = false;
     uint64_t v = 0;
-    for_valid_packets(*this, [&](size_t i) {
-        const uint64_t t = packet_timestamp()[i];
+    auto take = [&](uint64_t t) {
         v = found ? std::min(v, t) : t;
         found = true;
-    });
+    };
+    for_valid_packets(*this, [&](size_t i) { take(packet_timestamp()[i]); });
+    for_other_stream_stamps(*this, take);
     return ts_or_throw(found, v);
 }
 uint64_t LidarFrame::get_max_valid_packet_timestamp() const {
     bool found = false;
     uint64_t v = 0;
-    for_valid_packets(*this, [&](size_t i) {
-        const uint64_t t = packet_timestamp()[i];
+    auto take = [&](uint64_t t) {
         v = found ? std::max(v, t) : t;
         found = true;
-    });
+    };
+    for_valid_packets(*this, [&](size_t i) { take(packet_timestamp()[i]); });
+    for_other_stream_stamps(*this, take);
     return ts_or_throw(found, v);
 }
 

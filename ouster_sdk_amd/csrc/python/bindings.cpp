@@ -38,6 +38,7 @@ py::dtype dtype_of(ChanFieldType t) {
         case ChanFieldType::FLOAT32: return py::dtype::of<float>();
         case ChanFieldType::FLOAT64: return py::dtype::of<double>();
         case ChanFieldType::FLOAT16: return py::dtype("float16");
+        case ChanFieldType::CHAR: return py::dtype("S1");
         default: throw std::invalid_argument("Invalid field for LidarFrame");
     }
 }
@@ -48,7 +49,27 @@ ChanFieldType tag_of(const py::dtype& d) {
                    ChanFieldType::INT32, ChanFieldType::INT64, ChanFieldType::FLOAT32,
                    ChanFieldType::FLOAT64, ChanFieldType::FLOAT16})
         if (dtype_of(t).is(d) || dtype_of(t).equal(d)) return t;
+    if (d.kind() == 'S') return ChanFieldType::CHAR;
     throw std::invalid_argument("unsupported numpy dtype");
+}
+
+// FieldType from a numpy dtype-like: a fixed-width byte string ("S25") is CHAR with its width as one more trailing
+// dimension (python/src/cpp/client/client_common.cpp:129-154)
+FieldType make_field_type(const std::string& name, const py::object& dt, std::vector<size_t> extra, FieldClass c) {
+    const py::dtype d = py::dtype::from_args(dt);
+    const ChanFieldType t = tag_of(d);
+    if (t == ChanFieldType::CHAR && d.itemsize() > 0) extra.push_back(static_cast<size_t>(d.itemsize()));
+    return FieldType(name, t, std::move(extra), c);
+}
+std::vector<size_t> dims_of(const py::tuple& t) {
+    std::vector<size_t> v;
+    for (auto h : t) v.push_back(h.cast<size_t>());
+    return v;
+}
+py::tuple tuple_of(const std::vector<size_t>& v) {
+    py::tuple t(v.size());
+    for (size_t i = 0; i < v.size(); ++i) t[i] = py::int_(v[i]);
+    return t;
 }
 
 // numpy view over a Field's memory; `owner` keeps the frame alive
@@ -96,6 +117,49 @@ uint8_t* packet_bytes_mut(const py::object& o, size_t min_size) {
     if (static_cast<size_t>(info.size * info.itemsize) < min_size)
         throw std::invalid_argument("Incompatible argument: expected a bytearray of size >= " + std::to_string(min_size));
     return static_cast<uint8_t*>(info.ptr);
+}
+
+enum class ColHeaderSel { TIMESTAMP = 0, ENCODER_COUNT = 1, MEASUREMENT_ID = 2, STATUS = 3, FRAME_ID = 4 };
+
+size_t checked_col(const PacketFormat& pf, size_t col) {
+    if (col >= static_cast<size_t>(pf.columns_per_packet)) throw std::invalid_argument("col_idx out of bounds");
+    return col;
+}
+
+template <typename T, typename F>
+py::array header_array(const PacketFormat& pf, const uint8_t* pkt, F&& get) {
+    py::array_t<T> out(static_cast<py::ssize_t>(pf.columns_per_packet));
+    for (int i = 0; i < pf.columns_per_packet; ++i) out.mutable_data()[i] = static_cast<T>(get(pf.nth_col(i, pkt)));
+    return std::move(out);
+}
+
+// PacketFormat.set_field(packet, name, (H, columns_per_packet) array): python/src/cpp/client/packet.cpp:357-366
+template <typename T>
+bool try_set_field(const PacketFormat& pf, LidarPacket& p, const std::string& name, const py::array& a) {
+    if (!py::dtype::of<T>().equal(a.dtype())) return false;
+    auto arr = py::array_t<T, py::array::c_style | py::array::forcecast>::ensure(a);
+    if (!arr || arr.ndim() != 2 || arr.shape(0) != pf.pixels_per_column || arr.shape(1) != pf.columns_per_packet)
+        throw std::invalid_argument("field dimension mismatch");
+    if (p.buf.size() < pf.lidar_packet_size) throw std::invalid_argument("packet smaller than lidar_packet_size");
+    // set_block indexes the plane by the first column's measurement id and skips invalid columns: label the columns
+    // 0..n-1 and valid for the write, then put their headers back
+    const int n = pf.columns_per_packet;
+    std::vector<uint16_t> m_ids(n);
+    std::vector<uint32_t> statuses(n);
+    for (int i = 0; i < n; ++i) {
+        uint8_t* col = pf.nth_col(i, p.buf.data());
+        m_ids[i] = pf.col_measurement_id(col);
+        statuses[i] = pf.col_status(col);
+        pf.set_col_measurement_id(col, static_cast<uint16_t>(i));
+        pf.set_col_status(col, 0x1);
+    }
+    pf.set_block<T>(arr.data(), n, name, p.buf.data());
+    for (int i = 0; i < n; ++i) {
+        uint8_t* col = pf.nth_col(i, p.buf.data());
+        pf.set_col_measurement_id(col, m_ids[i]);
+        pf.set_col_status(col, statuses[i]);
+    }
+    return true;
 }
 
 template <typename T>
@@ -187,6 +251,13 @@ PYBIND11_MODULE(core, m) {
         .value("Lidar", PacketType::Lidar)
         .value("Imu", PacketType::Imu)
         .value("Zone", PacketType::Zone);
+    // column header selector of PacketFormat.packet_header (python/src/cpp/client/packet.cpp:213-256)
+    py::enum_<ColHeaderSel>(m, "ColHeader")
+        .value("TIMESTAMP", ColHeaderSel::TIMESTAMP)
+        .value("ENCODER_COUNT", ColHeaderSel::ENCODER_COUNT)
+        .value("MEASUREMENT_ID", ColHeaderSel::MEASUREMENT_ID)
+        .value("STATUS", ColHeaderSel::STATUS)
+        .value("FRAME_ID", ColHeaderSel::FRAME_ID);
     py::enum_<FieldClass>(m, "FieldClass")
         .value("PIXEL_FIELD", FieldClass::PIXEL_FIELD)
         .value("COLUMN_FIELD", FieldClass::COLUMN_FIELD)
@@ -211,17 +282,28 @@ PYBIND11_MODULE(core, m) {
         .def_readwrite("udp_profile_lidar", &SensorConfig::udp_profile_lidar);
     // lidar_frame.h:36-74; the element type travels as a numpy dtype
     py::class_<FieldType>(m, "FieldType")
-        .def(py::init([](const std::string& name, const py::object& dt, std::vector<size_t> extra, FieldClass c) {
-                 return FieldType(name, tag_of(py::dtype::from_args(dt)), std::move(extra), c);
+        .def(py::init([](const std::string& name, const py::object& dt, const py::tuple& extra, FieldClass c) {
+                 return make_field_type(name, dt, dims_of(extra), c);
              }),
-             py::arg("name"), py::arg("dtype"), py::arg("extra_dims") = std::vector<size_t>{},
+             py::arg("name"), py::arg("dtype"), py::arg("extra_dims") = py::tuple(),
              py::arg("field_class") = FieldClass::PIXEL_FIELD)
         .def_readwrite("name", &FieldType::name)
-        .def_property_readonly("element_type", [](const FieldType& f) { return dtype_of(f.element_type); })
-        .def_readwrite("extra_dims", &FieldType::extra_dims)
+        // python/src/cpp/client/field.cpp:117-138: switching to / from a fixed-width string moves its width in and out of extra_dims
+        .def_property("element_type", [](const FieldType& f) { return dtype_of(f.element_type); },
+                      [](FieldType& f, const py::object& dt) {
+                          const py::dtype d = py::dtype::from_args(dt);
+                          if (f.element_type == ChanFieldType::CHAR && !f.extra_dims.empty()) f.extra_dims.pop_back();
+                          const ChanFieldType t = tag_of(d);
+                          if (t == ChanFieldType::CHAR && d.itemsize() > 0) f.extra_dims.push_back(static_cast<size_t>(d.itemsize()));
+                          f.element_type = t;
+                      })
+        .def_property("extra_dims", [](const FieldType& f) { return tuple_of(f.extra_dims); },
+                      [](FieldType& f, const py::tuple& t) { f.extra_dims = dims_of(t); })
         .def_readwrite("field_class", &FieldType::field_class)
-        .def("__eq__", [](const FieldType& a, const FieldType& b) { return a == b; })
-        .def("__repr__", [](const FieldType& f) { return to_string(f); });
+        .def("__eq__", [](const FieldType& a, const py::object& b) { return py::isinstance<FieldType>(b) && a == b.cast<const FieldType&>(); })
+        .def("__lt__", [](const FieldType& a, const FieldType& b) { return a < b; })
+        .def("__str__", [](const FieldType& f) { return to_string(f); })
+        .def("__repr__", [](const FieldType& f) { return "<ouster.sdk.client.FieldType " + to_string(f) + ">"; });
 
     py::class_<DataFormat>(m, "DataFormat")
         .def(py::init<>())
@@ -272,6 +354,10 @@ PYBIND11_MODULE(core, m) {
 
     py::class_<PacketFormat, std::shared_ptr<PacketFormat>>(m, "PacketFormat")
         .def(py::init<const SensorInfo&>())
+        .def(py::init<const DataFormat&>())
+        // (held by shared_ptr here, so the cached format is handed out as a copy)
+        .def_static("from_info", [](const SensorInfo& info) { return std::make_shared<PacketFormat>(get_format(info)); })
+        .def_static("from_data_format", [](const DataFormat& f) { return std::make_shared<PacketFormat>(get_format(f)); })
         .def_readonly("lidar_packet_size", &PacketFormat::lidar_packet_size)
         .def_readonly("columns_per_packet", &PacketFormat::columns_per_packet)
         .def_readonly("pixels_per_column", &PacketFormat::pixels_per_column)
@@ -300,9 +386,9 @@ PYBIND11_MODULE(core, m) {
         .def("countdown_shot_limiting",
              [](const PacketFormat& pf, const py::object& b) { return pf.countdown_shot_limiting(packet_bytes(b, 32)); })
         .def("thermal_shutdown",
-             [](const PacketFormat& pf, const py::object& b) { return static_cast<int>(pf.thermal_shutdown(packet_bytes(b, 32))); })
+             [](const PacketFormat& pf, const py::object& b) { return pf.thermal_shutdown(packet_bytes(b, 32)); })
         .def("shot_limiting",
-             [](const PacketFormat& pf, const py::object& b) { return static_cast<int>(pf.shot_limiting(packet_bytes(b, 32))); })
+             [](const PacketFormat& pf, const py::object& b) { return pf.shot_limiting(packet_bytes(b, 32)); })
         .def("crc", [](const PacketFormat& pf, const py::object& b) -> py::object {
             const auto v = pf.crc(packet_bytes(b, 32), packet_size(b));
             if (!v) return py::none();
@@ -314,23 +400,23 @@ PYBIND11_MODULE(core, m) {
         .def("frame_id_difference", &PacketFormat::frame_id_difference)
         // column headers by column index
         .def("col_status", [](const PacketFormat& pf, const py::object& b, size_t col) {
-            return pf.col_status(pf.nth_col(col, packet_bytes(b, pf.lidar_packet_size)));
+            return pf.col_status(pf.nth_col(checked_col(pf, col), packet_bytes(b, pf.lidar_packet_size)));
         })
         .def("col_timestamp", [](const PacketFormat& pf, const py::object& b, size_t col) {
-            return pf.col_timestamp(pf.nth_col(col, packet_bytes(b, pf.lidar_packet_size)));
+            return pf.col_timestamp(pf.nth_col(checked_col(pf, col), packet_bytes(b, pf.lidar_packet_size)));
         })
         .def("col_measurement_id", [](const PacketFormat& pf, const py::object& b, size_t col) {
-            return pf.col_measurement_id(pf.nth_col(col, packet_bytes(b, pf.lidar_packet_size)));
+            return pf.col_measurement_id(pf.nth_col(checked_col(pf, col), packet_bytes(b, pf.lidar_packet_size)));
         })
         // setters (parsing.cpp:1007-1090), as the reference's Python module spells them: (packet, [column,] value)
         .def("set_col_status", [](const PacketFormat& pf, const py::object& b, size_t col, uint32_t v) {
-            pf.set_col_status(pf.nth_col(col, packet_bytes_mut(b, pf.lidar_packet_size)), v);
+            pf.set_col_status(pf.nth_col(checked_col(pf, col), packet_bytes_mut(b, pf.lidar_packet_size)), v);
         })
         .def("set_col_timestamp", [](const PacketFormat& pf, const py::object& b, size_t col, uint64_t v) {
-            pf.set_col_timestamp(pf.nth_col(col, packet_bytes_mut(b, pf.lidar_packet_size)), v);
+            pf.set_col_timestamp(pf.nth_col(checked_col(pf, col), packet_bytes_mut(b, pf.lidar_packet_size)), v);
         })
         .def("set_col_measurement_id", [](const PacketFormat& pf, const py::object& b, size_t col, uint16_t v) {
-            pf.set_col_measurement_id(pf.nth_col(col, packet_bytes_mut(b, pf.lidar_packet_size)), v);
+            pf.set_col_measurement_id(pf.nth_col(checked_col(pf, col), packet_bytes_mut(b, pf.lidar_packet_size)), v);
         })
         .def("set_frame_id", [](const PacketFormat& pf, const py::object& b, uint32_t v) { pf.set_frame_id(packet_bytes_mut(b, 32), v); })
         .def("set_init_id", [](const PacketFormat& pf, const py::object& b, uint32_t v) { pf.set_init_id(packet_bytes_mut(b, 32), v); })
@@ -345,8 +431,28 @@ PYBIND11_MODULE(core, m) {
         .def("field_value_mask", &PacketFormat::field_value_mask)
         .def("field_bitness", &PacketFormat::field_bitness)
         // python/src/cpp/client/packet.cpp:173-210 -- (H, columns_per_packet) array, GPU decode
-        .def("packet_field", [](const PacketFormat& pf, const std::string& name, const py::buffer& b) {
-            const uint8_t* p = buf_ptr(b, pf.lidar_packet_size);
+        .def("set_field", [](const PacketFormat& pf, LidarPacket& p, const std::string& name, const py::array& a) {
+            if (try_set_field<uint8_t>(pf, p, name, a) || try_set_field<uint16_t>(pf, p, name, a) ||
+                try_set_field<uint32_t>(pf, p, name, a) || try_set_field<uint64_t>(pf, p, name, a) ||
+                try_set_field<int8_t>(pf, p, name, a) || try_set_field<int16_t>(pf, p, name, a) ||
+                try_set_field<int32_t>(pf, p, name, a) || try_set_field<int64_t>(pf, p, name, a) ||
+                try_set_field<float>(pf, p, name, a) || try_set_field<double>(pf, p, name, a))
+                return;
+            throw std::invalid_argument("set_field: unsupported array dtype");
+        })
+        .def("packet_header", [](const PacketFormat& pf, ColHeaderSel which, const py::object& b) -> py::array {
+            const uint8_t* pkt = packet_bytes(b, pf.lidar_packet_size);
+            switch (which) {
+                case ColHeaderSel::TIMESTAMP: return header_array<uint64_t>(pf, pkt, [&](const uint8_t* c) { return pf.col_timestamp(c); });
+                case ColHeaderSel::ENCODER_COUNT: return header_array<uint32_t>(pf, pkt, [&](const uint8_t* c) { return pf.col_encoder(c); });
+                case ColHeaderSel::MEASUREMENT_ID: return header_array<uint16_t>(pf, pkt, [&](const uint8_t* c) { return pf.col_measurement_id(c); });
+                case ColHeaderSel::STATUS: return header_array<uint32_t>(pf, pkt, [&](const uint8_t* c) { return pf.col_status(c); });
+                case ColHeaderSel::FRAME_ID: return header_array<uint16_t>(pf, pkt, [&](const uint8_t* c) { return pf.col_frame_id(c); });
+            }
+            throw py::key_error("Invalid header index for PacketFormat");
+        })
+        .def("packet_field", [](const PacketFormat& pf, const std::string& name, const py::object& b) {
+            const uint8_t* p = packet_bytes(b, pf.lidar_packet_size);
             const FieldDecodeInfo& info = pf.field_decode_info(name);
             std::vector<uint8_t> pkt(p, p + pf.lidar_packet_size);
             pkt.resize(pkt.size() + 8, 0);
@@ -398,7 +504,18 @@ PYBIND11_MODULE(core, m) {
                       });
 
     py::class_<LidarFrame>(m, "LidarFrame")
+        .def(py::init<>())
         .def(py::init<const SensorInfo&>())
+        // a copy, optionally onto another field set: casts, zero-fills or drops fields (lidar_frame.h:262)
+        .def(py::init([](const LidarFrame& src) { return LidarFrame(src); }), py::arg("source"))
+        .def(py::init([](const LidarFrame& src, const std::vector<FieldType>& fields) { return LidarFrame(src, fields); }),
+             py::arg("source"), py::arg("field_types"))
+        .def(py::init([](size_t h, size_t w) {
+                 PyErr_WarnEx(PyExc_FutureWarning,
+                              "LidarFrame(h, w) is deprecated, use LidarFrame(h, w, field_types, columns_per_packet) instead", 1);
+                 return LidarFrame(h, w);
+             }),
+             py::arg("h"), py::arg("w"))
         .def(py::init([](const SensorInfo& info, const std::vector<FieldType>& fields) {
                  return LidarFrame(std::make_shared<SensorInfo>(info), fields);
              }),
@@ -430,12 +547,35 @@ PYBIND11_MODULE(core, m) {
         .def("field", [](py::object self, const std::string& name) {
             return field_view(self.cast<LidarFrame&>().field(name), self);
         })
+        // python/src/cpp/client/lidar_frame.cpp:273-370: (name, array[, class]) deep-copies the array in;
+        // (name, dtype[, extra_dims, class]) and (FieldType) add a zero-filled field
         .def("add_field",
-             [](py::object self, const std::string& name, const py::object& dt, std::vector<size_t> extra) {
+             [](py::object self, const std::string& name, const py::array& data, FieldClass c) {
                  LidarFrame& f = self.cast<LidarFrame&>();
-                 return field_view(f.add_field(name, tag_of(py::dtype::from_args(dt)), std::move(extra)), self);
+                 const py::array src = py::array::ensure(data, py::array::c_style);
+                 const py::dtype d = src.dtype();
+                 std::vector<size_t> shape(src.shape(), src.shape() + src.ndim());
+                 const ChanFieldType t = tag_of(d);
+                 if (t == ChanFieldType::CHAR && d.itemsize() > 0) shape.push_back(static_cast<size_t>(d.itemsize()));
+                 Field& fld = f.add_field(name, FieldDescriptor::array(t, shape), c);
+                 if (fld.bytes()) std::memcpy(fld.get(), src.data(), fld.bytes());
+                 return field_view(fld, self);
              },
-             py::arg("name"), py::arg("dtype"), py::arg("extra_dims") = std::vector<size_t>{})
+             py::arg("name"), py::arg("data"), py::arg("field_class") = FieldClass::PIXEL_FIELD)
+        .def("add_field",
+             [](py::object self, const std::string& name, const py::object& dt, const py::tuple& extra, FieldClass c) {
+                 LidarFrame& f = self.cast<LidarFrame&>();
+                 return field_view(f.add_field(make_field_type(name, dt, dims_of(extra), c)), self);
+             },
+             py::arg("name"), py::arg("dtype"), py::arg("shape") = py::tuple(), py::arg("field_class") = FieldClass::PIXEL_FIELD)
+        .def("add_field", [](py::object self, const FieldType& t) { return field_view(self.cast<LidarFrame&>().add_field(t), self); },
+             py::arg("type"))
+        .def("field_class", [](LidarFrame& f, const std::string& name) { return f.field(name).field_class(); })
+        .def_property_readonly("packet_count", &LidarFrame::packet_count)
+        .def("get_first_valid_packet_timestamp", [](const LidarFrame& f) { return f.get_first_valid_packet_timestamp(); })
+        .def("get_last_valid_packet_timestamp", [](const LidarFrame& f) { return f.get_last_valid_packet_timestamp(); })
+        .def("get_min_valid_packet_timestamp", [](const LidarFrame& f) { return f.get_min_valid_packet_timestamp(); })
+        .def("get_max_valid_packet_timestamp", [](const LidarFrame& f) { return f.get_max_valid_packet_timestamp(); })
         .def("del_field", [](LidarFrame& f, const std::string& n) { f.del_field(n); })
         .def_property_readonly("fields",
                                [](const LidarFrame& f) {

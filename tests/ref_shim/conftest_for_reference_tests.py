@@ -53,6 +53,16 @@ def packets(real_pcap_path: str, meta):
     return core.Packets([p for _, p in pcap.PcapPacketSource(real_pcap_path, sensor_info=[meta])], meta)
 
 
+@pytest.fixture
+def packet(real_pcap_path: str, meta):
+    """The first lidar packet of the capture."""
+    from ouster.sdk import pcap
+    for _, p in pcap.PcapPacketSource(real_pcap_path, sensor_info=[meta]):
+        if isinstance(p, core.LidarPacket):
+            return p
+    raise RuntimeError("Failed to find lidar packet in test fixture")
+
+
 @pytest.fixture(scope="package")
 def test_data_dir():
     from pathlib import Path
