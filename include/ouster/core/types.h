@@ -120,6 +120,10 @@ class SensorInfo {
     mutable std::shared_ptr<Cache> cache_;
 };
 
+/** Member-wise equality over what this mirror holds (sensor_info.cpp:128-151). */
+bool operator==(const SensorInfo& lhs, const SensorInfo& rhs);
+inline bool operator!=(const SensorInfo& lhs, const SensorInfo& rhs) { return !(lhs == rhs); }
+
 /** Read a metadata JSON file (sensor_info.h:413).  `skip_beam_validation` is accepted and ignored: nothing is validated. */
 SensorInfo metadata_from_json(const std::string& json_file, bool skip_beam_validation = false);
 

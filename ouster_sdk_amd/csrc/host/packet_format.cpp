@@ -757,12 +757,35 @@ mat4d default_beam_to_lidar_transform(const std::string& prod_line) {
     return m;
 }
 
+bool operator==(const SensorInfo& a, const SensorInfo& b) {
+    auto same_opt = [](const auto& x, const auto& y) { return bool(x) == bool(y) && (!x || *x == *y); };
+    return a.sn == b.sn && a.fw_rev == b.fw_rev && a.image_rev == b.image_rev && a.prod_line == b.prod_line &&
+           a.format == b.format && a.beam_azimuth_angles == b.beam_azimuth_angles &&
+           a.beam_altitude_angles == b.beam_altitude_angles &&
+           a.lidar_origin_to_beam_origin_mm == b.lidar_origin_to_beam_origin_mm &&
+           a.beam_to_lidar_transform == b.beam_to_lidar_transform && a.imu_to_sensor_transform == b.imu_to_sensor_transform &&
+           a.lidar_to_sensor_transform == b.lidar_to_sensor_transform && a.sensor_to_body == b.sensor_to_body &&
+           a.init_id == b.init_id && same_opt(a.config.lidar_mode, b.config.lidar_mode) &&
+           same_opt(a.config.udp_profile_lidar, b.config.udp_profile_lidar);
+}
+
 Version SensorInfo::get_version() const {
+    // sensor_info.cpp:391-393 parses image_rev ("ousteros-image-prod-aries-v2.3.0+2022...", "v3.2.0", "3.2.1"); a SensorInfo
+    // filled by hand with only fw_rev set is read from that
+    auto parse = [](const std::string& text, Version& out) {
+        for (const char* s = text.c_str(); *s; ++s) {
+            if (*s < '0' || *s > '9') continue;
+            unsigned a = 0, b = 0, c = 0;
+            if (std::sscanf(s, "%u.%u.%u", &a, &b, &c) == 3) {
+                out = Version(a, b, c);
+                return true;
+            }
+            while (s[1] >= '0' && s[1] <= '9') ++s;   // not a dotted triple: skip this run of digits
+        }
+        return false;
+    };
     Version v;
-    unsigned a = 0, b = 0, c = 0;
-    const char* s = fw_rev.c_str();
-    while (*s && (*s < '0' || *s > '9')) ++s;
-    if (std::sscanf(s, "%u.%u.%u", &a, &b, &c) == 3) v = Version(a, b, c);
+    if (!parse(image_rev, v)) parse(fw_rev, v);
     return v;
 }
 

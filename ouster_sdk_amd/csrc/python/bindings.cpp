@@ -207,7 +207,10 @@ void bind_lut(py::module_& m, const char* name) {
 PYBIND11_MODULE(core, m) {
     m.doc() = "MI355X implementation of the ouster.sdk.core hot path (decode, destagger, XYZLut)";
 
-    py::enum_<UDPProfileLidar>(m, "UDPProfileLidar")
+    // kept alive past module init: add_custom_profile registers its profile as a new member (python/src/cpp/client/data.cpp:620-643)
+    static py::enum_<UDPProfileLidar>* udp_profile_lidar = nullptr;
+    udp_profile_lidar = new py::enum_<UDPProfileLidar>(m, "UDPProfileLidar");
+    (*udp_profile_lidar)
         .value("LEGACY", UDPProfileLidar::LEGACY)
         .value("RNG19_RFL8_SIG16_NIR16_DUAL", UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_DUAL)
         .value("RNG19_RFL8_SIG16_NIR16", UDPProfileLidar::RNG19_RFL8_SIG16_NIR16)
@@ -223,6 +226,31 @@ PYBIND11_MODULE(core, m) {
         .value("RNG19_RFL8_SIG16_NIR16_RGB16_DUAL", UDPProfileLidar::RNG19_RFL8_SIG16_NIR16_RGB16_DUAL)
         .value("OFF", UDPProfileLidar::OFF)
         .def_static("from_string", [](const std::string& s) { return udp_profile_lidar_of_string(s).value_or(UDPProfileLidar::UNKNOWN); });
+    udp_profile_lidar->attr("__str__") = py::cpp_function([](UDPProfileLidar p) { return to_string(p); }, py::is_method(*udp_profile_lidar));
+    py::class_<FieldDecodeInfo>(m, "FieldDecodeInfo")
+        .def(py::init([](const py::object& dt, size_t offset, uint64_t mask, int shift, int num_elements) {
+                 return FieldDecodeInfo{tag_of(py::dtype::from_args(dt)), offset, mask, shift, num_elements};
+             }),
+             py::arg("dtype_arg"), py::arg("offset"), py::arg("mask"), py::arg("shift"), py::arg("num_elements") = 1)
+        .def_property_readonly("ty_tag", [](const FieldDecodeInfo& f) { return dtype_of(f.ty_tag); })
+        .def_readwrite("offset", &FieldDecodeInfo::offset)
+        .def_readwrite("mask", &FieldDecodeInfo::mask)
+        .def_readwrite("shift", &FieldDecodeInfo::shift)
+        .def_readwrite("num_elements", &FieldDecodeInfo::num_elements);
+    m.def("add_custom_profile",
+          [](const std::string& name, const std::vector<std::pair<std::string, FieldDecodeInfo>>& fields, size_t chan_data_size) {
+              const UDPProfileLidar nr = add_custom_profile(name, fields, chan_data_size);
+              udp_profile_lidar->value(name.c_str(), nr);
+              return static_cast<int>(nr);
+          },
+          py::arg("name"), py::arg("fields"), py::arg("chan_data_size"));
+    m.def("add_custom_profile",
+          [](int profile_nr, const std::string& name, const std::vector<std::pair<std::string, FieldDecodeInfo>>& fields,
+             size_t chan_data_size) {
+              add_custom_profile(profile_nr, name, fields, chan_data_size);
+              udp_profile_lidar->value(name.c_str(), static_cast<UDPProfileLidar>(profile_nr));
+          },
+          py::arg("profile_nr"), py::arg("name"), py::arg("fields"), py::arg("chan_data_size"));
     py::enum_<HeaderType>(m, "HeaderType").value("STANDARD", HeaderType::STANDARD).value("FUSA", HeaderType::FUSA);
     py::enum_<UDPProfileIMU>(m, "UDPProfileIMU")
         .value("LEGACY", UDPProfileIMU::LEGACY)
@@ -325,6 +353,7 @@ PYBIND11_MODULE(core, m) {
     py::class_<SensorInfo, std::shared_ptr<SensorInfo>>(m, "SensorInfo")
         .def(py::init<>())
         .def(py::init<const std::string&>(), py::arg("metadata_json"))   // sensor_info.h:229
+        .def("__eq__", [](const SensorInfo& a, const py::object& b) { return py::isinstance<SensorInfo>(b) && a == b.cast<const SensorInfo&>(); })
         .def("__copy__", [](const SensorInfo& s) { return SensorInfo(s); })
         .def("__deepcopy__", [](const SensorInfo& s, const py::dict&) { return SensorInfo(s); })
         .def_readwrite("config", &SensorInfo::config)
@@ -440,9 +469,11 @@ PYBIND11_MODULE(core, m) {
                 return;
             throw std::invalid_argument("set_field: unsupported array dtype");
         })
-        .def("packet_header", [](const PacketFormat& pf, ColHeaderSel which, const py::object& b) -> py::array {
+        .def("packet_header", [](const PacketFormat& pf, const py::object& header, const py::object& b) -> py::array {
             const uint8_t* pkt = packet_bytes(b, pf.lidar_packet_size);
-            switch (which) {
+            const py::object as_int = py::reinterpret_steal<py::object>(PyNumber_Long(header.ptr()));
+            if (!as_int) throw py::error_already_set();
+            switch (static_cast<ColHeaderSel>(as_int.cast<int>())) {
                 case ColHeaderSel::TIMESTAMP: return header_array<uint64_t>(pf, pkt, [&](const uint8_t* c) { return pf.col_timestamp(c); });
                 case ColHeaderSel::ENCODER_COUNT: return header_array<uint32_t>(pf, pkt, [&](const uint8_t* c) { return pf.col_encoder(c); });
                 case ColHeaderSel::MEASUREMENT_ID: return header_array<uint16_t>(pf, pkt, [&](const uint8_t* c) { return pf.col_measurement_id(c); });
@@ -632,6 +663,9 @@ PYBIND11_MODULE(core, m) {
         .def("dropped_packets", &FrameBatcher::dropped_packets);
     m.attr("ScanBatcher") = m.attr("FrameBatcher");
     m.attr("LidarScan") = m.attr("LidarFrame");
+
+    m.def("get_field_types", [](const SensorInfo& info) { return get_field_types(info); }, py::arg("info"));
+    m.def("get_field_types", [](UDPProfileLidar p) { return get_field_types(p); }, py::arg("udp_profile_lidar"));
 
     bind_lut<double>(m, "XYZLut");
     bind_lut<float>(m, "XYZLutFloat");

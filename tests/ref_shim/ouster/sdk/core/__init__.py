@@ -4,6 +4,8 @@ from ouster_sdk_amd.core import *  # noqa: F401,F403
 from ouster_sdk_amd import core as _core
 
 
+from .data import ColHeader  # noqa: E402,F401  (a Python Enum in the reference too)
+
 SensorInfo = _core.SensorInfo   # SensorInfo(json_text) is a constructor of the C++ class (csrc/host/metadata.cpp)
 
 
@@ -41,6 +43,12 @@ class Packets:
     def __iter__(self):
         return ((0, p) for p in self._packets)
 
+    is_live = False
+    is_indexed = False
+
+    def close(self):
+        pass
+
 
 PacketSource = Packets
 
@@ -49,3 +57,9 @@ class ImuPacket:
     """IMU packets are out of scope of this repo; the name exists so that test modules import."""
     def __init__(self, *args, **kwargs):
         raise NotImplementedError("IMU packets are out of scope")
+
+
+class Version:
+    """Firmware version parsing is not part of this repo's Python surface; the name exists so that test modules import."""
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("core.Version is out of scope")
