@@ -75,6 +75,10 @@ inline unsigned int frequency_of_lidar_mode(LidarMode mode) { return mode.fps; }
 struct SensorConfig {
     nonstd::optional<LidarMode> lidar_mode;
     nonstd::optional<UDPProfileLidar> udp_profile_lidar;
+    nonstd::optional<UDPProfileIMU> udp_profile_imu;
+    nonstd::optional<int> udp_port_lidar;   ///< destination ports of the sensor's streams (sensor_config.h); 0 = stream disabled
+    nonstd::optional<int> udp_port_imu;
+    nonstd::optional<int> udp_port_zm;
 };
 
 template <typename T> class XYZLutT;
@@ -151,6 +155,8 @@ class PacketFormat {
     const UDPProfileIMU udp_profile_imu;
     const HeaderType header_type;
     const size_t lidar_packet_size;
+    const size_t imu_packet_size;    ///< sizes only: IMU / zone packets are recognised (packet type by size), not parsed
+    const size_t zone_packet_size;
     const uint32_t columns_per_packet;
     const uint32_t pixels_per_column;
     const size_t packet_header_size;

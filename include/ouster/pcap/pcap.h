@@ -30,7 +30,7 @@ struct PacketInfo {
     int fragments_in_packet = 0;
     int ip_version = 0;
     int encapsulation_protocol = 0;  ///< pcap link type
-    uint64_t file_offset = 0;
+    uint64_t file_offset = 0;        ///< of the record the datagram starts in (its first fragment when it was reassembled)
     int network_protocol = 17;       ///< always UDP
 };
 

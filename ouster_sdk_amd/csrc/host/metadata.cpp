@@ -290,6 +290,10 @@ SensorInfo::SensorInfo(const std::string& metadata_json) {
     std::string imu_profile = df.at("udp_profile_imu").as_string();
     if (imu_profile.empty()) imu_profile = cfg.at("udp_profile_imu").as_string();
     if (const auto p = udp_profile_imu_of_string(imu_profile)) format.udp_profile_imu = *p;
+    if (const auto p = udp_profile_imu_of_string(cfg.at("udp_profile_imu").as_string())) config.udp_profile_imu = *p;
+    if (!cfg.at("udp_port_lidar").is_null()) config.udp_port_lidar = static_cast<int>(cfg.at("udp_port_lidar").as_i64());
+    if (!cfg.at("udp_port_imu").is_null()) config.udp_port_imu = static_cast<int>(cfg.at("udp_port_imu").as_i64());
+    if (!cfg.at("udp_port_zm").is_null()) config.udp_port_zm = static_cast<int>(cfg.at("udp_port_zm").as_i64());
     std::string header = df.at("header_type").as_string();
     if (header.empty()) header = cfg.at("header_type").as_string();
     if (const auto t = udp_profile_type_of_string(header)) format.header_type = *t;

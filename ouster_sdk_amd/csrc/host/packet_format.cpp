@@ -430,7 +430,7 @@ std::array<std::pair<UDPProfileLidar, ProfileEntry>, MAX_NUM_PROFILES> get_profi
 // ---------------------------------------------------------------------------------------
 struct PacketFormat::Impl {
     size_t packet_header_size{}, col_header_size{}, channel_data_size{}, col_footer_size{},
-        packet_footer_size{}, col_size{}, lidar_packet_size{};
+        packet_footer_size{}, col_size{}, lidar_packet_size{}, imu_packet_size{}, zone_packet_size{};
     uint32_t max_frame_id{};
     std::map<std::string, FieldDecodeInfo> fields;
     FieldDecodeInfo packet_type, frame_id, init_id, prod_sn, alert_flags, countdown_thermal,
@@ -449,6 +449,12 @@ struct PacketFormat::Impl {
         lidar_packet_size = packet_header_size + fmt.columns_per_packet * col_size + packet_footer_size;
         if (lidar_packet_size > 65535)
             throw std::invalid_argument("lidar_packet_size cannot exceed 65535");
+        // parsing.cpp:540-596: legacy IMU packets are 48 bytes; the newer profile frames a 100-byte NMEA block and 36-byte
+        // measurements between header and footer; a zone packet carries 8 + 32 bytes and sixteen 36-byte zone records
+        imu_packet_size = fmt.udp_profile_imu == UDPProfileIMU::LEGACY
+                              ? 48
+                              : packet_header_size + 100 + fmt.imu_measurements_per_packet * 36 + packet_footer_size;
+        zone_packet_size = packet_header_size + 8 + 32 + 36 * 16 + packet_footer_size;
         for (const auto& kv : e.fields) fields.emplace(kv.first, kv.second);
         max_frame_id = fmt.max_frame_id();
 
@@ -491,6 +497,8 @@ PacketFormat::PacketFormat(const DataFormat& format)
       udp_profile_imu{format.udp_profile_imu},
       header_type{format.header_type},
       lidar_packet_size{impl_->lidar_packet_size},
+      imu_packet_size{impl_->imu_packet_size},
+      zone_packet_size{impl_->zone_packet_size},
       columns_per_packet{format.columns_per_packet},
       pixels_per_column{format.pixels_per_column},
       packet_header_size{impl_->packet_header_size},
@@ -766,7 +774,9 @@ bool operator==(const SensorInfo& a, const SensorInfo& b) {
            a.beam_to_lidar_transform == b.beam_to_lidar_transform && a.imu_to_sensor_transform == b.imu_to_sensor_transform &&
            a.lidar_to_sensor_transform == b.lidar_to_sensor_transform && a.sensor_to_body == b.sensor_to_body &&
            a.init_id == b.init_id && same_opt(a.config.lidar_mode, b.config.lidar_mode) &&
-           same_opt(a.config.udp_profile_lidar, b.config.udp_profile_lidar);
+           same_opt(a.config.udp_profile_lidar, b.config.udp_profile_lidar) &&
+           same_opt(a.config.udp_profile_imu, b.config.udp_profile_imu) && same_opt(a.config.udp_port_lidar, b.config.udp_port_lidar) &&
+           same_opt(a.config.udp_port_imu, b.config.udp_port_imu) && same_opt(a.config.udp_port_zm, b.config.udp_port_zm);
 }
 
 Version SensorInfo::get_version() const {
@@ -807,8 +817,14 @@ int SensorInfo::num_returns() const {
 // is not explicitly of another kind is held against the lidar packet size)
 PacketValidationFailure validate_packet(const SensorInfo& info, const PacketFormat& format, const uint8_t* buf,
                                         uint64_t buf_size, PacketType type) {
-    if (type == PacketType::Unknown) type = PacketType::Lidar;
-    if (type == PacketType::Lidar && buf_size != format.lidar_packet_size) return PacketValidationFailure::PACKET_SIZE;
+    if (type == PacketType::Unknown)
+        type = buf_size == format.imu_packet_size    ? PacketType::Imu
+               : buf_size == format.zone_packet_size ? PacketType::Zone
+                                                     : PacketType::Lidar;
+    const size_t want = type == PacketType::Imu ? format.imu_packet_size
+                        : type == PacketType::Zone ? format.zone_packet_size
+                                                   : format.lidar_packet_size;
+    if (buf_size != want) return PacketValidationFailure::PACKET_SIZE;
     if (type == PacketType::Imu && format.udp_profile_imu == UDPProfileIMU::LEGACY) return PacketValidationFailure::NONE;
     const uint32_t init_id = format.init_id(buf);
     if (info.init_id != 0 && init_id != 0 && init_id != info.init_id) return PacketValidationFailure::ID;

@@ -38,6 +38,7 @@ struct FragBuf {
     size_t total = 0;                // known once the last fragment arrived
     int count = 0;
     uint64_t first_seen = 0;         // IP packet number of its first fragment (incomplete ones expire)
+    uint64_t first_offset = 0;       // file offset of the record that carried the first fragment seen
 };
 }  // namespace
 
@@ -95,7 +96,10 @@ struct PcapReader::Impl {
             for (auto it = frags.begin(); it != frags.end();)
                 it = (n_ipv4 - it->second.first_seen > 4096) ? frags.erase(it) : std::next(it);
         FragBuf& fb = frags[key];
-        if (fb.count == 0) fb.first_seen = n_ipv4;
+        if (fb.count == 0) {
+            fb.first_seen = n_ipv4;
+            fb.first_offset = info.file_offset;
+        }
         const size_t plen = tot - ihl;
         if (fb.data.size() < frag_off + plen) {
             fb.data.resize(frag_off + plen);
@@ -110,6 +114,9 @@ struct PcapReader::Impl {
             if (!fb.have[b]) return false;
         std::vector<uint8_t> whole(fb.data.begin(), fb.data.begin() + static_cast<long>(fb.total));
         info.fragments_in_packet = fb.count;
+        // a reassembled datagram is located by its first fragment, so that seek(file_offset) + next_packet() reads it again
+        // (the reference reports the record of the last fragment: ouster_pcap/src/pcap.cpp:166-169)
+        info.file_offset = fb.first_offset;
         frags.erase(key);
         return take_udp(whole.data(), whole.size());
     }
@@ -189,7 +196,11 @@ size_t PcapReader::next_packet() {
     for (;;) {
         const int64_t off = std::ftell(s.f);
         uint8_t rh[16];
-        if (std::fread(rh, 1, 16, s.f) != 16) return 0;
+        if (std::fread(rh, 1, 16, s.f) != 16) {
+            s.info.file_offset = static_cast<uint64_t>(off);   // at the end the cached info points past the last record
+            s.payload.clear();
+            return 0;
+        }
         const uint32_t sec = s.u32(rh), frac = s.u32(rh + 4), incl = s.u32(rh + 8);
         if (incl > (64u << 20)) return 0;  // corrupt record
         s.rec.resize(incl);

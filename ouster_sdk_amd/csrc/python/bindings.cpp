@@ -18,6 +18,7 @@
 #include "ouster/core/lidar_scan.h"
 #include "ouster/hip/frame_stream.h"
 #include "ouster/osf/osf.h"
+#include "ouster/pcap/indexed_pcap_reader.h"
 #include "ouster/pcap/pcap.h"
 
 namespace py = pybind11;
@@ -903,16 +904,42 @@ PYBIND11_MODULE(core, m) {
 
     // every UDP datagram of a classic pcap as (payload bytes, destination port, capture time in ns): the Python face of
     // ouster::sdk::pcap::PcapReader (include/ouster/pcap/pcap.h), enough to feed a FrameBatcher from a capture
-    m.def("read_pcap_udp", [](const std::string& path) {
+    m.def("read_pcap_udp", [](const std::string& path, uint64_t offset, int64_t max_packets) {
         ouster::sdk::pcap::PcapReader rd(path);
+        if (offset) rd.seek(offset);
         py::list out;
-        while (size_t n = rd.next_packet()) {
+        while (max_packets < 0 || static_cast<int64_t>(out.size()) < max_packets) {
+            const size_t n = rd.next_packet();
+            if (!n) break;
             const auto& info = rd.current_info();
             out.append(py::make_tuple(py::bytes(reinterpret_cast<const char*>(rd.current_data()), n), info.dst_port,
                                       static_cast<uint64_t>(info.timestamp.count()) * 1000ull));
         }
         return out;
-    });
+    }, py::arg("path"), py::arg("offset") = 0, py::arg("max_packets") = -1);
+    // a capture demultiplexed by sensor (include/ouster/pcap/indexed_pcap_reader.h): every UDP datagram as (sensor index or
+    // None, payload bytes, destination port, capture time in ns, file offset) plus, per sensor, the file offsets at which
+    // its frames start.  Sensors may share a port: datagrams are told apart by the ids in their packet headers.
+    m.def("index_pcap", [](const std::string& path, const std::vector<SensorInfo>& infos, bool soft_id_check) {
+        ouster::sdk::pcap::IndexedPcapReader rd(path, infos);
+        py::list packets;
+        while (size_t n = rd.next_packet()) {
+            rd.update_index_for_current_packet();
+            const auto& pi = rd.current_info();
+            const auto idx = rd.sensor_idx_for_current_packet(soft_id_check);
+            packets.append(py::make_tuple(idx ? py::object(py::int_(*idx)) : py::object(py::none()),
+                                          py::bytes(reinterpret_cast<const char*>(rd.current_data()), n), pi.dst_port,
+                                          static_cast<uint64_t>(pi.timestamp.count()) * 1000ull, pi.file_offset));
+        }
+        py::dict out;
+        out["packets"] = packets;
+        out["frame_offsets"] = rd.get_index().frame_indices;
+        py::list ports;
+        for (const SensorInfo& si : rd.sensor_info())
+            ports.append(py::make_tuple(si.config.udp_port_lidar.value_or(0), si.config.udp_port_imu.value_or(0)));
+        out["ports"] = ports;   // (lidar, imu) per sensor, guessed from the capture where the metadata does not name them
+        return out;
+    }, py::arg("path"), py::arg("sensor_info"), py::arg("soft_id_check") = false);
     m.def("default_lidar_to_sensor", [] { return mat_to(DEFAULT_LIDAR_TO_SENSOR); });
     m.def("default_beam_to_lidar_transform", [](const std::string& p) { return mat_to(default_beam_to_lidar_transform(p)); });
 }

@@ -296,3 +296,36 @@ def test_frame_stream_replays_a_capture(oracle):
     want = core.XYZLut(info, True)(first["RANGE"][0])
     assert first["xyz"].shape == (1, info.h, info.w, 3)
     assert np.abs(first["xyz"][0].astype(np.float64) - want).max() <= 4e-5
+
+
+def test_two_sensors_on_one_port_decode_like_the_oracle(oracle):
+    """The multi-sensor front end on a real capture (the reference's same_ports_nonlegacy.pcap): IndexedPcapReader routes the
+    IP-reassembled lidar packets of two sensors that share port 7502 by the serial number in their headers; each sensor's
+    FrameBatcher (GPU decode) then holds exactly its own packet's columns, equal to the oracle's col_field decode."""
+    O = oracle
+    metas = ("same_ports_nonlegacy.1.json", "same_ports_nonlegacy.2.non_colliding_imu.json")
+    infos = [core.SensorInfo(open(os.path.join(PCAPS, n)).read()) for n in metas]
+    r = core.index_pcap(os.path.join(PCAPS, "same_ports_nonlegacy.pcap"), infos)
+    seen = set()
+    for idx, info in enumerate(infos):
+        cal = O.calib_from_json(os.path.join(PCAPS, metas[idx]))
+        opf = cal.packet_format()
+        pk = [np.frombuffer(p, np.uint8) for i, p, port, ts, off in r["packets"] if i == idx and len(p) == opf.lidar_packet_size]
+        assert len(pk) == 1
+        frame, batch = core.LidarFrame(info), core.FrameBatcher(info)
+        for p in pk:
+            lp = core.LidarPacket(opf.lidar_packet_size)
+            lp.buf = p.tobytes()
+            assert not batch(lp, frame)
+        m_id = O.packet_header(opf, "MEASUREMENT_ID", pk[0])
+        valid = (O.packet_header(opf, "STATUS", pk[0]) & 1) != 0
+        assert valid.any() and frame.frame_id == core.PacketFormat(info).frame_id(pk[0].tobytes())
+        for name in frame.fields:
+            want = O.packet_field(opf, name, pk[0])[:, valid]
+            got = frame.field(name)[:, m_id[valid]]
+            assert np.array_equal(got, want), (idx, name)
+            rest = np.delete(frame.field(name), m_id[valid], axis=1)
+            assert not rest.any(), (idx, name)
+        assert np.array_equal(frame.timestamp[m_id[valid]], O.packet_header(opf, "TIMESTAMP", pk[0])[valid])
+        seen.add(int(core.PacketFormat(info).prod_sn(pk[0].tobytes())))
+    assert seen == {infos[0].sn, infos[1].sn}

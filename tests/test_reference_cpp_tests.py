@@ -1,7 +1,8 @@
 """The REFERENCE's own C++ tests of this path, run against this repo.
 
 `oracle/Makefile` (target refcpptests) compiles tests/packet_format_test.cpp, frame_batcher_test.cpp,
-profile_extension_test.cpp, fusa_profile_test.cpp, destagger_test.cpp and cartesian_test.cpp of ouster-sdk from where they lie against the mirror of the ouster_core API under include/
+profile_extension_test.cpp, fusa_profile_test.cpp, destagger_test.cpp, cartesian_test.cpp, lidar_frame_test.cpp,
+parsing_benchmark_test.cpp and pcap_test.cpp of ouster-sdk from where they lie against the mirror of the ouster_core API under include/
 and links them with ouster_sdk_amd/lib -- the reference's assertions (profile bit tables, header accessors, encode -> decode
 round trips, dropped / reordered / wrapped-around packets, the snapshot hashes of five recorded captures, init-id and serial
 number handling ...) then run on the product, FrameBatcher decoding on the GPU.  Not the reference's: a GoogleTest stand-in
@@ -22,7 +23,7 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "cpptests")
 DATA = os.path.join(ROOT, "tests", "golden", "pcaps")
 # test binary -> the least number of test cases it must hold (a staging accident that drops cases must not go unnoticed)
 SUITES = {"packet_format_test": 47, "frame_batcher_test": 49, "profile_extension_test": 1, "fusa_profile_test": 2,
-          "destagger_test": 10, "cartesian_test": 2, "lidar_frame_test": 21, "parsing_benchmark_test": 10}
+          "destagger_test": 10, "cartesian_test": 2, "lidar_frame_test": 21, "parsing_benchmark_test": 10, "pcap_test": 11}
 
 
 @pytest.mark.parametrize("name", sorted(SUITES))
