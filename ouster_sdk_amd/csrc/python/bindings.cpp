@@ -582,7 +582,9 @@ PYBIND11_MODULE(core, m) {
         // python/src/cpp/client/lidar_frame.cpp:273-370: (name, array[, class]) deep-copies the array in;
         // (name, dtype[, extra_dims, class]) and (FieldType) add a zero-filled field
         .def("add_field",
-             [](py::object self, const std::string& name, const py::array& data, FieldClass c) {
+             [](py::object self, const std::string& name, const py::object& data, FieldClass c) {
+                 // only a real array is a value; a dtype-like (np.uint8, "u4", np.dtype(...)) belongs to the next overload
+                 if (!py::isinstance<py::array>(data)) throw py::reference_cast_error();
                  LidarFrame& f = self.cast<LidarFrame&>();
                  const py::array src = py::array::ensure(data, py::array::c_style);
                  const py::dtype d = src.dtype();

@@ -28,8 +28,9 @@ def test_add_field_forms():
     d = fr.add_field("frame_vec", np.zeros((5,), np.uint8), core.FieldClass.FRAME_FIELD)
     assert d.shape == (5,)
     assert fr.add_field("empty", np.int8, (0,), core.FieldClass.FRAME_FIELD).shape == (0,)
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError, match="Duplicated field"):
         fr.add_field("by_dtype", np.int16)                               # duplicate
+    assert fr.add_field("two_args", np.uint8).shape == (8, 64) and fr.add_field("str_dtype", "u2").dtype == np.uint16
     with pytest.raises(ValueError):
         fr.add_field("zero_px", np.int8, (0,))                           # a pixel field cannot be empty
     with pytest.raises(ValueError):
