@@ -12,6 +12,7 @@
 //   dewarp<T>                                ouster_core/include/ouster/core/pose_util.h:38-56, impl/dewarp_impl.h:23-115
 // Memory-bound byte/bit work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -465,48 +466,87 @@ __device__ __forceinline__ uint32_t block_exscan_256(uint32_t v, uint32_t* s_wav
 }
 
 __global__ __launch_bounds__(256) void k_dwf_scan(DewarpFramesArgs a) {
+    // One workgroup per frame.  Every global access is coalesced (thread t takes columns t, t + 256, ...) and a block's
+    // loads are issued together from clamped addresses; the exclusive scan wants eight CONSECUTIVE columns per thread, so the
+    // counts cross an LDS image (2048 columns per block, +1 dword of padding every 32).  The first form of this kernel walked
+    // eight consecutive columns per thread straight from memory, twice, behind per-column guards: ~16 dependent round
+    // trips, 16 us for 256 frames; this one takes two round trips per block of 2048 columns.
+    constexpr uint32_t SEG = 8, BLK = 256 * SEG;
     __shared__ int s_lo, s_hi;
     __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_c[BLK + BLK / 32];
     const uint32_t W = a.w, f = blockIdx.x, tid = threadIdx.x;
     const uint32_t* st = a.status + (size_t)f * W;
     uint32_t* off = a.col_off + (size_t)f * (W + 1);
     if (tid == 0) { s_lo = 0x7fffffff; s_hi = -1; }
     __syncthreads();
+    // first / last valid column (status bit 0; lidar_frame.cpp:907-925)
     int lo = 0x7fffffff, hi = -1;
-    for (uint32_t x = tid; x < W; x += 256)
-        if (st[x] & 1u) { lo = min(lo, (int)x); hi = max(hi, (int)x); }
+    for (uint32_t base = 0; base < W; base += BLK) {
+        uint32_t v[SEG];
+#pragma unroll
+        for (uint32_t k = 0; k < SEG; ++k) v[k] = st[min(base + tid + 256u * k, W - 1u)];
+#pragma unroll
+        for (uint32_t k = 0; k < SEG; ++k) {
+            const uint32_t x = base + tid + 256u * k;
+            if (x < W && (v[k] & 1u)) { lo = min(lo, (int)x); hi = max(hi, (int)x); }
+        }
+    }
     if (hi >= 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
     __syncthreads();
     lo = s_lo; hi = s_hi;
-    // contiguous segment per thread
-    const uint32_t seg = (W + 255) / 256;
-    const uint32_t x0 = tid * seg, x1 = min(W, x0 + seg);
-    // kept points per column: k_dwf_count's, or the decode kernel's range-gate by-product (partial counts
-    // per row chunk, summed here)
+    // kept points per column: k_dwf_count's, or the decode kernel's range-gate by-product (partial counts per row chunk,
+    // summed here)
     const uint16_t* ext = a.gate_counts ? a.gate_counts + (size_t)f * OUSTER_HIP_GATE_CHUNKS * W : nullptr;
-    auto kept = [&](uint32_t x) -> uint32_t {
-        if (!ext) return off[x];
-        uint32_t n = 0;
+    auto pad = [](uint32_t i) { return i + (i >> 5); };
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < W; base += BLK) {
+        uint32_t v[SEG], n[SEG];
 #pragma unroll
-        for (uint32_t k = 0; k < OUSTER_HIP_GATE_CHUNKS; ++k) n += ext[(size_t)k * W + x];
-        return n;
-    };
-    uint32_t sum = 0;
-    for (uint32_t x = x0; x < x1; ++x) {
-        const bool keep = (int)x >= lo && (int)x <= hi && st[x] != 0;
-        sum += keep ? kept(x) : 0u;
-    }
-    uint32_t total;
-    uint32_t run = block_exscan_256(sum, s_wave, &total);
-    for (uint32_t x = x0; x < x1; ++x) {
-        const bool keep = (int)x >= lo && (int)x <= hi && st[x] != 0;
-        const uint32_t c = keep ? kept(x) : 0u;
-        off[x] = run;
-        run += c;
+        for (uint32_t k = 0; k < SEG; ++k) {
+            const uint32_t xc = min(base + tid + 256u * k, W - 1u);
+            v[k] = st[xc];
+            if (ext) {
+                uint32_t sum = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < OUSTER_HIP_GATE_CHUNKS; ++c) sum += ext[(size_t)c * W + xc];
+                n[k] = sum;
+            } else {
+                n[k] = off[xc];
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < SEG; ++k) {
+            const uint32_t x = base + tid + 256u * k;
+            const bool keep = x < W && (int)x >= lo && (int)x <= hi && v[k] != 0;
+            s_c[pad(tid + 256u * k)] = keep ? n[k] : 0u;
+        }
+        __syncthreads();
+        uint32_t c[SEG], sum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < SEG; ++i) {
+            c[i] = s_c[pad(tid * SEG + i)];
+            sum += c[i];
+        }
+        uint32_t total;
+        uint32_t run = carry + block_exscan_256(sum, s_wave, &total);   // (two barriers inside: s_c is read by now)
+#pragma unroll
+        for (uint32_t i = 0; i < SEG; ++i) {
+            s_c[pad(tid * SEG + i)] = run;
+            run += c[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < SEG; ++k) {
+            const uint32_t x = base + tid + 256u * k;
+            if (x < W) off[x] = s_c[pad(tid + 256u * k)];
+        }
+        carry += total;
+        __syncthreads();
     }
     if (tid == 0) {
-        off[W] = total;
-        a.frame_off[f + 1] = total;
+        off[W] = carry;
+        a.frame_off[f + 1] = carry;
     }
 }
 
@@ -538,11 +578,18 @@ __device__ __forceinline__ double bcast(double v, uint32_t src) {
     return __longlong_as_double((long long)r);
 }
 template <class T> struct __attribute__((packed, aligned(4))) Pt3 { T x, y, z; };
+// A pointer that was itself loaded from memory is a generic one and is read with flat_load, which counts on lgkmcnt as well
+// as vmcnt: the s_waitcnt lgkmcnt(0) in front of the next barrier then waits for it.  Device tables are global memory.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(const T* p) {
+    return (const __attribute__((address_space(1))) T*)(uintptr_t)p;
+}
 
 // column metadata of an emit tile, staged once in LDS and read back as wave-uniform broadcasts
 template <class T>
 struct __attribute__((aligned(16))) DwfColMeta {
-    T pose[12];      // rows 0..2 of the column's 4x4 pose, cast to the output type
+    T pose[12];      // rows 0..2 of the column's 4x4 pose, cast to the output type; rows 0 and 1 interleaved
+                     // (p0 p4 p1 p5 p2 p6 p3 p7 | p8..p11) so that x and y are formed by packed f32 FMAs on adjacent registers
     double col[5];   // separable LUT: cos, sin of the encoder angle and the column constant
     uint32_t base, cnt;
     uint64_t ts;
@@ -587,10 +634,14 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
             if (m.cnt) {
                 const double* pm = a.poses + ((size_t)f * W + mx) * 16;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) m.pose[k] = (T)pm[k];
+                for (int k = 0; k < 4; ++k) {
+                    m.pose[2 * k] = (T)pm[k];
+                    m.pose[2 * k + 1] = (T)pm[4 + k];
+                    m.pose[8 + k] = (T)pm[8 + k];
+                }
                 if constexpr (SEP) {
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) m.col[k] = lut.col_tab[(size_t)mx * 5 + k];
+                    for (int k = 0; k < 5; ++k) m.col[k] = as_global(lut.col_tab)[(size_t)mx * 5 + k];
                 }
                 if (a.timestamps_ns) m.ts = a.timestamp[(size_t)f * W + mx];
             }
@@ -605,53 +656,74 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
     constexpr bool roomy = decltype(easy_c)::value, no_zero = decltype(easy_c)::value;
     uint32_t m_run = 0;  // lane jj of the wave: points of its jj-th column already written (previous row chunks)
     for (uint32_t r0 = 0; r0 < H; r0 += ROWS) {
-        __syncthreads();  // previous chunk consumed (and, first time, the metadata published)
-#pragma unroll 4
-        for (uint32_t rr = ty; rr < (uint32_t)ROWS; rr += RPP) {
-            const uint32_t r = r0 + rr, col = c0 + 4 * q;
-            uint32_t v[4] = {0, 0, 0, 0};
-            if (r < H && col < W) {
-                if (vec) {
-                    const uint4 t = *(const uint4*)(rp + (size_t)r * W + col);
-                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                } else {
-                    for (uint32_t c = 0; c < 4 && col + c < W; ++c) v[c] = rp[(size_t)r * W + col + c];
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) s_rng[rr * PITCH + 4 * q + c] = v[c];
-        }
-        __syncthreads();
+        // the lane's rows of the beam table (a few KB shared by every tile): asked for before the tile is staged, so that the
+        // two latencies overlap
         uint32_t row[NR];
         double bt[NR][9];
 #pragma unroll
         for (int hh = 0; hh < NR; ++hh) {
             row[hh] = r0 + lane + 64 * hh;
             if constexpr (SEP) {
+                const uint32_t rc = min(row[hh], H - 1u);   // unconditional loads: a guarded one is waited for on its own
 #pragma unroll
-                for (int k = 0; k < 9; ++k) bt[hh][k] = row[hh] < H ? lut.beam_tab[(size_t)row[hh] * 9 + k] : 0.0;
+                for (int k = 0; k < 9; ++k) bt[hh][k] = as_global(lut.beam_tab)[(size_t)rc * 9 + k];
             }
         }
+        __syncthreads();  // previous chunk consumed (and, first time, the metadata published)
+        if (vec) {
+            // all passes' 16 B loads are issued before the first LDS write (clamped addresses instead of guards: a guarded
+            // load and its guarded write compile to load / s_waitcnt vmcnt(0) / write, one memory round trip per pass).
+            // Issuing them above the metadata block as well was tried: 164 VGPRs, three waves per SIMD, no gain.
+            constexpr int NP = ROWS / RPP;
+            uint4 t[NP];
+            const uint32_t col = c0 + 4 * q, cc = min(col, W - 4u);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const uint32_t rc = min(r0 + ty + (uint32_t)i * RPP, H - 1u);
+                t[i] = *(const uint4*)(rp + (size_t)rc * W + cc);
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const uint32_t rr = ty + (uint32_t)i * RPP;
+                const bool in = r0 + rr < H && col < W;
+                uint32_t* d = &s_rng[rr * PITCH + 4 * q];
+                d[0] = in ? t[i].x : 0u; d[1] = in ? t[i].y : 0u; d[2] = in ? t[i].z : 0u; d[3] = in ? t[i].w : 0u;
+            }
+        } else {
+            for (uint32_t rr = ty; rr < (uint32_t)ROWS; rr += RPP) {
+                const uint32_t r = r0 + rr, col = c0 + 4 * q;
+                uint32_t v[4] = {0, 0, 0, 0};
+                if (r < H)
+                    for (uint32_t c = 0; c < 4 && col + c < W; ++c) v[c] = rp[(size_t)r * W + col + c];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s_rng[rr * PITCH + 4 * q + c] = v[c];
+            }
+        }
+        __syncthreads();
+        // the column loop is software-pipelined over LDS: a column's ranges and count are read one column ahead, so the
+        // keep masks can be formed the moment the iteration starts and no LDS round trip stands between two columns
+        uint32_t rn[NR], cntn;
+        auto fetch_col = [&](uint32_t jj_next) {
+            const uint32_t jn = min(wave * CPW + jj_next, (uint32_t)TILE - 1u);
+            cntn = s_meta[jn].cnt;
+#pragma unroll
+            for (int hh = 0; hh < NR; ++hh) rn[hh] = s_rng[(lane + 64 * hh) * PITCH + jn];
+        };
+        fetch_col(0);
         for (uint32_t jj = 0; jj < (uint32_t)CPW; ++jj) {
             const uint32_t j = wave * CPW + jj, x = c0 + j;  // wave-uniform
             if (j >= ncol) break;
             const DwfColMeta<T>& m = s_meta[j];
-            if (__builtin_amdgcn_readfirstlane(m.cnt) == 0) continue;  // masked out or empty column
-            uint32_t r[NR], rank[NR];
-            bool keep[NR];
-            uint32_t n_keep = 0;
+            uint32_t r[NR];
 #pragma unroll
-            for (int hh = 0; hh < NR; ++hh) {
-                r[hh] = s_rng[(lane + 64 * hh) * PITCH + j];
-                keep[hh] = row[hh] < H && r[hh] >= a.min_r && r[hh] <= a.max_r;
-                const uint64_t mask = __builtin_amdgcn_ballot_w64(keep[hh]);
-                rank[hh] = n_keep + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                n_keep += (uint32_t)__popcll(mask);
+            for (int hh = 0; hh < NR; ++hh) r[hh] = rn[hh];
+            const uint32_t cnt = __builtin_amdgcn_readfirstlane(cntn);
+            if (cnt == 0) {  // masked out or empty column
+                fetch_col(jj + 1);
+                continue;
             }
-            if (n_keep == 0) continue;
-            const uint64_t g0 = fbase + __builtin_amdgcn_readfirstlane(m.base) + bcast_u32(m_run, jj);  // first point of this run
-            const uint64_t room = roomy ? ~0ull : (g0 < a.capacity ? a.capacity - g0 : 0);
-            T* const run = (T*)a.points + g0 * 3;   // wave-uniform: the stores take it as a scalar base + a 32-bit lane offset
+            // this column's constants first (they are needed soonest), then the next column's ranges
+            const uint32_t m_base = m.base;
             T ps[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) ps[k] = m.pose[k];
@@ -660,6 +732,25 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
                 cx = m.col[0]; sx = m.col[1];
                 kc[0] = m.col[2]; kc[1] = m.col[3]; kc[2] = m.col[4];
             }
+            fetch_col(jj + 1);
+            uint32_t rank[NR];
+            bool keep[NR];
+            uint32_t n_keep = 0;
+#pragma unroll
+            for (int hh = 0; hh < NR; ++hh) {
+                // rows past H were staged as range 0, which the easy path's gate (min_r > 0) rejects by itself: one
+                // subtract-and-compare whose result IS the ballot
+                if constexpr (no_zero) keep[hh] = r[hh] - a.min_r <= a.max_r - a.min_r;
+                else keep[hh] = row[hh] < H && r[hh] >= a.min_r && r[hh] <= a.max_r;
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(keep[hh]);
+                // kept rows below this lane (v_mbcnt_lo / _hi), on top of the rows kept by the earlier row groups
+                rank[hh] = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, n_keep));
+                n_keep += (uint32_t)__popcll(mask);
+            }
+            if (n_keep == 0) continue;
+            const uint64_t g0 = fbase + __builtin_amdgcn_readfirstlane(m_base) + bcast_u32(m_run, jj);  // first point of this run
+            const uint64_t room = roomy ? ~0ull : (g0 < a.capacity ? a.capacity - g0 : 0);
+            T* const run = (T*)a.points + g0 * 3;   // wave-uniform: the stores take it as a scalar base + a 32-bit lane offset
 #pragma unroll
             for (int hh = 0; hh < NR; ++hh) {
                 if (!(keep[hh] && (roomy || rank[hh] < room))) continue;
@@ -683,9 +774,10 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
                 }
                 const T px = pt[0], py = pt[1], pz = pt[2];
                 Pt3<T> o;
-                o.x = ps[0] * px + ps[1] * py + ps[2] * pz + ps[3];
-                o.y = ps[4] * px + ps[5] * py + ps[6] * pz + ps[7];
-                o.z = ps[8] * px + ps[9] * py + ps[10] * pz + ps[11];
+                // three fused multiply-adds per component, the translation as the innermost addend
+                o.x = fma(ps[0], px, fma(ps[2], py, fma(ps[4], pz, ps[6])));
+                o.y = fma(ps[1], px, fma(ps[3], py, fma(ps[5], pz, ps[7])));
+                o.z = fma(ps[8], px, fma(ps[9], py, fma(ps[10], pz, ps[11])));
 #if OUSTER_NT_STANDALONE
                 {
                     T* pd = run + rank[hh] * 3u;
@@ -923,9 +1015,10 @@ __global__ __launch_bounds__(NT) void k_dwf_single(DewarpFramesArgs a) {
                 }
                 const T px = (T)p[0], py = (T)p[1], pz = (T)p[2];
                 Pt3<T> o;
-                o.x = bcast(m_pose[0], jj) * px + bcast(m_pose[1], jj) * py + bcast(m_pose[2], jj) * pz + bcast(m_pose[3], jj);
-                o.y = bcast(m_pose[4], jj) * px + bcast(m_pose[5], jj) * py + bcast(m_pose[6], jj) * pz + bcast(m_pose[7], jj);
-                o.z = bcast(m_pose[8], jj) * px + bcast(m_pose[9], jj) * py + bcast(m_pose[10], jj) * pz + bcast(m_pose[11], jj);
+                // the same three nested FMAs per component as k_dwf_emit (the two routes agree bit for bit)
+                o.x = fma(bcast(m_pose[0], jj), px, fma(bcast(m_pose[1], jj), py, fma(bcast(m_pose[2], jj), pz, bcast(m_pose[3], jj))));
+                o.y = fma(bcast(m_pose[4], jj), px, fma(bcast(m_pose[5], jj), py, fma(bcast(m_pose[6], jj), pz, bcast(m_pose[7], jj))));
+                o.z = fma(bcast(m_pose[8], jj), px, fma(bcast(m_pose[9], jj), py, fma(bcast(m_pose[10], jj), pz, bcast(m_pose[11], jj))));
                 ((Pt3<T>*)a.points)[g0 + rank] = o;
             }
             if (a.col_idxs || a.frame_idxs || a.timestamps_ns) {

@@ -17,6 +17,7 @@ status = torch.ones((N, W), dtype=torch.uint32, device="cuda")
 poses = torch.eye(4, dtype=torch.float64, device="cuda").repeat(N, W, 1, 1).contiguous()
 pts = torch.randn((64, H * W, 3), dtype=torch.float32, device="cuda")
 poses64 = poses[:64].contiguous()
+ts0 = torch.zeros((N, W), dtype=torch.int64, device="cuda").to(torch.uint64)
 variants = [a.split("=", 1) for a in sys.argv[1:]]
 hps = {}
 for name, path in variants:
@@ -39,7 +40,10 @@ ops = {
     "cartesian_f64": lambda hp: hp.cartesian(nxt(rngs), dtype=torch.float64),
     "dewarp_f32": lambda hp: hp.dewarp(nxt(ptss), poses64),
     "dewarp_frames_f32": lambda hp: hp.dewarp_frames(nxt(rngs), status, poses, 0.5, 400.0, provenance=False),
+    "dewarp_frames_f32_provenance": lambda hp: hp.dewarp_frames(nxt(rngs), status, poses, 0.5, 400.0, timestamp=ts0, provenance=True),
 }
+if os.environ.get("AB_OPS"):
+    ops = {k: v for k, v in ops.items() if k in os.environ["AB_OPS"].split(",")}
 res = {}
 for op, fn in ops.items():
     times = {n: [] for n in hps}
