@@ -111,7 +111,7 @@ CHAN_FIELD = {1: "RANGE", 2: "RANGE2", 3: "SIGNAL", 4: "SIGNAL2", 5: "REFLECTIVI
 FIELD_DTYPE = {1: np.uint8, 2: np.uint16, 3: np.uint32, 4: np.uint64}
 # CHAN_FIELD_TYPE of os_sensor/common.fbs:4-19, as far as custom fields can carry them (encoded through uint views of the same size)
 CUSTOM_DTYPE = {1: np.uint8, 2: np.uint16, 3: np.uint32, 4: np.uint64, 5: np.int8, 6: np.int16, 7: np.int32, 8: np.int64,
-                9: np.float32, 10: np.float64}
+                9: np.float32, 10: np.float64, 11: "S1"}   # 11 = CHAR (field.cpp:62; e.g. POSITION_STRING): one byte per element
 
 
 class OsfFile:

@@ -165,7 +165,7 @@ CUSTOM1D = os.path.join(os.path.dirname(LB), "pose_delta_1_128.osf")
 
 
 def test_osf_custom_fields_of_a_reference_file(oracle):
-    """tests/osfs/pose_delta_1_128.osf stores six 1-D and three 2-D frame fields (IMU_TIMESTAMP, IMU_ACC, ...) in custom_fields:
+    """tests/osfs/pose_delta_1_128.osf stores six 1-D and four 2-D frame fields (IMU_TIMESTAMP, IMU_ACC, ..., the CHAR field POSITION_STRING) in custom_fields:
     the decoded frames carry them, equal to the oracle's restatement of fb_restore_fields (fb_common.cpp:250-330)."""
     from oracle import osf_oracle as Z
     from ouster_sdk_amd import core
@@ -180,7 +180,9 @@ def test_osf_custom_fields_of_a_reference_file(oracle):
     for fr, m in zip(frames, msgs):
         d = Z.decode_lidar_scan_msg(m, h, w, shifts)
         assert set(d["custom_fields"]) == {"POSITION_TIMESTAMP", "IMU_STATUS", "IMU_PACKET_TIMESTAMP", "IMU_ALERT_FLAGS",
-                                           "IMU_MEASUREMENT_ID", "IMU_TIMESTAMP", "IMU_ACC", "IMU_GYRO", "POSITION_LAT_LONG"}
+                                           "IMU_MEASUREMENT_ID", "IMU_TIMESTAMP", "IMU_ACC", "IMU_GYRO", "POSITION_LAT_LONG",
+                                           "POSITION_STRING"}
+        assert d["custom_fields"]["POSITION_STRING"]["array"].dtype == np.dtype("S1")   # a CHAR field: bytes through the 8-bit codec
         assert d["custom_fields"]["IMU_ACC"]["array"].ndim == 2       # 2-D float fields: through the image codec
         assert set(fr.fields) == set(d["fields"]) | set(d["custom_fields"])
         for name, c in d["custom_fields"].items():
