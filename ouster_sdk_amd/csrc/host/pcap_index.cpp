@@ -217,7 +217,9 @@ int IndexedPcapReader::update_index_for_current_packet() {
             }
         }
     }
-    return static_cast<int>(100.0f * static_cast<float>(current_offset()) / static_cast<float>(file_size()));
+    const int64_t size = file_size();
+    if (size <= 0) return 100;
+    return static_cast<int>(100.0f * static_cast<float>(current_offset()) / static_cast<float>(size));
 }
 
 void IndexedPcapReader::build_index() {
