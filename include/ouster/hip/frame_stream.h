@@ -63,6 +63,14 @@ class FrameStream {
      *  machine (frame-id boundaries, reorder cache, init-id changes) on the host and pushes every
      *  released frame.  A trailing incomplete frame is not emitted, like the reference's sources. */
     void push_packet(const core::Packet& lidar_packet);
+    /** Packet-level entry for several sensors (what follows pcap::IndexedPcapReader::sensor_idx_for_current_packet): one
+     *  FrameBatcher per sensor; the frames they release are pushed in TICKS -- one frame of every sensor, in sensor order,
+     *  which is the frame order a multi-sensor batch expects (frame i belongs to sensor i % n).  A sensor that has released
+     *  nothing while another is `max_skew_frames` frames ahead gets an empty (all-invalid) frame in that tick.
+     *  @throw std::out_of_range for an unknown sensor */
+    void push_packet(size_t sensor, const core::Packet& lidar_packet);
+    /** Frames a sensor may run ahead of the slowest one before ticks stop waiting for it (default 2). */
+    void set_max_skew_frames(size_t n) { max_skew_ = n ? n : 1; }
     /** Submit a partial batch and deliver everything still in flight. */
     void finish();
 
@@ -85,6 +93,11 @@ class FrameStream {
     std::vector<core::SensorInfo> sensors_;
     std::unique_ptr<core::FrameBatcher> splitter_;   // push_packet only
     std::unique_ptr<core::LidarFrame> splitter_frame_;
+    // push_packet(sensor, ...): per-sensor splitters and the frames (packet bytes) they released but no tick took yet
+    struct SensorLane;
+    std::vector<std::unique_ptr<SensorLane>> lanes_;
+    size_t max_skew_ = 2;
+    void emit_ticks(bool flush);
 };
 
 }  // namespace hip

@@ -1,6 +1,10 @@
 // frame_stream.cpp -- see include/ouster/hip/frame_stream.h
 #include "ouster/hip/frame_stream.h"
 
+#include <algorithm>
+#include <cstdint>
+#include <deque>
+
 #include <hip/hip_runtime_api.h>
 
 #include <cstring>
@@ -40,6 +44,12 @@ struct FrameStream::Slot {
     bool in_flight = false;
     uint64_t first_frame = 0;
     uint32_t n_frames = 0;
+};
+
+struct FrameStream::SensorLane {
+    std::unique_ptr<core::FrameBatcher> splitter;
+    std::unique_ptr<core::LidarFrame> frame;
+    std::deque<std::vector<std::vector<uint8_t>>> released;   // frames, each the packets the batcher handed over
 };
 
 FrameStream::FrameStream(const std::vector<core::SensorInfo>& sensors, const StreamOptions& options,
@@ -133,6 +143,49 @@ void FrameStream::push_packet(const core::Packet& lidar_packet) {
     (void)splitter_->batch(lidar_packet, *splitter_frame_);
 }
 
+void FrameStream::push_packet(size_t sensor, const core::Packet& lidar_packet) {
+    if (sensor >= sensors_.size()) throw std::out_of_range("FrameStream::push_packet: no such sensor");
+    if (lanes_.empty()) {
+        for (const core::SensorInfo& info : sensors_) {
+            auto lane = std::make_unique<SensorLane>();
+            lane->splitter = std::make_unique<core::FrameBatcher>(info);
+            lane->frame = std::make_unique<core::LidarFrame>(info);
+            SensorLane* raw = lane.get();
+            const size_t size = core::PacketFormat(info).lidar_packet_size;
+            // the sink's pointers are only good during the call: keep the bytes until the frame's tick
+            lane->splitter->set_packet_sink([raw, size](const std::vector<const uint8_t*>& packets) {
+                std::vector<std::vector<uint8_t>> fr;
+                fr.reserve(packets.size());
+                for (const uint8_t* p : packets) fr.emplace_back(p, p + size);
+                raw->released.push_back(std::move(fr));
+            });
+            lanes_.push_back(std::move(lane));
+        }
+    }
+    (void)lanes_[sensor]->splitter->batch(lidar_packet, *lanes_[sensor]->frame);
+    emit_ticks(false);
+}
+
+void FrameStream::emit_ticks(bool flush) {
+    for (;;) {
+        size_t shortest = SIZE_MAX, longest = 0;
+        for (const auto& lane : lanes_) {
+            shortest = std::min(shortest, lane->released.size());
+            longest = std::max(longest, lane->released.size());
+        }
+        if (longest == 0) return;
+        // a tick goes out when every sensor has a frame for it, when somebody is too far ahead, or at the end
+        if (shortest == 0 && longest < max_skew_ && !flush) return;
+        for (const auto& lane : lanes_) {
+            std::vector<const uint8_t*> ptrs;
+            if (!lane->released.empty())
+                for (const auto& pkt : lane->released.front()) ptrs.push_back(pkt.data());
+            push_frame(ptrs);   // no packets: an empty frame keeps the sensor order of the batch
+            if (!lane->released.empty()) lane->released.pop_front();
+        }
+    }
+}
+
 void FrameStream::submit(Slot& s) {
     ScopedContext on_my_context(ctx_);
     DeviceFrameBatch& bt = *s.batch;
@@ -192,6 +245,7 @@ void FrameStream::deliver(Slot& s) {
 
 void FrameStream::finish() {
     ScopedContext on_my_context(ctx_);
+    if (!lanes_.empty()) emit_ticks(true);   // frames some sensors released after the last complete tick
     if (slots_[cur_]->filled) {
         if (slots_[cur_]->in_flight) deliver(*slots_[cur_]);  // cannot happen (filled implies free), kept for safety
         submit(*slots_[cur_]);

@@ -752,9 +752,15 @@ PYBIND11_MODULE(core, m) {
     {
         namespace oh = ouster::sdk::hip;
         py::class_<oh::FrameStream>(m, "FrameStream")
-            .def(py::init([](const SensorInfo& info, py::function on_batch, uint32_t frames_per_batch,
+            // `info`: one SensorInfo, or a list of them (same data format; frame i of a batch belongs to sensor i % n)
+            .def(py::init([](const py::object& info_or_list, py::function on_batch, uint32_t frames_per_batch,
                              uint32_t batches_in_flight, std::vector<std::string> planes,
                              std::vector<std::string> destaggered, bool xyz) {
+                     std::vector<SensorInfo> infos;
+                     if (py::isinstance<SensorInfo>(info_or_list)) infos.push_back(info_or_list.cast<const SensorInfo&>());
+                     else infos = info_or_list.cast<std::vector<SensorInfo>>();
+                     if (infos.empty()) throw std::invalid_argument("FrameStream: no sensor");
+                     const SensorInfo& info = infos[0];
                      oh::StreamOptions opt;
                      opt.frames_per_batch = frames_per_batch;
                      opt.batches_in_flight = batches_in_flight;
@@ -787,7 +793,7 @@ PYBIND11_MODULE(core, m) {
                          }
                          on_batch(d);
                      };
-                     return std::make_unique<oh::FrameStream>(std::vector<SensorInfo>{info}, opt, cb);
+                     return std::make_unique<oh::FrameStream>(infos, opt, cb);
                  }),
                  py::arg("info"), py::arg("on_batch"), py::arg("frames_per_batch") = 32,
                  py::arg("batches_in_flight") = 3, py::arg("planes") = std::vector<std::string>{},
@@ -800,6 +806,9 @@ PYBIND11_MODULE(core, m) {
                      s.push_frame(ptrs);
                  })
             .def("push_packet", [](oh::FrameStream& s, const LidarPacket& p) { s.push_packet(p); })
+            .def("push_packet", [](oh::FrameStream& s, size_t sensor, const LidarPacket& p) { s.push_packet(sensor, p); },
+                 py::arg("sensor"), py::arg("packet"))
+            .def("set_max_skew_frames", &oh::FrameStream::set_max_skew_frames)
             .def("finish", &oh::FrameStream::finish)
             .def_property_readonly("frames_pushed", &oh::FrameStream::frames_pushed)
             .def_property_readonly("frames_delivered", &oh::FrameStream::frames_delivered);

@@ -329,3 +329,121 @@ def test_two_sensors_on_one_port_decode_like_the_oracle(oracle):
         assert np.array_equal(frame.timestamp[m_id[valid]], O.packet_header(opf, "TIMESTAMP", pk[0])[valid])
         seen.add(int(core.PacketFormat(info).prod_sn(pk[0].tobytes())))
     assert seen == {infos[0].sn, infos[1].sn}
+
+
+def _info_from_calib(O, cal):
+    names = {v: k for k, v in O.PROFILES.items()}
+    info = core.SensorInfo()
+    f = info.format
+    f.pixels_per_column, f.columns_per_frame, f.columns_per_packet = cal.h, cal.w, cal.cpp
+    f.column_window = (0, cal.w - 1)
+    f.udp_profile_lidar = core.UDPProfileLidar.from_string(names[cal.profile])
+    f.pixel_shift_by_row = [int(x) for x in cal.pixel_shift_by_row]
+    info.format = f
+    info.beam_azimuth_angles = list(cal.beam_azimuth_angles)
+    info.beam_altitude_angles = list(cal.beam_altitude_angles)
+    info.beam_to_lidar_transform = cal.beam_to_lidar
+    info.lidar_to_sensor_transform = cal.lidar_to_sensor
+    info.sensor_to_body = cal.extrinsic
+    info.init_id = cal.init_id
+    info.sn = cal.prod_sn
+    info.fw_rev = info.image_rev = "v3.2.0"
+    return info
+
+
+def test_two_sensor_capture_streams_through_the_multi_sensor_batch(oracle, tmp_path):
+    """configs[4] end to end on the host side: a capture in which two sensors of the same model send to ONE port ->
+    IndexedPcapReader (routing by init id / serial number) -> FrameStream.push_packet(sensor, packet) (a FrameBatcher per
+    sensor, frames released in ticks A0 B0 A1 B1 ...) -> the multi-sensor batch (frame i decoded with sensor i % 2's
+    tables and extrinsics).  Planes equal the frames the packets were synthesised from; XYZ equals each sensor's own
+    XYZLut."""
+    import copy
+    import struct
+    O = oracle
+    calA = O.synthetic_calib(h=32, w=512, cpp=16, profile="RNG19_RFL8_SIG16_NIR16")
+    calB = copy.deepcopy(calA)
+    calA.init_id, calA.prod_sn = 0x111111, 1001
+    calB.init_id, calB.prod_sn = 0x222222, 2002
+    calB.extrinsic = np.array([[0, -1, 0, 1.5], [1, 0, 0, -2.0], [0, 0, 1, 0.25], [0, 0, 0, 1.0]])   # mounted elsewhere
+    nf = 3
+    pkA, frA = O.synth_packets(calA, nf, seed=11)
+    pkB, frB = O.synth_packets(calB, nf, seed=22)
+    # one capture, both sensors on port 7502, packets interleaved
+    def record(payload, src):
+        udp = struct.pack(">HHHH", 4000, 7502, 8 + len(payload), 0) + payload
+        ip = struct.pack(">BBHHHBBH4s4s", 0x45, 0, 20 + len(udp), 1, 0, 64, 17, 0, bytes([10, 0, 0, src]), bytes([10, 0, 0, 9])) + udp
+        return bytes(12) + b"\x08\x00" + ip
+    recs = []
+    for f in range(nf):
+        for p in range(pkA.shape[1]):
+            recs.append(record(pkA[f, p].tobytes(), 1))
+            recs.append(record(pkB[f, p].tobytes(), 2))
+    blob = struct.pack("<IHHiIII", 0xA1B2C3D4, 2, 4, 0, 0, 65535, 1)
+    for i, r in enumerate(recs):
+        blob += struct.pack("<IIII", 100 + i // 1000, i % 1000, len(r), len(r)) + r
+    path = tmp_path / "two_sensors.pcap"
+    path.write_bytes(blob)
+
+    infos = [_info_from_calib(O, calA), _info_from_calib(O, calB)]
+    routed = core.index_pcap(str(path), infos)
+    assert [i for i, *_ in routed["packets"]] == [0, 1] * (nf * pkA.shape[1])
+    assert [len(v) for v in routed["frame_offsets"]] == [nf, nf]
+
+    got = []
+    stream = core.FrameStream(infos, lambda d: got.append({k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}),
+                              frames_per_batch=2, batches_in_flight=2, planes=["RANGE", "REFLECTIVITY", "SIGNAL"], xyz=True)
+    size = core.PacketFormat(infos[0]).lidar_packet_size
+    for idx, payload, port, ts, off in routed["packets"]:
+        lp = core.LidarPacket(size)
+        lp.buf = payload
+        lp.host_timestamp = ts      # a frame counts as complete once every packet slot carries a (non-zero) arrival time
+        stream.push_packet(idx, lp)
+    stream.finish()
+    frames = [(b, k) for b in got for k in range(b["n_frames"])]
+    assert stream.frames_pushed == 2 * nf and len(frames) == 2 * nf
+    luts = [core.XYZLut(infos[0], True), core.XYZLut(infos[1], True)]
+    for i, (b, k) in enumerate(frames):
+        sensor, f = i % 2, i // 2
+        src = (frA, frB)[sensor][f]
+        for name in ("RANGE", "REFLECTIVITY", "SIGNAL"):
+            assert np.array_equal(b[name][k], src.plane(name)), (i, name)
+        want = luts[sensor](b["RANGE"][k])
+        assert np.abs(b["xyz"][k].astype(np.float64) - want).max() <= 4e-5, i
+    # the two sensors see different worlds: the same range image lands elsewhere under B's extrinsics
+    assert np.abs(luts[0](frames[0][0]["RANGE"][0]) - luts[1](frames[0][0]["RANGE"][0])).max() > 1.0
+
+
+def test_multi_sensor_ticks_do_not_wait_for_a_silent_sensor(oracle):
+    """One of two sensors sends nothing: once the other is two frames ahead its frames go out anyway, each tick carrying an
+    empty (all-invalid) frame in the silent sensor's place, so frame i of a batch still belongs to sensor i % 2."""
+    import copy
+    O = oracle
+    calA = O.synthetic_calib(h=32, w=512, cpp=16, profile="RNG19_RFL8_SIG16_NIR16")
+    calB = copy.deepcopy(calA)
+    calB.init_id, calB.prod_sn = 0x222222, 2002
+    nf = 3
+    pkA, frA = O.synth_packets(calA, nf, seed=5)
+    infos = [_info_from_calib(O, calA), _info_from_calib(O, calB)]
+    got = []
+    stream = core.FrameStream(infos, lambda d: got.append({k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}),
+                              frames_per_batch=2, batches_in_flight=2, planes=["RANGE"], xyz=False)
+    size = core.PacketFormat(infos[0]).lidar_packet_size
+    pushed_after_frame = []
+    for f in range(nf):
+        for p in range(pkA.shape[1]):
+            lp = core.LidarPacket(size)
+            lp.buf = pkA[f, p].tobytes()
+            lp.host_timestamp = 1 + p
+            stream.push_packet(0, lp)
+        pushed_after_frame.append(stream.frames_pushed)
+    assert pushed_after_frame == [0, 2, 4]          # nothing while A is one frame ahead, a tick per frame from then on
+    stream.finish()
+    frames = [(b, k) for b in got for k in range(b["n_frames"])]
+    assert stream.frames_pushed == 2 * nf == len(frames)
+    for i, (b, k) in enumerate(frames):
+        if i % 2 == 0:
+            assert np.array_equal(b["RANGE"][k], frA[i // 2].plane("RANGE")) and (b["status"][k] & 1).all()
+        else:
+            assert not b["RANGE"][k].any() and not b["status"][k].any()
+    with pytest.raises(IndexError):
+        stream.push_packet(2, core.LidarPacket(size))
