@@ -553,13 +553,19 @@ def main():
                 cands.append((json.load(open(pj)).get("kernel_sources_sha256") != kernel_sources_sha256(), pj))
             except Exception:
                 pass
-        # counters recorded on THIS tree's kernel sources first, then the most recent directory name
-        for _, pj in sorted(cands, key=lambda c: c[0]):
+        # counters recorded on THIS tree's kernel sources first; among those the round's own directory ("r03") before its
+        # side runs ("r03_slowbox", ...); then the most recent directory name
+        for _, pj in sorted(cands, key=lambda c: (c[0], len(os.path.basename(os.path.dirname(c[1]))) if not c[0] else 0)):
             try:
                 t = json.load(open(pj))
                 if t.get("workload") == args.workload and t.get("frames_per_launch"):
-                    v = t.get("variants", {}).get(f"{kern}:{tc}") or \
-                        (t.get("variants_by_tile_columns", {}).get(str(tc)) if kern != "k_decode_stream" else None)
+                    # the two persistent kernels (k_decode_stream: every wave fetches; k_decode_stream2: loader waves) share
+                    # one key in the committed counters; the entry names the one that was profiled
+                    fam = "k_decode_stream" if kern.startswith("k_decode_stream") else kern
+                    v = t.get("variants", {}).get(f"{fam}:{tc}") or \
+                        (t.get("variants_by_tile_columns", {}).get(str(tc)) if fam != "k_decode_stream" else None)
+                    if v and fam == "k_decode_stream" and (kern + "<") not in v.get("kernel", kern + "<"):
+                        continue           # counters of the sibling persistent kernel: not this run's
                     if not v:
                         continue           # no committed counters for the variant that ran here
                     traffic = int(round(v["total_bytes"] * F / t["frames_per_launch"]))

@@ -372,8 +372,9 @@ int ouster_hip_timing_read(ouster_hip_ctx* ctx, double* avg_ms, uint32_t* n_laun
  * that, knob "wide" forces one). */
 int ouster_hip_last_decode_tile(ouster_hip_ctx* ctx, int* tile_cols, int* tile_rows);
 /* Name of the optimistic-pass kernel the last ouster_hip_decode launched: "k_decode" (64/32/16-column tiles,
- * also every general-mapping launch), "k_decode_wide" or "k_decode_stream" (persistent workgroups, tiles
- * double-buffered through LDS-DMA; knob "stream" = 0 disables it, 128 / 256 force that tile width). */
+ * also every general-mapping launch), "k_decode_wide", or one of the two persistent kernels (tiles double-buffered
+ * through LDS-DMA; knob "stream" = 0 disables them, 128 / 256 force that tile width): "k_decode_stream2" (dedicated
+ * loader waves, the default) or "k_decode_stream" (every wave fetches; knob "stream_loader" = 0). */
 const char* ouster_hip_last_decode_kernel(ouster_hip_ctx* ctx);
 
 #ifdef __cplusplus

@@ -1088,7 +1088,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         HIP_TRY(launch_decode_stream(da, sa, spec, stream, xyzm, ctx->device, st));
         ctx->last_tile_cols = stream;
         ctx->last_tile_rows = (int)da.rows_per_tile;
-        ctx->last_kernel = "k_decode_stream";
+        ctx->last_kernel = sa.loader ? "k_decode_stream2" : "k_decode_stream";   // dedicated loader waves / every wave fetches
     } else if (wide) {
         HIP_TRY(launch_decode_wide(da, spec, wide, xyzm, ctx->device, st));
         ctx->last_tile_cols = wide;

@@ -47,7 +47,7 @@ def _assert_variant_ran(hp, wide):
     tc, _ = hp.ctx.last_decode_tile()
     kernel = hp.ctx.last_decode_kernel()
     if isinstance(wide, str):
-        assert kernel == "k_decode_stream" and tc == int(wide[1:]), (kernel, tc, wide)
+        assert kernel in ("k_decode_stream", "k_decode_stream2") and tc == int(wide[1:]), (kernel, tc, wide)
     elif wide:
         assert kernel == "k_decode_wide" and tc == wide, (kernel, tc, wide)
     elif wide == 0:
@@ -557,7 +557,7 @@ def test_tuner_times_the_persistent_kernel_too(oracle):
         for k in first:
             assert torch.equal(first[k].view(torch.uint8), snap[k].view(torch.uint8)), (call, k, seen)
     kernels = {k for k, _, _ in seen}
-    assert {"k_decode", "k_decode_wide", "k_decode_stream"} <= kernels, seen
+    assert {"k_decode", "k_decode_wide"} <= kernels and kernels & {"k_decode_stream", "k_decode_stream2"}, seen
 
 
 # ---------------------------------------------------------------------------------------------
