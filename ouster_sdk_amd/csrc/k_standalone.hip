@@ -501,19 +501,29 @@ __global__ __launch_bounds__(256) void k_dwf_scan(DewarpFramesArgs a) {
     auto pad = [](uint32_t i) { return i + (i >> 5); };
     uint32_t carry = 0;
     for (uint32_t base = 0; base < W; base += BLK) {
-        uint32_t v[SEG], n[SEG];
+        uint32_t v[SEG], n[SEG], xc[SEG];
 #pragma unroll
         for (uint32_t k = 0; k < SEG; ++k) {
-            const uint32_t xc = min(base + tid + 256u * k, W - 1u);
-            v[k] = st[xc];
-            if (ext) {
-                uint32_t sum = 0;
+            xc[k] = min(base + tid + 256u * k, W - 1u);
+            v[k] = st[xc[k]];
+        }
+        // the branch on `ext` stays outside the column loop: inside it every column's partial counts were loaded and waited
+        // for on their own (eight round trips per block)
+        if (ext) {
+            uint16_t g[SEG][OUSTER_HIP_GATE_CHUNKS];
 #pragma unroll
-                for (uint32_t c = 0; c < OUSTER_HIP_GATE_CHUNKS; ++c) sum += ext[(size_t)c * W + xc];
-                n[k] = sum;
-            } else {
-                n[k] = off[xc];
+            for (uint32_t k = 0; k < SEG; ++k)
+#pragma unroll
+                for (uint32_t c = 0; c < OUSTER_HIP_GATE_CHUNKS; ++c) g[k][c] = ext[(size_t)c * W + xc[k]];
+#pragma unroll
+            for (uint32_t k = 0; k < SEG; ++k) {
+                n[k] = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < OUSTER_HIP_GATE_CHUNKS; ++c) n[k] += g[k][c];
             }
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < SEG; ++k) n[k] = off[xc[k]];
         }
 #pragma unroll
         for (uint32_t k = 0; k < SEG; ++k) {
