@@ -605,6 +605,121 @@ struct __attribute__((aligned(16))) DwfColMeta {
     uint64_t ts;
 };
 
+// The column loop of the emit kernels: wave = CPW columns of a tile that sits in LDS (ranges, pitch TILE + 1) with its
+// column metadata (count, output base, pose, table row), lane = row (NR rows per lane).  EASY: everything the tile emits lies
+// below `capacity` and no kept range can be zero (the gate's lower bound is at least 1) -- then the loop carries neither the
+// per-point room check nor the zero-range select.
+template <class T, bool SEP, int TILE, int ROWS, bool EASY>
+__device__ __forceinline__ void dwf_column_loop(const DewarpFramesArgs& a, const LutDev& lut, const uint32_t* s_rng,
+                                                const DwfColMeta<T>* s_meta, uint32_t f, uint32_t c0, uint32_t ncol,
+                                                uint64_t fbase, const uint32_t (&row)[ROWS / 64],
+                                                const double (&bt)[ROWS / 64][9], uint32_t& m_run) {
+    constexpr int PITCH = TILE + 1, CPW = TILE / 4, NR = ROWS / 64;
+    constexpr bool roomy = EASY, no_zero = EASY;
+    const uint32_t W = a.w, H = a.h;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the column loop is software-pipelined over LDS: a column's ranges and count are read one column ahead, so the
+    // keep masks can be formed the moment the iteration starts and no LDS round trip stands between two columns
+    uint32_t rn[NR], cntn;
+    auto fetch_col = [&](uint32_t jj_next) {
+        const uint32_t jn = min(wave * CPW + jj_next, (uint32_t)TILE - 1u);
+        cntn = s_meta[jn].cnt;
+#pragma unroll
+        for (int hh = 0; hh < NR; ++hh) rn[hh] = s_rng[(lane + 64 * hh) * PITCH + jn];
+    };
+    fetch_col(0);
+    for (uint32_t jj = 0; jj < (uint32_t)CPW; ++jj) {
+        const uint32_t j = wave * CPW + jj, x = c0 + j;  // wave-uniform
+        if (j >= ncol) break;
+        const DwfColMeta<T>& m = s_meta[j];
+        uint32_t r[NR];
+#pragma unroll
+        for (int hh = 0; hh < NR; ++hh) r[hh] = rn[hh];
+        const uint32_t cnt = __builtin_amdgcn_readfirstlane(cntn);
+        if (cnt == 0) {  // masked out or empty column
+            fetch_col(jj + 1);
+            continue;
+        }
+        // this column's constants first (they are needed soonest), then the next column's ranges
+        const uint32_t m_base = m.base;
+        T ps[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) ps[k] = m.pose[k];
+        double cx = 0, sx = 0, kc[3] = {0, 0, 0};
+        if constexpr (SEP) {
+            cx = m.col[0]; sx = m.col[1];
+            kc[0] = m.col[2]; kc[1] = m.col[3]; kc[2] = m.col[4];
+        }
+        fetch_col(jj + 1);
+        uint32_t rank[NR];
+        bool keep[NR];
+        uint32_t n_keep = 0;
+#pragma unroll
+        for (int hh = 0; hh < NR; ++hh) {
+            // rows past H were staged as range 0, which the easy path's gate (min_r > 0) rejects by itself: one
+            // subtract-and-compare whose result IS the ballot
+            if constexpr (no_zero) keep[hh] = r[hh] - a.min_r <= a.max_r - a.min_r;
+            else keep[hh] = row[hh] < H && r[hh] >= a.min_r && r[hh] <= a.max_r;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(keep[hh]);
+            // kept rows below this lane (v_mbcnt_lo / _hi), on top of the rows kept by the earlier row groups
+            rank[hh] = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, n_keep));
+            n_keep += (uint32_t)__popcll(mask);
+        }
+        if (n_keep == 0) continue;
+        const uint64_t g0 = fbase + __builtin_amdgcn_readfirstlane(m_base) + bcast_u32(m_run, jj);  // first point of this run
+        const uint64_t room = roomy ? ~0ull : (g0 < a.capacity ? a.capacity - g0 : 0);
+        T* const run = (T*)a.points + g0 * 3;   // wave-uniform: the stores take it as a scalar base + a 32-bit lane offset
+#pragma unroll
+        for (int hh = 0; hh < NR; ++hh) {
+            if (!(keep[hh] && (roomy || rank[hh] < room))) continue;
+            T pt[3];
+            if constexpr (SEP) {
+                const double rm = (double)r[hh] - lut.n;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double d = fma(cx, bt[hh][k], fma(sx, bt[hh][3 + k], bt[hh][6 + k]));
+                    const T t = (T)fma(rm, d, kc[k]);
+                    pt[k] = (no_zero || r[hh]) ? t : (T)0;
+                }
+            } else {
+                double p[3];
+                const size_t pix = (size_t)row[hh] * W + x;
+                if (lut.full_dtype == OUSTER_HIP_F32)
+                    project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs, pix, r[hh], p);
+                else
+                    project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs, pix, r[hh], p);
+                pt[0] = (T)p[0]; pt[1] = (T)p[1]; pt[2] = (T)p[2];
+            }
+            const T px = pt[0], py = pt[1], pz = pt[2];
+            Pt3<T> o;
+            // three fused multiply-adds per component, the translation as the innermost addend
+            o.x = fma(ps[0], px, fma(ps[2], py, fma(ps[4], pz, ps[6])));
+            o.y = fma(ps[1], px, fma(ps[3], py, fma(ps[5], pz, ps[7])));
+            o.z = fma(ps[8], px, fma(ps[9], py, fma(ps[10], pz, ps[11])));
+#if OUSTER_NT_STANDALONE
+            {
+                T* pd = run + rank[hh] * 3u;
+                __builtin_nontemporal_store(o.x, pd);
+                __builtin_nontemporal_store(o.y, pd + 1);
+                __builtin_nontemporal_store(o.z, pd + 2);
+            }
+#else
+            ((Pt3<T>*)run)[rank[hh]] = o;
+#endif
+        }
+        // every point of the run carries the same provenance: dense lanes 0..n_keep-1
+        if (a.col_idxs || a.frame_idxs || a.timestamps_ns) {
+            const uint64_t ts = m.ts;
+            for (uint32_t i = lane; i < n_keep && i < room; i += 64) {
+                if (a.col_idxs) a.col_idxs[g0 + i] = x;
+                if (a.frame_idxs) a.frame_idxs[g0 + i] = f;
+                if (a.timestamps_ns) a.timestamps_ns[g0 + i] = ts;
+            }
+        }
+        if (lane == jj) m_run += n_keep;
+    }
+}
+
 template <class T, bool SEP, int TILE, int ROWS>
 __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
     // tile = TILE columns x ROWS rows (64 x 128: a 128-beam sensor's whole columns).  A wave owns CPW
@@ -662,8 +777,6 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
     // zero (the gate's lower bound is at least 1): then the column loop carries neither the per-point room check nor the
     // zero-range select.
     const bool easy = fbase + off[c0 + ncol] <= a.capacity && a.min_r > 0;
-    auto emit_tile = [&](auto easy_c) {
-    constexpr bool roomy = decltype(easy_c)::value, no_zero = decltype(easy_c)::value;
     uint32_t m_run = 0;  // lane jj of the wave: points of its jj-th column already written (previous row chunks)
     for (uint32_t r0 = 0; r0 < H; r0 += ROWS) {
         // the lane's rows of the beam table (a few KB shared by every tile): asked for before the tile is staged, so that the
@@ -710,110 +823,9 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
             }
         }
         __syncthreads();
-        // the column loop is software-pipelined over LDS: a column's ranges and count are read one column ahead, so the
-        // keep masks can be formed the moment the iteration starts and no LDS round trip stands between two columns
-        uint32_t rn[NR], cntn;
-        auto fetch_col = [&](uint32_t jj_next) {
-            const uint32_t jn = min(wave * CPW + jj_next, (uint32_t)TILE - 1u);
-            cntn = s_meta[jn].cnt;
-#pragma unroll
-            for (int hh = 0; hh < NR; ++hh) rn[hh] = s_rng[(lane + 64 * hh) * PITCH + jn];
-        };
-        fetch_col(0);
-        for (uint32_t jj = 0; jj < (uint32_t)CPW; ++jj) {
-            const uint32_t j = wave * CPW + jj, x = c0 + j;  // wave-uniform
-            if (j >= ncol) break;
-            const DwfColMeta<T>& m = s_meta[j];
-            uint32_t r[NR];
-#pragma unroll
-            for (int hh = 0; hh < NR; ++hh) r[hh] = rn[hh];
-            const uint32_t cnt = __builtin_amdgcn_readfirstlane(cntn);
-            if (cnt == 0) {  // masked out or empty column
-                fetch_col(jj + 1);
-                continue;
-            }
-            // this column's constants first (they are needed soonest), then the next column's ranges
-            const uint32_t m_base = m.base;
-            T ps[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) ps[k] = m.pose[k];
-            double cx = 0, sx = 0, kc[3] = {0, 0, 0};
-            if constexpr (SEP) {
-                cx = m.col[0]; sx = m.col[1];
-                kc[0] = m.col[2]; kc[1] = m.col[3]; kc[2] = m.col[4];
-            }
-            fetch_col(jj + 1);
-            uint32_t rank[NR];
-            bool keep[NR];
-            uint32_t n_keep = 0;
-#pragma unroll
-            for (int hh = 0; hh < NR; ++hh) {
-                // rows past H were staged as range 0, which the easy path's gate (min_r > 0) rejects by itself: one
-                // subtract-and-compare whose result IS the ballot
-                if constexpr (no_zero) keep[hh] = r[hh] - a.min_r <= a.max_r - a.min_r;
-                else keep[hh] = row[hh] < H && r[hh] >= a.min_r && r[hh] <= a.max_r;
-                const uint64_t mask = __builtin_amdgcn_ballot_w64(keep[hh]);
-                // kept rows below this lane (v_mbcnt_lo / _hi), on top of the rows kept by the earlier row groups
-                rank[hh] = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, n_keep));
-                n_keep += (uint32_t)__popcll(mask);
-            }
-            if (n_keep == 0) continue;
-            const uint64_t g0 = fbase + __builtin_amdgcn_readfirstlane(m_base) + bcast_u32(m_run, jj);  // first point of this run
-            const uint64_t room = roomy ? ~0ull : (g0 < a.capacity ? a.capacity - g0 : 0);
-            T* const run = (T*)a.points + g0 * 3;   // wave-uniform: the stores take it as a scalar base + a 32-bit lane offset
-#pragma unroll
-            for (int hh = 0; hh < NR; ++hh) {
-                if (!(keep[hh] && (roomy || rank[hh] < room))) continue;
-                T pt[3];
-                if constexpr (SEP) {
-                    const double rm = (double)r[hh] - lut.n;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const double d = fma(cx, bt[hh][k], fma(sx, bt[hh][3 + k], bt[hh][6 + k]));
-                        const T t = (T)fma(rm, d, kc[k]);
-                        pt[k] = (no_zero || r[hh]) ? t : (T)0;
-                    }
-                } else {
-                    double p[3];
-                    const size_t pix = (size_t)row[hh] * W + x;
-                    if (lut.full_dtype == OUSTER_HIP_F32)
-                        project_full<float>((const float*)lut.full_dir, (const float*)lut.full_ofs, pix, r[hh], p);
-                    else
-                        project_full<double>((const double*)lut.full_dir, (const double*)lut.full_ofs, pix, r[hh], p);
-                    pt[0] = (T)p[0]; pt[1] = (T)p[1]; pt[2] = (T)p[2];
-                }
-                const T px = pt[0], py = pt[1], pz = pt[2];
-                Pt3<T> o;
-                // three fused multiply-adds per component, the translation as the innermost addend
-                o.x = fma(ps[0], px, fma(ps[2], py, fma(ps[4], pz, ps[6])));
-                o.y = fma(ps[1], px, fma(ps[3], py, fma(ps[5], pz, ps[7])));
-                o.z = fma(ps[8], px, fma(ps[9], py, fma(ps[10], pz, ps[11])));
-#if OUSTER_NT_STANDALONE
-                {
-                    T* pd = run + rank[hh] * 3u;
-                    __builtin_nontemporal_store(o.x, pd);
-                    __builtin_nontemporal_store(o.y, pd + 1);
-                    __builtin_nontemporal_store(o.z, pd + 2);
-                }
-#else
-                ((Pt3<T>*)run)[rank[hh]] = o;
-#endif
-            }
-            // every point of the run carries the same provenance: dense lanes 0..n_keep-1
-            if (a.col_idxs || a.frame_idxs || a.timestamps_ns) {
-                const uint64_t ts = m.ts;
-                for (uint32_t i = lane; i < n_keep && i < room; i += 64) {
-                    if (a.col_idxs) a.col_idxs[g0 + i] = x;
-                    if (a.frame_idxs) a.frame_idxs[g0 + i] = f;
-                    if (a.timestamps_ns) a.timestamps_ns[g0 + i] = ts;
-                }
-            }
-            if (lane == jj) m_run += n_keep;
-        }
+        if (easy) dwf_column_loop<T, SEP, TILE, ROWS, true>(a, lut, s_rng, s_meta, f, c0, ncol, fbase, row, bt, m_run);
+        else dwf_column_loop<T, SEP, TILE, ROWS, false>(a, lut, s_rng, s_meta, f, c0, ncol, fbase, row, bt, m_run);
     }
-    };
-    if (easy) emit_tile(std::true_type{});
-    else emit_tile(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------
@@ -843,7 +855,8 @@ constexpr uint64_t DWF_AGG = 1ull << 62, DWF_INC = 2ull << 62, DWF_VAL = (1ull <
 // instruction bound (rocprofv3 --pmc: ~2600 VALU + ~1600 SALU per wave, the v_readlane broadcasts of the
 // column metadata), and the whole-column tile (33 KB of LDS) halves the waves per CU that hide it; the
 // range plane read it saves (65-75 us of k_dwf_count) does not pay for that.  Kept behind the
-// "dewarp_single_pass" knob; the three kernels stay the default.
+// "dewarp_single_pass" knob for sensors of more than 128 beams (k_dwf_fused below serves the others); the three kernels
+// stay the default.
 template <class T, bool SEP, int NT>
 __global__ __launch_bounds__(NT) void k_dwf_single(DewarpFramesArgs a) {
     constexpr int TILE = 64, PITCH = TILE + 1, LPR = 16, RPP = NT / LPR, CPW = TILE / (NT / 64);
@@ -1043,6 +1056,197 @@ __global__ __launch_bounds__(NT) void k_dwf_single(DewarpFramesArgs a) {
             if (ml == jj) m_run += n_keep;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------
+// k_dwf_fused: the single-pass dewarp for sensors of up to 128 beams, rebuilt on k_dwf_emit's tile (64 columns x all
+// rows in LDS, column metadata in LDS, dwf_column_loop) -- k_dwf_single above keeps every row count but walks memory the
+// slow way (a guarded status scan per tile, guarded staging, metadata in lanes).  Per tile:
+//   1. ticket -> (frame, tile); EVERY global read of the prologue is issued at once from clamped addresses: the frame's
+//      status words (first / last valid column), the tile's range pieces, the 64 columns' poses / table rows / timestamps;
+//   2. LDS: ranges, metadata; per-column kept counts from LDS (wave = 16 columns, lane = row);
+//   3. wave 0: masked exclusive scan of the 64 counts -> column bases; publish the tile total; decoupled look-back;
+//   4. dwf_column_loop with fbase = the tile's global start.
+// Output, order and provenance are those of k_dwf_count / scan / emit.
+// ------------------------------------------------------------------------------------
+template <class T, bool SEP, int ROWS>
+__global__ __launch_bounds__(256) void k_dwf_fused(DewarpFramesArgs a) {
+    constexpr int TILE = 64, LPR = TILE / 4, PITCH = TILE + 1, CPW = TILE / 4, NR = ROWS / 64, RPP = 256 / LPR, NP = ROWS / RPP;
+    constexpr uint32_t SEG = 8;
+    __shared__ uint32_t s_rng[ROWS * PITCH];
+    __shared__ DwfColMeta<T> s_meta[TILE];
+    __shared__ uint32_t s_cnt[TILE], s_ticket, s_total;
+    __shared__ int s_lo, s_hi;
+    __shared__ uint64_t s_base;
+    const uint32_t W = a.w, H = a.h, tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t q = tid % LPR, ty = tid / LPR;
+    const uint32_t tiles = (W + TILE - 1) / TILE;
+    if (tid == 0) {
+        const uint32_t cls = blockIdx.x & 7u;
+        s_ticket = (uint32_t)atomicAdd((unsigned long long*)&a.tile_state[16 * cls], 1ull) * 8u + cls;
+        s_lo = 0x7fffffff;
+        s_hi = -1;
+    }
+    __syncthreads();
+    const uint32_t t = s_ticket, f = t / tiles, tile = t - f * tiles;
+    const uint32_t c0 = tile * TILE, ncol = min((uint32_t)TILE, W - c0);
+    const uint32_t* rp = a.range + (size_t)f * W * H;
+    const uint32_t* st = a.status + (size_t)f * W;
+    const LutDev lut = a.luts[f % a.n_luts];
+    const bool vec = (W % 4 == 0) && ((((uintptr_t)a.range) & 15) == 0);
+
+    // ---- 1. the prologue's reads
+    uint4 tp[NP];
+    if (vec) {
+        const uint32_t cc = min(c0 + 4 * q, W - 4u);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) tp[i] = *(const uint4*)(rp + (size_t)min(ty + (uint32_t)i * RPP, H - 1u) * W + cc);
+    }
+    DwfColMeta<T> m;
+    uint32_t my_status = 0;
+    if (tid < (uint32_t)TILE) {
+        const uint32_t mx = min(c0 + tid, W - 1u);
+        const double* pm = a.poses + ((size_t)f * W + mx) * 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m.pose[2 * k] = (T)pm[k];
+            m.pose[2 * k + 1] = (T)pm[4 + k];
+            m.pose[8 + k] = (T)pm[8 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) m.col[k] = SEP ? as_global(lut.col_tab)[(size_t)mx * 5 + k] : 0.0;
+        m.ts = a.timestamps_ns ? a.timestamp[(size_t)f * W + mx] : 0;
+        m.base = m.cnt = 0;
+        my_status = st[mx];
+    }
+    {
+        int lo = 0x7fffffff, hi = -1;
+        for (uint32_t base = 0; base < W; base += 256u * SEG) {
+            uint32_t v[SEG];
+#pragma unroll
+            for (uint32_t k = 0; k < SEG; ++k) v[k] = st[min(base + tid + 256u * k, W - 1u)];
+#pragma unroll
+            for (uint32_t k = 0; k < SEG; ++k) {
+                const uint32_t x = base + tid + 256u * k;
+                if (x < W && (v[k] & 1u)) { lo = min(lo, (int)x); hi = max(hi, (int)x); }
+            }
+        }
+        if (hi >= 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    }
+    // ---- 2. LDS image of the tile and its metadata
+    if (vec) {
+        const uint32_t col = c0 + 4 * q;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const uint32_t rr = ty + (uint32_t)i * RPP;
+            const bool in = rr < H && col < W;
+            uint32_t* d = &s_rng[rr * PITCH + 4 * q];
+            d[0] = in ? tp[i].x : 0u; d[1] = in ? tp[i].y : 0u; d[2] = in ? tp[i].z : 0u; d[3] = in ? tp[i].w : 0u;
+        }
+    } else {
+        for (uint32_t rr = ty; rr < (uint32_t)ROWS; rr += RPP) {
+            const uint32_t col = c0 + 4 * q;
+            uint32_t v[4] = {0, 0, 0, 0};
+            if (rr < H)
+                for (uint32_t c = 0; c < 4 && col + c < W; ++c) v[c] = rp[(size_t)rr * W + col + c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_rng[rr * PITCH + 4 * q + c] = v[c];
+        }
+    }
+    if (tid < (uint32_t)TILE) {
+        m.cnt = (tid < ncol && my_status != 0) ? 1u : 0u;   // for now: "this column may emit"; the count follows
+        s_meta[tid] = m;
+    }
+    // the lane's rows of the beam table (L2 hits), asked for before the counting pass needs nothing from memory
+    uint32_t row[NR];
+    double bt[NR][9];
+#pragma unroll
+    for (int hh = 0; hh < NR; ++hh) {
+        row[hh] = lane + 64 * hh;
+        if constexpr (SEP) {
+            const uint32_t rc = min(row[hh], H - 1u);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) bt[hh][k] = as_global(lut.beam_tab)[(size_t)rc * 9 + k];
+        }
+    }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
+    // kept points per column: wave = 16 columns, lane = row; lane jj ends up with column jj's count
+    {
+        uint32_t mine = 0;
+        for (uint32_t jj = 0; jj < (uint32_t)CPW; ++jj) {
+            const uint32_t j = wave * CPW + jj;
+            uint32_t n = 0;
+#pragma unroll
+            for (int hh = 0; hh < NR; ++hh) {
+                const uint32_t r = s_rng[(lane + 64 * hh) * PITCH + min(j, (uint32_t)TILE - 1u)];
+                n += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(row[hh] < H && r >= a.min_r && r <= a.max_r));
+            }
+            if (lane == jj) mine = n;
+        }
+        if (lane < (uint32_t)CPW) s_cnt[wave * CPW + lane] = mine;
+    }
+    __syncthreads();
+    // ---- 3. column bases inside the tile, then where the tile starts (wave 0)
+    if (wave == 0) {
+        const uint32_t jx = lane;
+        const bool on = jx < ncol && (int)(c0 + jx) >= lo && (int)(c0 + jx) <= hi && s_meta[jx].cnt != 0;
+        const uint32_t v = on ? s_cnt[jx] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if (lane >= (uint32_t)d) inc += up;
+        }
+        const uint32_t tile_total = __shfl(inc, 63, 64);
+        s_meta[jx].base = inc - v;
+        s_meta[jx].cnt = v;
+        uint64_t excl = 0;
+        unsigned long long* my = (unsigned long long*)&a.tile_state[DWF_WORDS + t];
+        if (t == 0) {
+            if (lane == 0) __hip_atomic_store(my, DWF_INC | (uint64_t)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(my, DWF_AGG | (uint64_t)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t back = (int64_t)t - 1;        // nearest predecessor not yet accounted for
+            // (asking for four windows of predecessors per step instead of one was tried: slower, 0.245 -> 0.259 ms; the wait is
+            // for the slowest prologue among the few hundred tiles that started just before this one, not for the steps)
+            while (true) {
+                const int64_t i = back - (int64_t)lane;
+                uint64_t w = DWF_INC;             // lanes before the first tile: a zero inclusive prefix
+                if (i >= 0) {
+                    do {
+                        w = __hip_atomic_load((unsigned long long*)&a.tile_state[DWF_WORDS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((w >> 62) == 0);
+                }
+                const uint64_t inc_mask = __ballot((w >> 62) == 2);
+                const uint32_t first_inc = inc_mask ? (uint32_t)__builtin_ctzll(inc_mask) : 64u;
+                uint64_t part = lane <= first_inc ? (w & DWF_VAL) : 0ull;   // aggregates up to (incl.) the first inclusive word
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+                excl += part;
+                if (first_inc < 64u) break;
+                back -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(my, DWF_INC | (excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_base = excl;
+            s_total = tile_total;
+            if (tile == 0) a.frame_off[f] = excl;
+            if (t + 1 == a.n_frames * tiles) a.frame_off[a.n_frames] = excl + tile_total;
+        }
+    }
+    __syncthreads();
+    const uint64_t fbase = s_base;
+    const uint32_t tile_total = s_total;
+    if (tile_total == 0) return;
+    // ---- 4. emit
+    uint32_t m_run = 0;
+    if (fbase + tile_total <= a.capacity && a.min_r > 0)
+        dwf_column_loop<T, SEP, TILE, ROWS, true>(a, lut, s_rng, s_meta, f, c0, ncol, fbase, row, bt, m_run);
+    else
+        dwf_column_loop<T, SEP, TILE, ROWS, false>(a, lut, s_rng, s_meta, f, c0, ncol, fbase, row, bt, m_run);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1386,6 +1590,20 @@ hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipSt
             hipLaunchKernelGGL(kernel, grid, dim3(DWF_NT), lds, st, a);
             return hipGetLastError();
         };
+        if (a.h <= 128) {   // the rebuilt single pass: static LDS, k_dwf_emit's tile
+            auto fused = [&](auto rows) -> hipError_t {
+                constexpr int R = decltype(rows)::value;
+                if (a.dtype == OUSTER_HIP_F32) {
+                    if (separable) hipLaunchKernelGGL((k_dwf_fused<float, true, R>), grid, dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((k_dwf_fused<float, false, R>), grid, dim3(256), 0, st, a);
+                } else {
+                    if (separable) hipLaunchKernelGGL((k_dwf_fused<double, true, R>), grid, dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((k_dwf_fused<double, false, R>), grid, dim3(256), 0, st, a);
+                }
+                return hipGetLastError();
+            };
+            return a.h > 64 ? fused(std::integral_constant<int, 128>{}) : fused(std::integral_constant<int, 64>{});
+        }
         if (a.dtype == OUSTER_HIP_F32)
             return separable ? go(k_dwf_single<float, true, DWF_NT>) : go(k_dwf_single<float, false, DWF_NT>);
         return separable ? go(k_dwf_single<double, true, DWF_NT>) : go(k_dwf_single<double, false, DWF_NT>);
