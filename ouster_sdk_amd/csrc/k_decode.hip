@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
         const uint8_t* fend = fbase + (size_t)a.slots_per_frame * a.packet_stride;
         uint32_t j = tid / NCH, ch = tid - j * NCH;
         const uint32_t dj = NT / NCH, dc = NT - dj * NCH;
-        constexpr int DEPTH = 18;  // 256 columns x 17 chunks = 17 per thread for 256 B pieces
+        constexpr int DEPTH = 9;   // 256 columns x 17 chunks = 17 per thread for 256 B pieces: two batches of loads (18 in one batch cost 231 VGPRs = two waves per SIMD; 9 keep the 155 of the row loop)
         for (uint32_t base = 0; base < total; base += NT * DEPTH) {
             u32x4 t[DEPTH];
             // (column j << 16) | (piece-relative dword index of t[k].x as int16; -32768 drops all four):
@@ -634,29 +634,29 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             uint32_t pj[DEPTH];
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
-                pj[k] = 0x8000u;
-                t[k] = u32x4{0, 0, 0, 0};
-                if (base + k * NT + tid < total) {
-                    const uint32_t ofs = s_colofs[j];
-                    if (ofs != 0xffffffffu) {
-                        const uint8_t* src = fbase + ofs + rowofs;
-                        const uint32_t delta = (uint32_t)((uintptr_t)src & 15u);
-                        const u32x4* q = (const u32x4*)(src - delta) + ch;
-                        if (ch * 16u < delta + piece * 4u) {
+                // Every load is issued, from an address that is always safe to read; what must not land in the tile is dropped
+                // through pj[k].  (Guarded loads -- the form this loop had -- are each waited for on their own: the compiler
+                // ends every guarded region with s_waitcnt vmcnt(0), eighteen memory round trips per tile instead of one.)
+                const bool in = base + k * NT + tid < total;
+                const uint32_t ofs = s_colofs[in ? j : 0u];
+                bool ok = in && ofs != 0xffffffffu;
+                const uint8_t* src = fbase + (ok ? ofs : 0u) + rowofs;
+                const uint32_t delta = (uint32_t)((uintptr_t)src & 15u);
+                const uint8_t* q = src - delta + ch * 16u;
+                ok = ok && ch * 16u < delta + piece * 4u;
+                // the last chunk of the frame buffer may reach past its end: read the 16 bytes that end there instead; its
+                // dwords then sit `shift` positions later in the register, i.e. the first one belongs `shift` dwords earlier
+                // in the piece (those are bytes of the same packet, written with the same values by the chunk before)
+                const uint8_t* lim = fend - 16;
+                const bool tail = q > lim;
+                const uint8_t* qs = ok ? (tail ? lim : q) : fbase;
+                const int32_t shift = tail ? (int32_t)((q - lim) >> 2) : 0;
 #if OUSTER_NT_LOADS
-                            if ((const uint8_t*)(q + 1) <= fend) t[k] = __builtin_nontemporal_load(q);
+                t[k] = __builtin_nontemporal_load((const u32x4*)qs);
 #else
-                            if ((const uint8_t*)(q + 1) <= fend) t[k] = *q;
+                t[k] = *(const u32x4*)qs;
 #endif
-                            else {  // last chunk of the frame buffer: stay inside it
-                                const uint32_t* qd = (const uint32_t*)q;
-                                for (int w = 0; w < 4; ++w)
-                                    if ((const uint8_t*)(qd + w + 1) <= fend) t[k][w] = qd[w];
-                            }
-                            pj[k] = (j << 16) | (uint32_t)(((int32_t)(ch * 4u) - (int32_t)(delta >> 2)) & 0xffff);
-                        }
-                    }
-                }
+                pj[k] = ok ? ((j << 16) | (uint32_t)(((int32_t)(ch * 4u) - (int32_t)(delta >> 2) - shift) & 0xffff)) : 0x8000u;
                 j += dj; ch += dc;
                 if (ch >= NCH) { ch -= NCH; ++j; }
             }

@@ -690,3 +690,34 @@ def test_bench_size_loss_paths(oracle, path):
     ref = _oracle_frames(O, cal, pf, [by_frame[f] for f in check], True)
     worst = _compare(O, cal, hp, out, ref, dst, xyz, frames=list(zip(check, ref)))
     assert worst <= 4e-5
+
+
+@pytest.mark.parametrize("wide", [256, 128])
+@pytest.mark.parametrize("misalign", [4, 8, 12])
+def test_wide_tiles_on_a_packet_buffer_that_is_not_16_byte_aligned(oracle, wide, misalign):
+    """The wide kernel stages 16-byte chunks aligned to ABSOLUTE addresses.  When the packet buffer starts 4 / 8 / 12 bytes
+    off a 16-byte boundary and is packed tightly (LEGACY: no packet footer), the last chunk of the last packet of a frame
+    would reach past the frame's bytes: it is read as the 16 bytes that END there and its dwords are shifted into place.
+    All frames -- the last one ends at the last byte of the allocation -- equal the oracle."""
+    O = oracle
+    profile = "LEGACY"
+    cal = O.synthetic_calib(h=128, w=1024, profile=profile)
+    pf = cal.packet_format()
+    n = 3
+    packets, src = O.synth_packets(cal, n)
+    slots = cal.w // cal.cpp
+    total = n * slots * pf.lidar_packet_size
+    flat = torch.zeros(total + 16, dtype=torch.uint8, device="cuda")
+    assert flat.data_ptr() % 16 == 0
+    flat[misalign:misalign + total] = torch.from_numpy(np.ascontiguousarray(packets).reshape(-1)).cuda()
+    dev = flat[misalign:misalign + total].view(n, slots, pf.lidar_packet_size)
+    assert dev.data_ptr() % 16 == misalign
+    hp = _hotpath(cal, profile, wide=wide, use_extrinsics=False)
+    names = [x for x, _ in hp.fields]
+    out = hp.alloc_outputs(n, destagger=["RANGE"], xyz=["RANGE"])
+    for t in out.values():
+        t.view(torch.uint8).fill_(0x3B)
+    hp.decode(dev, out)
+    hp.sync()
+    _assert_variant_ran(hp, wide)
+    _compare(O, cal, hp, out, src, ["RANGE"], ["RANGE"])
