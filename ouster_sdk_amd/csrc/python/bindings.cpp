@@ -308,7 +308,11 @@ PYBIND11_MODULE(core, m) {
     py::class_<SensorConfig>(m, "SensorConfig")
         .def(py::init<>())
         .def_readwrite("lidar_mode", &SensorConfig::lidar_mode)
-        .def_readwrite("udp_profile_lidar", &SensorConfig::udp_profile_lidar);
+        .def_readwrite("udp_profile_lidar", &SensorConfig::udp_profile_lidar)
+        .def_readwrite("udp_profile_imu", &SensorConfig::udp_profile_imu)
+        .def_readwrite("udp_port_lidar", &SensorConfig::udp_port_lidar)   // None = not known (a capture reader may guess it)
+        .def_readwrite("udp_port_imu", &SensorConfig::udp_port_imu)
+        .def_readwrite("udp_port_zm", &SensorConfig::udp_port_zm);
     // lidar_frame.h:36-74; the element type travels as a numpy dtype
     py::class_<FieldType>(m, "FieldType")
         .def(py::init([](const std::string& name, const py::object& dt, const py::tuple& extra, FieldClass c) {

@@ -48,6 +48,14 @@ def real_pcap_path(base_name: str, meta) -> str:
 
 
 @pytest.fixture
+def real_pcap(real_pcap_path: str, meta):
+    from ouster.sdk import pcap
+    source = pcap.PcapPacketSource(real_pcap_path, sensor_info=[meta])
+    yield source
+    source.close()
+
+
+@pytest.fixture
 def packets(real_pcap_path: str, meta):
     from ouster.sdk import pcap
     return core.Packets([p for _, p in pcap.PcapPacketSource(real_pcap_path, sensor_info=[meta])], meta)

@@ -6,6 +6,7 @@ from ouster_sdk_amd import core as _core
 
 from .data import ColHeader  # noqa: E402,F401  (a Python Enum in the reference too)
 
+Packet = _core.LidarPacket      # the base class of the reference's packet types; only lidar packets exist here
 SensorInfo = _core.SensorInfo   # SensorInfo(json_text) is a constructor of the C++ class (csrc/host/metadata.cpp)
 
 

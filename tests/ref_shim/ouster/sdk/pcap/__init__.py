@@ -32,9 +32,20 @@ class PcapPacketSource:
     """Iterates (sensor index, packet); only lidar packets of the first sensor are produced."""
 
     def __init__(self, path, sensor_info=None, **_):
+        import copy
         self._path = path
-        self.sensor_info = _infos(path, sensor_info)
+        self.sensor_info = [copy.copy(i) for i in _infos(path, sensor_info)]
         self._pf = _core.PacketFormat(self.sensor_info[0])
+        # ports the metadata does not name are inferred from the capture (IndexedPcapReader: payload sizes per stream)
+        try:
+            ports = _core.index_pcap(path, self.sensor_info)["ports"]
+        except RuntimeError:
+            ports = []
+        for info, (lidar, imu) in zip(self.sensor_info, ports):
+            if info.config.udp_port_lidar is None:
+                info.config.udp_port_lidar = lidar
+            if info.config.udp_port_imu is None:
+                info.config.udp_port_imu = imu
 
     def __iter__(self):
         fmt = self._pf

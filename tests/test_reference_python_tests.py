@@ -38,6 +38,9 @@ OUT_OF_SCOPE = {
 FILES = ("test_xyzlut.py", "test_destagger.py", "test_batching.py", "test_parsing.py", "test_data.py", "test_core.py",
          "test_extended_profiles.py")
 HELPERS = ("multi.py",)     # tests/multi.py of the reference: its packet-batching `Frames` source, used by test_core.py
+# files of which only the named tests are in scope (the rest of test_pcap.py records captures, reads IMU packets, indexes
+# and seeks through the reference's Python pcap package): real captures read back, ports inferred from the capture
+ONLY = {"test_pcap.py": ("test_pcap_read_real", "test_pcap_guess_real")}
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(STAGED, "test_batching.py")),
@@ -48,7 +51,7 @@ def test_reference_python_tests_pass_unmodified(tmp_path):
     pkg = tmp_path / "tests"
     pkg.mkdir()
     (pkg / "__init__.py").write_text("")
-    for name in FILES + HELPERS:
+    for name in FILES + HELPERS + tuple(ONLY):
         shutil.copy(os.path.join(STAGED, name), pkg / name)          # byte-identical copies
     shutil.copy(os.path.join(SHIM, "conftest_for_reference_tests.py"), pkg / "conftest.py")
     env = dict(os.environ)
@@ -57,9 +60,11 @@ def test_reference_python_tests_pass_unmodified(tmp_path):
     env["OUSTER_REF_STAGED"] = STAGED          # the shim's ouster.sdk.core._digest executes the staged reference module
     deselect = " and ".join("not " + k for k in OUT_OF_SCOPE)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", "--rootdir", str(tmp_path),
-                        "-c", os.devnull, "-k", deselect, str(pkg)], env=env, capture_output=True, text=True, timeout=1500)
+                        "-c", os.devnull, "-k", deselect] + [str(pkg / n) for n in FILES] +
+                       [f"{pkg / n}::{t}" for n, ts in ONLY.items() for t in ts],
+                       env=env, capture_output=True, text=True, timeout=1500)
     tail = "\n".join(r.stdout.strip().splitlines()[-40:])
     m = re.search(r"(\d+) passed", r.stdout)
     passed = int(m.group(1)) if m else 0
     print(f"reference python tests: {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]}")
-    assert r.returncode == 0 and passed >= 138 and "failed" not in r.stdout.splitlines()[-1], tail + r.stderr[-2000:]
+    assert r.returncode == 0 and passed >= 148 and "failed" not in r.stdout.splitlines()[-1], tail + r.stderr[-2000:]
