@@ -8,7 +8,10 @@ frame of the batch (BASELINE.json configs[2]: OS-2-128 2048x128 RNG15_RFL8_NIR8 
 A "point" is one (pixel, return) with XYZ produced: 524288 per frame.
 
   python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by torch.distributed.run, one rank per GPU; frames are independent, so
+N > 1, one rank per GPU over RCCL: either an external launcher starts the ranks (the driver's
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: WORLD_SIZE is set and must equal N),
+or plain `python bench.py --gpus N` starts them itself through the same torch.distributed.run command line
+(`plan_launch`); a box with fewer than N GPUs is an error, not a smaller run.  Frames are independent, so
 ranks shard the batch with no data-path collective ("weak": per-GPU work fixed).  Rank 0
 prints ONE JSON line with the whole-job rate, the roofline of the dominant kernel
 (k_decode, timed with HIP events on its stream) and the CPU baseline (the oracle's
@@ -294,6 +297,33 @@ def time_loss_paths(hp, packets, out, F, bytes_per_frame, steps=30):
     return res
 
 
+def plan_launch(gpus: int, environ, argv, n_devices=None):
+    """What `bench.py --gpus N` does about its ranks (no torch import: unit-tested on CPU).
+      ("run", world)   this process is one rank of `world` (1 without a launcher); under an external launcher
+                       (WORLD_SIZE set) --gpus must agree with it, anything else is a mis-launch and raises;
+      ("spawn", cmd)   no launcher and N > 1: the torch.distributed.run command line that starts N ranks of this script,
+                       one per GPU, rendezvous on 127.0.0.1 at a free port.
+    `n_devices` (when known) must cover N unless BENCH_ONE_DEVICE=1 (test knob: every rank on cuda:0)."""
+    if gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" in environ:
+        world = int(environ["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit(f"bench.py --gpus {gpus} was started by a launcher with WORLD_SIZE={world}: "
+                             "the two must agree (n_gpus in the JSON line is the number of ranks that ran)")
+        return "run", world
+    if gpus == 1:
+        return "run", 1
+    if n_devices is not None and n_devices < gpus and environ.get("BENCH_ONE_DEVICE") != "1":
+        raise SystemExit(f"bench.py --gpus {gpus}: only {n_devices} GPU(s) visible on this box")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    return "spawn", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+                     "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,6 +345,8 @@ def main():
     ap.add_argument("--placement-tries", type=int, default=24,
                     help="--placement draws: candidate allocations of the output set (1 = the same as --placement first)")
     ap.add_argument("--no-loss-paths", action="store_true", help="skip the loss-path timings after the timed region")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the other BASELINE configs and the small-batch latency block after the timed region")
     ap.add_argument("--workload", default="dual", choices=sorted(WORKLOADS),
                     help="'dual' is the metric (configs[2]); the others are extra report rows")
     ap.add_argument("--outputs", default="full", choices=["full", "xyz", "planes", "planes+dst"],
@@ -326,14 +358,19 @@ def main():
     args = ap.parse_args()
 
     import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the hot path)")
+    action, plan = plan_launch(args.gpus, os.environ, sys.argv[1:], torch.cuda.device_count())
+    if action == "spawn":      # plain `python bench.py --gpus N`: start the N ranks, pass their one JSON line through
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(plan, env=env))
     import torch.distributed as dist
     from ouster_sdk_amd.device import HotPath
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback for the hot path)")
+    world = plan
     # test knobs: BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and BENCH_BACKEND=gloo swaps RCCL
     # for gloo, so the N>1 launch path can be smoke-tested on a 1-GPU box
     one_device = os.environ.get("BENCH_ONE_DEVICE") == "1"

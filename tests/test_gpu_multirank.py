@@ -65,6 +65,35 @@ def _two_ranks(script_args):
     return _last_json(p.stdout), backend
 
 
+def test_plain_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2 ...` with NO launcher in the test: bench.py re-executes itself through
+    torch.distributed.run (bench.plan_launch) and rank 0's line says n_gpus == 2.  Two GPUs visible: RCCL, one rank per
+    GPU, no fallback.  One GPU: both ranks on cuda:0 (BENCH_ONE_DEVICE), RCCL first, gloo when it refuses the duplicate."""
+    args = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "32", "--no-cpu",
+            "--placement", "first", "--no-loss-paths", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_ONE_DEVICE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if _n_gpus() >= 2:
+        tries = [dict(env, BENCH_BACKEND="nccl")]
+    else:
+        tries = [dict(env, BENCH_BACKEND="nccl", BENCH_ONE_DEVICE="1"), dict(env, BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1")]
+    for e in tries:
+        p = subprocess.run(args, capture_output=True, text=True, env=e, timeout=900, cwd=ROOT)
+        if p.returncode == 0:
+            break
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = _last_json(p.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0, line
+    assert line["config"]["sharding"].startswith("frames x2")
+    if e["BENCH_BACKEND"] == "nccl":
+        assert line["rccl_ranks"] == 2
+    # a box with fewer GPUs than asked for is an error, never a smaller run
+    if _n_gpus() < 4:
+        p = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--steps", "1"], capture_output=True, text=True,
+                           env=env, timeout=300, cwd=ROOT)
+        assert p.returncode != 0 and "GPU(s) visible" in p.stderr
+
+
 def test_bench_two_ranks_with_exchange():
     line, backend = _two_ranks(["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--frames", "32",
                                 "--no-cpu", "--exchange", "--placement", "first", "--no-loss-paths"])

@@ -70,3 +70,28 @@ def test_bench_workload_definition(oracle):
     alt, az, shifts, b2l, l2s = bench.synth_calibration()
     assert np.array_equal(shifts, cal.pixel_shift_by_row)
     assert np.allclose(b2l, cal.beam_to_lidar) and np.allclose(l2s, cal.lidar_to_sensor)
+
+
+def test_bench_gpus_flag_plans_the_launch():
+    """`bench.py --gpus N`: one rank per GPU either way -- under a launcher WORLD_SIZE must equal N, without one the
+    script starts N ranks itself through torch.distributed.run on 127.0.0.1."""
+    import sys
+    import bench
+    assert bench.plan_launch(1, {}, [], 1) == ("run", 1)
+    assert bench.plan_launch(8, {"WORLD_SIZE": "8", "RANK": "3"}, [], 8) == ("run", 8)
+    with pytest.raises(SystemExit, match="must agree"):
+        bench.plan_launch(8, {"WORLD_SIZE": "1"}, [], 8)
+    with pytest.raises(SystemExit, match="must agree"):
+        bench.plan_launch(1, {"WORLD_SIZE": "2"}, [], 8)
+    with pytest.raises(SystemExit, match="only 1 GPU"):
+        bench.plan_launch(2, {}, [], 1)
+    with pytest.raises(SystemExit):
+        bench.plan_launch(0, {}, [], 1)
+    argv = ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    action, cmd = bench.plan_launch(4, {}, argv, 8)
+    assert action == "spawn" and cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-len(argv) - 1].endswith("bench.py") and cmd[-len(argv):] == argv
+    # the one-device test knob lets a 1-GPU box exercise the N > 1 launch
+    assert bench.plan_launch(2, {"BENCH_ONE_DEVICE": "1"}, argv, 1)[0] == "spawn"
