@@ -110,13 +110,13 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     // ---- LDS carve-up (all offsets 16 B aligned)
     uint32_t* s_tile = smem;                                    // TILE * col_size (+16) bytes
     const uint32_t tile_bytes = (TILE * col_size + 16 + 15) & ~15u;
-    int32_t* s_src = (int32_t*)(smem + (tile_bytes >> 2));      // [TILE] source slot (general modes)
-    uint64_t* s_masks = (uint64_t*)(s_src + TILE);              // [0] valid, [1] group-ok / stray
+    int32_t* s_src = (int32_t*)(smem + (tile_bytes >> 2));      // [TILE] slot that supplies the column's pixels (general modes)
+    int32_t* s_hsrc = s_src + TILE;                             // [TILE] slot that supplies its header (general modes)
+    uint64_t* s_masks = (uint64_t*)(s_hsrc + TILE);             // [0] valid, [1] group-ok / stray
     int32_t* s_off = (int32_t*)(s_masks + 4);                   // [H] destagger offsets
     double* s_beam = (double*)(s_off + ((H + 3) & ~3u));        // [H][9] per-beam xyz constants (a.beam_lds)
     float4* s_xyz = (float4*)(s_beam + (a.beam_lds ? H * 9 + (H & 1) : 0));  // [4 waves][192] (OUSTER_XYZ_PERMUTE=0 builds)
-    int32_t* s_pk = (int32_t*)((uint8_t*)s_xyz + XYZ_SCRATCH_BYTES);  // general modes, tile 0: [npo] packet map
-    uint32_t* s_vb = (uint32_t*)(s_pk + npo);                   //   [(W+31)/32] valid-column bitmap, [+1] count
+    // general modes: resolve_frame's scratch starts at smem[0] -- it is done before anything above is written
 
     const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
     uint32_t count = a.slots_per_frame;
@@ -144,52 +144,22 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
         }
         if (tile == 0 && tid == 0 && a.frame_meta) a.frame_meta[f] = frame_meta_first_present(a.g, fbase, a.packet_stride, count);
     } else {
-        // general mapping: scan every received column header of the frame, keep the last slot per
-        // destination column of my tile; tile 0 also resolves the packet-level outputs and counts
-        for (uint32_t j = tid; j < (uint32_t)TILE; j += NT) s_src[j] = -1;
-        const uint32_t vwords = (W + 31) / 32;
-        if (tile == 0) {
-            for (uint32_t i = tid; i < npo; i += NT) s_pk[i] = -1;
-            for (uint32_t i = tid; i <= vwords; i += NT) s_vb[i] = 0;
-        }
-        __syncthreads();
-        const uint32_t nslots = count * cpp;
-        constexpr int U = 4;  // headers per thread per round, all loads in flight before the first use
-        for (uint32_t base = 0; base < nslots; base += NT * U) {
-            uint64_t w_mid[U], w_st[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t s = base + (uint32_t)u * NT + tid;
-                w_mid[u] = w_st[u] = 0;
-                if (s < nslots) {
-                    const uint32_t p = s / cpp, ic = s - p * cpp;
-                    const uint8_t* colp = fbase + (size_t)p * a.packet_stride + a.g.packet_header_size +
-                                          (size_t)ic * col_size;
-                    w_mid[u] = window_global_masked(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask);
-                    w_st[u] = window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t s = base + (uint32_t)u * NT + tid;
-                if (s >= nslots) continue;
-                const uint32_t m_id = (uint16_t)apply_bits(w_mid[u], a.g.col_measurement_id.mask,
-                                                           a.g.col_measurement_id.shift);
-                const uint32_t st = (uint32_t)apply_bits(w_st[u], a.g.col_status.mask, a.g.col_status.shift);
-                const bool live = (st & 1u) && m_id < W;
-                if (live && m_id - c0 < (uint32_t)TILE) atomicMax(&s_src[m_id - c0], (int32_t)s);
-                if (tile == 0) {
-                    if (live) atomicOr(&s_vb[m_id >> 5], 1u << (m_id & 31u));
-                    const uint32_t p = s / cpp;
-                    if (s == p * cpp && m_id / cpp < npo) atomicMax(&s_pk[m_id / cpp], (int32_t)p);
-                }
-            }
-        }
-        __syncthreads();
+        // general mapping: what FrameBatcher leaves behind after batching the frame's packets in buffer order
+        // (resolve_frame, kernels_common.h); my tile keeps its columns, tile 0 also writes the packet-level outputs and counts
+        int32_t* r_pix = (int32_t*)smem;
+        int32_t* r_hdr = r_pix + W;
+        int32_t* r_z = r_hdr + W;
+        int32_t* r_pkm = r_z + W;
+        uint32_t* r_pkt = (uint32_t*)(r_pkm + npo);
+        __shared__ uint32_t s_nvalid;
+        if (tid == 0) s_nvalid = 0;
+        resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, r_pix, r_hdr, r_z, tile == 0 ? r_pkm : nullptr, r_pkt);
+        int32_t my_pix = -1, my_hdr = -1;
+        if (tid < TILE && c0 + tid < W) { my_pix = r_pix[c0 + tid]; my_hdr = r_hdr[c0 + tid]; }
         if (tile == 0) {
             // packet_timestamp is zeroed at frame start (lidar_frame.cpp:1719), alert_flags is not
             for (uint32_t i = tid; i < npo; i += NT) {
-                const int32_t p = s_pk[i];
+                const int32_t p = r_pkm[i];
                 if (a.packet_timestamp && a.host_timestamps)
                     a.packet_timestamp[(size_t)f * npo + i] =
                         p >= 0 ? a.host_timestamps[(size_t)f * a.slots_per_frame + p] : 0ull;
@@ -200,18 +170,41 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
             }
             if (a.frame_meta) {
                 uint32_t n = 0;
-                for (uint32_t i = tid; i < vwords; i += NT) n += (uint32_t)__popc(s_vb[i]);
-                if (n) atomicAdd(&s_vb[vwords], n);
+                for (uint32_t i = tid; i < W; i += NT) n += r_hdr[i] >= 0 ? 1u : 0u;
+                if (n) atomicAdd(&s_nvalid, n);
                 __syncthreads();
                 if (tid == 0) {
                     ouster_hip_frame_meta m = frame_meta_of(a.g, fbase, count > 0);
-                    m.n_valid_columns = s_vb[vwords];
+                    m.n_valid_columns = s_nvalid;
                     a.frame_meta[f] = m;
                 }
             }
         }
+        if constexpr (GENERAL_ONLY) {
+            // The fix-up pass: the optimistic pass has already written this tile under "slot c holds column c, anything else
+            // reads as zeros".  Where the frame's real mapping says the same for every column of the tile there is nothing to redo.
+            bool dirty = false;
+            if (tid < TILE && c0 + tid < W) {
+                const uint32_t c = c0 + tid, p = c / cpp;
+                int32_t expect = -1;
+                if (p < count && (uint64_t)a.slots_per_frame * cpp == W) {
+                    const uint8_t* colp = fbase + (size_t)p * a.packet_stride + a.g.packet_header_size + (size_t)(c - p * cpp) * col_size;
+                    const uint32_t m_id = (uint16_t)apply_bits(window_global_masked(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask),
+                                                               a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
+                    const uint32_t st = (uint32_t)apply_bits(window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask),
+                                                             a.g.col_status.mask, a.g.col_status.shift);
+                    if ((st & 1u) && m_id == c) expect = (int32_t)c;
+                }
+                dirty = my_pix != expect || my_hdr != expect;
+            }
+            if (!__syncthreads_or(dirty ? 1 : 0)) return;
+        } else {
+            __syncthreads();   // the scratch is about to be overwritten
+        }
         if (tid < TILE) {
-            const int32_t src = s_src[tid];
+            s_src[tid] = my_pix;
+            s_hsrc[tid] = my_hdr;
+            const int32_t src = my_pix;
             const uint32_t j0 = tid - tid % cpp;  // first column of my packet group in the tile
             // "group ok": my packet's cpp columns sit in order, packet-aligned, all present
             const int32_t head = __shfl(src, (int)(j0 & 63u));
@@ -306,6 +299,8 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     }
     if (tid < 4) s_tile[(TILE * col_size >> 2) + tid] = 0;  // slack read by 64-bit windows
     __syncthreads();
+    int32_t my_ps = 0, my_hs = 0;   // general modes: my column's pixel / header source slot (s_src is about to be reused)
+    if (!fast && tid < TILE) { my_ps = s_src[tid]; my_hs = s_hsrc[tid]; }
     uint32_t* s_gate = a.gate_counts ? (uint32_t*)s_src : nullptr;  // the slot map is dead after staging
     if (s_gate) {
         if (tid < TILE) s_gate[tid] = 0;
@@ -340,24 +335,36 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
             }
         }
         __syncthreads();
-        if (s_masks[1]) return;  // the fix-up pass redoes this frame
+        // a stray column reads as zeros here, like in the wide kernels: the fix-up pass redoes exactly the tiles whose real
+        // mapping differs from "slot c holds column c or nothing"
         validmask = s_masks[0];
     }
 
     // ---- phase 2a: column headers (timestamp / measurement_id / status), one lane per column
     if (tid < TILE && c0 + tid < W) {
         const uint32_t c = c0 + tid;
-        const bool v = (validmask >> tid) & 1;
-        const uint32_t cb = tid * col_size;
-        if (a.timestamp)
-            a.timestamp[(size_t)f * W + c] =
-                v ? apply_bits(window_lds(s_tile, cb + a.g.col_timestamp.offset),
-                               a.g.col_timestamp.mask, a.g.col_timestamp.shift) : 0ull;
+        bool v = (validmask >> tid) & 1;
+        uint64_t ts = 0;
+        uint32_t st = 0;
+        const int32_t hs = my_hs;
+        if (!fast && hs != my_ps) {
+            // the header comes from another slot than the pixels (an all-valid packet with non-consecutive ids, parse_by_block)
+            v = hs >= 0;
+            if (v) {
+                const uint32_t p = (uint32_t)hs / cpp;
+                const uint8_t* colp = fbase + (size_t)p * a.packet_stride + a.g.packet_header_size + (size_t)((uint32_t)hs - p * cpp) * col_size;
+                ts = apply_bits(window_global(colp + a.g.col_timestamp.offset), a.g.col_timestamp.mask, a.g.col_timestamp.shift);
+                st = (uint32_t)apply_bits(window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask), a.g.col_status.mask,
+                                          a.g.col_status.shift);
+            }
+        } else if (v) {
+            const uint32_t cb = tid * col_size;
+            ts = apply_bits(window_lds(s_tile, cb + a.g.col_timestamp.offset), a.g.col_timestamp.mask, a.g.col_timestamp.shift);
+            st = (uint32_t)apply_bits(window_lds(s_tile, cb + a.g.col_status.offset), a.g.col_status.mask, a.g.col_status.shift);
+        }
+        if (a.timestamp) a.timestamp[(size_t)f * W + c] = ts;
         if (a.measurement_id) a.measurement_id[(size_t)f * W + c] = v ? (uint16_t)c : (uint16_t)0;
-        if (a.status)
-            a.status[(size_t)f * W + c] =
-                v ? (uint32_t)apply_bits(window_lds(s_tile, cb + a.g.col_status.offset),
-                                         a.g.col_status.mask, a.g.col_status.shift) : 0u;
+        if (a.status) a.status[(size_t)f * W + c] = st;
     }
 
     // ---- phase 2b: pixels
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256) void k_decode_fixup(DecodeArgs a) {
     __shared__ uint32_t s_n;
     __shared__ uint32_t s_cnt[FIXUP_CHUNK / 64];   // flagged frames per 64-frame group of the chunk
     const uint32_t tid = threadIdx.x, tpf = a.tiles_per_frame;
-    const uint32_t fast_tiles = a.lds_col_slot;  // column tiles of the optimistic pass (slots of tile_valid)
+    const uint32_t fast_tiles = a.fast_tiles;    // column tiles of the optimistic pass (slots of tile_valid)
     uint16_t* s_list = (uint16_t*)(smem + (a.rows_per_tile >> 2));  // rows_per_tile: byte offset of the list here
     const uint64_t tag = a.frame_state[FS_TAG];
     for (uint32_t base = 0; base < a.n_frames; base += FIXUP_CHUNK) {
@@ -479,20 +486,16 @@ __global__ __launch_bounds__(256) void k_decode_fixup(DecodeArgs a) {
 // status) words of its columns next to its staging loads, the first row chunk of a column tile does
 // the stray check, the column headers and the packet-level outputs.
 // ------------------------------------------------------------------------------------
-template <class S, int TW, int XYZM, bool POSES = false>
-__global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
+// LMAPS: the column maps of the frame lie in LDS (l_pix / l_hdr, resolve_frame's output in the fix-up pass; they may lie
+// under the tile image: they are read before the first barrier); otherwise a.slot_map / a.hdr_map in global memory, or none.
+template <class S, int TW, int XYZM, bool POSES, bool LMAPS>
+__device__ __forceinline__ void wide_tile(const DecodeArgs& a, uint32_t* smem, uint32_t f, uint32_t tile, uint32_t rc,
+                                          const int32_t* l_pix, const int32_t* l_hdr) {
     constexpr int NT = 256;
     constexpr int NJ = (TW + NT - 1) / NT;        // columns per thread in the per-column phases
     static_assert(TW % 64 == 0 && TW / 4 <= NT * 4, "tile width");
-    extern __shared__ __align__(16) uint32_t smem[];
 
     const uint32_t TR = a.rows_per_tile, nch = a.row_chunks;
-    uint32_t f, sub;
-    if (!block_to_frame(a, a.tiles_per_frame * nch, f, sub)) return;
-    // the column tiles of one row chunk are neighbouring blocks of an XCD: together they write whole
-    // 8 KB rows at the same time (ordering the row chunks of a column tile next to each other instead
-    // shares input cache lines but measured 6 % slower)
-    const uint32_t tile = sub % a.tiles_per_frame, rc = sub / a.tiles_per_frame;
     const uint32_t tid = threadIdx.x;
     const uint32_t W = a.g.columns_per_frame, H = a.g.pixels_per_column;
     const uint32_t cpp = a.g.columns_per_packet, col_size = a.g.col_size;
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     const uint32_t slot = a.lds_col_slot >> 2;     // LDS dwords per column (piece + pad)
 
     uint32_t* s_tile = smem;                                  // [TW][slot]
-    uint32_t* s_colofs = smem + TW * slot + 4;                // [TW] byte offset of the column in the frame buffer
+    uint32_t* s_colofs = smem + a.wide_img_words;             // [TW] byte offset of the column in the frame buffer (TW * slot + 4 words in, or behind resolve_frame's scratch)
     uint32_t* s_valid = s_colofs + TW;                        // [TW] 1 = received, valid, at home
     uint32_t* s_acc = s_valid + TW;                           // [0] valid columns, [1] strays (+2 pad)
     int32_t* s_off = (int32_t*)(s_acc + 4);                   // [TR] destagger offsets of my rows
@@ -524,22 +527,30 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     PHASE_STAMP(0);
 
     // ---- phase 0: where my columns live (slot c holds column c): arithmetic only, nothing is loaded
+    const bool mapped = LMAPS || a.slot_map != nullptr;
+    uint32_t hofs[NJ];   // mapped: byte offset of the column whose HEADER lands in my column (0xffffffff: none)
 #pragma unroll
     for (int k = 0; k < NJ; ++k) {
         const uint32_t j = tid + (uint32_t)k * NT, c = c0 + j;
+        hofs[k] = 0xffffffffu;
         if (j >= (uint32_t)TW) continue;
         uint32_t ofs = 0xffffffffu;
         if (c < W) {
-            // source slot of destination column c: itself (the optimistic pass), or what k_slotmap found (general mapping)
-            const int32_t sl = a.slot_map ? a.slot_map[(size_t)f * W + c] : (int32_t)c;
+            // source slot of destination column c: itself (the optimistic pass), or what resolve_frame found (general mapping)
+            int32_t sl = (int32_t)c, hs = (int32_t)c;
+            if constexpr (LMAPS) { sl = l_pix[c]; hs = l_hdr[c]; }
+            else if (a.slot_map) { sl = a.slot_map[(size_t)f * W + c]; hs = a.hdr_map[(size_t)f * W + c]; }
             if (sl >= 0) {
                 const uint32_t p = (uint32_t)sl / cpp, ic = (uint32_t)sl - p * cpp;
                 ofs = p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
             }
+            if (hs >= 0) {
+                const uint32_t p = (uint32_t)hs / cpp, ic = (uint32_t)hs - p * cpp;
+                hofs[k] = p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
+            }
         }
         s_colofs[j] = ofs;
     }
-    const bool mapped = a.slot_map != nullptr;
     if (tid < 4) s_acc[tid] = 0;
     for (uint32_t j = tid; j < (uint32_t)TW; j += NT) s_gate[j] = 0;
     const LutDev lut = (XYZM != 0) ? a.luts[f % a.n_luts] : LutDev{};
@@ -569,7 +580,7 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             const uint32_t p = c / cpp, ic = c - p * cpp;
             uint32_t cofs = p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
             if (mapped) {
-                cofs = s_colofs[j];   // written before the barrier below, read behind it (the staging loop calls this)
+                cofs = hofs[k];
                 if (cofs == 0xffffffffu) continue;
             } else if (p >= count) continue;
             const uint8_t* colp = fbase + cofs;
@@ -716,14 +727,15 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
             const uint32_t j = tid + (uint32_t)k * NT, c = c0 + j;
             if (j >= (uint32_t)TW) continue;
             const uint32_t p = c / cpp;
-            const bool present = c < W && (mapped ? s_colofs[j] != 0xffffffffu : p < count);
+            const bool present = c < W && (mapped ? hofs[k] != 0xffffffffu : p < count);
             const uint32_t m_id = (uint16_t)apply_bits(window_compose(w_mid[k]), a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
             const uint32_t st = (uint32_t)apply_bits(window_compose(w_st[k]), a.g.col_status.mask, a.g.col_status.shift);
             const bool live = present && (st & 1u) && m_id < W;
-            bool stray = live && m_id != c;   // never under the general mapping: the map holds slots whose column IS c
-            const bool v = live && !stray;
-            s_valid[j] = v ? 1u : 0u;
-            n_dead += (!v && c < W) ? 1u : 0u;
+            bool stray = live && m_id != c;   // never under the general mapping: the header map holds slots whose column IS c
+            const bool v = live && !stray;    // the column's header
+            const bool vp = mapped ? (c < W && s_colofs[j] != 0xffffffffu) : v;   // its pixels (another slot's under the block path)
+            s_valid[j] = vp ? 1u : 0u;
+            n_dead += (!vp && c < W) ? 1u : 0u;
             if (rc != 0 || c >= W) continue;
             if (c == p * cpp && !mapped) {  // batch_lidar_packet, lidar_frame.cpp:1534-1539
                 const bool want_pk = a.packet_timestamp || a.alert_flags;
@@ -781,6 +793,157 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
         pt_[5] = __builtin_readcyclecounter();
     }
 #endif
+}
+
+template <class S, int TW, int XYZM, bool POSES = false>
+__global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
+    extern __shared__ __align__(16) uint32_t smem[];
+    uint32_t f, sub;
+    if (!block_to_frame(a, a.tiles_per_frame * a.row_chunks, f, sub)) return;
+    // the column tiles of one row chunk are neighbouring blocks of an XCD: together they write whole
+    // 8 KB rows at the same time (ordering the row chunks of a column tile next to each other instead
+    // shares input cache lines but measured 6 % slower)
+    wide_tile<S, TW, XYZM, POSES, false>(a, smem, f, sub % a.tiles_per_frame, sub / a.tiles_per_frame, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------
+// k_decode_wide_fixup: the fix-up pass on wide tiles (round 4; k_decode_fixup's 64-column tiles remain for formats the wide
+// tiles cannot take).  A persistent grid as before: every workgroup lists the frames flagged with this call's tag; the
+// k-th flagged frame belongs to XCD k % 8 (its tiles' partial cache lines meet in one L2), whose workgroups share the
+// frame's (column tile, row chunk) items out through a ticket counter -- an item costs anything between a look at the
+// frame's column headers and a full tile, a fixed share would leave most workgroups idle.
+// An item: resolve_frame gives the frame's real column maps; the optimistic pass has already written this tile as "slot c
+// holds column c, anything else reads as zeros", so the tile is redone only where the maps say something else -- a frame
+// with two packets swapped costs one column tile, not the frame (r03: every flagged frame was redone whole, 3.8 - 4.8 us
+// each).  Item (tile 0, row chunk 0) also writes the frame's packet-level outputs, frame-level values and valid-column count.
+// The ticket counters live in frame_state behind the sequence words, one set per tag parity: this call's start at zero
+// (zeroed by the call before), the other set is zeroed for the next call; nothing is waited for.
+// ------------------------------------------------------------------------------------
+template <class S, int TW, int XYZM, bool POSES = false>
+__global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
+    constexpr int NT = 256;
+    extern __shared__ __align__(16) uint32_t smem[];
+    __shared__ uint16_t s_list[FIXUP_CHUNK];
+    __shared__ uint32_t s_cnt[FIXUP_CHUNK / 64];
+    __shared__ uint32_t s_n, s_nvalid;
+    __shared__ unsigned long long s_ticket;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = a.g.columns_per_frame, cpp = a.g.columns_per_packet, npo = a.n_packets_out;
+    const uint32_t bpf = a.tiles_per_frame * a.row_chunks;
+    const uint64_t tag = a.frame_state[FS_TAG];
+    const bool by_xcd = gridDim.x >= 16 && (gridDim.x & 7u) == 0;
+    const uint32_t xcd = by_xcd ? (blockIdx.x & 7u) : 0u, nx = by_xcd ? 8u : 1u;
+    unsigned long long* ctr = (unsigned long long*)&a.frame_state[FS_TICKET + (tag & 1u) * 8u + xcd];
+    if (blockIdx.x < 8 && tid == 0) a.frame_state[FS_TICKET + ((tag + 1u) & 1u) * 8u + blockIdx.x] = 0;   // the next call's counters
+    auto pull = [&]() -> unsigned long long {
+        __syncthreads();
+        if (tid == 0) s_ticket = atomicAdd(ctr, 1ull);
+        __syncthreads();
+        return s_ticket;
+    };
+    unsigned long long ticket = 0, done = 0;
+    bool have = false;
+    for (uint32_t base = 0; base < a.n_frames; base += FIXUP_CHUNK) {
+        // the flagged frames of this chunk, in frame order, the same list in every workgroup (see k_decode_fixup)
+        const uint32_t nfr = min(FIXUP_CHUNK, a.n_frames - base);
+        constexpr uint32_t ROUNDS = FIXUP_CHUNK / NT;
+        uint64_t mine[ROUNDS];
+        bool flagged[ROUNDS];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < ROUNDS; ++r) {
+            const uint32_t i = r * NT + tid;
+            flagged[r] = i < nfr && a.frame_state[FS_WORDS + base + i] == tag;
+            mine[r] = __ballot(flagged[r]);
+            if ((tid & 63u) == 0) s_cnt[i >> 6] = (uint32_t)__popcll(mine[r]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < ROUNDS; ++r) {
+            const uint32_t i = r * NT + tid, grp = i >> 6;
+            uint32_t before = 0;
+            for (uint32_t k = 0; k < grp; ++k) before += s_cnt[k];
+            if (flagged[r]) s_list[before + (uint32_t)__popcll(mine[r] & ((1ull << (tid & 63u)) - 1ull))] = (uint16_t)i;
+        }
+        if (tid == 0) {
+            uint32_t n = 0;
+            for (uint32_t k = 0; k < FIXUP_CHUNK / 64; ++k) n += s_cnt[k];
+            s_n = n;
+        }
+        __syncthreads();
+        const uint32_t n_flagged = s_n;
+        const uint32_t my_frames = n_flagged > xcd ? (n_flagged - xcd + nx - 1u) / nx : 0u;   // flagged frames of my XCD
+        const unsigned long long items = (unsigned long long)my_frames * bpf;
+        if (items == 0) continue;
+        if (!have) { ticket = pull(); have = true; }
+        while (ticket < done + items) {
+            const uint32_t it = (uint32_t)(ticket - done);
+            const uint32_t f = base + s_list[(it / bpf) * nx + xcd], sub = it % bpf;
+            const uint32_t tile = sub % a.tiles_per_frame, rc = sub / a.tiles_per_frame, c0 = tile * TW;
+            const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
+            uint32_t count = a.slots_per_frame;
+            if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
+            int32_t* r_pix = (int32_t*)smem;
+            int32_t* r_hdr = r_pix + W;
+            int32_t* r_z = r_hdr + W;
+            int32_t* r_pkm = r_z + W;
+            uint32_t* r_pkt = (uint32_t*)(r_pkm + npo);
+            const bool lead = tile == 0 && rc == 0;
+            if (tid == 0) s_nvalid = 0;
+            resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, r_pix, r_hdr, r_z, lead ? r_pkm : nullptr, r_pkt);
+            if (lead) {
+                // packet_timestamp is zeroed at frame start (lidar_frame.cpp:1719), alert_flags is not
+                for (uint32_t i = tid; i < npo; i += NT) {
+                    const int32_t p = r_pkm[i];
+                    if (a.packet_timestamp && a.host_timestamps)
+                        a.packet_timestamp[(size_t)f * npo + i] = p >= 0 ? a.host_timestamps[(size_t)f * a.slots_per_frame + p] : 0ull;
+                    if (a.alert_flags && p >= 0)
+                        a.alert_flags[(size_t)f * npo + i] = (uint8_t)apply_bits(
+                            window_global(fbase + (size_t)p * a.packet_stride + a.g.alert_flags.offset), a.g.alert_flags.mask,
+                            a.g.alert_flags.shift);
+                }
+                if (a.frame_meta) {
+                    uint32_t n = 0;
+                    for (uint32_t i = tid; i < W; i += NT) n += r_hdr[i] >= 0 ? 1u : 0u;
+                    if (n) atomicAdd(&s_nvalid, n);
+                    __syncthreads();
+                    if (tid == 0) {
+                        ouster_hip_frame_meta m = frame_meta_of(a.g, fbase, count > 0);
+                        m.n_valid_columns = s_nvalid;
+                        a.frame_meta[f] = m;
+                    }
+                }
+            }
+            // what the optimistic pass wrote for my columns: slot c where it is live and at home, zeros otherwise
+            bool dirty = false;
+            for (uint32_t j = tid; j < (uint32_t)TW && c0 + j < W; j += NT) {
+                const uint32_t c = c0 + j, p = c / cpp;
+                int32_t expect = -1;
+                if (p < count) {
+                    const uint8_t* colp = fbase + (size_t)p * a.packet_stride + a.g.packet_header_size + (size_t)(c - p * cpp) * a.g.col_size;
+                    const uint32_t m_id = (uint16_t)apply_bits(window_global_masked(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask),
+                                                               a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
+                    const uint32_t st = (uint32_t)apply_bits(window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask),
+                                                             a.g.col_status.mask, a.g.col_status.shift);
+                    if ((st & 1u) && m_id == c) expect = (int32_t)c;
+                }
+                dirty |= r_pix[c] != expect || r_hdr[c] != expect;
+            }
+            if (__syncthreads_or(dirty ? 1 : 0)) wide_tile<S, TW, XYZM, POSES, true>(a, smem, f, tile, rc, r_pix, r_hdr);
+            ticket = pull();
+        }
+        done += items;
+    }
+    // valid-column counts of the clean frames (flagged ones got theirs from their lead item)
+    if (a.frame_meta) {
+        for (uint32_t f = blockIdx.x * NT + tid; f < a.n_frames; f += gridDim.x * NT) {
+            if (a.frame_state[FS_WORDS + f] == tag) continue;
+            uint32_t n = 0;
+            for (uint32_t t = 0; t < a.fast_tiles; ++t) n += a.tile_valid[(size_t)f * a.fast_tiles + t];
+            a.frame_meta[f].n_valid_columns = n;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) a.frame_state[FS_SEQ] = tag;  // the next call tags with tag + 1
 }
 
 // ------------------------------------------------------------------------------------
@@ -867,7 +1030,7 @@ hipError_t OUSTER_SPEC_FN(launch_decode)(const DecodeArgs& a_in, int tile, int x
     const uint32_t tpf = a_in.tiles_per_frame;
     if (a_in.mode == MODE_FIXUP) {
         DecodeArgs a = a_in;
-        const size_t body = decode_lds_bytes(a.g, tile, true, a.beam_lds != 0);
+        const size_t body = decode_lds_bytes(a.g, tile, true, a.beam_lds != 0, a.slots_per_frame);
         a.rows_per_tile = (uint32_t)body;  // where the frame list starts
         size_t lds = (body + FIXUP_CHUNK * 2 + 15) & ~(size_t)15;
         a.pose_lds_off = (uint32_t)lds;
@@ -885,7 +1048,7 @@ hipError_t OUSTER_SPEC_FN(launch_decode)(const DecodeArgs& a_in, int tile, int x
     DecodeArgs a = a_in;
     const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * tpf : a.n_frames * tpf;
     const dim3 grid(nblocks);
-    size_t lds = (decode_lds_bytes(a.g, tile, a.mode != MODE_FAST, a.beam_lds != 0) + 15) & ~(size_t)15;
+    size_t lds = (decode_lds_bytes(a.g, tile, a.mode != MODE_FAST, a.beam_lds != 0, a.slots_per_frame) + 15) & ~(size_t)15;
     a.pose_lds_off = (uint32_t)lds;
     lds += pose_lds_bytes(a, xyzm, tile);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -924,15 +1087,60 @@ static hipError_t launch_decode_wide_t(const DecodeArgs& a, int xyzm, dim3 grid,
     }
 }
 
-hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a_in, int tw, int xyzm, int device, hipStream_t st) {
+template <class S, int TW, int XYZM>
+static hipError_t launch_wide_fixup_x(const DecodeArgs& a, dim3 grid, size_t lds, int device, hipStream_t st) {
+    if constexpr (XYZM == 1 || XYZM == 2) {
+        if (a.xyz_poses) {
+            static LdsGrant done_p;
+            hipError_t e = allow_lds(k_decode_wide_fixup<S, TW, XYZM, true>, lds, device, done_p);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_decode_wide_fixup<S, TW, XYZM, true>), grid, dim3(256), lds, st, a);
+            return hipGetLastError();
+        }
+    }
+    static LdsGrant done;
+    hipError_t e = allow_lds(k_decode_wide_fixup<S, TW, XYZM>, lds, device, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode_wide_fixup<S, TW, XYZM>), grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <class S, int TW>
+static hipError_t launch_wide_fixup_t(const DecodeArgs& a, int xyzm, dim3 grid, size_t lds, int device, hipStream_t st) {
+    switch (xyzm) {
+        case 0: return launch_wide_fixup_x<S, TW, 0>(a, grid, lds, device, st);
+        case 1: return launch_wide_fixup_x<S, TW, 1>(a, grid, lds, device, st);
+        case 2: return launch_wide_fixup_x<S, TW, 2>(a, grid, lds, device, st);
+        default: return launch_wide_fixup_x<S, TW, 3>(a, grid, lds, device, st);
+    }
+}
+
+// a.mode == MODE_FIXUP: the persistent fix-up grid (a.row_chunks etc. describe its tiles, a.fast_tiles the optimistic pass's
+// column tiles, `resident` the workgroups the device keeps resident); otherwise one workgroup per tile
+hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a_in, int tw, int xyzm, int device, hipStream_t st, uint32_t resident) {
     DecodeArgs a = a_in;
     const uint32_t bpf = a.tiles_per_frame * a.row_chunks;
-    const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * bpf : a.n_frames * bpf;
-    const dim3 grid(nblocks);
-    size_t lds = (decode_wide_lds_bytes(tw, a.rows_per_tile, a.lds_col_slot) + 15) & ~(size_t)15;
+    const bool fix = a.mode == MODE_FIXUP;
+    a.wide_img_words = (uint32_t)tw * (a.lds_col_slot >> 2) + 4u;
+    if (fix)   // resolve_frame's scratch lies under the tile image
+        a.wide_img_words = std::max<uint32_t>(a.wide_img_words, (uint32_t)((slotmap_lds_bytes(a.g.columns_per_frame, a.n_packets_out, a.slots_per_frame) / 4 + 3) & ~(size_t)3));
+    size_t lds = (decode_wide_lds_bytes(tw, a.rows_per_tile, a.wide_img_words) + 15) & ~(size_t)15;
     a.pose_lds_off = (uint32_t)lds;
     lds += pose_lds_bytes(a, xyzm, tw);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (fix) {
+        const uint64_t items = (uint64_t)a.n_frames * bpf;
+        uint32_t g = (uint32_t)std::min<uint64_t>(items, resident ? resident : 512u);
+        if (g >= 16) g &= ~7u;   // whole XCD rounds: workgroup b runs on XCD b % 8
+        const dim3 grid(g);
+        switch (tw) {
+            case 64: return launch_wide_fixup_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
+            case 128: return launch_wide_fixup_t<SpecT, 128>(a, xyzm, grid, lds, device, st);
+            default: return launch_wide_fixup_t<SpecT, 256>(a, xyzm, grid, lds, device, st);
+        }
+    }
+    const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * bpf : a.n_frames * bpf;
+    const dim3 grid(nblocks);
     switch (tw) {
         case 64: return launch_decode_wide_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
         case 128: return launch_decode_wide_t<SpecT, 128>(a, xyzm, grid, lds, device, st);

@@ -12,6 +12,9 @@
 //   dewarp<T>                                ouster_core/include/ouster/core/pose_util.h:38-56, impl/dewarp_impl.h:23-115
 // Memory-bound byte/bit work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1330,27 +1333,28 @@ __global__ __launch_bounds__(256) void k_osf_unpack(OsfUnpackArgs a) {
 // ------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------
-size_t decode_lds_bytes(const Geometry& g, int tile, bool general, bool beam_lds) {
+size_t decode_lds_bytes(const Geometry& g, int tile, bool general, bool beam_lds, uint32_t slots_per_frame) {
     size_t tile_bytes = ((size_t)tile * g.col_size + 16 + 15) & ~(size_t)15;
     size_t h4 = (g.pixels_per_column + 3) & ~3u;
-    size_t n = tile_bytes + (size_t)tile * 4 + 32 + h4 * 4 + XYZ_SCRATCH_BYTES;
+    size_t n = tile_bytes + (size_t)tile * 8 + 32 + h4 * 4 + XYZ_SCRATCH_BYTES;
     if (beam_lds) n += ((size_t)g.pixels_per_column * 9 + (g.pixels_per_column & 1)) * 8;
-    if (general) {  // tile 0: packet map [W / cpp] + valid-column bitmap [(W + 31) / 32] + its count
-        const size_t npo = g.columns_per_frame / g.columns_per_packet;
-        n += (npo + (g.columns_per_frame + 31) / 32 + 1) * 4;
+    if (general) {  // resolve_frame's scratch lies over the tile image (it is done before the tile is staged)
+        const uint32_t npo = g.columns_per_frame / g.columns_per_packet;
+        n = std::max(n, slotmap_lds_bytes(g.columns_per_frame, npo, slots_per_frame ? slots_per_frame : npo));
         n = (n + 15) & ~(size_t)15;
     }
     return n;
 }
 
-size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_slot) {
-    return ((size_t)tw * (lds_col_slot >> 2) + 4 + 3 * (size_t)tw + 4 + ((rows_per_tile + 3) & ~3u)) * 4 +
+// img_words: the tile image [tw][column slot] + 4 slack words (the fix-up pass: at least resolve_frame's scratch)
+size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t img_words) {
+    return ((size_t)img_words + 3 * (size_t)tw + 4 + ((rows_per_tile + 3) & ~3u)) * 4 +
            ((size_t)rows_per_tile * 9 + (rows_per_tile & 1)) * 8 + XYZ_SCRATCH_BYTES;
 }
 
 #define OUSTER_DECL_SPEC(sfx)                                                                             \
     hipError_t launch_decode_##sfx(const DecodeArgs& a, int tile, int xyzm, int device, hipStream_t st); \
-    hipError_t launch_decode_wide_##sfx(const DecodeArgs& a, int tw, int xyzm, int device, hipStream_t st);
+    hipError_t launch_decode_wide_##sfx(const DecodeArgs& a, int tw, int xyzm, int device, hipStream_t st, uint32_t resident);
 OUSTER_DECL_SPEC(generic)
 OUSTER_DECL_SPEC(dual_lb)
 OUSTER_DECL_SPEC(lb)
@@ -1370,14 +1374,14 @@ hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, i
     }
 }
 
-hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, int device, hipStream_t st) {
+hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, int device, hipStream_t st, uint32_t resident) {
     switch (spec_id) {
-        case SPEC_DUAL_LB: return launch_decode_wide_dual_lb(a, tw, xyzm, device, st);
-        case SPEC_LB: return launch_decode_wide_lb(a, tw, xyzm, device, st);
-        case SPEC_SINGLE: return launch_decode_wide_single(a, tw, xyzm, device, st);
-        case SPEC_DUAL: return launch_decode_wide_dual(a, tw, xyzm, device, st);
-        case SPEC_LEGACY: return launch_decode_wide_legacy(a, tw, xyzm, device, st);
-        default: return launch_decode_wide_generic(a, tw, xyzm, device, st);
+        case SPEC_DUAL_LB: return launch_decode_wide_dual_lb(a, tw, xyzm, device, st, resident);
+        case SPEC_LB: return launch_decode_wide_lb(a, tw, xyzm, device, st, resident);
+        case SPEC_SINGLE: return launch_decode_wide_single(a, tw, xyzm, device, st, resident);
+        case SPEC_DUAL: return launch_decode_wide_dual(a, tw, xyzm, device, st, resident);
+        case SPEC_LEGACY: return launch_decode_wide_legacy(a, tw, xyzm, device, st, resident);
+        default: return launch_decode_wide_generic(a, tw, xyzm, device, st, resident);
     }
 }
 
@@ -1405,64 +1409,41 @@ hipError_t launch_decode_stream(const DecodeArgs& a, const StreamArgs& sp, int s
 // ------------------------------------------------------------------------------------
 // k_slotmap: the general column mapping of a whole frame, once (one workgroup per frame) -- for buffers that do not have
 // one slot per column of the frame (compacted after drops, any order, duplicates), where round 2 let EVERY 64-column tile
-// of k_decode scan the frame's column headers.  destination column c <- the LAST slot in buffer order whose live column
-// (status & 1, measurement_id < W) carries measurement_id c: what FrameBatcher::parse_by_col leaves behind
-// (ouster_core/src/lidar_frame.cpp:1422-1466, "the packet batched later overwrites").  Also everything the general path's
-// tile 0 used to resolve: packet-level outputs (batch_lidar_packet :1534-1539), the frame-level values (start_frame
-// :1709-1741, from the first packet of the buffer) and the valid-column count.  k_decode_wide then decodes from the map.
+// of k_decode scan the frame's column headers.  resolve_frame (kernels_common.h) restates what FrameBatcher leaves behind
+// after batching the frame's packets in buffer order, block path and column path alike
+// (ouster_core/src/lidar_frame.cpp:1422-1576): per destination column the slot that supplies its pixels (slot_map) and the
+// slot that supplies its header (hdr_map; the two differ only for an all-valid packet whose ids are not consecutive).
+// Also everything the general path's tile 0 used to resolve: packet-level outputs (batch_lidar_packet :1534-1539), the
+// frame-level values (start_frame :1709-1741, from the first packet of the buffer) and the valid-column count.
+// k_decode_wide then decodes from the maps.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_slotmap(DecodeArgs a) {
     constexpr int NT = 256;
     extern __shared__ __align__(16) uint32_t smem[];
+    __shared__ uint32_t s_n;
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
-    const uint32_t W = a.g.columns_per_frame, cpp = a.g.columns_per_packet, npo = a.n_packets_out;
-    int32_t* s_map = (int32_t*)smem;          // [W]
-    int32_t* s_pk = s_map + W;                // [npo]
-    uint32_t* s_n = (uint32_t*)(s_pk + npo);  // [1]
+    const uint32_t W = a.g.columns_per_frame, npo = a.n_packets_out;
     const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
     uint32_t count = a.slots_per_frame;
     if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
-    for (uint32_t i = tid; i < W; i += NT) s_map[i] = -1;
-    for (uint32_t i = tid; i < npo; i += NT) s_pk[i] = -1;
-    if (tid == 0) *s_n = 0;
-    __syncthreads();
-    const uint32_t nslots = count * cpp;
-    constexpr int U = 4;   // headers per thread per round, all loads in flight before the first use
-    for (uint32_t base = 0; base < nslots; base += NT * U) {
-        uint64_t w_mid[U], w_st[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t s = base + (uint32_t)u * NT + tid;
-            w_mid[u] = w_st[u] = 0;
-            if (s < nslots) {
-                const uint32_t p = s / cpp, ic = s - p * cpp;
-                const uint8_t* colp = fbase + (size_t)p * a.packet_stride + a.g.packet_header_size + (size_t)ic * a.g.col_size;
-                w_mid[u] = window_global_masked(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask);
-                w_st[u] = window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t s = base + (uint32_t)u * NT + tid;
-            if (s >= nslots) continue;
-            const uint32_t m_id = (uint16_t)apply_bits(w_mid[u], a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
-            const uint32_t stv = (uint32_t)apply_bits(w_st[u], a.g.col_status.mask, a.g.col_status.shift);
-            if ((stv & 1u) && m_id < W) atomicMax(&s_map[m_id], (int32_t)s);
-            const uint32_t p = s / cpp;
-            if (s == p * cpp && m_id / cpp < npo) atomicMax(&s_pk[m_id / cpp], (int32_t)p);
-        }
-    }
-    __syncthreads();
+    int32_t* s_pix = (int32_t*)smem;          // [W]
+    int32_t* s_hdr = s_pix + W;               // [W]
+    int32_t* s_z = s_hdr + W;                 // [W]
+    int32_t* s_pkm = s_z + W;                 // [npo]
+    uint32_t* s_pkt = (uint32_t*)(s_pkm + npo);   // [2 * slots_per_frame]
+    if (tid == 0) s_n = 0;
+    resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, s_pix, s_hdr, s_z, s_pkm, s_pkt);
     uint32_t n = 0;
     for (uint32_t i = tid; i < W; i += NT) {
-        const int32_t v = s_map[i];
-        a.slot_map[(size_t)f * W + i] = v;
-        n += v >= 0 ? 1u : 0u;
+        const int32_t h = s_hdr[i];
+        a.slot_map[(size_t)f * W + i] = s_pix[i];
+        a.hdr_map[(size_t)f * W + i] = h;
+        n += h >= 0 ? 1u : 0u;
     }
-    if (n) atomicAdd(s_n, n);
+    if (n) atomicAdd(&s_n, n);
     // packet_timestamp is zeroed at frame start (lidar_frame.cpp:1719), alert_flags is not
     for (uint32_t i = tid; i < npo; i += NT) {
-        const int32_t p = s_pk[i];
+        const int32_t p = s_pkm[i];
         if (a.packet_timestamp && a.host_timestamps)
             a.packet_timestamp[(size_t)f * npo + i] = p >= 0 ? a.host_timestamps[(size_t)f * a.slots_per_frame + p] : 0ull;
         if (a.alert_flags && p >= 0)
@@ -1472,14 +1453,24 @@ __global__ __launch_bounds__(256) void k_slotmap(DecodeArgs a) {
     __syncthreads();
     if (tid == 0 && a.frame_meta) {
         ouster_hip_frame_meta m = frame_meta_of(a.g, fbase, count > 0);
-        m.n_valid_columns = *s_n;
+        m.n_valid_columns = s_n;
         a.frame_meta[f] = m;
     }
 }
 
-hipError_t launch_slotmap(const DecodeArgs& a, hipStream_t st) {
-    const size_t lds = ((size_t)a.g.columns_per_frame + a.n_packets_out + 4) * 4;
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+size_t slotmap_lds_bytes(uint32_t W, uint32_t npo, uint32_t slots_per_frame) {
+    return ((size_t)3 * W + npo + 2 * (size_t)slots_per_frame + 4) * 4;
+}
+
+hipError_t launch_slotmap(const DecodeArgs& a, int device, hipStream_t st) {
+    const size_t lds = slotmap_lds_bytes(a.g.columns_per_frame, a.n_packets_out, a.slots_per_frame);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static std::atomic<uint32_t> granted[16];
+    if (lds > 48 * 1024 && granted[device & 15].load(std::memory_order_acquire) < lds) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_slotmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        granted[device & 15].store((uint32_t)lds, std::memory_order_release);
+    }
     hipLaunchKernelGGL(k_slotmap, dim3(a.n_frames), dim3(256), lds, st, a);
     return hipGetLastError();
 }

@@ -503,7 +503,8 @@ __device__ __forceinline__ void project_full(const LT* dir, const LT* ofs, size_
 //                   its home slot"); any other value means clean.  Flags are never cleared: the next
 //                   call uses a larger tag.  64 bits do not wrap.
 // ------------------------------------------------------------------------------------
-constexpr uint32_t FS_SEQ = 0, FS_TAG = 1, FS_WORDS = 2;
+//   [FS_TICKET ..]  2 x 8 ticket counters of k_decode_wide_fixup (tag parity x XCD), see there
+// (the indices FS_* are in ouster_hip_dev.h: the host sizes the buffer)
 
 // (measurement_id, status) of a column header staged in LDS at byte offset cb
 __device__ __forceinline__ void col_header_lds(const Geometry& g, const uint32_t* s_tile, uint32_t cb,
@@ -553,6 +554,132 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_first_present(const 
         if (any) return frame_meta_of(g, pkt, true);
     }
     return frame_meta_of(g, fbase, false);
+}
+
+// ------------------------------------------------------------------------------------
+// resolve_frame: the general column mapping of ONE frame -- what FrameBatcher leaves behind after batching the frame's
+// packets in buffer order (ouster_core/src/lidar_frame.cpp:1422-1576), restated as "last event wins" so that it can be
+// computed in parallel.  The reference walks the packets one after the other with one piece of state, next_valid_m_id:
+//   block path  (every column valid, measurement_id < W, every block of BD = block_parsable() columns ends inside the frame;
+//               batch_lidar_packet :1542-1573, parse_by_block :1492-1528): if m_id(col 0) >= next_valid, columns
+//               [next_valid, m_id(col 0)) of planes AND headers are zeroed and next_valid = m_id(col 0) + cpp; column headers
+//               go to every column's own m_id; PIXELS of block b go to m_id(first column of b) + x (block_field,
+//               parsing.cpp:628-654) -- not to the columns' own ids;
+//   column path (anything else; parse_by_col :1422-1466): every valid column with m_id < W: if m_id >= next_valid, columns
+//               [next_valid, m_id) are zeroed and next_valid = m_id + 1; header and pixels go to m_id;
+//   finalize    planes (not headers) of [next_valid, W) are zeroed (:1612-1617); headers were zeroed at frame start.
+// next_valid never decreases and every zeroed range ends where the next can begin, so the ranges are disjoint: a column is
+// zeroed at most once, by one trigger slot z.  Its final source is then the LAST slot written to it, if that slot is not
+// older than z -- max over the candidates, kept when >= z.  For packets with consecutive ids (every sensor) both maps are
+// "the last slot whose live column carries that measurement_id", what rounds 1-3 computed.
+// Output, in LDS: s_pix[c] / s_hdr[c] = buffer slot (packet * cpp + column) that supplies destination column c's pixels /
+// its header, or -1 (zeros).  s_pkm[i] (may be nullptr) = last packet whose first column's m_id / cpp == i (packet-level
+// outputs, batch_lidar_packet :1534-1539).  Returns next_valid at the end of the frame.
+// Pixel columns the reference neither writes nor zeroes (BD < cpp and a block's ids not consecutive with the block before)
+// keep the previous contents of the caller's LidarFrame there; here they read as zeros (documented).
+// LDS scratch: s_pkt[2 * count] words.  All NT threads call it; it ends with a barrier.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_parsable_dev(uint32_t H, uint32_t cpp) {   // parsing.cpp:958-966
+    for (uint32_t d : {16u, 8u, 4u})
+        if (H % d == 0 && cpp % d == 0) return d;
+    return 0u;
+}
+
+template <int NT>
+__device__ __forceinline__ uint32_t resolve_frame(const Geometry& g, const uint8_t* fbase, size_t packet_stride, uint32_t count,
+                                                  uint32_t npo, int32_t* s_pix, int32_t* s_hdr, int32_t* s_z, int32_t* s_pkm,
+                                                  uint32_t* s_pkt) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = g.columns_per_frame, cpp = g.columns_per_packet;
+    const uint32_t BD = block_parsable_dev(g.pixels_per_column, cpp);
+    for (uint32_t i = tid; i < W; i += NT) { s_pix[i] = -1; s_hdr[i] = -1; s_z[i] = 0; }
+    if (s_pkm) for (uint32_t i = tid; i < npo; i += NT) s_pkm[i] = -1;
+    // (measurement_id, valid) of column ic of packet p
+    auto header = [&](uint32_t p, uint32_t ic, uint32_t& m_id, bool& valid) {
+        const uint8_t* colp = fbase + (size_t)p * packet_stride + g.packet_header_size + (size_t)ic * g.col_size;
+        m_id = (uint16_t)apply_bits(window_global_masked(colp + g.col_measurement_id.offset, g.col_measurement_id.mask),
+                                    g.col_measurement_id.mask, g.col_measurement_id.shift);
+        valid = ((uint32_t)apply_bits(window_global_masked(colp + g.col_status.offset, g.col_status.mask), g.col_status.mask,
+                                      g.col_status.shift) & 1u) != 0u;
+    };
+    // ---- A: one thread per packet: which path does the reference take, and what does it do to next_valid?
+    //      s_pkt[2p] = F | block << 31 (F = m_id of column 0), s_pkt[2p + 1] = M = max over live columns of m_id + 1
+    for (uint32_t p = tid; p < count; p += NT) {
+        bool allv = true, fit = BD != 0;
+        uint32_t first = 0, top = 0;
+        for (uint32_t ic = 0; ic < cpp; ++ic) {
+            uint32_t m; bool v;
+            header(p, ic, m, v);
+            if (ic == 0) first = m;
+            const bool live = v && m < W;
+            allv &= live;
+            if (live) top = max(top, m + 1u);
+            if (BD && ic % BD == 0) fit &= m + BD <= W;
+        }
+        s_pkt[2 * p] = first | ((allv && fit) ? 0x80000000u : 0u);
+        s_pkt[2 * p + 1] = top;
+        if (s_pkm && first / cpp < npo) atomicMax(&s_pkm[first / cpp], (int32_t)p);
+    }
+    __syncthreads();
+    // ---- B: next_valid before every packet: a serial walk, done by wave 0 on registers (64 packets per round)
+    __shared__ uint32_t s_nv_final;
+    if (tid < 64) {
+        uint32_t nv = 0;
+        for (uint32_t base = 0; base < count; base += 64) {
+            const uint32_t p = base + tid;
+            const uint32_t a0 = p < count ? s_pkt[2 * p] : 0u, a1 = p < count ? s_pkt[2 * p + 1] : 0u;
+            uint32_t mine = 0;
+            const uint32_t n = min(64u, count - base);
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)a0, (int)k);
+                const uint32_t f1 = (uint32_t)__builtin_amdgcn_readlane((int)a1, (int)k);
+                if (tid == k) mine = nv;
+                if (f0 & 0x80000000u) {
+                    const uint32_t first = f0 & 0x7fffffffu;
+                    if (first >= nv) nv = first + cpp;
+                } else {
+                    nv = max(nv, f1);
+                }
+            }
+            if (p < count) s_pkt[2 * p + 1] = mine;   // M is not needed any more: next_valid before packet p
+        }
+        if (tid == 0) s_nv_final = nv;
+    }
+    __syncthreads();
+    // ---- C: one thread per packet again: the zeroed ranges it triggers and the columns it writes
+    for (uint32_t p = tid; p < count; p += NT) {
+        const bool block = (s_pkt[2 * p] & 0x80000000u) != 0u;
+        uint32_t nv = s_pkt[2 * p + 1];
+        uint32_t block_first = 0;
+        for (uint32_t ic = 0; ic < cpp; ++ic) {
+            uint32_t m; bool v;
+            header(p, ic, m, v);
+            const int32_t slot = (int32_t)(p * cpp + ic);
+            if (block) {
+                if (ic == 0 && m >= nv)
+                    for (uint32_t c = nv; c < m; ++c) s_z[c] = slot;
+                if (ic % BD == 0) block_first = m;
+                atomicMax(&s_hdr[m], slot);
+                atomicMax(&s_pix[block_first + ic % BD], slot);
+            } else if (v && m < W) {
+                if (m >= nv) {
+                    for (uint32_t c = nv; c < m; ++c) s_z[c] = slot;
+                    nv = m + 1u;
+                }
+                atomicMax(&s_hdr[m], slot);
+                atomicMax(&s_pix[m], slot);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nv_final = s_nv_final;
+    for (uint32_t c = tid; c < W; c += NT) {
+        const int32_t z = s_z[c];
+        if (s_hdr[c] < z) s_hdr[c] = -1;
+        if (s_pix[c] < z || c >= nv_final) s_pix[c] = -1;
+    }
+    __syncthreads();
+    return nv_final;
 }
 
 // The per-column poses of a tile, cast to the xyz element type, in LDS (12 values per column); all threads of the

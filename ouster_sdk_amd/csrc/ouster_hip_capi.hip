@@ -80,6 +80,7 @@ struct Knobs {
     int dewarp_single_pass = 0;  // OUSTER_HIP_DWF_SINGLE: 1 = k_dwf_single instead of count / scan / emit (slower)
     int beam_lds = 1;         // OUSTER_HIP_BEAM_LDS: 0 keeps k_decode's per-beam table in global memory (A/B)
     int fixup = 1;            // tests only: 0 skips the fix-up pass (flagged frames are then left undone)
+    int fixup_wide = 1;       // OUSTER_HIP_FIXUP_WIDE: 1 = the fix-up pass on wide tiles where the format allows | 0 = 64-column tiles | 64 / 128 / 256 force
     int stream = -1;          // OUSTER_HIP_STREAM: -1 auto | 0 never | 128 / 256 force k_decode_stream with that tile width when eligible
     int stream_rows = 0;      // OUSTER_HIP_STREAM_ROWS: force the rows of a streamed tile (experiments)
     int stream_wait = 1;      // OUSTER_HIP_STREAM_WAIT: 1 vmcnt(0) before a prefetched tile is used | 0 rely on the in-order counter
@@ -298,6 +299,7 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.stream_order = env_int("OUSTER_HIP_STREAM_ORDER", k.stream_order);
         k.stream_loader = env_int("OUSTER_HIP_STREAM_LOADER", k.stream_loader);
         k.slotmap = env_int("OUSTER_HIP_SLOTMAP", k.slotmap);
+        k.fixup_wide = env_int("OUSTER_HIP_FIXUP_WIDE", k.fixup_wide);
     }
     if (stream == OUSTER_HIP_STREAM_NULL) {
         c->stream = nullptr;  // the null stream
@@ -369,6 +371,7 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "xcd") k.xcd = value;
     else if (n == "fast") k.fast = value;
     else if (n == "fixup") k.fixup = value;
+    else if (n == "fixup_wide") k.fixup_wide = value;
     else if (n == "beam_lds") k.beam_lds = value;
     else if (n == "dewarp_single_pass") k.dewarp_single_pass = value;
     else if (n == "stream") k.stream = value;
@@ -702,7 +705,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // itself), destagger offsets, LUT descriptors, packet counts
     {
         const void* before = ctx->state.p;
-        if (ctx->state.ensure(((size_t)n_frames + 2) * 8)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(state) failed");
+        if (ctx->state.ensure(((size_t)n_frames + FS_WORDS) * 8)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(state) failed");
         if (ctx->state.p != before || ctx->state_dirty) HIP_TRY(hipMemsetAsync(ctx->state.p, 0, ctx->state.cap, st));
         ctx->state_dirty = fast_possible(kn, slots_per_frame, g);  // until the fix-up pass has been queued
     }
@@ -821,34 +824,38 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // tile width: widest tile that still lets two workgroups share a CU's 160 KiB LDS
     int tile = 0;
     for (int t : {64, 32, 16})
-        if (decode_lds_bytes(g, t, true, false) + 16 + t * pose_per_col <= 80 * 1024) { tile = t; break; }
+        if (decode_lds_bytes(g, t, true, false, slots_per_frame) + 16 + t * pose_per_col <= 80 * 1024) { tile = t; break; }
     if (!tile)
         for (int t : {64, 32, 16})
-            if (decode_lds_bytes(g, t, true, false) + 2048 + t * pose_per_col <= 160 * 1024) { tile = t; break; }
+            if (decode_lds_bytes(g, t, true, false, slots_per_frame) + 2048 + t * pose_per_col <= 160 * 1024) { tile = t; break; }
     if (!tile) return fail(OUSTER_HIP_ERR_UNSUPPORTED, "column of %u bytes does not fit in LDS", g.col_size);
     // small batches: prefer narrower tiles so that at least ~2 workgroups per CU exist
     // (one 128x2048 frame is only 32 tiles of 64 columns -- latency, not bandwidth, bound)
     while (tile > 16 && (size_t)n_frames * ((W + tile - 1) / tile) < 512) tile /= 2;
     if ((kn.tile == 64 || kn.tile == 32 || kn.tile == 16) &&
-        decode_lds_bytes(g, kn.tile, true, false) + 2048 + kn.tile * pose_per_col <= 160 * 1024)
+        decode_lds_bytes(g, kn.tile, true, false, slots_per_frame) + 2048 + kn.tile * pose_per_col <= 160 * 1024)
         tile = kn.tile;
     // the per-beam xyz table goes to LDS (no vector load left in the row loop: stores are never waited
     // for) whenever that does not cost k_decode a workgroup per CU
     if (xyzm == 1 || xyzm == 2) {
         const size_t extra = 2048 + tile * pose_per_col;   // fix-up frame list + pose table
-        const size_t without = decode_lds_bytes(g, tile, true, false) + extra, with = decode_lds_bytes(g, tile, true, true) + extra;
+        const size_t without = decode_lds_bytes(g, tile, true, false, slots_per_frame) + extra, with = decode_lds_bytes(g, tile, true, true, slots_per_frame) + extra;
         da.beam_lds = (kn.beam_lds && with <= 160 * 1024 && (160 * 1024) / with == (160 * 1024) / without) ? 1u : 0u;
     }
     // wide, short tiles (k_decode_wide): TW columns x TR rows with TW*TR*chan <= ~64 KB, TR chosen so that
     // the row chunks are equal.  Needs a batch large enough to fill the chip; fast mode only.
     const uint32_t narrow_tiles = (W + tile - 1) / tile;
     // General mapping on wide tiles: the column -> slot map of every frame is resolved once (k_slotmap), not by every tile
-    const bool mapped_ok = !fast && kn.slotmap && kn.tile == 0 && ((size_t)W + da.n_packets_out + 4) * 4 <= 64 * 1024;
-    auto setup_wide = [&](int want) -> bool {
+    const size_t resolver_lds = slotmap_lds_bytes(W, da.n_packets_out, slots_per_frame);
+    const bool mapped_ok = !fast && kn.slotmap && kn.tile == 0 && resolver_lds <= 160 * 1024;
+    // for_fix: the tiles of the fix-up pass (k_decode_wide_fixup): resolve_frame's scratch lies under the tile image, and the
+    // grid is persistent (no minimum number of blocks)
+    auto setup_wide = [&](int want, bool for_fix = false) -> bool {
         const uint32_t chan = g.channel_data_size;
         if (!((fast || mapped_ok) && (want == 64 || want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 &&
               W >= (uint32_t)want))
             return false;
+        if (for_fix && (want == 512 || out->gate_counts)) return false;
         if (da.xyz_poses && ((uintptr_t)da.xyz_poses & 15u)) return false;   // the wide tiles fetch the poses in 16 B pieces
         const uint32_t rpp = 1024u / (uint32_t)want;  // rows per pass of the 256-thread workgroup
         uint32_t budget = (uint32_t)(kn.wide_kb > 0 ? kn.wide_kb : 64) * 1024u;
@@ -869,12 +876,14 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         nch = (H + tr - 1) / tr;
         if (out->gate_counts && nch > OUSTER_HIP_GATE_CHUNKS) return false;  // one count slot per row chunk
         const uint32_t tiles = (W + want - 1) / want;
-        if ((size_t)n_frames * tiles * nch < (size_t)std::max(kn.wide_min_blocks, 0)) return false;
+        if (!for_fix && (size_t)n_frames * tiles * nch < (size_t)std::max(kn.wide_min_blocks, 0)) return false;
         da.rows_per_tile = tr;
         da.row_chunks = nch;
         da.lds_col_slot = (tr * chan / 4 + 1) * 4;  // +1 dword: bank spread
         da.tiles_per_frame = tiles;
-        return decode_wide_lds_bytes(want, tr, da.lds_col_slot) + 16 + (size_t)want * pose_per_col <= 160 * 1024;
+        size_t img_words = (size_t)want * (da.lds_col_slot >> 2) + 4;
+        if (for_fix) img_words = std::max(img_words, (resolver_lds / 4 + 3) & ~(size_t)3);
+        return decode_wide_lds_bytes(want, tr, (uint32_t)img_words) + 16 + (size_t)want * pose_per_col <= (for_fix ? 80u : 160u) * 1024;
     };
     // Persistent, double-buffered tiles filled by LDS-DMA (k_decode_stream): the optimistic pass of
     // the static profiles on large batches whose buffers keep every 16 B cell's phase fixed.
@@ -1080,9 +1089,10 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         HIP_TRY(hipEventRecord(tuning->ev[tune_slot][0], st));
     }
     if (wide && !fast) {
-        if (ctx->slotmap.ensure((size_t)n_frames * W * sizeof(int32_t))) return fail(OUSTER_HIP_ERR_RUNTIME, "out of device memory (slot map)");
+        if (ctx->slotmap.ensure((size_t)n_frames * W * sizeof(int32_t) * 2)) return fail(OUSTER_HIP_ERR_RUNTIME, "out of device memory (slot map)");
         da.slot_map = (int32_t*)ctx->slotmap.p;
-        HIP_TRY(launch_slotmap(da, st));
+        da.hdr_map = da.slot_map + (size_t)n_frames * W;
+        HIP_TRY(launch_slotmap(da, ctx->device, st));
     }
     if (stream) {
         HIP_TRY(launch_decode_stream(da, sa, spec, stream, xyzm, ctx->device, st));
@@ -1103,14 +1113,27 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     if (tuning) HIP_TRY(hipEventRecord(tuning->ev[tune_slot][1], st));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
     if (fast && kn.fixup) {
-        // fix-up pass: frames the optimistic pass flagged are redone with the general mapping; the
-        // workgroups of clean frames leave after one atomic.  Always k_decode.
+        // fix-up pass: the tiles of the frames the optimistic pass flagged are looked at again with the frame's real column
+        // maps and redone where those differ from "slot c holds column c"; the workgroups of a clean batch leave after one
+        // read of the flags.  Wide tiles (k_decode_wide_fixup) where the format allows them, 64-column tiles otherwise.
         da.mode = MODE_FIXUP;
-        da.rows_per_tile = 0;
-        da.lds_col_slot = da.tiles_per_frame;  // column tiles of the pass above (slots of tile_valid)
-        da.row_chunks = ctx->resident_wgs;     // persistent grid: what the device keeps resident
-        da.tiles_per_frame = narrow_tiles;
-        HIP_TRY(launch_decode(da, spec, tile, xyzm, ctx->device, st));
+        da.fast_tiles = da.tiles_per_frame;    // column tiles of the pass above (slots of tile_valid)
+        int fix_wide = 0;
+        if (kn.fixup_wide && kn.tile == 0) {
+            if (kn.fixup_wide > 1) { if (setup_wide(kn.fixup_wide, true)) fix_wide = kn.fixup_wide; }
+            else if (setup_wide(256, true) && da.rows_per_tile * g.channel_data_size >= 256) fix_wide = 256;
+            else if (setup_wide(128, true)) fix_wide = 128;
+            else if (setup_wide(256, true)) fix_wide = 256;
+        }
+        if (fix_wide) {
+            HIP_TRY(launch_decode_wide(da, spec, fix_wide, xyzm, ctx->device, st, ctx->resident_wgs));
+        } else {
+            da.rows_per_tile = 0;
+            da.lds_col_slot = 0;
+            da.row_chunks = ctx->resident_wgs;     // persistent grid: what the device keeps resident
+            da.tiles_per_frame = narrow_tiles;
+            HIP_TRY(launch_decode(da, spec, tile, xyzm, ctx->device, st));
+        }
         ctx->state_dirty = false;
     }
     return OUSTER_HIP_OK;

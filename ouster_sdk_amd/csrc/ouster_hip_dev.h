@@ -40,6 +40,9 @@ enum DecodeMode : uint32_t {
     MODE_GENERAL = 2,  // every frame through the scan-the-frame path (slots_per_frame*cpp != W)
 };
 
+// frame_state words (kernels_common.h): sequence, tag, 2 x 8 ticket counters, then one word per frame
+constexpr uint32_t FS_SEQ = 0, FS_TAG = 1, FS_TICKET = 2, FS_WORDS = 18;
+
 struct DecodeArgs {
     Geometry g;
     const uint8_t* packets;
@@ -85,6 +88,10 @@ struct DecodeArgs {
     int32_t* slot_map;        // device [n_frames][W] or nullptr.  General mapping on wide tiles: k_slotmap writes, per
                               //   destination column, the LAST buffer slot whose live column carries that measurement_id
                               //   (-1: none), k_decode_wide takes its source columns from it instead of "slot c holds column c"
+    int32_t* hdr_map;         // device [n_frames][W], with slot_map: the slot whose HEADER lands in destination column c (differs from
+                              //   slot_map only for all-valid packets with non-consecutive ids: the reference's block path)
+    uint32_t wide_img_words;  // k_decode_wide: LDS words of the tile image (set by the launcher; the fix-up pass keeps resolve_frame's scratch there)
+    uint32_t fast_tiles;      // fix-up pass: column tiles of the optimistic pass before it (slots of tile_valid per frame)
     const double* xyz_poses;  // device [n_frames][W][16] or nullptr: per-column pose applied to the xyz outputs
     uint32_t pose_lds_off;    // byte offset of the tile's pose table in dynamic LDS (set by the launchers)
 #ifdef OUSTER_PHASE_TIMING
@@ -183,13 +190,14 @@ struct FieldC {
 const FieldC* spec_fields(int spec_id, int* nf, uint32_t* chan, int* r1, int* r2);
 
 // LDS of one k_decode workgroup (the general modes add the per-frame packet map and valid bitmap)
-size_t decode_lds_bytes(const Geometry& g, int tile, bool general, bool beam_lds);
-size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t lds_col_slot);
+size_t decode_lds_bytes(const Geometry& g, int tile, bool general, bool beam_lds, uint32_t slots_per_frame = 0);
+size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t img_words);
 // device: HIP device ordinal of the stream (per-device cache of the one-off kernel attributes)
 hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, int device, hipStream_t st);
-hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, int device, hipStream_t st);
+hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, int device, hipStream_t st, uint32_t resident = 0);
 hipError_t launch_decode_stream(const DecodeArgs& a, const StreamArgs& sp, int spec_id, int tw, int xyzm, int device, hipStream_t st);
-hipError_t launch_slotmap(const DecodeArgs& a, hipStream_t st);
+size_t slotmap_lds_bytes(uint32_t W, uint32_t npo, uint32_t slots_per_frame);
+hipError_t launch_slotmap(const DecodeArgs& a, int device, hipStream_t st);
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st);
 hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
 hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);
