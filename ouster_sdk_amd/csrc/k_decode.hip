@@ -146,14 +146,11 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
     } else {
         // general mapping: what FrameBatcher leaves behind after batching the frame's packets in buffer order
         // (resolve_frame, kernels_common.h); my tile keeps its columns, tile 0 also writes the packet-level outputs and counts
-        int32_t* r_pix = (int32_t*)smem;
-        int32_t* r_hdr = r_pix + W;
-        int32_t* r_z = r_hdr + W;
-        int32_t* r_pkm = r_z + W;
-        uint32_t* r_pkt = (uint32_t*)(r_pkm + npo);
+        const ResolveLds L(smem, W, npo, a.slots_per_frame);
+        int32_t *r_pix = L.pix, *r_hdr = L.hdr, *r_pkm = L.pkm;
         __shared__ uint32_t s_nvalid;
         if (tid == 0) s_nvalid = 0;
-        resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, r_pix, r_hdr, r_z, tile == 0 ? r_pkm : nullptr, r_pkt);
+        resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, tile == 0);
         int32_t my_pix = -1, my_hdr = -1;
         if (tid < TILE && c0 + tid < W) { my_pix = r_pix[c0 + tid]; my_hdr = r_hdr[c0 + tid]; }
         if (tile == 0) {
@@ -187,14 +184,7 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
             if (tid < TILE && c0 + tid < W) {
                 const uint32_t c = c0 + tid, p = c / cpp;
                 int32_t expect = -1;
-                if (p < count && (uint64_t)a.slots_per_frame * cpp == W) {
-                    const uint8_t* colp = fbase + (size_t)p * a.packet_stride + a.g.packet_header_size + (size_t)(c - p * cpp) * col_size;
-                    const uint32_t m_id = (uint16_t)apply_bits(window_global_masked(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask),
-                                                               a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
-                    const uint32_t st = (uint32_t)apply_bits(window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask),
-                                                             a.g.col_status.mask, a.g.col_status.shift);
-                    if ((st & 1u) && m_id == c) expect = (int32_t)c;
-                }
+                if (p < count && L.hd[c] == (c | 0x10000u)) expect = (int32_t)c;   // slot c is live and at home
                 dirty = my_pix != expect || my_hdr != expect;
             }
             if (!__syncthreads_or(dirty ? 1 : 0)) return;
@@ -883,14 +873,11 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
             const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
             uint32_t count = a.slots_per_frame;
             if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
-            int32_t* r_pix = (int32_t*)smem;
-            int32_t* r_hdr = r_pix + W;
-            int32_t* r_z = r_hdr + W;
-            int32_t* r_pkm = r_z + W;
-            uint32_t* r_pkt = (uint32_t*)(r_pkm + npo);
+            const ResolveLds L(smem, W, npo, a.slots_per_frame);
+            int32_t *r_pix = L.pix, *r_hdr = L.hdr, *r_pkm = L.pkm;
             const bool lead = tile == 0 && rc == 0;
             if (tid == 0) s_nvalid = 0;
-            resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, r_pix, r_hdr, r_z, lead ? r_pkm : nullptr, r_pkt);
+            resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, lead);
             if (lead) {
                 // packet_timestamp is zeroed at frame start (lidar_frame.cpp:1719), alert_flags is not
                 for (uint32_t i = tid; i < npo; i += NT) {
@@ -919,14 +906,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
             for (uint32_t j = tid; j < (uint32_t)TW && c0 + j < W; j += NT) {
                 const uint32_t c = c0 + j, p = c / cpp;
                 int32_t expect = -1;
-                if (p < count) {
-                    const uint8_t* colp = fbase + (size_t)p * a.packet_stride + a.g.packet_header_size + (size_t)(c - p * cpp) * a.g.col_size;
-                    const uint32_t m_id = (uint16_t)apply_bits(window_global_masked(colp + a.g.col_measurement_id.offset, a.g.col_measurement_id.mask),
-                                                               a.g.col_measurement_id.mask, a.g.col_measurement_id.shift);
-                    const uint32_t st = (uint32_t)apply_bits(window_global_masked(colp + a.g.col_status.offset, a.g.col_status.mask),
-                                                             a.g.col_status.mask, a.g.col_status.shift);
-                    if ((st & 1u) && m_id == c) expect = (int32_t)c;
-                }
+                if (p < count && L.hd[c] == (c | 0x10000u)) expect = (int32_t)c;   // slot c is live and at home
                 dirty |= r_pix[c] != expect || r_hdr[c] != expect;
             }
             if (__syncthreads_or(dirty ? 1 : 0)) wide_tile<S, TW, XYZM, POSES, true>(a, smem, f, tile, rc, r_pix, r_hdr);
@@ -1087,6 +1067,83 @@ static hipError_t launch_decode_wide_t(const DecodeArgs& a, int xyzm, dim3 grid,
     }
 }
 
+// ------------------------------------------------------------------------------------
+// k_decode_wide_resolved: ONE launch for small batches (a tick of a few sensors, a single frame): every workgroup resolves
+// its frame's column maps itself (resolve_frame: one round of header reads that hit L2 after the first tile, then LDS work)
+// and decodes its tile from them.  No optimistic pass, no flags, no second launch: a second launch costs such a batch more
+// than its own decode (5 - 7 us on the stream against 6 - 10), while the redundant resolution of a few hundred tiles costs
+// a few microseconds of latency and no bandwidth worth counting.  Any buffer shape (it is the general mapping).
+// ------------------------------------------------------------------------------------
+template <class S, int TW, int XYZM, bool POSES = false>
+__global__ __launch_bounds__(256) void k_decode_wide_resolved(DecodeArgs a) {
+    constexpr int NT = 256;
+    extern __shared__ __align__(16) uint32_t smem[];
+    __shared__ uint32_t s_nvalid;
+    const uint32_t tid = threadIdx.x;
+    uint32_t f, sub;
+    if (!block_to_frame(a, a.tiles_per_frame * a.row_chunks, f, sub)) return;
+    const uint32_t tile = sub % a.tiles_per_frame, rc = sub / a.tiles_per_frame;
+    const uint32_t W = a.g.columns_per_frame, npo = a.n_packets_out;
+    const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
+    uint32_t count = a.slots_per_frame;
+    if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
+    const ResolveLds L(smem, W, npo, a.slots_per_frame);
+    const bool lead = tile == 0 && rc == 0;
+    if (tid == 0) s_nvalid = 0;
+    resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, lead);
+    if (lead) {
+        // packet_timestamp is zeroed at frame start (lidar_frame.cpp:1719), alert_flags is not
+        for (uint32_t i = tid; i < npo; i += NT) {
+            const int32_t p = L.pkm[i];
+            if (a.packet_timestamp && a.host_timestamps)
+                a.packet_timestamp[(size_t)f * npo + i] = p >= 0 ? a.host_timestamps[(size_t)f * a.slots_per_frame + p] : 0ull;
+            if (a.alert_flags && p >= 0)
+                a.alert_flags[(size_t)f * npo + i] = (uint8_t)apply_bits(
+                    window_global(fbase + (size_t)p * a.packet_stride + a.g.alert_flags.offset), a.g.alert_flags.mask, a.g.alert_flags.shift);
+        }
+        if (a.frame_meta) {
+            uint32_t n = 0;
+            for (uint32_t i = tid; i < W; i += NT) n += L.hdr[i] >= 0 ? 1u : 0u;
+            if (n) atomicAdd(&s_nvalid, n);
+            __syncthreads();
+            if (tid == 0) {
+                ouster_hip_frame_meta m = frame_meta_of(a.g, fbase, count > 0);
+                m.n_valid_columns = s_nvalid;
+                a.frame_meta[f] = m;
+            }
+        }
+    }
+    wide_tile<S, TW, XYZM, POSES, true>(a, smem, f, tile, rc, L.pix, L.hdr);
+}
+
+template <class S, int TW, int XYZM>
+static hipError_t launch_wide_resolved_x(const DecodeArgs& a, dim3 grid, size_t lds, int device, hipStream_t st) {
+    if constexpr (XYZM == 1 || XYZM == 2) {
+        if (a.xyz_poses) {
+            static LdsGrant done_p;
+            hipError_t e = allow_lds(k_decode_wide_resolved<S, TW, XYZM, true>, lds, device, done_p);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_decode_wide_resolved<S, TW, XYZM, true>), grid, dim3(256), lds, st, a);
+            return hipGetLastError();
+        }
+    }
+    static LdsGrant done;
+    hipError_t e = allow_lds(k_decode_wide_resolved<S, TW, XYZM>, lds, device, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_decode_wide_resolved<S, TW, XYZM>), grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <class S, int TW>
+static hipError_t launch_wide_resolved_t(const DecodeArgs& a, int xyzm, dim3 grid, size_t lds, int device, hipStream_t st) {
+    switch (xyzm) {
+        case 0: return launch_wide_resolved_x<S, TW, 0>(a, grid, lds, device, st);
+        case 1: return launch_wide_resolved_x<S, TW, 1>(a, grid, lds, device, st);
+        case 2: return launch_wide_resolved_x<S, TW, 2>(a, grid, lds, device, st);
+        default: return launch_wide_resolved_x<S, TW, 3>(a, grid, lds, device, st);
+    }
+}
+
 template <class S, int TW, int XYZM>
 static hipError_t launch_wide_fixup_x(const DecodeArgs& a, dim3 grid, size_t lds, int device, hipStream_t st) {
     if constexpr (XYZM == 1 || XYZM == 2) {
@@ -1120,10 +1177,10 @@ static hipError_t launch_wide_fixup_t(const DecodeArgs& a, int xyzm, dim3 grid, 
 hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a_in, int tw, int xyzm, int device, hipStream_t st, uint32_t resident) {
     DecodeArgs a = a_in;
     const uint32_t bpf = a.tiles_per_frame * a.row_chunks;
-    const bool fix = a.mode == MODE_FIXUP;
+    const bool fix = a.mode == MODE_FIXUP, resolved = a.mode == MODE_RESOLVED;
     a.wide_img_words = (uint32_t)tw * (a.lds_col_slot >> 2) + 4u;
-    if (fix)   // resolve_frame's scratch lies under the tile image
-        a.wide_img_words = std::max<uint32_t>(a.wide_img_words, (uint32_t)((slotmap_lds_bytes(a.g.columns_per_frame, a.n_packets_out, a.slots_per_frame) / 4 + 3) & ~(size_t)3));
+    if (fix || resolved)   // resolve_frame's scratch lies under the tile image
+        a.wide_img_words = std::max<uint32_t>(a.wide_img_words, (uint32_t)((slotmap_lds_bytes(a.g.columns_per_frame, a.g.columns_per_packet, a.slots_per_frame) / 4 + 3) & ~(size_t)3));
     size_t lds = (decode_wide_lds_bytes(tw, a.rows_per_tile, a.wide_img_words) + 15) & ~(size_t)15;
     a.pose_lds_off = (uint32_t)lds;
     lds += pose_lds_bytes(a, xyzm, tw);
@@ -1141,6 +1198,13 @@ hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a_in, int tw, in
     }
     const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * bpf : a.n_frames * bpf;
     const dim3 grid(nblocks);
+    if (resolved) {
+        switch (tw) {
+            case 64: return launch_wide_resolved_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
+            case 128: return launch_wide_resolved_t<SpecT, 128>(a, xyzm, grid, lds, device, st);
+            default: return launch_wide_resolved_t<SpecT, 256>(a, xyzm, grid, lds, device, st);
+        }
+    }
     switch (tw) {
         case 64: return launch_decode_wide_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
         case 128: return launch_decode_wide_t<SpecT, 128>(a, xyzm, grid, lds, device, st);

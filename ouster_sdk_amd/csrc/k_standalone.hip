@@ -1340,7 +1340,7 @@ size_t decode_lds_bytes(const Geometry& g, int tile, bool general, bool beam_lds
     if (beam_lds) n += ((size_t)g.pixels_per_column * 9 + (g.pixels_per_column & 1)) * 8;
     if (general) {  // resolve_frame's scratch lies over the tile image (it is done before the tile is staged)
         const uint32_t npo = g.columns_per_frame / g.columns_per_packet;
-        n = std::max(n, slotmap_lds_bytes(g.columns_per_frame, npo, slots_per_frame ? slots_per_frame : npo));
+        n = std::max(n, slotmap_lds_bytes(g.columns_per_frame, g.columns_per_packet, slots_per_frame ? slots_per_frame : npo));
         n = (n + 15) & ~(size_t)15;
     }
     return n;
@@ -1426,13 +1426,10 @@ __global__ __launch_bounds__(256) void k_slotmap(DecodeArgs a) {
     const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
     uint32_t count = a.slots_per_frame;
     if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
-    int32_t* s_pix = (int32_t*)smem;          // [W]
-    int32_t* s_hdr = s_pix + W;               // [W]
-    int32_t* s_z = s_hdr + W;                 // [W]
-    int32_t* s_pkm = s_z + W;                 // [npo]
-    uint32_t* s_pkt = (uint32_t*)(s_pkm + npo);   // [2 * slots_per_frame]
+    const ResolveLds L(smem, W, npo, a.slots_per_frame);
+    int32_t *s_pix = L.pix, *s_hdr = L.hdr, *s_pkm = L.pkm;
     if (tid == 0) s_n = 0;
-    resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, s_pix, s_hdr, s_z, s_pkm, s_pkt);
+    resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, true);
     uint32_t n = 0;
     for (uint32_t i = tid; i < W; i += NT) {
         const int32_t h = s_hdr[i];
@@ -1458,12 +1455,12 @@ __global__ __launch_bounds__(256) void k_slotmap(DecodeArgs a) {
     }
 }
 
-size_t slotmap_lds_bytes(uint32_t W, uint32_t npo, uint32_t slots_per_frame) {
-    return ((size_t)3 * W + npo + 2 * (size_t)slots_per_frame + 4) * 4;
+size_t slotmap_lds_bytes(uint32_t W, uint32_t cpp, uint32_t slots_per_frame) {
+    return resolve_lds_words(W, W / cpp, slots_per_frame, cpp) * 4;
 }
 
 hipError_t launch_slotmap(const DecodeArgs& a, int device, hipStream_t st) {
-    const size_t lds = slotmap_lds_bytes(a.g.columns_per_frame, a.n_packets_out, a.slots_per_frame);
+    const size_t lds = slotmap_lds_bytes(a.g.columns_per_frame, a.g.columns_per_packet, a.slots_per_frame);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static std::atomic<uint32_t> granted[16];
     if (lds > 48 * 1024 && granted[device & 15].load(std::memory_order_acquire) < lds) {

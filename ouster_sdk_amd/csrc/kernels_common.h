@@ -577,7 +577,7 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_first_present(const 
 // outputs, batch_lidar_packet :1534-1539).  Returns next_valid at the end of the frame.
 // Pixel columns the reference neither writes nor zeroes (BD < cpp and a block's ids not consecutive with the block before)
 // keep the previous contents of the caller's LidarFrame there; here they read as zeros (documented).
-// LDS scratch: s_pkt[2 * count] words.  All NT threads call it; it ends with a barrier.
+// All NT threads call it; it ends with a barrier.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t block_parsable_dev(uint32_t H, uint32_t cpp) {   // parsing.cpp:958-966
     for (uint32_t d : {16u, 8u, 4u})
@@ -585,33 +585,65 @@ __device__ __forceinline__ uint32_t block_parsable_dev(uint32_t H, uint32_t cpp)
     return 0u;
 }
 
+// s_hd[count * cpp]: (measurement_id | valid << 16) of every buffer slot, left behind for the caller (the fix-up pass looks
+// up "is slot c live and at home" there).  LDS words needed: resolve_lds_words().
+__host__ __device__ inline size_t resolve_lds_words(uint32_t W, uint32_t npo, uint32_t slots_per_frame, uint32_t cpp) {
+    return (size_t)3 * W + npo + 2 * (size_t)slots_per_frame + (size_t)slots_per_frame * cpp + 4;
+}
+struct ResolveLds {
+    int32_t *pix, *hdr, *z, *pkm;
+    uint32_t *pkt, *hd;
+    __device__ __forceinline__ ResolveLds(uint32_t* base, uint32_t W, uint32_t npo, uint32_t slots_per_frame) {
+        pix = (int32_t*)base; hdr = pix + W; z = hdr + W; pkm = z + W;
+        pkt = (uint32_t*)(pkm + npo); hd = pkt + 2 * (size_t)slots_per_frame;
+    }
+};
+
 template <int NT>
 __device__ __forceinline__ uint32_t resolve_frame(const Geometry& g, const uint8_t* fbase, size_t packet_stride, uint32_t count,
-                                                  uint32_t npo, int32_t* s_pix, int32_t* s_hdr, int32_t* s_z, int32_t* s_pkm,
-                                                  uint32_t* s_pkt) {
+                                                  uint32_t npo, const ResolveLds& L, bool want_pkm) {
     const uint32_t tid = threadIdx.x;
     const uint32_t W = g.columns_per_frame, cpp = g.columns_per_packet;
     const uint32_t BD = block_parsable_dev(g.pixels_per_column, cpp);
+    int32_t *s_pix = L.pix, *s_hdr = L.hdr, *s_z = L.z, *s_pkm = want_pkm ? L.pkm : nullptr;
+    uint32_t *s_pkt = L.pkt, *s_hd = L.hd;
+    // ---- 0: every slot's (measurement_id, valid), all threads, eight slots each in flight (the only global reads)
+    const uint32_t nslots = count * cpp;
+    constexpr int U = 8;
+    for (uint32_t base = 0; base < nslots; base += NT * U) {
+        uint64_t w_mid[U], w_st[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t s = base + (uint32_t)u * NT + tid;
+            w_mid[u] = w_st[u] = 0;
+            if (s < nslots) {
+                const uint32_t p = s / cpp, ic = s - p * cpp;
+                const uint8_t* colp = fbase + (size_t)p * packet_stride + g.packet_header_size + (size_t)ic * g.col_size;
+                w_mid[u] = window_global_masked(colp + g.col_measurement_id.offset, g.col_measurement_id.mask);
+                w_st[u] = window_global_masked(colp + g.col_status.offset, g.col_status.mask);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t s = base + (uint32_t)u * NT + tid;
+            if (s >= nslots) continue;
+            const uint32_t m_id = (uint16_t)apply_bits(w_mid[u], g.col_measurement_id.mask, g.col_measurement_id.shift);
+            const uint32_t st = (uint32_t)apply_bits(w_st[u], g.col_status.mask, g.col_status.shift);
+            s_hd[s] = m_id | ((st & 1u) << 16);
+        }
+    }
     for (uint32_t i = tid; i < W; i += NT) { s_pix[i] = -1; s_hdr[i] = -1; s_z[i] = 0; }
     if (s_pkm) for (uint32_t i = tid; i < npo; i += NT) s_pkm[i] = -1;
-    // (measurement_id, valid) of column ic of packet p
-    auto header = [&](uint32_t p, uint32_t ic, uint32_t& m_id, bool& valid) {
-        const uint8_t* colp = fbase + (size_t)p * packet_stride + g.packet_header_size + (size_t)ic * g.col_size;
-        m_id = (uint16_t)apply_bits(window_global_masked(colp + g.col_measurement_id.offset, g.col_measurement_id.mask),
-                                    g.col_measurement_id.mask, g.col_measurement_id.shift);
-        valid = ((uint32_t)apply_bits(window_global_masked(colp + g.col_status.offset, g.col_status.mask), g.col_status.mask,
-                                      g.col_status.shift) & 1u) != 0u;
-    };
+    __syncthreads();
     // ---- A: one thread per packet: which path does the reference take, and what does it do to next_valid?
     //      s_pkt[2p] = F | block << 31 (F = m_id of column 0), s_pkt[2p + 1] = M = max over live columns of m_id + 1
     for (uint32_t p = tid; p < count; p += NT) {
         bool allv = true, fit = BD != 0;
         uint32_t first = 0, top = 0;
         for (uint32_t ic = 0; ic < cpp; ++ic) {
-            uint32_t m; bool v;
-            header(p, ic, m, v);
+            const uint32_t h = s_hd[p * cpp + ic], m = h & 0xffffu;
             if (ic == 0) first = m;
-            const bool live = v && m < W;
+            const bool live = (h >> 16) && m < W;
             allv &= live;
             if (live) top = max(top, m + 1u);
             if (BD && ic % BD == 0) fit &= m + BD <= W;
@@ -652,8 +684,8 @@ __device__ __forceinline__ uint32_t resolve_frame(const Geometry& g, const uint8
         uint32_t nv = s_pkt[2 * p + 1];
         uint32_t block_first = 0;
         for (uint32_t ic = 0; ic < cpp; ++ic) {
-            uint32_t m; bool v;
-            header(p, ic, m, v);
+            const uint32_t h = s_hd[p * cpp + ic], m = h & 0xffffu;
+            const bool v = (h >> 16) != 0u;
             const int32_t slot = (int32_t)(p * cpp + ic);
             if (block) {
                 if (ic == 0 && m >= nv)

@@ -80,6 +80,7 @@ struct Knobs {
     int dewarp_single_pass = 0;  // OUSTER_HIP_DWF_SINGLE: 1 = k_dwf_single instead of count / scan / emit (slower)
     int beam_lds = 1;         // OUSTER_HIP_BEAM_LDS: 0 keeps k_decode's per-beam table in global memory (A/B)
     int fixup = 1;            // tests only: 0 skips the fix-up pass (flagged frames are then left undone)
+    int small = 1;            // OUSTER_HIP_SMALL: 0 = small batches stay on the optimistic pass + fix-up pass (k_decode's narrow tiles)
     int fixup_wide = 1;       // OUSTER_HIP_FIXUP_WIDE: 1 = the fix-up pass on wide tiles where the format allows | 0 = 64-column tiles | 64 / 128 / 256 force
     int stream = -1;          // OUSTER_HIP_STREAM: -1 auto | 0 never | 128 / 256 force k_decode_stream with that tile width when eligible
     int stream_rows = 0;      // OUSTER_HIP_STREAM_ROWS: force the rows of a streamed tile (experiments)
@@ -300,6 +301,7 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.stream_loader = env_int("OUSTER_HIP_STREAM_LOADER", k.stream_loader);
         k.slotmap = env_int("OUSTER_HIP_SLOTMAP", k.slotmap);
         k.fixup_wide = env_int("OUSTER_HIP_FIXUP_WIDE", k.fixup_wide);
+        k.small = env_int("OUSTER_HIP_SMALL", k.small);
     }
     if (stream == OUSTER_HIP_STREAM_NULL) {
         c->stream = nullptr;  // the null stream
@@ -372,6 +374,7 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "fast") k.fast = value;
     else if (n == "fixup") k.fixup = value;
     else if (n == "fixup_wide") k.fixup_wide = value;
+    else if (n == "small") k.small = value;
     else if (n == "beam_lds") k.beam_lds = value;
     else if (n == "dewarp_single_pass") k.dewarp_single_pass = value;
     else if (n == "stream") k.stream = value;
@@ -846,16 +849,18 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // the row chunks are equal.  Needs a batch large enough to fill the chip; fast mode only.
     const uint32_t narrow_tiles = (W + tile - 1) / tile;
     // General mapping on wide tiles: the column -> slot map of every frame is resolved once (k_slotmap), not by every tile
-    const size_t resolver_lds = slotmap_lds_bytes(W, da.n_packets_out, slots_per_frame);
+    const size_t resolver_lds = slotmap_lds_bytes(W, g.columns_per_packet, slots_per_frame);
     const bool mapped_ok = !fast && kn.slotmap && kn.tile == 0 && resolver_lds <= 160 * 1024;
     // for_fix: the tiles of the fix-up pass (k_decode_wide_fixup): resolve_frame's scratch lies under the tile image, and the
     // grid is persistent (no minimum number of blocks)
-    auto setup_wide = [&](int want, bool for_fix = false) -> bool {
+    // small: the tiles of the one-launch form for small batches (k_decode_wide_resolved): the scratch again, and the rows of a
+    // tile chosen so that the few frames still make about two workgroups per CU
+    auto setup_wide = [&](int want, bool for_fix = false, bool small = false) -> bool {
         const uint32_t chan = g.channel_data_size;
-        if (!((fast || mapped_ok) && (want == 64 || want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 &&
+        if (!((fast || mapped_ok || small) && (want == 64 || want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 &&
               W >= (uint32_t)want))
             return false;
-        if (for_fix && (want == 512 || out->gate_counts)) return false;
+        if ((for_fix || small) && (want == 512 || out->gate_counts || resolver_lds > 64 * 1024)) return false;
         if (da.xyz_poses && ((uintptr_t)da.xyz_poses & 15u)) return false;   // the wide tiles fetch the poses in 16 B pieces
         const uint32_t rpp = 1024u / (uint32_t)want;  // rows per pass of the 256-thread workgroup
         uint32_t budget = (uint32_t)(kn.wide_kb > 0 ? kn.wide_kb : 64) * 1024u;
@@ -871,19 +876,25 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             const uint32_t t2 = up((H + n2 - 1) / n2);
             if (t2 <= tr_max && t2 * n2 == H && t2 * 4 >= tr * 3) { nch = n2; tr = t2; break; }   // not at the price of much smaller tiles
         }
+        const uint32_t tiles = (W + want - 1) / want;
+        if (small) {
+            if ((size_t)n_frames * tiles * nch >= (size_t)std::max(kn.wide_min_blocks, 0)) return false;   // not a small batch
+            const uint32_t want_blocks = 2u * ctx->cus;
+            const uint32_t need = (want_blocks + n_frames * tiles - 1) / (n_frames * tiles);   // row chunks for that many workgroups
+            tr = std::max(rpp, std::min(tr, H / std::max(need, 1u) / rpp * rpp));
+        }
         if (kn.wide_rows > 0) tr = std::min((uint32_t)kn.wide_rows, H);
         if (tr > 84) return false;   // k_decode_wide keeps a row chunk's table rows in registers (3 doubles per thread) while its tile loads
         nch = (H + tr - 1) / tr;
         if (out->gate_counts && nch > OUSTER_HIP_GATE_CHUNKS) return false;  // one count slot per row chunk
-        const uint32_t tiles = (W + want - 1) / want;
-        if (!for_fix && (size_t)n_frames * tiles * nch < (size_t)std::max(kn.wide_min_blocks, 0)) return false;
+        if (!for_fix && !small && (size_t)n_frames * tiles * nch < (size_t)std::max(kn.wide_min_blocks, 0)) return false;
         da.rows_per_tile = tr;
         da.row_chunks = nch;
         da.lds_col_slot = (tr * chan / 4 + 1) * 4;  // +1 dword: bank spread
         da.tiles_per_frame = tiles;
         size_t img_words = (size_t)want * (da.lds_col_slot >> 2) + 4;
-        if (for_fix) img_words = std::max(img_words, (resolver_lds / 4 + 3) & ~(size_t)3);
-        return decode_wide_lds_bytes(want, tr, (uint32_t)img_words) + 16 + (size_t)want * pose_per_col <= (for_fix ? 80u : 160u) * 1024;
+        if (for_fix || small) img_words = std::max(img_words, (resolver_lds / 4 + 3) & ~(size_t)3);
+        return decode_wide_lds_bytes(want, tr, (uint32_t)img_words) + 16 + (size_t)want * pose_per_col <= ((for_fix || small) ? 80u : 160u) * 1024;
     };
     // Persistent, double-buffered tiles filled by LDS-DMA (k_decode_stream): the optimistic pass of
     // the static profiles on large batches whose buffers keep every 16 B cell's phase fixed.
@@ -974,7 +985,20 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // 1.5 - 3 % ahead where the memory system is fastest and up to 10 % behind where it is slowest.
     int stream = 0, wide = 0;
     int stream_auto = 0;   // tile width of the persistent candidate (0: not eligible)
-    if (kn.stream > 0) {
+    // Small batches (one tick of a few sensors, a single frame): one launch, every wide tile resolves its frame's column maps
+    // itself -- neither an optimistic pass nor a second launch, whatever the buffer looks like.
+    bool resolved = false;
+    if (kn.small && kn.stream <= 0 && kn.wide < 0 && kn.tile == 0 && kn.fast) {
+        for (int tw : {256, 128, 64})
+            if (W >= (uint32_t)tw || tw == 64) {
+                resolved = setup_wide(tw, false, true);
+                if (resolved) wide = tw;
+                break;
+            }
+    }
+    if (resolved) {
+        // nothing else to choose
+    } else if (kn.stream > 0) {
         if (setup_stream(kn.stream)) stream = kn.stream;
     } else if (kn.stream < 0 && kn.wide < 0 && kn.tile == 0) {
         // column pieces of at least 256 B per tile row chunk: 256 columns for the 8 / 16 / 4 B/px profiles, 128 for 12 B/px
@@ -984,8 +1008,8 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     }
     ouster_hip_ctx::Tune* tuning = nullptr;
     int tune_slot = -1;
-    if (stream) {
-        // forced
+    if (stream || resolved) {
+        // forced / nothing to choose
     } else if (kn.wide >= 0) {  // forced (experiments, tests)
         if (kn.wide && setup_wide(kn.wide)) wide = kn.wide;
     } else if (!fast) {
@@ -1068,7 +1092,8 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         da.tiles_per_frame = narrow_tiles;
     }
     da.xcd_map = (kn.xcd && n_frames >= 8) ? 1u : 0u;
-    da.mode = fast ? MODE_FAST : MODE_GENERAL;
+    da.mode = resolved ? MODE_RESOLVED : fast ? MODE_FAST : MODE_GENERAL;
+    if (resolved) ctx->state_dirty = false;   // this call leaves the frame words alone
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
@@ -1088,7 +1113,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             if (!tuning->ev[tune_slot][k]) HIP_TRY(hipEventCreate(&tuning->ev[tune_slot][k]));
         HIP_TRY(hipEventRecord(tuning->ev[tune_slot][0], st));
     }
-    if (wide && !fast) {
+    if (wide && !fast && !resolved) {
         if (ctx->slotmap.ensure((size_t)n_frames * W * sizeof(int32_t) * 2)) return fail(OUSTER_HIP_ERR_RUNTIME, "out of device memory (slot map)");
         da.slot_map = (int32_t*)ctx->slotmap.p;
         da.hdr_map = da.slot_map + (size_t)n_frames * W;
@@ -1103,7 +1128,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         HIP_TRY(launch_decode_wide(da, spec, wide, xyzm, ctx->device, st));
         ctx->last_tile_cols = wide;
         ctx->last_tile_rows = (int)da.rows_per_tile;
-        ctx->last_kernel = "k_decode_wide";
+        ctx->last_kernel = resolved ? "k_decode_wide_resolved" : "k_decode_wide";
     } else {
         HIP_TRY(launch_decode(da, spec, tile, xyzm, ctx->device, st));
         ctx->last_tile_cols = tile;
@@ -1112,7 +1137,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     }
     if (tuning) HIP_TRY(hipEventRecord(tuning->ev[tune_slot][1], st));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
-    if (fast && kn.fixup) {
+    if (fast && kn.fixup && !resolved) {
         // fix-up pass: the tiles of the frames the optimistic pass flagged are looked at again with the frame's real column
         // maps and redone where those differ from "slot c holds column c"; the workgroups of a clean batch leave after one
         // read of the flags.  Wide tiles (k_decode_wide_fixup) where the format allows them, 64-column tiles otherwise.

@@ -38,6 +38,7 @@ enum DecodeMode : uint32_t {
                        //   flag their frame in frame_state
     MODE_FIXUP = 1,    // second pass: redo the frames the fast pass flagged (the others return at once)
     MODE_GENERAL = 2,  // every frame through the scan-the-frame path (slots_per_frame*cpp != W)
+    MODE_RESOLVED = 3, // small batches, one launch: every wide tile resolves its frame's column maps itself (k_decode_wide_resolved)
 };
 
 // frame_state words (kernels_common.h): sequence, tag, 2 x 8 ticket counters, then one word per frame
@@ -196,7 +197,7 @@ size_t decode_wide_lds_bytes(int tw, uint32_t rows_per_tile, uint32_t img_words)
 hipError_t launch_decode(const DecodeArgs& a, int spec_id, int tile, int xyzm, int device, hipStream_t st);
 hipError_t launch_decode_wide(const DecodeArgs& a, int spec_id, int tw, int xyzm, int device, hipStream_t st, uint32_t resident = 0);
 hipError_t launch_decode_stream(const DecodeArgs& a, const StreamArgs& sp, int spec_id, int tw, int xyzm, int device, hipStream_t st);
-size_t slotmap_lds_bytes(uint32_t W, uint32_t npo, uint32_t slots_per_frame);
+size_t slotmap_lds_bytes(uint32_t W, uint32_t cpp, uint32_t slots_per_frame);   // resolve_frame's LDS scratch
 hipError_t launch_slotmap(const DecodeArgs& a, int device, hipStream_t st);
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st);
 hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
