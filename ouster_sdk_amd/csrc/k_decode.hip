@@ -171,7 +171,7 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
                 if (n) atomicAdd(&s_nvalid, n);
                 __syncthreads();
                 if (tid == 0) {
-                    ouster_hip_frame_meta m = frame_meta_of(a.g, fbase, count > 0);
+                    ouster_hip_frame_meta m = frame_meta_general(a, fbase, count);
                     m.n_valid_columns = s_nvalid;
                     a.frame_meta[f] = m;
                 }
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
                     if (n) atomicAdd(&s_nvalid, n);
                     __syncthreads();
                     if (tid == 0) {
-                        ouster_hip_frame_meta m = frame_meta_of(a.g, fbase, count > 0);
+                        ouster_hip_frame_meta m = frame_meta_general(a, fbase, count);
                         m.n_valid_columns = s_nvalid;
                         a.frame_meta[f] = m;
                     }
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_resolved(DecodeArgs a) {
             if (n) atomicAdd(&s_nvalid, n);
             __syncthreads();
             if (tid == 0) {
-                ouster_hip_frame_meta m = frame_meta_of(a.g, fbase, count > 0);
+                ouster_hip_frame_meta m = frame_meta_general(a, fbase, count);
                 m.n_valid_columns = s_nvalid;
                 a.frame_meta[f] = m;
             }

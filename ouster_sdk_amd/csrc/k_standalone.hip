@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(256) void k_slotmap(DecodeArgs a) {
     }
     __syncthreads();
     if (tid == 0 && a.frame_meta) {
-        ouster_hip_frame_meta m = frame_meta_of(a.g, fbase, count > 0);
+        ouster_hip_frame_meta m = frame_meta_general(a, fbase, count);
         m.n_valid_columns = s_n;
         a.frame_meta[f] = m;
     }

@@ -556,6 +556,15 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_first_present(const 
     return frame_meta_of(g, fbase, false);
 }
 
+// The general mapping's frame-level values: from the first packet of the buffer -- the first one the reference receives
+// (start_frame) -- unless the buffer has one slot per column of the frame, where a lost packet is a zeroed slot (this
+// library's own staging convention: FrameStream, DeviceFrameBatch) and the first slot that holds a packet counts.
+__device__ __forceinline__ ouster_hip_frame_meta frame_meta_general(const DecodeArgs& a, const uint8_t* fbase, uint32_t count) {
+    if ((uint64_t)a.slots_per_frame * a.g.columns_per_packet == a.g.columns_per_frame)
+        return frame_meta_first_present(a.g, fbase, a.packet_stride, count);
+    return frame_meta_of(a.g, fbase, count > 0);
+}
+
 // ------------------------------------------------------------------------------------
 // resolve_frame: the general column mapping of ONE frame -- what FrameBatcher leaves behind after batching the frame's
 // packets in buffer order (ouster_core/src/lidar_frame.cpp:1422-1576), restated as "last event wins" so that it can be
@@ -635,8 +644,33 @@ __device__ __forceinline__ uint32_t resolve_frame(const Geometry& g, const uint8
     for (uint32_t i = tid; i < W; i += NT) { s_pix[i] = -1; s_hdr[i] = -1; s_z[i] = 0; }
     if (s_pkm) for (uint32_t i = tid; i < npo; i += NT) s_pkm[i] = -1;
     __syncthreads();
-    // ---- A: one thread per packet: which path does the reference take, and what does it do to next_valid?
+    // ---- A: which path does the reference take for a packet, and what does the packet do to next_valid?
     //      s_pkt[2p] = F | block << 31 (F = m_id of column 0), s_pkt[2p + 1] = M = max over live columns of m_id + 1
+    // One lane per slot where a packet's columns are a power-of-two group of lanes (every sensor: 16): consecutive lanes
+    // read consecutive words and update consecutive counters.  (One thread per packet -- the fallback below -- walks 16 words
+    // 16 words apart from its neighbour's: 16-way bank conflicts on every read and every LDS atomic, 35 us per frame.)
+    const bool lanes = cpp <= 64 && (cpp & (cpp - 1)) == 0 && BD != 0;
+    const uint32_t lane = tid & 63u, ic_l = lane & (cpp - 1u);
+    const uint64_t grp_mask = cpp >= 64 ? ~0ull : ((1ull << cpp) - 1ull);
+    if (lanes) {
+        for (uint32_t base = 0; base < nslots; base += NT) {
+            const uint32_t s = base + tid;
+            const bool in = s < nslots;
+            const uint32_t h = in ? s_hd[s] : 0u, m = h & 0xffffu;
+            const bool live = in && (h >> 16) && m < W;
+            const uint64_t lv = __ballot(live) >> (lane - ic_l);
+            const uint64_t ft = __ballot(!in || (ic_l % BD) != 0 || m + BD <= W) >> (lane - ic_l);
+            uint32_t top = live ? m + 1u : 0u;
+            for (uint32_t d = 1; d < cpp; d <<= 1) top = max(top, (uint32_t)__shfl_xor((int)top, (int)d));
+            if (in && ic_l == 0) {
+                const uint32_t p = s / cpp;
+                const bool block = (lv & grp_mask) == grp_mask && (ft & grp_mask) == grp_mask;
+                s_pkt[2 * p] = m | (block ? 0x80000000u : 0u);
+                s_pkt[2 * p + 1] = top;
+                if (s_pkm && m / cpp < npo) atomicMax(&s_pkm[m / cpp], (int32_t)p);
+            }
+        }
+    } else
     for (uint32_t p = tid; p < count; p += NT) {
         bool allv = true, fit = BD != 0;
         uint32_t first = 0, top = 0;
@@ -678,7 +712,37 @@ __device__ __forceinline__ uint32_t resolve_frame(const Geometry& g, const uint8
         if (tid == 0) s_nv_final = nv;
     }
     __syncthreads();
-    // ---- C: one thread per packet again: the zeroed ranges it triggers and the columns it writes
+    // ---- C: the zeroed ranges a packet triggers and the columns it writes (one lane per slot, or one thread per packet)
+    if (lanes) {
+        for (uint32_t base = 0; base < nslots; base += NT) {
+            const uint32_t s = base + tid;
+            const bool in = s < nslots;
+            const uint32_t h = in ? s_hd[s] : 0u, m = h & 0xffffu, p = s / cpp;
+            const bool live = in && (h >> 16) && m < W;
+            const bool block = in && (s_pkt[2 * p] & 0x80000000u) != 0u;
+            const uint32_t nv_in = in ? s_pkt[2 * p + 1] : 0u;
+            const uint32_t block_first = (uint32_t)__shfl((int)m, (int)(lane - ic_l % BD));
+            // column path: next_valid before my column = max(before the packet, the live columns before me in it)
+            uint32_t pre = live ? m + 1u : 0u;
+            for (uint32_t d = 1; d < cpp; d <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)pre, d, (int)cpp);
+                if (ic_l >= d) pre = max(pre, y);
+            }
+            const uint32_t excl = (uint32_t)__shfl_up((int)pre, 1u, (int)cpp);
+            const uint32_t nvb = max(nv_in, ic_l ? excl : 0u);
+            if (block) {
+                if (ic_l == 0 && m >= nv_in)
+                    for (uint32_t c = nv_in; c < m; ++c) s_z[c] = (int32_t)s;
+                atomicMax(&s_hdr[m], (int32_t)s);
+                atomicMax(&s_pix[block_first + ic_l % BD], (int32_t)s);
+            } else if (live) {
+                if (m >= nvb)
+                    for (uint32_t c = nvb; c < m; ++c) s_z[c] = (int32_t)s;
+                atomicMax(&s_hdr[m], (int32_t)s);
+                atomicMax(&s_pix[m], (int32_t)s);
+            }
+        }
+    } else
     for (uint32_t p = tid; p < count; p += NT) {
         const bool block = (s_pkt[2 * p] & 0x80000000u) != 0u;
         uint32_t nv = s_pkt[2 * p + 1];
