@@ -150,7 +150,8 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
         int32_t *r_pix = L.pix, *r_hdr = L.hdr, *r_pkm = L.pkm;
         __shared__ uint32_t s_nvalid;
         if (tid == 0) s_nvalid = 0;
-        resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, tile == 0);
+        resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, tile == 0,
+                          (GENERAL_ONLY && a.hdr_words) ? a.hdr_words + (size_t)f * W : nullptr);
         int32_t my_pix = -1, my_hdr = -1;
         if (tid < TILE && c0 + tid < W) { my_pix = r_pix[c0 + tid]; my_hdr = r_hdr[c0 + tid]; }
         if (tile == 0) {
@@ -168,7 +169,8 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
             if (a.frame_meta) {
                 uint32_t n = 0;
                 for (uint32_t i = tid; i < W; i += NT) n += r_hdr[i] >= 0 ? 1u : 0u;
-                if (n) atomicAdd(&s_nvalid, n);
+                n = wave_sum(n);
+                if (n && (tid & 63u) == 0) atomicAdd(&s_nvalid, n);
                 __syncthreads();
                 if (tid == 0) {
                     ouster_hip_frame_meta m = frame_meta_general(a, fbase, count);
@@ -306,6 +308,7 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, uint32_t* smem,
             if (present) col_header_lds(a.g, s_tile, tid * col_size, m_id, st);
             const bool live = present && (st & 1u) && m_id < W;
             bool stray = live && m_id != c;
+            if (a.hdr_words && c < W) a.hdr_words[(size_t)f * W + c] = present ? (m_id | ((st & 1u) << 16)) : 0u;
             if (pk_lane) {
                 // batch_lidar_packet (lidar_frame.cpp:1534-1539): packet-level values go to index
                 // m_id(first column) / cpp whether or not that column is valid
@@ -508,7 +511,7 @@ __device__ __forceinline__ void wide_tile(const DecodeArgs& a, uint32_t* smem, u
     uint32_t count = a.slots_per_frame;
     if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
 #ifdef OUSTER_PHASE_TIMING
-    uint64_t* pt_ = a.phase_times ? a.phase_times + (size_t)blockIdx.x * 8 : nullptr;
+    uint64_t* pt_ = (a.phase_times && a.mode != MODE_FIXUP) ? a.phase_times + (size_t)blockIdx.x * 16 : nullptr;
 #define PHASE_STAMP(i) do { if (pt_ && tid == 0) pt_[i] = __builtin_readcyclecounter(); } while (0)
     if (pt_ && tid == 0) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); pt_[7] = xcc; }
 #else
@@ -529,7 +532,10 @@ __device__ __forceinline__ void wide_tile(const DecodeArgs& a, uint32_t* smem, u
             // source slot of destination column c: itself (the optimistic pass), or what resolve_frame found (general mapping)
             int32_t sl = (int32_t)c, hs = (int32_t)c;
             if constexpr (LMAPS) { sl = l_pix[c]; hs = l_hdr[c]; }
-            else if (a.slot_map) { sl = a.slot_map[(size_t)f * W + c]; hs = a.hdr_map[(size_t)f * W + c]; }
+            else if (a.slot_map) {   // agent-scope loads: in the fix-up pass another XCD's workgroup wrote them moments ago
+                sl = __hip_atomic_load(&a.slot_map[(size_t)f * W + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hs = __hip_atomic_load(&a.hdr_map[(size_t)f * W + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (sl >= 0) {
                 const uint32_t p = (uint32_t)sl / cpp, ic = (uint32_t)sl - p * cpp;
                 ofs = p * (uint32_t)a.packet_stride + a.g.packet_header_size + ic * col_size;
@@ -727,6 +733,7 @@ __device__ __forceinline__ void wide_tile(const DecodeArgs& a, uint32_t* smem, u
             s_valid[j] = vp ? 1u : 0u;
             n_dead += (!vp && c < W) ? 1u : 0u;
             if (rc != 0 || c >= W) continue;
+            if (a.hdr_words && !mapped) a.hdr_words[(size_t)f * W + c] = present ? (m_id | ((st & 1u) << 16)) : 0u;
             if (c == p * cpp && !mapped) {  // batch_lidar_packet, lidar_frame.cpp:1534-1539
                 const bool want_pk = a.packet_timestamp || a.alert_flags;
                 const bool home = present && m_id / cpp == p;
@@ -744,11 +751,15 @@ __device__ __forceinline__ void wide_tile(const DecodeArgs& a, uint32_t* smem, u
             if (a.measurement_id) a.measurement_id[(size_t)f * W + c] = v ? (uint16_t)c : (uint16_t)0;
             if (a.status) a.status[(size_t)f * W + c] = v ? st : 0u;
         }
-        if (rc == 0) {
-            if (n_valid) atomicAdd(&s_acc[0], n_valid);
-            if (n_stray) atomicAdd(&s_acc[1], n_stray);
+        // one LDS atomic per wave, not per lane: 256 lanes adding to one word are served one after the other
+        const uint32_t packed = wave_sum(n_valid | (n_stray << 10) | (n_dead << 20));   // at most 4 columns per lane: 256 per wave
+        if ((tid & 63u) == 0) {
+            if (rc == 0) {
+                if (packed & 0x3ffu) atomicAdd(&s_acc[0], packed & 0x3ffu);
+                if ((packed >> 10) & 0x3ffu) atomicAdd(&s_acc[1], (packed >> 10) & 0x3ffu);
+            }
+            if (packed >> 20) atomicAdd(&s_acc[2], packed >> 20);
         }
-        if (n_dead) atomicAdd(&s_acc[2], n_dead);
     }
     __syncthreads();
     if (rc == 0 && tid == 0 && !mapped) {
@@ -799,31 +810,54 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
 // ------------------------------------------------------------------------------------
 // k_decode_wide_fixup: the fix-up pass on wide tiles (round 4; k_decode_fixup's 64-column tiles remain for formats the wide
 // tiles cannot take).  A persistent grid as before: every workgroup lists the frames flagged with this call's tag; the
-// k-th flagged frame belongs to XCD k % 8 (its tiles' partial cache lines meet in one L2), whose workgroups share the
-// frame's (column tile, row chunk) items out through a ticket counter -- an item costs anything between a look at the
-// frame's column headers and a full tile, a fixed share would leave most workgroups idle.
-// An item: resolve_frame gives the frame's real column maps; the optimistic pass has already written this tile as "slot c
-// holds column c, anything else reads as zeros", so the tile is redone only where the maps say something else -- a frame
-// with two packets swapped costs one column tile, not the frame (r03: every flagged frame was redone whole, 3.8 - 4.8 us
-// each).  Item (tile 0, row chunk 0) also writes the frame's packet-level outputs, frame-level values and valid-column count.
+// workgroups share the work out through a ticket counter.  Tickets, in this order:
+//   one per flagged frame      RESOLVE: resolve_frame gives the frame's real column maps (from the packed header words the
+//                              optimistic pass left behind); they go to a.slot_map / a.hdr_map, together with the mask of
+//                              column tiles whose maps differ from what the optimistic pass assumed ("slot c holds column c,
+//                              anything else reads as zeros"), the frame's packet-level outputs, frame-level values and
+//                              valid-column count; then the frame's ready word is released (tag | mask).
+//   one per (frame, tile, row chunk)   REDO: waits for the frame's ready word, leaves at once when the tile is not in the
+//                              mask -- a frame with two packets swapped costs one column tile, not the frame (r03: every
+//                              flagged frame was redone whole) -- and decodes the tile from the maps otherwise.  Short tiles
+//                              (8 rows): the few flagged frames of a batch are spread over the whole XCD instead of keeping a
+//                              handful of workgroups busy for 50 us each.
+// A ticket is only ever held by a running workgroup and RESOLVE tickets come first and never wait, so a REDO ticket waits
+// for a workgroup that is making progress.  The wait is bounded all the same: after SPIN_LIMIT polls the workgroup
+// resolves the frame itself (the maps are a pure function of the packets).  Maps and ready words are written and read with
+// agent-scope atomics: the XCDs' L2s are not coherent with each other for plain accesses.
 // The ticket counters live in frame_state behind the sequence words, one set per tag parity: this call's start at zero
-// (zeroed by the call before), the other set is zeroed for the next call; nothing is waited for.
+// (zeroed by the call before), the other set is zeroed for the next call; the ready words ([ready_off + f], the buffer's second half)
+// carry the tag and are never cleared.
 // ------------------------------------------------------------------------------------
+constexpr uint32_t SPIN_LIMIT = 1u << 16;
+#ifdef OUSTER_PHASE_TIMING   // experiment builds (tools/ab/phase_timing.sh): per workgroup 64 words: [0] start, [1] events, then 4 per ticket
+#define FSTAMP_BEGIN() uint64_t fs0_ = __builtin_readcyclecounter(), fs1_ = 0
+#define FSTAMP_MID() do { fs1_ = __builtin_readcyclecounter(); } while (0)
+#define FSTAMP_END(kind, n) do { if (a.phase_times && tid == 0) { uint64_t* q_ = a.phase_times + (size_t)blockIdx.x * 64; const uint64_t e_ = q_[1]; \
+    if (e_ < 15) { q_[2 + 4 * e_] = (kind) | ((uint64_t)(n) << 8); q_[3 + 4 * e_] = fs0_; q_[4 + 4 * e_] = fs1_; q_[5 + 4 * e_] = __builtin_readcyclecounter(); q_[1] = e_ + 1; } } } while (0)
+#else
+#define FSTAMP_BEGIN() do {} while (0)
+#define FSTAMP_MID() do {} while (0)
+#define FSTAMP_END(kind, n) do {} while (0)
+#endif
 template <class S, int TW, int XYZM, bool POSES = false>
 __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
     constexpr int NT = 256;
     extern __shared__ __align__(16) uint32_t smem[];
     __shared__ uint16_t s_list[FIXUP_CHUNK];
     __shared__ uint32_t s_cnt[FIXUP_CHUNK / 64];
-    __shared__ uint32_t s_n, s_nvalid;
-    __shared__ unsigned long long s_ticket;
+    __shared__ uint32_t s_n, s_nvalid, s_dirty;
+    __shared__ unsigned long long s_ticket, s_ready;
     const uint32_t tid = threadIdx.x;
     const uint32_t W = a.g.columns_per_frame, cpp = a.g.columns_per_packet, npo = a.n_packets_out;
-    const uint32_t bpf = a.tiles_per_frame * a.row_chunks;
+    constexpr uint32_t SPLIT_MAX = 8;   // REDO tickets per (frame, row chunk): ticket s takes every SPLIT-th dirty column tile
     const uint64_t tag = a.frame_state[FS_TAG];
-    const bool by_xcd = gridDim.x >= 16 && (gridDim.x & 7u) == 0;
-    const uint32_t xcd = by_xcd ? (blockIdx.x & 7u) : 0u, nx = by_xcd ? 8u : 1u;
+    // One counter for the whole grid: a flagged frame's tiles go wherever a workgroup is free.  (Keeping a frame on one XCD
+    // -- right for k_decode_fixup's 64-column tiles, whose partial cache lines must meet in one L2 -- limits ONE damaged frame
+    // to an eighth of the chip's bandwidth: 115 us for a frame with eight dirty column tiles, tools/ab/fixup_kinds2.py.)
+    const uint32_t xcd = 0u, nx = 1u;
     unsigned long long* ctr = (unsigned long long*)&a.frame_state[FS_TICKET + (tag & 1u) * 8u + xcd];
+    unsigned long long* ready = (unsigned long long*)&a.frame_state[a.ready_off];
     if (blockIdx.x < 8 && tid == 0) a.frame_state[FS_TICKET + ((tag + 1u) & 1u) * 8u + blockIdx.x] = 0;   // the next call's counters
     auto pull = [&]() -> unsigned long long {
         __syncthreads();
@@ -831,8 +865,72 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
         __syncthreads();
         return s_ticket;
     };
+    // the next ticket is asked for when an item starts and looked at when it ends: the round trip hides behind the item
+    unsigned long long ahead = 0;
+    auto pull_ahead = [&]() { if (tid == 0) ahead = atomicAdd(ctr, 1ull); };
+    auto take_ahead = [&]() -> unsigned long long {
+        __syncthreads();
+        if (tid == 0) s_ticket = ahead;
+        __syncthreads();
+        return s_ticket;
+    };
+#ifdef OUSTER_PHASE_TIMING
+    if (a.phase_times && tid == 0) { a.phase_times[(size_t)blockIdx.x * 64] = __builtin_readcyclecounter(); a.phase_times[(size_t)blockIdx.x * 64 + 1] = 0; }
+#endif
+    const ResolveLds L(smem, W, npo, a.slots_per_frame);
+    // the frame's maps in LDS (L.pix / L.hdr); `lead`: also its packet-level outputs, frame-level values and valid-column count
+    auto resolve = [&](uint32_t f, bool lead) {
+        const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
+        uint32_t count = a.slots_per_frame;
+        if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
+        if (tid == 0) { s_nvalid = 0; s_dirty = 0; }
+        resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, lead, a.hdr_words ? a.hdr_words + (size_t)f * W : nullptr);
+        if (!lead) return;
+        // the maps, and which column tiles the optimistic pass got wrong: it wrote slot c where that is live and at home,
+        // zeros otherwise
+        uint32_t n = 0, dm = 0;
+        for (uint32_t c = tid; c < W; c += NT) {
+            const int32_t px = L.pix[c], hd = L.hdr[c];
+            __hip_atomic_store(&a.slot_map[(size_t)f * W + c], px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.hdr_map[(size_t)f * W + c], hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n += hd >= 0 ? 1u : 0u;
+            int32_t expect = -1;
+            if (c / cpp < count && L.hd[c] == (c | 0x10000u)) expect = (int32_t)c;
+            if (px != expect || hd != expect) dm |= 1u << (c / TW);
+        }
+        n = wave_sum(n);
+        dm = wave_or(dm);
+        if ((tid & 63u) == 0) {
+            if (n) atomicAdd(&s_nvalid, n);
+            if (dm) atomicOr(&s_dirty, dm);
+        }
+        // The maps were stored with agent-scope atomics (written through to where the other XCDs can see them); every wave
+        // waits for its stores before the barrier, the word that announces them is stored behind it.  No cache-wide
+        // release: a buffer_wbl2 here would have to write back every tile the XCD has redone so far.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(&ready[f], (unsigned long long)((tag << 32) | s_dirty), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Nobody waits for the rest: the frame's packet-level outputs (packet_timestamp is zeroed at frame start,
+        // lidar_frame.cpp:1719, alert_flags is not), frame-level values and valid-column count
+        for (uint32_t i = tid; i < npo; i += NT) {
+            const int32_t p = L.pkm[i];
+            if (a.packet_timestamp && a.host_timestamps)
+                a.packet_timestamp[(size_t)f * npo + i] = p >= 0 ? a.host_timestamps[(size_t)f * a.slots_per_frame + p] : 0ull;
+            if (a.alert_flags && p >= 0)
+                a.alert_flags[(size_t)f * npo + i] = (uint8_t)apply_bits(
+                    window_global(fbase + (size_t)p * a.packet_stride + a.g.alert_flags.offset), a.g.alert_flags.mask,
+                    a.g.alert_flags.shift);
+        }
+        if (tid == 0 && a.frame_meta) {
+            ouster_hip_frame_meta m = frame_meta_general(a, fbase, count);
+            m.n_valid_columns = s_nvalid;
+            a.frame_meta[f] = m;
+        }
+    };
     unsigned long long ticket = 0, done = 0;
     bool have = false;
+    pull_ahead();   // the first ticket's round trip overlaps with the reading of the flags (a clean batch wastes one ticket per workgroup)
     for (uint32_t base = 0; base < a.n_frames; base += FIXUP_CHUNK) {
         // the flagged frames of this chunk, in frame order, the same list in every workgroup (see k_decode_fixup)
         const uint32_t nfr = min(FIXUP_CHUNK, a.n_frames - base);
@@ -863,58 +961,76 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
         __syncthreads();
         const uint32_t n_flagged = s_n;
         const uint32_t my_frames = n_flagged > xcd ? (n_flagged - xcd + nx - 1u) / nx : 0u;   // flagged frames of my XCD
-        const unsigned long long items = (unsigned long long)my_frames * bpf;
+        // few damaged frames: one ticket per dirty tile (the chip is idle, latency counts); many: fewer tickets that find no work
+        const uint32_t SPLIT = n_flagged <= 8u ? SPLIT_MAX : n_flagged <= 48u ? 4u : 2u;
+        const uint32_t bpf = a.row_chunks * SPLIT;
+        const unsigned long long items = (unsigned long long)my_frames * (1u + bpf);
         if (items == 0) continue;
-        if (!have) { ticket = pull(); have = true; }
+        if (!have) { ticket = take_ahead(); have = true; }
         while (ticket < done + items) {
             const uint32_t it = (uint32_t)(ticket - done);
-            const uint32_t f = base + s_list[(it / bpf) * nx + xcd], sub = it % bpf;
-            const uint32_t tile = sub % a.tiles_per_frame, rc = sub / a.tiles_per_frame, c0 = tile * TW;
-            const uint8_t* fbase = a.packets + (size_t)f * a.slots_per_frame * a.packet_stride;
-            uint32_t count = a.slots_per_frame;
-            if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
-            const ResolveLds L(smem, W, npo, a.slots_per_frame);
-            int32_t *r_pix = L.pix, *r_hdr = L.hdr, *r_pkm = L.pkm;
-            const bool lead = tile == 0 && rc == 0;
-            if (tid == 0) s_nvalid = 0;
-            resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, lead);
-            if (lead) {
-                // packet_timestamp is zeroed at frame start (lidar_frame.cpp:1719), alert_flags is not
-                for (uint32_t i = tid; i < npo; i += NT) {
-                    const int32_t p = r_pkm[i];
-                    if (a.packet_timestamp && a.host_timestamps)
-                        a.packet_timestamp[(size_t)f * npo + i] = p >= 0 ? a.host_timestamps[(size_t)f * a.slots_per_frame + p] : 0ull;
-                    if (a.alert_flags && p >= 0)
-                        a.alert_flags[(size_t)f * npo + i] = (uint8_t)apply_bits(
-                            window_global(fbase + (size_t)p * a.packet_stride + a.g.alert_flags.offset), a.g.alert_flags.mask,
-                            a.g.alert_flags.shift);
-                }
-                if (a.frame_meta) {
-                    uint32_t n = 0;
-                    for (uint32_t i = tid; i < W; i += NT) n += r_hdr[i] >= 0 ? 1u : 0u;
-                    if (n) atomicAdd(&s_nvalid, n);
-                    __syncthreads();
-                    if (tid == 0) {
-                        ouster_hip_frame_meta m = frame_meta_general(a, fbase, count);
-                        m.n_valid_columns = s_nvalid;
-                        a.frame_meta[f] = m;
+            pull_ahead();
+            FSTAMP_BEGIN();
+            if (it < my_frames) {
+                resolve(base + s_list[it * nx + xcd], true);
+                FSTAMP_END(1u, 0u);
+            } else {
+                const uint32_t j = it - my_frames;
+                const uint32_t f = base + s_list[(j / bpf) * nx + xcd], sub = j % bpf;
+                const uint32_t rc = sub % a.row_chunks, share = sub / a.row_chunks;
+                if (tid == 0) {
+                    unsigned long long v = 0;
+                    for (uint32_t spin = 0; spin < SPIN_LIMIT; ++spin) {
+                        v = __hip_atomic_load(&ready[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((v >> 32) == (tag & 0xffffffffull)) break;
+                        __builtin_amdgcn_s_sleep(8);
                     }
+                    s_ready = v;
                 }
+                __syncthreads();
+                FSTAMP_MID();
+                const unsigned long long v = s_ready;
+                uint32_t mask = (uint32_t)v;
+                const bool published = (v >> 32) == (tag & 0xffffffffull);
+                if (!published) {
+                    // never seen so far (SPIN_LIMIT polls): do the frame's resolution here; same maps, nothing is published
+                    resolve(f, false);
+                    uint32_t cnt = a.slots_per_frame;
+                    if (a.packet_counts) cnt = min(a.packet_counts[f], a.slots_per_frame);
+                    uint32_t dm = 0;
+                    for (uint32_t c = tid; c < W; c += NT) {
+                        int32_t expect = -1;
+                        if (c / cpp < cnt && L.hd[c] == (c | 0x10000u)) expect = (int32_t)c;
+                        if (L.pix[c] != expect || L.hdr[c] != expect) dm |= 1u << (c / TW);
+                    }
+                    dm = wave_or(dm);
+                    if ((tid & 63u) == 0 && dm) atomicOr(&s_dirty, dm);
+                    __syncthreads();
+                    mask = s_dirty;
+                    // the tiles below read the maps from global memory (the LDS copy lies under the tile image): store them, the same
+                    // values the RESOLVE ticket's workgroup stores
+                    for (uint32_t c = tid; c < W; c += NT) {
+                        __hip_atomic_store(&a.slot_map[(size_t)f * W + c], L.pix[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&a.hdr_map[(size_t)f * W + c], L.hdr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+                uint32_t rank = 0, ntl = 0;
+                for (uint32_t m = mask; m; m &= m - 1u, ++rank) {
+                    if (rank % SPLIT != share) continue;
+                    const uint32_t tile = (uint32_t)__builtin_ctz(m);
+                    wide_tile<S, TW, XYZM, POSES, false>(a, smem, f, tile, rc, nullptr, nullptr);   // reads the maps with agent-scope loads
+                    __syncthreads();
+                    ++ntl;
+                }
+                FSTAMP_END(2u, ntl);
             }
-            // what the optimistic pass wrote for my columns: slot c where it is live and at home, zeros otherwise
-            bool dirty = false;
-            for (uint32_t j = tid; j < (uint32_t)TW && c0 + j < W; j += NT) {
-                const uint32_t c = c0 + j, p = c / cpp;
-                int32_t expect = -1;
-                if (p < count && L.hd[c] == (c | 0x10000u)) expect = (int32_t)c;   // slot c is live and at home
-                dirty |= r_pix[c] != expect || r_hdr[c] != expect;
-            }
-            if (__syncthreads_or(dirty ? 1 : 0)) wide_tile<S, TW, XYZM, POSES, true>(a, smem, f, tile, rc, r_pix, r_hdr);
-            ticket = pull();
+            ticket = take_ahead();
         }
         done += items;
     }
-    // valid-column counts of the clean frames (flagged ones got theirs from their lead item)
+    // valid-column counts of the clean frames (flagged ones got theirs from their RESOLVE ticket)
     if (a.frame_meta) {
         for (uint32_t f = blockIdx.x * NT + tid; f < a.n_frames; f += gridDim.x * NT) {
             if (a.frame_state[FS_WORDS + f] == tag) continue;
@@ -924,6 +1040,9 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
         }
     }
     if (blockIdx.x == 0 && tid == 0) a.frame_state[FS_SEQ] = tag;  // the next call tags with tag + 1
+#ifdef OUSTER_PHASE_TIMING
+    if (a.phase_times && tid == 0) a.phase_times[(size_t)blockIdx.x * 64 + 63] = __builtin_readcyclecounter();
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -1090,7 +1209,11 @@ __global__ __launch_bounds__(256) void k_decode_wide_resolved(DecodeArgs a) {
     const ResolveLds L(smem, W, npo, a.slots_per_frame);
     const bool lead = tile == 0 && rc == 0;
     if (tid == 0) s_nvalid = 0;
+#ifdef OUSTER_PHASE_TIMING
+    resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, lead, nullptr, a.phase_times ? a.phase_times + (size_t)blockIdx.x * 16 : nullptr);
+#else
     resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, lead);
+#endif
     if (lead) {
         // packet_timestamp is zeroed at frame start (lidar_frame.cpp:1719), alert_flags is not
         for (uint32_t i = tid; i < npo; i += NT) {
@@ -1104,7 +1227,8 @@ __global__ __launch_bounds__(256) void k_decode_wide_resolved(DecodeArgs a) {
         if (a.frame_meta) {
             uint32_t n = 0;
             for (uint32_t i = tid; i < W; i += NT) n += L.hdr[i] >= 0 ? 1u : 0u;
-            if (n) atomicAdd(&s_nvalid, n);
+            n = wave_sum(n);
+            if (n && (tid & 63u) == 0) atomicAdd(&s_nvalid, n);
             __syncthreads();
             if (tid == 0) {
                 ouster_hip_frame_meta m = frame_meta_general(a, fbase, count);
@@ -1188,7 +1312,6 @@ hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a_in, int tw, in
     if (fix) {
         const uint64_t items = (uint64_t)a.n_frames * bpf;
         uint32_t g = (uint32_t)std::min<uint64_t>(items, resident ? resident : 512u);
-        if (g >= 16) g &= ~7u;   // whole XCD rounds: workgroup b runs on XCD b % 8
         const dim3 grid(g);
         switch (tw) {
             case 64: return launch_wide_fixup_t<SpecT, 64>(a, xyzm, grid, lds, device, st);

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(512) void k_decode_stream(DecodeArgs a, StreamArgs 
             const bool v = live && !stray;
             s_valid[j] = v ? 1u : 0u;
             if (rc == 0) {
+                if (a.hdr_words) a.hdr_words[(size_t)f * W + c] = present ? (m_id | ((st & 1u) << 16)) : 0u;
                 if (c == p * cpp) {   // batch_lidar_packet, lidar_frame.cpp:1534-1539
                     const bool want_pk = a.packet_timestamp || a.alert_flags;
                     const bool home = present && m_id / cpp == p;
@@ -496,13 +497,14 @@ __global__ __launch_bounds__(768) void k_decode_stream2(DecodeArgs a, StreamArgs
         const double* s_beam = (const double*)(s_pix + (sp.beam_off >> 2));
 
         // ---- my four columns, from their fetched header words (slot c holds column c: DESIGN.md 3.1)
-        uint32_t vq = 0, sq = 0, st4[4];
+        uint32_t vq = 0, sq = 0, st4[4], hw4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const uint32_t j = q * 4u + c, col = c0 + j;
             const bool present = pidx[c] < count;
             const uint32_t m_id = (uint16_t)plan_field(s_hdr, TW, j, sp.mid, a.g.col_measurement_id);
             const uint32_t st = (uint32_t)plan_field(s_hdr, TW, j, sp.st, a.g.col_status);
+            hw4[c] = present ? (m_id | ((st & 1u) << 16)) : 0u;
             const bool live = present && (st & 1u) && m_id < W;
             bool stray = live && m_id != col;
             const bool v = live && !stray;
@@ -538,6 +540,7 @@ __global__ __launch_bounds__(768) void k_decode_stream2(DecodeArgs a, StreamArgs
                 st8(a.measurement_id + (size_t)f * W + col, mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16));
             }
             if (a.status) st16(a.status + (size_t)f * W + col, st4[0], st4[1], st4[2], st4[3]);
+            if (a.hdr_words) st16(a.hdr_words + (size_t)f * W + col, hw4[0], hw4[1], hw4[2], hw4[3]);
             // the tile's valid-column count and stray flag: all of its columns sit in these QPR lanes of wave 0
             const uint64_t lm = QPR >= 64 ? ~0ull : ((1ull << QPR) - 1);
             uint32_t nv = 0;

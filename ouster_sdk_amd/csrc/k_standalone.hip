@@ -1437,7 +1437,8 @@ __global__ __launch_bounds__(256) void k_slotmap(DecodeArgs a) {
         a.hdr_map[(size_t)f * W + i] = h;
         n += h >= 0 ? 1u : 0u;
     }
-    if (n) atomicAdd(&s_n, n);
+    n = wave_sum(n);
+    if (n && (tid & 63u) == 0) atomicAdd(&s_n, n);
     // packet_timestamp is zeroed at frame start (lidar_frame.cpp:1719), alert_flags is not
     for (uint32_t i = tid; i < npo; i += NT) {
         const int32_t p = s_pkm[i];

@@ -34,6 +34,19 @@ __device__ __forceinline__ uint64_t funnel3(uint32_t d0, uint32_t d1, uint32_t d
     return v;
 }
 
+// wave-wide reductions (every lane gets the result): one LDS / global atomic per wave instead of one per lane -- 256 lanes
+// adding to ONE LDS word are served one after the other (20 - 40 us for 2000 of them, tools/ab/phase_fixup.py)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v |= (uint32_t)__shfl_xor((int)v, d);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    return v;
+}
+
 // 64-bit little-endian window at an arbitrary byte address in global memory
 __device__ __forceinline__ uint64_t window_global(const uint8_t* p) {
     uintptr_t a = (uintptr_t)p;
@@ -594,6 +607,7 @@ __device__ __forceinline__ uint32_t block_parsable_dev(uint32_t H, uint32_t cpp)
     return 0u;
 }
 
+// hdr_words (optional): the frame's slots' (measurement_id | valid << 16) already packed in global memory.
 // s_hd[count * cpp]: (measurement_id | valid << 16) of every buffer slot, left behind for the caller (the fix-up pass looks
 // up "is slot c live and at home" there).  LDS words needed: resolve_lds_words().
 __host__ __device__ inline size_t resolve_lds_words(uint32_t W, uint32_t npo, uint32_t slots_per_frame, uint32_t cpp) {
@@ -610,64 +624,119 @@ struct ResolveLds {
 
 template <int NT>
 __device__ __forceinline__ uint32_t resolve_frame(const Geometry& g, const uint8_t* fbase, size_t packet_stride, uint32_t count,
-                                                  uint32_t npo, const ResolveLds& L, bool want_pkm) {
+                                                  uint32_t npo, const ResolveLds& L, bool want_pkm,
+                                                  const uint32_t* hdr_words = nullptr, uint64_t* pt = nullptr) {
     const uint32_t tid = threadIdx.x;
+#ifdef OUSTER_PHASE_TIMING
+#define RSTAMP(i) do { if (pt && tid == 0) pt[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RSTAMP(i) do { (void)pt; } while (0)
+#endif
+    RSTAMP(8);
     const uint32_t W = g.columns_per_frame, cpp = g.columns_per_packet;
     const uint32_t BD = block_parsable_dev(g.pixels_per_column, cpp);
     int32_t *s_pix = L.pix, *s_hdr = L.hdr, *s_z = L.z, *s_pkm = want_pkm ? L.pkm : nullptr;
     uint32_t *s_pkt = L.pkt, *s_hd = L.hd;
-    // ---- 0: every slot's (measurement_id, valid), all threads, eight slots each in flight (the only global reads)
+    // ---- 0: every slot's (measurement_id, valid), all threads, eight slots each in flight (the only global reads).
+    // Unconditional loads from clamped addresses (a load inside a guarded region is waited for on its own at the end of the
+    // region), and only the DISTINCT dwords the two fields live in -- one for the standard column header, two for LEGACY:
+    // every lane's column is another cache line, so each load instruction is 64 line requests and a workgroup's 2048 slots
+    // x 4 dwords kept its CU's address unit busy for 12 us.
     const uint32_t nslots = count * cpp;
     constexpr int U = 8;
-    for (uint32_t base = 0; base < nslots; base += NT * U) {
-        uint64_t w_mid[U], w_st[U];
+    const uint32_t mid_lo = (uint32_t)__builtin_ctzll(g.col_measurement_id.mask | (1ull << 63)) >> 3,
+                   mid_hi = (63u - (uint32_t)__builtin_clzll(g.col_measurement_id.mask | 1ull)) >> 3;
+    const uint32_t st_lo = (uint32_t)__builtin_ctzll(g.col_status.mask | (1ull << 63)) >> 3,
+                   st_hi = (63u - (uint32_t)__builtin_clzll(g.col_status.mask | 1ull)) >> 3;
+    // byte offsets (from the column start, columns are 4-byte aligned) of the dwords the fields touch
+    const uint32_t want[4] = {(g.col_measurement_id.offset + mid_lo) & ~3u, (g.col_measurement_id.offset + mid_hi) & ~3u,
+                              (g.col_status.offset + st_lo) & ~3u, (g.col_status.offset + st_hi) & ~3u};
+    uint32_t dw[4], n_dw = 0, which[4];
+    for (int k = 0; k < 4; ++k) {
+        uint32_t j = 0;
+        while (j < n_dw && dw[j] != want[k]) ++j;
+        if (j == n_dw) dw[n_dw++] = want[k];
+        which[k] = j;
+    }
+    auto load_headers = [&](auto ndw_) {
+        constexpr int ND = decltype(ndw_)::value;
+        for (uint32_t base = 0; base < nslots; base += NT * U) {
+            uint32_t d[U][ND];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t s = base + (uint32_t)u * NT + tid;
-            w_mid[u] = w_st[u] = 0;
-            if (s < nslots) {
+            for (int u = 0; u < U; ++u) {
+                const uint32_t s = min(base + (uint32_t)u * NT + tid, nslots - 1u);
                 const uint32_t p = s / cpp, ic = s - p * cpp;
                 const uint8_t* colp = fbase + (size_t)p * packet_stride + g.packet_header_size + (size_t)ic * g.col_size;
-                w_mid[u] = window_global_masked(colp + g.col_measurement_id.offset, g.col_measurement_id.mask);
-                w_st[u] = window_global_masked(colp + g.col_status.offset, g.col_status.mask);
+#pragma unroll
+                for (int k = 0; k < ND; ++k) d[u][k] = *(const uint32_t*)(colp + dw[k]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t s = base + (uint32_t)u * NT + tid;
+                if (s >= nslots) continue;
+                // the 64-bit window at the field's offset from the (at most two, for fields of up to four bytes) dwords read
+                auto window = [&](uint32_t off, uint32_t k0, uint32_t k1) -> uint64_t {
+                    uint32_t d0 = 0, d1 = 0;
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) { d0 = which[k0] == (uint32_t)k ? d[u][k] : d0; d1 = which[k1] == (uint32_t)k ? d[u][k] : d1; }
+                    const int32_t sh0 = ((int32_t)want[k0] - (int32_t)off) * 8, sh1 = ((int32_t)want[k1] - (int32_t)off) * 8;
+                    uint64_t v = sh0 >= 0 ? (uint64_t)d0 << sh0 : (uint64_t)d0 >> (-sh0);
+                    if (want[k1] != want[k0]) v |= sh1 < 64 ? (uint64_t)d1 << sh1 : 0ull;
+                    return v;
+                };
+                const uint32_t m_id = (uint16_t)apply_bits(window(g.col_measurement_id.offset, 0, 1), g.col_measurement_id.mask,
+                                                           g.col_measurement_id.shift);
+                const uint32_t st = (uint32_t)apply_bits(window(g.col_status.offset, 2, 3), g.col_status.mask, g.col_status.shift);
+                s_hd[s] = m_id | ((st & 1u) << 16);
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t s = base + (uint32_t)u * NT + tid;
-            if (s >= nslots) continue;
-            const uint32_t m_id = (uint16_t)apply_bits(w_mid[u], g.col_measurement_id.mask, g.col_measurement_id.shift);
-            const uint32_t st = (uint32_t)apply_bits(w_st[u], g.col_status.mask, g.col_status.shift);
-            s_hd[s] = m_id | ((st & 1u) << 16);
-        }
-    }
+    };
+    if (hdr_words) {   // the optimistic pass before this fix-up pass left them packed (DecodeArgs::hdr_words)
+        for (uint32_t s = tid; s < nslots; s += NT) s_hd[s] = hdr_words[s];
+    } else if (n_dw == 1) load_headers(std::integral_constant<int, 1>{});
+    else if (n_dw == 2) load_headers(std::integral_constant<int, 2>{});
+    else load_headers(std::integral_constant<int, 4>{});
     for (uint32_t i = tid; i < W; i += NT) { s_pix[i] = -1; s_hdr[i] = -1; s_z[i] = 0; }
     if (s_pkm) for (uint32_t i = tid; i < npo; i += NT) s_pkm[i] = -1;
     __syncthreads();
+    RSTAMP(9);
     // ---- A: which path does the reference take for a packet, and what does the packet do to next_valid?
-    //      s_pkt[2p] = F | block << 31 (F = m_id of column 0), s_pkt[2p + 1] = M = max over live columns of m_id + 1
+    //      s_pkt[2p] = block path: F | 1 << 31 (F = m_id of column 0); column path: M = max over live columns of m_id + 1
     // One lane per slot where a packet's columns are a power-of-two group of lanes (every sensor: 16): consecutive lanes
     // read consecutive words and update consecutive counters.  (One thread per packet -- the fallback below -- walks 16 words
-    // 16 words apart from its neighbour's: 16-way bank conflicts on every read and every LDS atomic, 35 us per frame.)
+    // 16 words apart from its neighbour's: 16-way bank conflicts on every read and every LDS atomic.)  Eight slots per
+    // thread at a time: the shuffle chains of the eight are independent and overlap.
     const bool lanes = cpp <= 64 && (cpp & (cpp - 1)) == 0 && BD != 0;
     const uint32_t lane = tid & 63u, ic_l = lane & (cpp - 1u);
     const uint64_t grp_mask = cpp >= 64 ? ~0ull : ((1ull << cpp) - 1ull);
     if (lanes) {
-        for (uint32_t base = 0; base < nslots; base += NT) {
-            const uint32_t s = base + tid;
-            const bool in = s < nslots;
-            const uint32_t h = in ? s_hd[s] : 0u, m = h & 0xffffu;
-            const bool live = in && (h >> 16) && m < W;
-            const uint64_t lv = __ballot(live) >> (lane - ic_l);
-            const uint64_t ft = __ballot(!in || (ic_l % BD) != 0 || m + BD <= W) >> (lane - ic_l);
-            uint32_t top = live ? m + 1u : 0u;
-            for (uint32_t d = 1; d < cpp; d <<= 1) top = max(top, (uint32_t)__shfl_xor((int)top, (int)d));
-            if (in && ic_l == 0) {
-                const uint32_t p = s / cpp;
-                const bool block = (lv & grp_mask) == grp_mask && (ft & grp_mask) == grp_mask;
-                s_pkt[2 * p] = m | (block ? 0x80000000u : 0u);
-                s_pkt[2 * p + 1] = top;
-                if (s_pkm && m / cpp < npo) atomicMax(&s_pkm[m / cpp], (int32_t)p);
+        for (uint32_t base = 0; base < nslots; base += NT * U) {
+            uint32_t m[U], top[U];
+            uint64_t lv[U], ft[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t s = base + (uint32_t)u * NT + tid;
+                const bool in = s < nslots;
+                const uint32_t h = in ? s_hd[s] : 0u;
+                m[u] = h & 0xffffu;
+                const bool live = in && (h >> 16) && m[u] < W;
+                lv[u] = __ballot(live) >> (lane - ic_l);
+                ft[u] = __ballot(!in || (ic_l % BD) != 0 || m[u] + BD <= W) >> (lane - ic_l);
+                top[u] = live ? m[u] + 1u : 0u;
+            }
+            for (uint32_t d = 1; d < cpp; d <<= 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) top[u] = max(top[u], (uint32_t)__shfl_xor((int)top[u], (int)d));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t s = base + (uint32_t)u * NT + tid;
+                if (s < nslots && ic_l == 0) {
+                    const uint32_t p = s / cpp;
+                    const bool block = (lv[u] & grp_mask) == grp_mask && (ft[u] & grp_mask) == grp_mask;
+                    s_pkt[2 * p] = block ? (m[u] | 0x80000000u) : top[u];
+                    if (s_pkm && m[u] / cpp < npo) atomicMax(&s_pkm[m[u] / cpp], (int32_t)p);
+                }
             }
         }
     } else
@@ -682,64 +751,125 @@ __device__ __forceinline__ uint32_t resolve_frame(const Geometry& g, const uint8
             if (live) top = max(top, m + 1u);
             if (BD && ic % BD == 0) fit &= m + BD <= W;
         }
-        s_pkt[2 * p] = first | ((allv && fit) ? 0x80000000u : 0u);
-        s_pkt[2 * p + 1] = top;
+        s_pkt[2 * p] = (allv && fit) ? (first | 0x80000000u) : top;
         if (s_pkm && first / cpp < npo) atomicMax(&s_pkm[first / cpp], (int32_t)p);
     }
     __syncthreads();
-    // ---- B: next_valid before every packet: a serial walk, done by wave 0 on registers (64 packets per round)
-    __shared__ uint32_t s_nv_final;
-    if (tid < 64) {
-        uint32_t nv = 0;
-        for (uint32_t base = 0; base < count; base += 64) {
+    RSTAMP(10);
+    // ---- B: next_valid before every packet.  A block packet moves it to F + cpp when F >= next_valid, a column-path packet
+    // to max(next_valid, M).  Guess: the running maximum of those targets (an exclusive prefix maximum, a parallel scan).
+    // The guess is exact when every block packet either passes its test under the guess or, failing it, has a target the
+    // maximum already covers -- in order, with drops, in any order, with duplicates: always, for packets whose ids are
+    // multiples of cpp.  Anything else walks the packets one by one (wave 0, on registers).
+    __shared__ uint32_t s_nv_final, s_wmax[NT / 64];
+    bool exact = true;
+    {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < count; base += NT) {
             const uint32_t p = base + tid;
-            const uint32_t a0 = p < count ? s_pkt[2 * p] : 0u, a1 = p < count ? s_pkt[2 * p + 1] : 0u;
-            uint32_t mine = 0;
-            const uint32_t n = min(64u, count - base);
-            for (uint32_t k = 0; k < n; ++k) {
-                const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)a0, (int)k);
-                const uint32_t f1 = (uint32_t)__builtin_amdgcn_readlane((int)a1, (int)k);
-                if (tid == k) mine = nv;
-                if (f0 & 0x80000000u) {
-                    const uint32_t first = f0 & 0x7fffffffu;
-                    if (first >= nv) nv = first + cpp;
-                } else {
-                    nv = max(nv, f1);
-                }
+            const uint32_t f0 = p < count ? s_pkt[2 * p] : 0u;
+            const bool blk = (f0 & 0x80000000u) != 0u;
+            const uint32_t first = f0 & 0x7fffffffu, target = blk ? first + cpp : first;
+            uint32_t inc = target;   // inclusive prefix maximum inside my wave
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)inc, d);
+                if (lane >= d) inc = max(inc, y);
             }
-            if (p < count) s_pkt[2 * p + 1] = mine;   // M is not needed any more: next_valid before packet p
+            if (lane == 63) s_wmax[tid >> 6] = inc;
+            __syncthreads();
+            uint32_t before = carry;
+            for (uint32_t w = 0; w < (tid >> 6); ++w) before = max(before, s_wmax[w]);
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, 1u);
+            const uint32_t nv_in = max(before, lane ? up : 0u);
+            if (p < count) {
+                if (blk && first < nv_in && target > nv_in) exact = false;
+                s_pkt[2 * p + 1] = nv_in;
+            }
+            uint32_t all = carry;
+            for (uint32_t w = 0; w < NT / 64; ++w) all = max(all, s_wmax[w]);
+            carry = all;
+            __syncthreads();
         }
-        if (tid == 0) s_nv_final = nv;
+        if (tid == 0) s_nv_final = carry;
     }
-    __syncthreads();
+    if (!__syncthreads_and(exact ? 1 : 0)) {
+        if (tid < 64) {
+            uint32_t nv = 0;
+            for (uint32_t base = 0; base < count; base += 64) {
+                const uint32_t p = base + tid;
+                const uint32_t a0 = p < count ? s_pkt[2 * p] : 0u;
+                uint32_t mine = 0;
+                const uint32_t n = min(64u, count - base);
+                for (uint32_t k = 0; k < n; ++k) {
+                    const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)a0, (int)k);
+                    if (tid == k) mine = nv;
+                    if (f0 & 0x80000000u) {
+                        const uint32_t first = f0 & 0x7fffffffu;
+                        if (first >= nv) nv = first + cpp;
+                    } else {
+                        nv = max(nv, f0);
+                    }
+                }
+                if (p < count) s_pkt[2 * p + 1] = mine;
+            }
+            if (tid == 0) s_nv_final = nv;
+        }
+        __syncthreads();
+    }
+    // s_pkt[2p] bit 31: block path; s_pkt[2p + 1] = next_valid before packet p
+    RSTAMP(11);
     // ---- C: the zeroed ranges a packet triggers and the columns it writes (one lane per slot, or one thread per packet)
     if (lanes) {
-        for (uint32_t base = 0; base < nslots; base += NT) {
-            const uint32_t s = base + tid;
-            const bool in = s < nslots;
-            const uint32_t h = in ? s_hd[s] : 0u, m = h & 0xffffu, p = s / cpp;
-            const bool live = in && (h >> 16) && m < W;
-            const bool block = in && (s_pkt[2 * p] & 0x80000000u) != 0u;
-            const uint32_t nv_in = in ? s_pkt[2 * p + 1] : 0u;
-            const uint32_t block_first = (uint32_t)__shfl((int)m, (int)(lane - ic_l % BD));
-            // column path: next_valid before my column = max(before the packet, the live columns before me in it)
-            uint32_t pre = live ? m + 1u : 0u;
-            for (uint32_t d = 1; d < cpp; d <<= 1) {
-                const uint32_t y = (uint32_t)__shfl_up((int)pre, d, (int)cpp);
-                if (ic_l >= d) pre = max(pre, y);
+        for (uint32_t base = 0; base < nslots; base += NT * U) {
+            uint32_t m[U], nvb[U], bf[U];
+            uint32_t flags[U];   // 1 in, 2 live, 4 block path
+            bool anycol = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t s = base + (uint32_t)u * NT + tid;
+                const bool in = s < nslots;
+                const uint32_t h = in ? s_hd[s] : 0u, p = s / cpp;
+                m[u] = h & 0xffffu;
+                const bool live = in && (h >> 16) && m[u] < W;
+                const bool block = in && (s_pkt[2 * p] & 0x80000000u) != 0u;
+                nvb[u] = in ? s_pkt[2 * p + 1] : 0u;
+                flags[u] = (in ? 1u : 0u) | (live ? 2u : 0u) | (block ? 4u : 0u);
+                anycol |= __ballot(in && !block) != 0ull;
+                bf[u] = (uint32_t)__shfl((int)m[u], (int)(lane - ic_l % BD));
             }
-            const uint32_t excl = (uint32_t)__shfl_up((int)pre, 1u, (int)cpp);
-            const uint32_t nvb = max(nv_in, ic_l ? excl : 0u);
-            if (block) {
-                if (ic_l == 0 && m >= nv_in)
-                    for (uint32_t c = nv_in; c < m; ++c) s_z[c] = (int32_t)s;
-                atomicMax(&s_hdr[m], (int32_t)s);
-                atomicMax(&s_pix[block_first + ic_l % BD], (int32_t)s);
-            } else if (live) {
-                if (m >= nvb)
-                    for (uint32_t c = nvb; c < m; ++c) s_z[c] = (int32_t)s;
-                atomicMax(&s_hdr[m], (int32_t)s);
-                atomicMax(&s_pix[m], (int32_t)s);
+            if (anycol) {
+                // column path: next_valid before my column = max(before the packet, the live columns before me in it)
+                uint32_t pre[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) pre[u] = (flags[u] & 2u) ? m[u] + 1u : 0u;
+                for (uint32_t d = 1; d < cpp; d <<= 1) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t y = (uint32_t)__shfl_up((int)pre[u], d, (int)cpp);
+                        if (ic_l >= d) pre[u] = max(pre[u], y);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t excl = (uint32_t)__shfl_up((int)pre[u], 1u, (int)cpp);
+                    if (!(flags[u] & 4u)) nvb[u] = max(nvb[u], ic_l ? excl : 0u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int32_t s = (int32_t)(base + (uint32_t)u * NT + tid);
+                if (flags[u] & 4u) {
+                    if (ic_l == 0 && m[u] >= nvb[u])
+                        for (uint32_t c = nvb[u]; c < m[u]; ++c) s_z[c] = s;
+                    atomicMax(&s_hdr[m[u]], s);
+                    atomicMax(&s_pix[bf[u] + ic_l % BD], s);
+                } else if (flags[u] & 2u) {
+                    if (m[u] >= nvb[u])
+                        for (uint32_t c = nvb[u]; c < m[u]; ++c) s_z[c] = s;
+                    atomicMax(&s_hdr[m[u]], s);
+                    atomicMax(&s_pix[m[u]], s);
+                }
             }
         }
     } else
@@ -768,6 +898,7 @@ __device__ __forceinline__ uint32_t resolve_frame(const Geometry& g, const uint8
         }
     }
     __syncthreads();
+    RSTAMP(12);
     const uint32_t nv_final = s_nv_final;
     for (uint32_t c = tid; c < W; c += NT) {
         const int32_t z = s_z[c];
@@ -775,6 +906,7 @@ __device__ __forceinline__ uint32_t resolve_frame(const Geometry& g, const uint8
         if (s_pix[c] < z || c >= nv_final) s_pix[c] = -1;
     }
     __syncthreads();
+    RSTAMP(13);
     return nv_final;
 }
 

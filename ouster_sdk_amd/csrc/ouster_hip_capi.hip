@@ -80,7 +80,10 @@ struct Knobs {
     int dewarp_single_pass = 0;  // OUSTER_HIP_DWF_SINGLE: 1 = k_dwf_single instead of count / scan / emit (slower)
     int beam_lds = 1;         // OUSTER_HIP_BEAM_LDS: 0 keeps k_decode's per-beam table in global memory (A/B)
     int fixup = 1;            // tests only: 0 skips the fix-up pass (flagged frames are then left undone)
-    int small = 1;            // OUSTER_HIP_SMALL: 0 = small batches stay on the optimistic pass + fix-up pass (k_decode's narrow tiles)
+    int small = 1;            // OUSTER_HIP_SMALL: small batches: 1 = wide tiles of few rows (optimistic pass + fix-up pass; any other buffer shape: the
+                              //   one-launch k_decode_wide_resolved) | 2 = the one-launch form always | 0 = k_decode's narrow tiles as in r03
+    int fixup_rows = 0;       // OUSTER_HIP_FIXUP_ROWS: rows of a fix-up tile (0: 8)
+    int hdr_words = 1;        // OUSTER_HIP_HDR_WORDS: 0 = the fix-up pass reads the column headers from the packets again (A/B)
     int fixup_wide = 1;       // OUSTER_HIP_FIXUP_WIDE: 1 = the fix-up pass on wide tiles where the format allows | 0 = 64-column tiles | 64 / 128 / 256 force
     int stream = -1;          // OUSTER_HIP_STREAM: -1 auto | 0 never | 128 / 256 force k_decode_stream with that tile width when eligible
     int stream_rows = 0;      // OUSTER_HIP_STREAM_ROWS: force the rows of a streamed tile (experiments)
@@ -96,7 +99,7 @@ struct ouster_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf state, tile_valid, offsets, luts, counts, scratch, slotmap;
+    DevBuf state, tile_valid, offsets, luts, counts, scratch, slotmap, hdrw;
     uint32_t resident_wgs = 512;         // 2 workgroups (80 KB LDS each) per CU
     uint32_t cus = 256;                  // compute units (k_decode_stream: one persistent workgroup each)
     const char* last_kernel = "";        // name of the decode kernel the last ouster_hip_decode launched
@@ -302,6 +305,8 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.slotmap = env_int("OUSTER_HIP_SLOTMAP", k.slotmap);
         k.fixup_wide = env_int("OUSTER_HIP_FIXUP_WIDE", k.fixup_wide);
         k.small = env_int("OUSTER_HIP_SMALL", k.small);
+        k.hdr_words = env_int("OUSTER_HIP_HDR_WORDS", k.hdr_words);
+        k.fixup_rows = env_int("OUSTER_HIP_FIXUP_ROWS", k.fixup_rows);
     }
     if (stream == OUSTER_HIP_STREAM_NULL) {
         c->stream = nullptr;  // the null stream
@@ -334,6 +339,7 @@ void ouster_hip_ctx_destroy(ouster_hip_ctx* c) {
     c->counts.release();
     c->scratch.release();
     c->slotmap.release();
+    c->hdrw.release();
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -375,6 +381,8 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "fixup") k.fixup = value;
     else if (n == "fixup_wide") k.fixup_wide = value;
     else if (n == "small") k.small = value;
+    else if (n == "hdr_words") k.hdr_words = value;
+    else if (n == "fixup_rows") k.fixup_rows = value;
     else if (n == "beam_lds") k.beam_lds = value;
     else if (n == "dewarp_single_pass") k.dewarp_single_pass = value;
     else if (n == "stream") k.stream = value;
@@ -708,7 +716,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // itself), destagger offsets, LUT descriptors, packet counts
     {
         const void* before = ctx->state.p;
-        if (ctx->state.ensure(((size_t)n_frames + FS_WORDS) * 8)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(state) failed");
+        if (ctx->state.ensure(((size_t)2 * n_frames + FS_WORDS) * 8)) return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(state) failed");
         if (ctx->state.p != before || ctx->state_dirty) HIP_TRY(hipMemsetAsync(ctx->state.p, 0, ctx->state.cap, st));
         ctx->state_dirty = fast_possible(kn, slots_per_frame, g);  // until the fix-up pass has been queued
     }
@@ -762,6 +770,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     da.packet_counts = d_counts;
     da.host_timestamps = host_timestamps;
     da.frame_state = (uint64_t*)ctx->state.p;
+    da.ready_off = FS_WORDS + (uint32_t)((ctx->state.cap / 8 - FS_WORDS) / 2);   // the second half of the buffer: moves only when it is reallocated (and zeroed)
     if (out->xyz_poses && xyzm == 3)
         return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "xyz_poses need LUTs with separable tables (ouster_hip_lut_create)");
     da.xyz_poses = xyzm ? out->xyz_poses : nullptr;
@@ -776,6 +785,8 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         const char* e = getenv("OUSTER_HIP_PHASE_BUF");
         da.phase_times = e ? (uint64_t*)strtoull(e, nullptr, 0) : nullptr;
     }
+    uint64_t* const phase_times_all = da.phase_times;
+    if (getenv("OUSTER_HIP_PHASE_FIXUP_ONLY")) da.phase_times = nullptr;   // only the fix-up pass stamps
 #endif
     da.dst_offsets = (const int32_t*)ctx->offsets.p;
     da.luts = (const LutDev*)ctx->luts.p;
@@ -883,6 +894,13 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             const uint32_t need = (want_blocks + n_frames * tiles - 1) / (n_frames * tiles);   // row chunks for that many workgroups
             tr = std::max(rpp, std::min(tr, H / std::max(need, 1u) / rpp * rpp));
         }
+        if (for_fix) {
+            // short tiles: the (few) flagged frames of a batch spread over a whole XCD instead of keeping a handful of
+            // workgroups busy for a full-height tile each (tools/ab/fixup_prof.sh: 57 us for ONE flagged frame with 32-row tiles)
+            const uint32_t rows = kn.fixup_rows > 0 ? (uint32_t)kn.fixup_rows : 8u;
+            tr = std::max(rpp, std::min(tr, up(rows)));
+            if (tiles > 32) return false;   // the frame's ready word carries one bit per column tile
+        }
         if (kn.wide_rows > 0) tr = std::min((uint32_t)kn.wide_rows, H);
         if (tr > 84) return false;   // k_decode_wide keeps a row chunk's table rows in registers (3 doubles per thread) while its tile loads
         nch = (H + tr - 1) / tr;
@@ -987,16 +1005,23 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     int stream_auto = 0;   // tile width of the persistent candidate (0: not eligible)
     // Small batches (one tick of a few sensors, a single frame): one launch, every wide tile resolves its frame's column maps
     // itself -- neither an optimistic pass nor a second launch, whatever the buffer looks like.
-    bool resolved = false;
+    // Measured (tools/ab/small_batch.py, 4 x 128 x 2048 dual return): optimistic wide tiles of 8 rows + the fix-up launch 27 us
+    // per call, k_decode's 16-column tiles + fix-up 33 us, the one-launch form 35 us (its workgroups resolve the frame
+    // before they can start: 14 us against the 3 us a second launch costs).  So: a buffer with one slot per column takes the
+    // optimistic wide tiles, any other shape the one-launch form (kn.small = 2 forces it for both).
+    bool resolved = false, small_wide = false;
     if (kn.small && kn.stream <= 0 && kn.wide < 0 && kn.tile == 0 && kn.fast) {
         for (int tw : {256, 128, 64})
             if (W >= (uint32_t)tw || tw == 64) {
-                resolved = setup_wide(tw, false, true);
-                if (resolved) wide = tw;
+                if (setup_wide(tw, false, true)) {
+                    wide = tw;
+                    resolved = !fast || kn.small == 2;
+                    small_wide = !resolved;
+                }
                 break;
             }
     }
-    if (resolved) {
+    if (resolved || small_wide) {
         // nothing else to choose
     } else if (kn.stream > 0) {
         if (setup_stream(kn.stream)) stream = kn.stream;
@@ -1008,7 +1033,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     }
     ouster_hip_ctx::Tune* tuning = nullptr;
     int tune_slot = -1;
-    if (stream || resolved) {
+    if (stream || resolved || small_wide) {
         // forced / nothing to choose
     } else if (kn.wide >= 0) {  // forced (experiments, tests)
         if (kn.wide && setup_wide(kn.wide)) wide = kn.wide;
@@ -1091,6 +1116,10 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         da.rows_per_tile = da.row_chunks = da.lds_col_slot = 0;
         da.tiles_per_frame = narrow_tiles;
     }
+    if (fast && kn.fixup && !resolved && kn.hdr_words) {   // the optimistic pass leaves the packed column ids for the fix-up pass
+        if (ctx->hdrw.ensure((size_t)n_frames * W * sizeof(uint32_t))) return fail(OUSTER_HIP_ERR_RUNTIME, "out of device memory (header words)");
+        da.hdr_words = (uint32_t*)ctx->hdrw.p;
+    }
     da.xcd_map = (kn.xcd && n_frames >= 8) ? 1u : 0u;
     da.mode = resolved ? MODE_RESOLVED : fast ? MODE_FAST : MODE_GENERAL;
     if (resolved) ctx->state_dirty = false;   // this call leaves the frame words alone
@@ -1142,6 +1171,9 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         // maps and redone where those differ from "slot c holds column c"; the workgroups of a clean batch leave after one
         // read of the flags.  Wide tiles (k_decode_wide_fixup) where the format allows them, 64-column tiles otherwise.
         da.mode = MODE_FIXUP;
+#ifdef OUSTER_PHASE_TIMING
+        da.phase_times = phase_times_all;
+#endif
         da.fast_tiles = da.tiles_per_frame;    // column tiles of the pass above (slots of tile_valid)
         int fix_wide = 0;
         if (kn.fixup_wide && kn.tile == 0) {
@@ -1150,7 +1182,10 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             else if (setup_wide(128, true)) fix_wide = 128;
             else if (setup_wide(256, true)) fix_wide = 256;
         }
+        if (fix_wide && ctx->slotmap.ensure((size_t)n_frames * W * sizeof(int32_t) * 2)) fix_wide = 0;
         if (fix_wide) {
+            da.slot_map = (int32_t*)ctx->slotmap.p;
+            da.hdr_map = da.slot_map + (size_t)n_frames * W;
             HIP_TRY(launch_decode_wide(da, spec, fix_wide, xyzm, ctx->device, st, ctx->resident_wgs));
         } else {
             da.rows_per_tile = 0;

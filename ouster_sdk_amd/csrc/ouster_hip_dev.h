@@ -91,6 +91,10 @@ struct DecodeArgs {
                               //   (-1: none), k_decode_wide takes its source columns from it instead of "slot c holds column c"
     int32_t* hdr_map;         // device [n_frames][W], with slot_map: the slot whose HEADER lands in destination column c (differs from
                               //   slot_map only for all-valid packets with non-consecutive ids: the reference's block path)
+    uint32_t ready_off;       // frame_state word index of the fix-up pass's per-frame ready words (k_decode_wide_fixup)
+    uint32_t* hdr_words;      // device [n_frames][W] or nullptr.  The optimistic pass leaves every slot's (measurement_id | valid << 16)
+                              //   here, packed: the fix-up pass resolves a flagged frame from 8 KB of consecutive words instead of
+                              //   2048 column headers a kilobyte apart (7 us of a workgroup's address unit per tile)
     uint32_t wide_img_words;  // k_decode_wide: LDS words of the tile image (set by the launcher; the fix-up pass keeps resolve_frame's scratch there)
     uint32_t fast_tiles;      // fix-up pass: column tiles of the optimistic pass before it (slots of tile_valid per frame)
     const double* xyz_poses;  // device [n_frames][W][16] or nullptr: per-column pose applied to the xyz outputs

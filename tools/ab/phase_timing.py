@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 wl = sys.argv[1] if len(sys.argv) > 1 else "single"
 NWG = 1 << 16
-buf = torch.zeros((NWG, 8), dtype=torch.int64, device="cuda")
+buf = torch.zeros((NWG, 16), dtype=torch.int64, device="cuda")
 os.environ["OUSTER_HIP_PHASE_BUF"] = hex(buf.data_ptr())
 os.environ.setdefault("OUSTER_HIP_WIDE", "128")
 import bench

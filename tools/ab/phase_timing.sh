@@ -10,6 +10,7 @@ if [ "$1" = build ]; then
   mkdir -p $O
   F="--offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result -DOUSTER_PHASE_TIMING"
   for i in 0 1 2 3 4 5; do hipcc $F -DOUSTER_SPEC_ID=$i -c -o $O/k_decode_$i.o ouster_sdk_amd/csrc/k_decode.hip & done
+  for i in 1 2 3 4 5; do hipcc $F -DOUSTER_SPEC_ID=$i -c -o $O/k_decode_stream_$i.o ouster_sdk_amd/csrc/k_decode_stream.hip & done
   hipcc $F -c -o $O/k_standalone.o ouster_sdk_amd/csrc/k_standalone.hip &
   hipcc $F -c -o $O/capi.o ouster_sdk_amd/csrc/ouster_hip_capi.hip &
   wait
