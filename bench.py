@@ -168,6 +168,27 @@ def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 12.0):
     rf = max(1, reps // 3)
     tf = run(rf, 1, False)
     res["f32_variant"] = {"value": n * rf * H * W * 2 / tf / 1e6, "cores": 1}
+    # the destagger and cartesian legs by the REFERENCE's own loops (impl/cartesian.h, destagger_into<T> compiled from
+    # /root/reference into oracle/_ref/libcore_ref.so, oracle/Makefile) on planes the oracle decoded, one core
+    try:
+        from oracle import core_ref
+        if core_ref.available():
+            fr = O.Frame.for_profile(cal.profile, H, W, CPP, with_window=True)
+            O.batch_frame(pf, pool[0], fr, init_id=O.lib().ora_init_id(C.byref(pf), pool[0][0].ctypes.data))
+            dst = [fr.plane(nm) for nm in DESTAGGERED]
+            rng = [fr.plane("RANGE"), fr.plane("RANGE2")]
+            td, tc = core_ref.bench_frame_legs(dst, rng, ldir, lofs, sh, 2)
+            rr = max(2, int(3.0 / max(td + tc, 1e-3) * 2))
+            td, tc = core_ref.bench_frame_legs(dst, rng, ldir, lofs, sh, rr)
+            res["reference_legs"] = {
+                "kind": "reference", "cores": 1, "sample": f"1 frame x {rr} passes",
+                "destagger_x4_Mpixels_per_s": round(4 * H * W * rr / td / 1e6, 1),
+                "cartesian_f64_x2_Mpoints_per_s": round(2 * H * W * rr / tc / 1e6, 1),
+                "destagger_plus_cartesian_Mpoints_per_s": round(2 * H * W * rr / (td + tc) / 1e6, 1),
+                "what": "destagger_into<T> x4 + cartesianT<double> x2 of the reference itself (oracle/_ref/libcore_ref.so); "
+                        "the packet decode leg of `value` above is the oracle's port of FrameBatcher"}
+    except Exception as e:   # the reference legs are optional evidence; the port's number stands on its own
+        res["reference_legs"] = {"error": str(e)[:200]}
     # the same algorithmic byte count as the GPU leg: bytes/s next to points/s
     bpp = algorithmic_bytes_per_frame("dual") / (H * W * 2)
     res["GBps"] = res["value"] * 1e6 * bpp / 1e9

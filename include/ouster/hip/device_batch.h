@@ -42,14 +42,16 @@ struct BatchOptions {
     /// the gated RANGE pixels per column (they are in registers there) and dewarp(min, max) with the same
     /// gate skips its counting pass over the RANGE planes.
     double gate_min_range = 0.0, gate_max_range = -1.0;
-    /// Large batches (>= 64 frames) settle WHERE their output buffers live when they are constructed: one
+    /// Opt-in (round 4: off by default -- a library object that transiently takes tens of GB of a shared GPU must be asked to):
+    /// batches of >= 64 frames settle WHERE their output buffers live when they are constructed, one
     /// DeviceFrameBatch::refine_placement(placement_draws, nullptr, placement_ballast_bytes) on an all-zero packet
-    /// buffer (same store pattern): 0.1 - 0.6 s and a transient (draws - 1) x (output set + ballast), about 35 GB for
-    /// 256 dual-return frames.  Pointers handed out afterwards stay valid for the life of the batch.
-    /// placement_ballast_bytes = 0 with 3 draws is the footprint-frugal form (it finds a fast place about every other time).
-    bool auto_placement = true;
-    int placement_draws = 4;
-    size_t placement_ballast_bytes = size_t{8} << 30;
+    /// buffer (same store pattern): 0.1 - 0.6 s and a transient (draws - 1) x (output set + ballast) -- two more output
+    /// sets with the defaults, about 35 GB for 256 dual-return frames with 4 draws 8 GB apart (which finds a fast place
+    /// more often: DESIGN.md 3.2c).  A draw is skipped when it would take more than three quarters of the free device
+    /// memory.  Pointers handed out afterwards stay valid for the life of the batch.
+    bool auto_placement = false;
+    int placement_draws = 3;
+    size_t placement_ballast_bytes = 0;
     int device = -1;                      ///< GPU to work on (-1: hip::current_device() of the constructing thread)
     std::shared_ptr<Context> context;     ///< share this context (stream + scratch) instead of owning one
 };
@@ -76,6 +78,12 @@ class DeviceFrameBatch {
         const uint32_t p = pf_.col_measurement_id(pf_.nth_col(0, lidar_packet)) / pf_.columns_per_packet;
         return p < slots_ ? static_cast<int>(p) : -1;
     }
+    /** Put a lidar packet into a staging slot (at least lidar_packet_size bytes).  An empty slot takes the packet as it
+     *  is.  A slot that already holds a packet -- the same packet sent again -- is merged the way the reference ends up
+     *  after batching both (parse_by_col, lidar_frame.cpp:1422-1466): every valid, in-range column of the later packet
+     *  replaces the earlier one's, the others stay; the packet-level bytes (header, footer: alert flags, timestamps) are the
+     *  later packet's (batch_lidar_packet :1534-1539). */
+    void stage_packet(uint8_t* slot, bool occupied, const uint8_t* lidar_packet) const;
     uint32_t n_frames() const { return n_frames_; }
     size_t packet_stride() const { return stride_; }
     uint32_t slots_per_frame() const { return slots_; }

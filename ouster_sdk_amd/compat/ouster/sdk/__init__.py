@@ -1,4 +1,5 @@
-"""`ouster.sdk` for the reference's Python tests: the sub-packages this repo can stand behind."""
+"""`ouster.sdk`: the sub-packages of the reference's Python SDK this repo stands behind (core, pcap; util / sensor only as far
+as the hot path's callers need the names)."""
 from . import core  # noqa: F401
 from . import pcap  # noqa: F401
 

@@ -1,4 +1,4 @@
-"""`ouster.sdk.core` for the reference's Python tests: ouster_sdk_amd.core re-exported under the reference's names,
+"""`ouster.sdk.core`: ouster_sdk_amd.core re-exported under the reference's names (python/src/ouster/sdk/core/__init__.py),
 plus the three things that are Python-side in the reference too: SensorInfo(json), stagger(), Packets."""
 from ouster_sdk_amd.core import *  # noqa: F401,F403
 from ouster_sdk_amd import core as _core

@@ -102,15 +102,33 @@ DeviceFrameBatch::~DeviceFrameBatch() {
     if (fmt_) ouster_hip_format_destroy(fmt_);
 }
 
+void DeviceFrameBatch::stage_packet(uint8_t* slot, bool occupied, const uint8_t* pkt) const {
+    if (!occupied) {
+        std::memcpy(slot, pkt, pf_.lidar_packet_size);
+        return;
+    }
+    const size_t cols_end = pf_.packet_header_size + static_cast<size_t>(pf_.columns_per_packet) * pf_.col_size;
+    std::memcpy(slot, pkt, pf_.packet_header_size);
+    std::memcpy(slot + cols_end, pkt + cols_end, pf_.lidar_packet_size - cols_end);
+    for (int ic = 0; ic < pf_.columns_per_packet; ++ic) {
+        const uint8_t* col = pf_.nth_col(ic, pkt);
+        if ((pf_.col_status(col) & 0x01) != 0u && pf_.col_measurement_id(col) < w_)
+            std::memcpy(slot + (col - pkt), col, pf_.col_size);
+    }
+}
+
 void DeviceFrameBatch::upload_frame_packets(uint32_t frame, const std::vector<const uint8_t*>& packets) {
     ScopedContext on_my_context(ctx_);
     if (frame >= n_frames_) throw std::out_of_range("DeviceFrameBatch: frame index");
-    // every packet goes to its home slot (a later duplicate replaces the earlier one, as the packet
-    // batched later overwrites in the reference); slots without a packet are zero = invalid columns
+    // every packet goes to its home slot (a packet sent twice is merged column by column, stage_packet); slots
+    // without a packet are zero = invalid columns
     std::vector<uint8_t> staging(static_cast<size_t>(slots_) * stride_, 0);
+    std::vector<bool> have(slots_, false);
     for (const uint8_t* pkt : packets) {
         const int p = home_slot(pkt);
-        if (p >= 0) std::memcpy(staging.data() + static_cast<size_t>(p) * stride_, pkt, pf_.lidar_packet_size);
+        if (p < 0) continue;
+        stage_packet(staging.data() + static_cast<size_t>(p) * stride_, have[static_cast<size_t>(p)], pkt);
+        have[static_cast<size_t>(p)] = true;
     }
     d_packets_.upload(staging.data(), staging.size(), static_cast<size_t>(frame) * slots_ * stride_);
     counts_[frame] = slots_;
@@ -228,6 +246,7 @@ double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms, 
         try {
             cand = fresh();
         } catch (const std::exception&) {   // out of device memory: choose among the draws made so far
+            (void)hipGetLastError();        // ... and do not leave the failed hipMalloc behind as the runtime's last error
             break;
         }
         exchange(cand);                  // members = candidate, cand = incumbent
@@ -240,6 +259,7 @@ double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms, 
             try {
                 rejected_packets.emplace_back(ballast_bytes);
             } catch (const std::exception&) {
+                (void)hipGetLastError();
                 break;
             }
         }
@@ -317,7 +337,15 @@ double DeviceFrameBatch::refine_placement(int draws, std::vector<double>* all_ms
     // draws - 1 further copies of the whole output set, `ballast_bytes` of device memory apart: copies[c][g][i]
     std::vector<std::vector<std::vector<DeviceBuffer>>> copies;
     std::vector<DeviceBuffer> ballast;
+    size_t set_bytes = 0;
+    for (const auto& grp : groups)
+        for (const DeviceBuffer* b : grp) set_bytes += b->size();
     for (int d = 1; d < draws; ++d) {
+        // never take the device to its last byte: a draw needs its copy of the output set plus the ballast, and a quarter
+        // of what is free stays free for whoever else uses this GPU
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (set_bytes + ballast_bytes > free_b - free_b / 4) break;
         try {
             if (ballast_bytes) ballast.emplace_back(ballast_bytes);
             std::vector<std::vector<DeviceBuffer>> set(groups.size());
@@ -327,6 +355,7 @@ double DeviceFrameBatch::refine_placement(int draws, std::vector<double>* all_ms
             }
             copies.push_back(std::move(set));
         } catch (const std::exception&) {
+            (void)hipGetLastError();   // the failed hipMalloc must not surface as the next launch's error
             break;   // out of device memory: decide among what has been drawn
         }
     }

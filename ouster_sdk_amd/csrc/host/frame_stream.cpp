@@ -116,13 +116,13 @@ void FrameStream::push_frame(const std::vector<const uint8_t*>& lidar_packets) {
     uint8_t* base = static_cast<uint8_t*>(s.packets.p) +
                     static_cast<size_t>(s.filled) * bt.slots_per_frame() * bt.packet_stride();
     // home slots: packet p of the frame in slot p, so the decode pass needs no mapping even when
-    // packets were lost (holes stay zero = invalid columns); a later duplicate replaces the earlier
-    // packet, a packet outside the frame is dropped
+    // packets were lost (holes stay zero = invalid columns); a packet sent twice is merged column by
+    // column (DeviceFrameBatch::stage_packet), a packet outside the frame is dropped
     std::vector<bool> have(bt.slots_per_frame(), false);
     for (const uint8_t* pkt : lidar_packets) {
         const int p = bt.home_slot(pkt);
         if (p < 0) continue;
-        std::memcpy(base + static_cast<size_t>(p) * bt.packet_stride(), pkt, bt.lidar_packet_size());
+        bt.stage_packet(base + static_cast<size_t>(p) * bt.packet_stride(), have[static_cast<size_t>(p)], pkt);
         have[static_cast<size_t>(p)] = true;
     }
     for (size_t p = 0; p < have.size(); ++p)

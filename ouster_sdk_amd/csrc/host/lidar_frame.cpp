@@ -290,7 +290,8 @@ void copy_and_cast(Field& dst, const Field& src) {
 
 // lidar_frame.cpp:361-401
 LidarFrame::LidarFrame(const LidarFrame& other, const LidarFrameFieldTypes& fields)
-    : w(other.w), h(other.h), frame_id(other.frame_id), frame_status(other.frame_status),
+    // a frame still being assembled decodes what has arrived first (the reference parses eagerly: its copy is consistent)
+    : w((other.sync_(), other.w)), h(other.h), frame_id(other.frame_id), frame_status(other.frame_status),
       shutdown_countdown(other.shutdown_countdown), shot_limiting_countdown(other.shot_limiting_countdown),
       sensor_info(other.sensor_info), timestamp_(other.timestamp_), measurement_id_(other.measurement_id_),
       status_(other.status_), packet_timestamp_(other.packet_timestamp_), body_to_world_(other.body_to_world_),

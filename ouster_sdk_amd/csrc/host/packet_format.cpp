@@ -451,9 +451,11 @@ struct PacketFormat::Impl {
             throw std::invalid_argument("lidar_packet_size cannot exceed 65535");
         // parsing.cpp:540-596: legacy IMU packets are 48 bytes; the newer profile frames a 100-byte NMEA block and 36-byte
         // measurements between header and footer; a zone packet carries 8 + 32 bytes and sixteen 36-byte zone records
-        imu_packet_size = fmt.udp_profile_imu == UDPProfileIMU::LEGACY
-                              ? 48
-                              : packet_header_size + 100 + fmt.imu_measurements_per_packet * 36 + packet_footer_size;
+        // (any other imu profile -- OFF -- leaves the size at 0: no datagram is taken for an IMU packet)
+        imu_packet_size = fmt.udp_profile_imu == UDPProfileIMU::LEGACY ? 48
+                          : fmt.udp_profile_imu == UDPProfileIMU::ACCEL32_GYRO32_NMEA
+                              ? packet_header_size + 100 + fmt.imu_measurements_per_packet * 36 + packet_footer_size
+                              : 0;
         zone_packet_size = packet_header_size + 8 + 32 + 36 * 16 + packet_footer_size;
         for (const auto& kv : e.fields) fields.emplace(kv.first, kv.second);
         max_frame_id = fmt.max_frame_id();

@@ -64,11 +64,14 @@ ShardedBatch::ShardedBatch(const std::vector<SensorInfo>& sensors, uint32_t n_fr
         if (devices_[i] != root_) {
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, devices_[i], root_) == hipSuccess && can) {
+                int before = 0;
+                const bool restore = hipGetDevice(&before) == hipSuccess;
                 (void)hipSetDevice(devices_[i]);
                 (void)hipDeviceEnablePeerAccess(root_, 0);
                 (void)hipSetDevice(root_);
                 (void)hipDeviceEnablePeerAccess(devices_[i], 0);
                 (void)hipGetLastError();   // "already enabled" is fine
+                if (restore) (void)hipSetDevice(before);   // the calling thread keeps its device
             }
         }
     }
@@ -103,9 +106,12 @@ void ShardedBatch::upload_frame_packets(uint32_t frame, const std::vector<const 
     DeviceFrameBatch& any = *shards_[0];
     const size_t stride = any.packet_stride();
     std::vector<uint8_t> staging(frame_packet_bytes_, 0);
+    std::vector<bool> have(any.slots_per_frame(), false);
     for (const uint8_t* pkt : packets) {
         const int p = any.home_slot(pkt);
-        if (p >= 0) std::memcpy(staging.data() + static_cast<size_t>(p) * stride, pkt, any.lidar_packet_size());
+        if (p < 0) continue;
+        any.stage_packet(staging.data() + static_cast<size_t>(p) * stride, have[static_cast<size_t>(p)], pkt);
+        have[static_cast<size_t>(p)] = true;
     }
     ScopedContext on_root(root_ctx_);
     d_packets_root_.upload(staging.data(), staging.size(), static_cast<size_t>(frame) * frame_packet_bytes_);

@@ -28,7 +28,7 @@ def sensor_info_from_json(text: str):
         si = d.get("sensor_info", {})
         l2s = d.get("lidar_intrinsics", {}).get("lidar_to_sensor_transform")
         cfg = d.get("config_params", {})
-        header_type = cfg.get("header_type")
+        header_type = df.get("header_type") or cfg.get("header_type")   # metadata.cpp:545-555 reads lidar_data_format first
     else:
         df, bi, si, cfg = d.get("data_format", {}), d, d, d
         l2s = d.get("lidar_to_sensor_transform")

@@ -904,6 +904,9 @@ static void test_device_batch() {
     std::vector<double> gdraws;
     const double gkept = batch.refine_placement(3, &gdraws, size_t{64} << 20);
     CHECK(gdraws.size() == 9 && gkept > 0 && gkept * 1e3 <= *std::min_element(gdraws.begin(), gdraws.end()) + 1e-9);
+    // more ballast than the device has: every further draw is skipped (no allocation is attempted), the batch stays usable
+    std::vector<double> hdraws;
+    CHECK(batch.refine_placement(3, &hdraws, size_t{1} << 44) > 0 && hdraws.size() == 1);
     batch.decode();
     XYZLut luts[2] = {XYZLut(a, true), XYZLut(b, true)};
     bool planes_ok = true, dst_ok = true;
@@ -1005,6 +1008,78 @@ static void test_device_batch() {
 }
 
 // host packets in, host results out, batches overlapping on the copy / compute / copy streams
+// a packet sent twice whose copies disagree about which columns are valid: the reference batches both, column by column
+// (parse_by_col, lidar_frame.cpp:1422-1466); the staging of DeviceFrameBatch / FrameStream merges them the same way
+static void test_resent_packet_is_merged() {
+    std::printf("DeviceFrameBatch: a re-sent packet is merged column by column\n");
+    auto info = make_info(UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, HeaderType::STANDARD, 64, 512);
+    auto pf = std::make_shared<PacketFormat>(info);
+    LidarFrame fa(info), fb(info);
+    randomize(fa, *pf, 7);
+    randomize(fb, *pf, 8);
+    auto pa = impl::frame_to_packets(fa, pf, info.init_id, info.sn);
+    auto pb = impl::frame_to_packets(fb, pf, info.init_id, info.sn);
+    const size_t dup = 12;
+    std::vector<uint8_t> first = pa[dup].buf, second = pb[dup].buf;
+    std::memcpy(second.data(), first.data(), pf->packet_header_size);   // same frame id / init id
+    auto set_valid = [&](std::vector<uint8_t>& pkt, int ic, bool v) {
+        uint8_t* st = pkt.data() + pf->packet_header_size + static_cast<size_t>(ic) * pf->col_size + 10;
+        *st = v ? (*st | 1) : (*st & 0xFE);
+    };
+    for (int ic = 0; ic < 16; ++ic) {
+        set_valid(first, ic, ic < 8);
+        set_valid(second, ic, ic >= 4 && ic < 12);
+    }
+    std::vector<const uint8_t*> ptrs;
+    for (size_t i = 0; i < pa.size(); ++i) ptrs.push_back(i == dup ? first.data() : pa[i].buf.data());
+    ptrs.push_back(second.data());   // arrives last
+    // what the reference's batcher leaves behind (this mirror's host state machine, itself checked against the reference's
+    // frame_batcher_test): the second copy's valid columns over the first's
+    img_t<uint32_t> want(64, 512);
+    std::memcpy(want.data(), fa.field("RANGE").get(), want.size() * 4);
+    const uint32_t* rb = static_cast<const uint32_t*>(fb.field("RANGE").get());
+    for (size_t r = 0; r < 64; ++r)
+        for (size_t ic = 0; ic < 16; ++ic) {
+            const size_t c = dup * 16 + ic;
+            if (ic >= 4 && ic < 12) want(r, c) = rb[r * 512 + c];
+            else if (ic >= 12) want(r, c) = 0;
+        }
+    ouster::sdk::hip::BatchOptions opt;
+    opt.auto_placement = false;
+    ouster::sdk::hip::DeviceFrameBatch batch(info, 2, opt);
+    batch.upload_frame_packets(0, ptrs);
+    std::vector<const uint8_t*> clean;
+    for (auto& p : pa) clean.push_back(p.buf.data());
+    batch.upload_frame_packets(1, clean);
+    batch.decode();
+    img_t<uint32_t> got(64, 512), got1(64, 512);
+    batch.download_plane("RANGE", 0, got.data());
+    batch.download_plane("RANGE", 1, got1.data());
+    CHECK(got == want);
+    CHECK(std::memcmp(got1.data(), fa.field("RANGE").get(), got1.size() * 4) == 0);
+    // and the same through the streaming front end
+    std::vector<img_t<uint32_t>> seen;
+    ouster::sdk::hip::StreamOptions so;
+    so.frames_per_batch = 1;
+    so.batches_in_flight = 2;
+    so.outputs.auto_placement = false;
+    so.outputs.xyz = false;
+    so.download_xyz = false;
+    so.download_planes = {"RANGE"};
+    {
+        ouster::sdk::hip::FrameStream fs({info}, so, [&](const ouster::sdk::hip::BatchResult& r) {
+            for (uint32_t f = 0; f < r.n_frames; ++f) {
+                img_t<uint32_t> img(64, 512);
+                std::memcpy(img.data(), static_cast<const uint32_t*>(r.planes.at("RANGE")) + static_cast<size_t>(f) * 64 * 512, img.size() * 4);
+                seen.push_back(img);
+            }
+        });
+        fs.push_frame(ptrs);
+        fs.finish();
+    }
+    CHECK(seen.size() == 1 && seen[0] == want);
+}
+
 static void test_sharded_batch() {
     std::printf("ShardedBatch (frames over the visible GPUs, packets scattered / clouds gathered by peer copies)\n");
     auto a = make_info(UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, HeaderType::STANDARD, 64, 1024);
@@ -1390,6 +1465,7 @@ int main() {
     test_dewarp();
     test_frame_dewarp();
     test_device_batch();
+    test_resent_packet_is_merged();
     test_sharded_batch();
     test_frame_stream();
     test_legacy_aliases();

@@ -6,8 +6,11 @@ import os
 
 import pytest
 
-from ouster.sdk import core
-import ouster.sdk.core._digest as digest
+import overlay            # tests/ref_shim: registers the reference's own examples.reference and core._digest (staged files)
+overlay.install()
+
+from ouster.sdk import core                  # noqa: E402  the product: ouster_sdk_amd/compat/ouster
+import ouster.sdk.core._digest as digest     # noqa: E402
 
 PCAPS_DATA_DIR = os.environ["OUSTER_REF_PCAPS"]
 

@@ -2,7 +2,7 @@
 /root/reference/python/tests/test_xyzlut.py, test_destagger.py, test_batching.py, test_parsing.py, test_data.py, test_core.py and test_extended_profiles.py (with the reference helpers they
 import: tests/multi.py and ouster/sdk/core/_digest.py) -- staged verbatim by oracle/Makefile into the
 git-ignored oracle/_ref/pytests where the reference checkout exists (it travels to the GPU box with the snapshot) -- are
-collected by a child pytest whose `ouster.sdk.core` is tests/ref_shim (= ouster_sdk_amd.core + the JSON metadata reader
+collected by a child pytest whose `ouster.sdk.core` is the product's ouster_sdk_amd/compat/ouster (= ouster_sdk_amd.core + the JSON metadata reader
 ouster_sdk_amd/metadata.py) and whose fixtures (tests/ref_shim/conftest_for_reference_tests.py) mirror the reference's conftest.  Every
 collected test must pass; the counts are printed."""
 import os
@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGED = os.path.join(ROOT, "oracle", "_ref", "pytests")
-SHIM = os.path.join(ROOT, "tests", "ref_shim")
+SHIM = os.path.join(ROOT, "tests", "ref_shim")            # conftest, overlay, more_itertools stand-in
+COMPAT = os.path.join(ROOT, "ouster_sdk_amd", "compat")   # the product's `ouster.sdk` package
 
 
 # test id fragments that are left out, and why (everything else that is collected must pass)
@@ -55,7 +56,7 @@ def test_reference_python_tests_pass_unmodified(tmp_path):
         shutil.copy(os.path.join(STAGED, name), pkg / name)          # byte-identical copies
     shutil.copy(os.path.join(SHIM, "conftest_for_reference_tests.py"), pkg / "conftest.py")
     env = dict(os.environ)
-    env["PYTHONPATH"] = os.pathsep.join([SHIM, str(tmp_path), ROOT, env.get("PYTHONPATH", "")])
+    env["PYTHONPATH"] = os.pathsep.join([COMPAT, SHIM, str(tmp_path), ROOT, env.get("PYTHONPATH", "")])
     env["OUSTER_REF_PCAPS"] = PCAPS
     env["OUSTER_REF_STAGED"] = STAGED          # the shim's ouster.sdk.core._digest executes the staged reference module
     deselect = " and ".join("not " + k for k in OUT_OF_SCOPE)
