@@ -173,6 +173,7 @@ class DeviceFrameBatch {
     DeviceBuffer d_gate_;   // u16 [n_frames][8][w] kept counts per column (gate by-product of decode)
     bool gate_valid_ = false;
     DeviceBuffer d_poses_, d_dw_pts_, d_dw_fi_, d_dw_ci_, d_dw_ts_, d_dw_off_;
+    DeviceBuffer d_pose_rows_;   // float output: rows 0..2 of the poses cast to float, [n_frames][w][12]
     std::vector<uint64_t> dw_offsets_;
     bool dw_prov_ = false;
 };

@@ -324,6 +324,16 @@ int ouster_hip_dewarp_frames_counted(ouster_hip_ctx* ctx, const ouster_hip_lut* 
                                      double min_range, double max_range, int dtype, void* points,
                                      uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
                                      uint64_t capacity, uint64_t* frame_offsets, const uint16_t* gate_counts);
+/* The same with the poses given the way dewarp<float> uses them: pose_rows [n_frames][w][12] float = rows 0..2 of every
+ * column's body_to_world (row-major 3 x 4), already cast to float -- dewarp<T> casts the pose to T before it multiplies
+ * (pose_util.h:38-56), so for float output this table IS what the arithmetic sees, at 48 B per column instead of the 128 B
+ * of a double 4 x 4 (67 MB -> 25 MB per 256 frames of 2048 columns; a caller that stages poses on the host converts them
+ * there).  float output only; gate_counts as above (may be NULL). */
+int ouster_hip_dewarp_frames_rows(ouster_hip_ctx* ctx, const ouster_hip_lut* const* luts, uint32_t n_luts,
+                                  const uint32_t* range, const uint32_t* status, const uint64_t* timestamp,
+                                  const float* pose_rows, uint32_t n_frames, double min_range, double max_range,
+                                  void* points, uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
+                                  uint64_t capacity, uint64_t* frame_offsets, const uint16_t* gate_counts);
 /* The raw gate ouster_hip_dewarp_frames derives from metres: min_r = ceil(min_range*1e3), max_r =
  * floor(max_range*1e3), clamped to u32; returns 0 and sets *empty when nothing can pass. */
 int ouster_hip_range_gate(double min_range, double max_range, uint32_t* min_r, uint32_t* max_r, int* empty);

@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "ouster_hip_last_error", "ouster_hip_version", "ouster_hip_format_create",
     "ouster_hip_format_destroy", "ouster_hip_lut_create", "ouster_hip_lut_create_from_arrays",
     "ouster_hip_lut_export", "ouster_hip_lut_destroy", "ouster_hip_decode", "ouster_hip_destagger",
-    "ouster_hip_cartesian", "ouster_hip_osf_unpack", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_dewarp_frames_counted", "ouster_hip_range_gate", "ouster_hip_timing_enable", "ouster_hip_timing_read", "ouster_hip_last_decode_tile", "ouster_hip_last_decode_kernel",
+    "ouster_hip_cartesian", "ouster_hip_osf_unpack", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_dewarp_frames_counted", "ouster_hip_dewarp_frames_rows", "ouster_hip_range_gate", "ouster_hip_timing_enable", "ouster_hip_timing_read", "ouster_hip_last_decode_tile", "ouster_hip_last_decode_kernel",
 ]
 
 _hip = None
@@ -143,6 +143,9 @@ def load_hip(private_path: Optional[str] = None):
                                                        C.c_double, C.c_int, vp, vp, vp, vp, C.c_uint64, vp, vp]
         L.ouster_hip_range_gate.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                             C.POINTER(C.c_int)]
+    if hasattr(L, "ouster_hip_dewarp_frames_rows"):
+        L.ouster_hip_dewarp_frames_rows.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, C.c_double, C.c_double,
+                                                    vp, vp, vp, vp, C.c_uint64, vp, vp]
     L.ouster_hip_timing_enable.argtypes = [vp, C.c_int]
     L.ouster_hip_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.ouster_hip_last_decode_tile.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]

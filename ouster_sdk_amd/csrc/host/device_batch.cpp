@@ -423,6 +423,23 @@ void DeviceFrameBatch::upload_poses(uint32_t frame, const double* poses) {
         d_poses_.upload(ident.data(), ident.size() * 8);
     }
     if (poses) d_poses_.upload(poses, per, per * frame);
+    // float output: the range-gated dewarp takes the poses as rows 0..2 cast to float (what dewarp<float> multiplies with,
+    // pose_util.h:38-56), converted here on the host: 48 B per column on the device instead of 128
+    if (!opt_.xyz_f64) {
+        const size_t rows_per = static_cast<size_t>(w_) * 12;
+        if (d_pose_rows_.size() == 0) {
+            std::vector<float> ident(static_cast<size_t>(n_frames_) * rows_per, 0.0f);
+            for (size_t i = 0; i < ident.size(); i += 12) ident[i] = ident[i + 5] = ident[i + 10] = 1.0f;
+            d_pose_rows_.resize(ident.size() * 4);
+            d_pose_rows_.upload(ident.data(), ident.size() * 4);
+        }
+        if (poses) {
+            std::vector<float> rows(rows_per);
+            for (size_t c = 0; c < w_; ++c)
+                for (size_t k = 0; k < 12; ++k) rows[c * 12 + k] = static_cast<float>(poses[c * 16 + k]);
+            d_pose_rows_.upload(rows.data(), rows_per * 4, rows_per * 4 * frame);
+        }
+    }
 }
 
 uint64_t DeviceFrameBatch::dewarp(double min_range, double max_range, bool provenance) {
@@ -444,6 +461,16 @@ uint64_t DeviceFrameBatch::dewarp(double min_range, double max_range, bool prove
     for (const auto& l : luts_) luts.push_back(l.device().handle);
     // decode() already counted the gated pixels per column when it ran with this very gate
     const bool counted = gate_valid_ && min_range == opt_.gate_min_range && max_range == opt_.gate_max_range;
+    if (!opt_.xyz_f64 && d_pose_rows_.size())
+        check(ouster_hip_dewarp_frames_rows(
+            default_ctx(), luts.data(), static_cast<uint32_t>(luts.size()),
+            static_cast<const uint32_t*>(rp->second.data()), static_cast<const uint32_t*>(d_status_.data()),
+            static_cast<const uint64_t*>(d_ts_.data()), static_cast<const float*>(d_pose_rows_.data()), n_frames_, min_range,
+            max_range, d_dw_pts_.data(), provenance ? static_cast<uint32_t*>(d_dw_fi_.data()) : nullptr,
+            provenance ? static_cast<uint32_t*>(d_dw_ci_.data()) : nullptr,
+            provenance ? static_cast<uint64_t*>(d_dw_ts_.data()) : nullptr, cap, static_cast<uint64_t*>(d_dw_off_.data()),
+            counted ? static_cast<const uint16_t*>(d_gate_.data()) : nullptr));
+    else
     check(ouster_hip_dewarp_frames_counted(
         default_ctx(), luts.data(), static_cast<uint32_t>(luts.size()),
         static_cast<const uint32_t*>(rp->second.data()), static_cast<const uint32_t*>(d_status_.data()),

@@ -598,6 +598,29 @@ __device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(
     return (const __attribute__((address_space(1))) T*)(uintptr_t)p;
 }
 
+// rows 0..2 of a column's pose in the emit kernels' register order (rows 0 and 1 interleaved, see DwfColMeta), cast to T:
+// from the caller's float table (48 B per column, three 16 B loads) or from the 4 x 4 doubles (128 B)
+template <class T>
+__device__ __forceinline__ void load_pose_rows(const DewarpFramesArgs& a, size_t col, T (&pose)[12]) {
+    if constexpr (sizeof(T) == 4) {
+        if (a.pose_rows) {
+            const float4* pr = (const float4*)(a.pose_rows + col * 12);
+            const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2];
+            pose[0] = r0.x; pose[2] = r0.y; pose[4] = r0.z; pose[6] = r0.w;
+            pose[1] = r1.x; pose[3] = r1.y; pose[5] = r1.z; pose[7] = r1.w;
+            pose[8] = r2.x; pose[9] = r2.y; pose[10] = r2.z; pose[11] = r2.w;
+            return;
+        }
+    }
+    const double* pm = a.poses + col * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pose[2 * k] = (T)pm[k];
+        pose[2 * k + 1] = (T)pm[4 + k];
+        pose[8 + k] = (T)pm[8 + k];
+    }
+}
+
 // column metadata of an emit tile, staged once in LDS and read back as wave-uniform broadcasts
 template <class T>
 struct __attribute__((aligned(16))) DwfColMeta {
@@ -760,13 +783,7 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
             m.base = off[mx];
             m.cnt = off[mx + 1] - m.base;
             if (m.cnt) {
-                const double* pm = a.poses + ((size_t)f * W + mx) * 16;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    m.pose[2 * k] = (T)pm[k];
-                    m.pose[2 * k + 1] = (T)pm[4 + k];
-                    m.pose[8 + k] = (T)pm[8 + k];
-                }
+                load_pose_rows<T>(a, (size_t)f * W + mx, m.pose);
                 if constexpr (SEP) {
 #pragma unroll
                     for (int k = 0; k < 5; ++k) m.col[k] = as_global(lut.col_tab)[(size_t)mx * 5 + k];

@@ -1292,12 +1292,12 @@ int ouster_hip_dewarp_frames(ouster_hip_ctx* ctx, const ouster_hip_lut* const* l
                                             frame_offsets, nullptr);
 }
 
-int ouster_hip_dewarp_frames_counted(ouster_hip_ctx* ctx, const ouster_hip_lut* const* luts, uint32_t n_luts,
-                                     const uint32_t* range, const uint32_t* status,
-                                     const uint64_t* timestamp, const double* poses, uint32_t n_frames,
-                                     double min_range, double max_range, int dtype, void* points,
-                                     uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
-                                     uint64_t capacity, uint64_t* frame_offsets, const uint16_t* gate_counts) {
+static int dewarp_frames_impl(ouster_hip_ctx* ctx, const ouster_hip_lut* const* luts, uint32_t n_luts,
+                              const uint32_t* range, const uint32_t* status,
+                              const uint64_t* timestamp, const double* poses, const float* pose_rows, uint32_t n_frames,
+                              double min_range, double max_range, int dtype, void* points,
+                              uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
+                              uint64_t capacity, uint64_t* frame_offsets, const uint16_t* gate_counts) {
     if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (dtype != OUSTER_HIP_F32 && dtype != OUSTER_HIP_F64)
         return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "dtype must be F32 or F64");
@@ -1317,7 +1317,9 @@ int ouster_hip_dewarp_frames_counted(ouster_hip_ctx* ctx, const ouster_hip_lut* 
         HIP_TRY(hipMemsetAsync(frame_offsets, 0, sizeof(uint64_t), ctx->stream));
         return OUSTER_HIP_OK;
     }
-    if (!range || !status || !poses || (!points && capacity))
+    if (pose_rows && (((uintptr_t)pose_rows) & 15u))
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "pose_rows must be 16-byte aligned");
+    if (!range || !status || (!poses && !pose_rows) || (!points && capacity))
         return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL pointer");
     const uint32_t w = luts[0]->w, h = luts[0]->h;
     // uint32_t min_r = ceil(min_range * 1e3), max_r = floor(max_range * 1e3): dewarp_impl.h:33-34
@@ -1339,6 +1341,7 @@ int ouster_hip_dewarp_frames_counted(ouster_hip_ctx* ctx, const ouster_hip_lut* 
     a.status = status;
     a.timestamp = timestamp;
     a.poses = poses;
+    a.pose_rows = pose_rows;
     a.luts = (const LutDev*)ctx->luts.p;
     a.n_luts = n_luts;
     a.w = w;
@@ -1349,7 +1352,7 @@ int ouster_hip_dewarp_frames_counted(ouster_hip_ctx* ctx, const ouster_hip_lut* 
     a.dtype = dtype;
     a.col_off = (uint32_t*)ctx->scratch.p;
     a.gate_counts = gate_counts;
-    a.tile_state = (ctx->knobs.dewarp_single_pass && !gate_counts) ? (uint64_t*)((uint8_t*)ctx->scratch.p + col_off_bytes) : nullptr;
+    a.tile_state = (ctx->knobs.dewarp_single_pass && !gate_counts && !pose_rows) ? (uint64_t*)((uint8_t*)ctx->scratch.p + col_off_bytes) : nullptr;
     a.frame_off = frame_offsets;
     a.points = points;
     a.frame_idxs = frame_idxs;
@@ -1358,6 +1361,26 @@ int ouster_hip_dewarp_frames_counted(ouster_hip_ctx* ctx, const ouster_hip_lut* 
     a.capacity = capacity;
     HIP_TRY(launch_dewarp_frames(a, luts[0]->separable, ctx->stream));
     return OUSTER_HIP_OK;
+}
+
+int ouster_hip_dewarp_frames_counted(ouster_hip_ctx* ctx, const ouster_hip_lut* const* luts, uint32_t n_luts,
+                                     const uint32_t* range, const uint32_t* status,
+                                     const uint64_t* timestamp, const double* poses, uint32_t n_frames,
+                                     double min_range, double max_range, int dtype, void* points,
+                                     uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
+                                     uint64_t capacity, uint64_t* frame_offsets, const uint16_t* gate_counts) {
+    return dewarp_frames_impl(ctx, luts, n_luts, range, status, timestamp, poses, nullptr, n_frames, min_range, max_range, dtype,
+                              points, frame_idxs, col_idxs, timestamps_ns, capacity, frame_offsets, gate_counts);
+}
+
+int ouster_hip_dewarp_frames_rows(ouster_hip_ctx* ctx, const ouster_hip_lut* const* luts, uint32_t n_luts,
+                                  const uint32_t* range, const uint32_t* status, const uint64_t* timestamp,
+                                  const float* pose_rows, uint32_t n_frames, double min_range, double max_range,
+                                  void* points, uint32_t* frame_idxs, uint32_t* col_idxs, uint64_t* timestamps_ns,
+                                  uint64_t capacity, uint64_t* frame_offsets, const uint16_t* gate_counts) {
+    if (!pose_rows && n_frames) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL pointer");
+    return dewarp_frames_impl(ctx, luts, n_luts, range, status, timestamp, nullptr, pose_rows, n_frames, min_range, max_range,
+                              OUSTER_HIP_F32, points, frame_idxs, col_idxs, timestamps_ns, capacity, frame_offsets, gate_counts);
 }
 
 // ---- OSF field planes ---------------------------------------------------------------------------

@@ -162,6 +162,7 @@ struct DewarpFramesArgs {
     const uint32_t* status;     // [n_frames][w]
     const uint64_t* timestamp;  // [n_frames][w], nullable unless timestamps_ns is set
     const double* poses;        // [n_frames][w][16]
+    const float* pose_rows;     // [n_frames][w][12]: rows 0..2 already cast to float (poses unused then; float output only)
     const LutDev* luts;         // device array, luts[f % n_luts]
     uint32_t n_luts;
     uint32_t w, h, n_frames;

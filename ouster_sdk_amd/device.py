@@ -394,16 +394,21 @@ class HotPath:
                       capacity: Optional[int] = None,
                       gate_counts: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Range-gated, compacting dewarp of a batch of frames (impl/dewarp_impl.h:23-115).
-        rng [n, h, w] u32, status [n, w] u32, poses [n, w, 4, 4] f64, timestamp [n, w] u64.
+        rng [n, h, w] u32, status [n, w] u32, poses [n, w, 4, 4] f64 -- or, for float output, [n, w, 3, 4] f32 = rows 0..2 of
+        the poses already cast to float (pose_rows(): what dewarp<float> multiplies with anyway, 48 B per column instead of
+        128) --, timestamp [n, w] u64.
         Returns {"points" [cap, 3], "frame_offsets" [n + 1] u64, and with provenance
         "frame_idxs", "col_idxs" (u32) and, when timestamp is given, "timestamps_ns" (u64)};
         the first frame_offsets[n] rows are valid."""
         assert rng.is_cuda and rng.is_contiguous() and rng.dtype == torch.uint32
         assert status.is_cuda and status.is_contiguous() and status.dtype == torch.uint32
-        assert poses.is_cuda and poses.is_contiguous() and poses.dtype == torch.float64
+        rows = poses.dtype == torch.float32
+        assert poses.is_cuda and poses.is_contiguous() and (rows or poses.dtype == torch.float64)
         n = rng.shape[0]
+        if rows and dtype != torch.float32:
+            raise ValueError("float pose rows serve float output only")
         if rng.numel() != n * self.h * self.w or status.numel() != n * self.w or \
-                poses.numel() != n * self.w * 16:
+                poses.numel() != n * self.w * (12 if rows else 16):
             raise ValueError("unexpected image dimensions")
         luts = list(luts) if luts is not None else self.luts
         cap = n * self.h * self.w if capacity is None else int(capacity)
@@ -420,6 +425,14 @@ class HotPath:
         if gate_counts is not None:
             assert gate_counts.is_cuda and gate_counts.dtype == torch.uint16 and gate_counts.is_contiguous()
             assert tuple(gate_counts.shape) == (n, 8, self.w)
+        if rows:
+            capi.check(self.ctx.L.ouster_hip_dewarp_frames_rows(
+                self.ctx.h, luts_arr, len(luts), rng.data_ptr(), status.data_ptr(),
+                timestamp.data_ptr() if timestamp is not None else None, poses.data_ptr(), n,
+                float(min_range), float(max_range), out["points"].data_ptr(), ptr("frame_idxs"), ptr("col_idxs"),
+                ptr("timestamps_ns"), cap, out["frame_offsets"].data_ptr(),
+                gate_counts.data_ptr() if gate_counts is not None else None))
+            return out
         capi.check(self.ctx.L.ouster_hip_dewarp_frames_counted(
             self.ctx.h, luts_arr, len(luts), rng.data_ptr(), status.data_ptr(),
             timestamp.data_ptr() if timestamp is not None else None, poses.data_ptr(), n,
@@ -428,6 +441,13 @@ class HotPath:
             cap, out["frame_offsets"].data_ptr(),
             gate_counts.data_ptr() if gate_counts is not None else None))
         return out
+
+    @staticmethod
+    def pose_rows(poses) -> torch.Tensor:
+        """[n, w, 4, 4] float64 poses (host array or tensor, any device) -> [n, w, 3, 4] float32 CUDA tensor: rows 0..2 cast
+        to float, the form dewarp<float> uses (pose_util.h:38-56)."""
+        t = torch.as_tensor(poses)
+        return t[..., :3, :].to(torch.float32).contiguous().cuda()
 
     def sync(self):
         self.ctx.sync()

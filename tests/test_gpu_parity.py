@@ -435,6 +435,13 @@ def test_dewarp_frames_matches_oracle(oracle, h, w, n, path):
             if tot:
                 wp = np.concatenate([x[0] for x in want]).astype(np.float64)
                 assert np.abs(_np(got["points"])[:tot].astype(np.float64) - wp).max() <= tol
+            if tdt == torch.float32:
+                # the poses as float rows (ouster_hip_dewarp_frames_rows: 48 B per column): dewarp<float> casts the pose to
+                # float before it multiplies, so every byte of every output is the same
+                rows = hp.dewarp_frames(d_r, d_st, HotPath.pose_rows(poses), lo, hi, timestamp=d_ts, dtype=tdt)
+                for k in got:
+                    n_k = tot if k != "frame_offsets" else len(offs)
+                    assert torch.equal(rows[k][:n_k], got[k][:n_k]), (k, lo, hi)
     # user-supplied f32 LUT: the reference's own XYZLutT<float> arithmetic, then the pose in f32
     l32 = hp.add_lut_arrays(ldir.astype(np.float32), lofs.astype(np.float32))
     got = hp.dewarp_frames(d_r, d_st, d_po, 1.0, 60.0, luts=[l32], dtype=torch.float32, provenance=False)

@@ -84,6 +84,26 @@ def main():
         byts = npx * 4 + kept * (12 + (16 if prov else 0)) + N * W * (128 + 4)
         res[name] = {"GBps": round(byts / s / 1e9, 1), "Mpixels_per_s": round(npx / s / 1e6, 1),
                      "kept_fraction": round(kept / npx, 3), "ms": round(s * 1e3, 3)}
+    # the same with the poses as float rows (ouster_hip_dewarp_frames_rows: what a caller that stages poses on the host hands
+    # over: 48 B per column) and with the per-column counts the decode leaves behind when it runs with the gate
+    # (ouster_hip_frame_out::gate_counts: no counting pass over the range planes) -- DeviceFrameBatch::dewarp's route
+    rowsN = HotPath.pose_rows(posesN)
+    hp2 = HotPath("RNG15_RFL8_NIR8_DUAL", H, W, 16)
+    hp2.set_pixel_shift_by_row(shifts)
+    hp2.add_lut(b2l, l2s, az, alt)
+    pk = torch.from_numpy(bench.synth_packets(8)).cuda().repeat(N // 8, 1, 1).contiguous()
+    dout = hp2.alloc_outputs(N, planes=["RANGE"], xyz=[])
+    hp2.decode(pk, dout, gate=(0.5, 400.0))
+    drng, dst_, dgc = dout["RANGE"], dout["status"], dout["gate_counts"]
+    for name, kw in (("dewarp_frames_f32_rows", dict(rng=rz, st=status, gc=None)),
+                     ("dewarp_frames_f32_rows_counted", dict(rng=drng, st=dst_, gc=dgc))):
+        out = hp.dewarp_frames(kw["rng"], kw["st"], rowsN, 0.5, 400.0, provenance=False, luts=[lut], gate_counts=kw["gc"])
+        kept = int(out["frame_offsets"][-1].item())
+        rr_ = Rot(kw["rng"])
+        s = timeit(lambda: hp.dewarp_frames(rr_(), kw["st"], rowsN, 0.5, 400.0, luts=[lut], provenance=False, gate_counts=kw["gc"]))
+        byts = npx * 4 + kept * 12 + N * W * (48 + 4) + (N * W * 2 * 8 if kw["gc"] is not None else 0)
+        res[name] = {"GBps": round(byts / s / 1e9, 1), "Mpixels_per_s": round(npx / s / 1e6, 1),
+                     "kept_fraction": round(kept / npx, 3), "ms": round(s * 1e3, 3), "algorithmic_bytes": int(byts)}
     res["note"] = (f"{N} images of {H}x{W}; {R} copies of every input used in turn (cold input for every call); "
                    "includes torch.empty_like of the output per call")
     print(json.dumps(res))
