@@ -5,9 +5,9 @@ TAG=${1:-r02}
 WL=${2:-dual}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --workload $WL --steps 20 --warmup 3 --no-cpu --no-loss-paths > $O/bench_under_rocprof.json 2> $O/trace.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --placement first --no-loss-paths > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --placement first --no-loss-paths > /dev/null 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --workload $WL --steps 20 --warmup 3 --no-cpu --no-loss-paths --no-extras > $O/bench_under_rocprof.json 2> $O/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --placement first --no-loss-paths --no-extras > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu --placement first --no-loss-paths --no-extras > /dev/null 2> $O/pmc_write.err
 # the counters of THIS run become profiles/<tag>/pmc_traffic.json before the plain bench line is taken, so that its
 # roofline.traffic cites them (recorded on this tree's kernel sources) and not an older directory's
 cd $R; python tools/summarize_profile.py $O $WL > /dev/null 2>&1 || true
