@@ -821,9 +821,9 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
 //                              flagged frame was redone whole) -- and decodes the tile from the maps otherwise.  Short tiles
 //                              (8 rows): the few flagged frames of a batch are spread over the whole XCD instead of keeping a
 //                              handful of workgroups busy for 50 us each.
-// A ticket is only ever held by a running workgroup and RESOLVE tickets come first and never wait, so a REDO ticket waits
-// for a workgroup that is making progress.  The wait is bounded all the same: after SPIN_LIMIT polls the workgroup
-// resolves the frame itself (the maps are a pure function of the packets).  Maps and ready words are written and read with
+// RESOLVE tickets come first and never wait, so a REDO ticket normally waits for a workgroup that is making progress; the wait
+// is bounded all the same: after SPIN_LIMIT polls the workgroup resolves the frame itself (the maps are a pure function of
+// the packets).  Maps and ready words are written and read with
 // agent-scope atomics: the XCDs' L2s are not coherent with each other for plain accesses.
 // The ticket counters live in frame_state behind the sequence words, one set per tag parity: this call's start at zero
 // (zeroed by the call before), the other set is zeroed for the next call; the ready words ([ready_off + f], the buffer's second half)
@@ -859,15 +859,13 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
     unsigned long long* ctr = (unsigned long long*)&a.frame_state[FS_TICKET + (tag & 1u) * 8u + xcd];
     unsigned long long* ready = (unsigned long long*)&a.frame_state[a.ready_off];
     if (blockIdx.x < 8 && tid == 0) a.frame_state[FS_TICKET + ((tag + 1u) & 1u) * 8u + blockIdx.x] = 0;   // the next call's counters
-    auto pull = [&]() -> unsigned long long {
-        __syncthreads();
-        if (tid == 0) s_ticket = atomicAdd(ctr, 1ull);
-        __syncthreads();
-        return s_ticket;
-    };
-    // the next ticket is asked for when an item starts and looked at when it ends: the round trip hides behind the item
+    // A workgroup's first ticket is its own number -- no atomic at all on a clean batch (512 workgroups adding to one word
+    // are served one after the other: 4 us on every call), no round trip before a flagged batch's work starts -- and the
+    // counter hands out the tickets behind those.  (A first ticket may thus belong to a workgroup that is not running yet;
+    // whoever waits for it gives up after SPIN_LIMIT polls and resolves the frame itself.)
+    // The next ticket is asked for when an item starts and looked at when it ends: the round trip hides behind the item.
     unsigned long long ahead = 0;
-    auto pull_ahead = [&]() { if (tid == 0) ahead = atomicAdd(ctr, 1ull); };
+    auto pull_ahead = [&]() { if (tid == 0) ahead = atomicAdd(ctr, 1ull) + gridDim.x; };
     auto take_ahead = [&]() -> unsigned long long {
         __syncthreads();
         if (tid == 0) s_ticket = ahead;
@@ -928,9 +926,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
             a.frame_meta[f] = m;
         }
     };
-    unsigned long long ticket = 0, done = 0;
-    bool have = false;
-    pull_ahead();   // the first ticket's round trip overlaps with the reading of the flags (a clean batch wastes one ticket per workgroup)
+    unsigned long long ticket = blockIdx.x, done = 0;
     for (uint32_t base = 0; base < a.n_frames; base += FIXUP_CHUNK) {
         // the flagged frames of this chunk, in frame order, the same list in every workgroup (see k_decode_fixup)
         const uint32_t nfr = min(FIXUP_CHUNK, a.n_frames - base);
@@ -966,7 +962,6 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
         const uint32_t bpf = a.row_chunks * SPLIT;
         const unsigned long long items = (unsigned long long)my_frames * (1u + bpf);
         if (items == 0) continue;
-        if (!have) { ticket = take_ahead(); have = true; }
         while (ticket < done + items) {
             const uint32_t it = (uint32_t)(ticket - done);
             pull_ahead();
