@@ -897,7 +897,9 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         if (for_fix) {
             // short tiles: the (few) flagged frames of a batch spread over a whole XCD instead of keeping a handful of
             // workgroups busy for a full-height tile each (tools/ab/fixup_prof.sh: 57 us for ONE flagged frame with 32-row tiles)
-            const uint32_t rows = kn.fixup_rows > 0 ? (uint32_t)kn.fixup_rows : 8u;
+            // about 16 KB of packet bytes per tile (8 rows of 256 dual-return columns, 16 rows of 128 single-return ones): smaller
+            // tiles are all prologue (the 12 B/px profile's 128 x 8 tiles made its fix-up pass slower than r03's)
+            const uint32_t rows = kn.fixup_rows > 0 ? (uint32_t)kn.fixup_rows : (16384u + (uint32_t)want * chan - 1u) / ((uint32_t)want * chan);
             tr = std::max(rpp, std::min(tr, up(rows)));
             if (tiles > 32) return false;   // the frame's ready word carries one bit per column tile
         }
