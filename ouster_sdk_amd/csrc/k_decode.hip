@@ -822,14 +822,14 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
 //                              (8 rows): the few flagged frames of a batch are spread over the whole XCD instead of keeping a
 //                              handful of workgroups busy for 50 us each.
 // RESOLVE tickets come first and never wait, so a REDO ticket normally waits for a workgroup that is making progress; the wait
-// is bounded all the same: after SPIN_LIMIT polls the workgroup resolves the frame itself (the maps are a pure function of
+// is bounded all the same: after spin_limit polls the workgroup resolves the frame itself (the maps are a pure function of
 // the packets).  Maps and ready words are written and read with
 // agent-scope atomics: the XCDs' L2s are not coherent with each other for plain accesses.
 // The ticket counters live in frame_state behind the sequence words, one set per tag parity: this call's start at zero
 // (zeroed by the call before), the other set is zeroed for the next call; the ready words ([ready_off + f], the buffer's second half)
 // carry the tag and are never cleared.
 // ------------------------------------------------------------------------------------
-constexpr uint32_t SPIN_LIMIT = 1u << 16;
+// polls of a frame's ready word before a REDO ticket gives up and resolves the frame itself: DecodeArgs::spin_limit (65536 x ~0.25 us)
 #ifdef OUSTER_PHASE_TIMING   // experiment builds (tools/ab/phase_timing.sh): per workgroup 64 words: [0] start, [1] events, then 4 per ticket
 #define FSTAMP_BEGIN() uint64_t fs0_ = __builtin_readcyclecounter(), fs1_ = 0
 #define FSTAMP_MID() do { fs1_ = __builtin_readcyclecounter(); } while (0)
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
     // A workgroup's first ticket is its own number -- no atomic at all on a clean batch (512 workgroups adding to one word
     // are served one after the other: 4 us on every call), no round trip before a flagged batch's work starts -- and the
     // counter hands out the tickets behind those.  (A first ticket may thus belong to a workgroup that is not running yet;
-    // whoever waits for it gives up after SPIN_LIMIT polls and resolves the frame itself.)
+    // whoever waits for it gives up after spin_limit polls and resolves the frame itself.)
     // The next ticket is asked for when an item starts and looked at when it ends: the round trip hides behind the item.
     unsigned long long ahead = 0;
     auto pull_ahead = [&]() { if (tid == 0) ahead = atomicAdd(ctr, 1ull) + gridDim.x; };
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
                 const uint32_t rc = sub % a.row_chunks, share = sub / a.row_chunks;
                 if (tid == 0) {
                     unsigned long long v = 0;
-                    for (uint32_t spin = 0; spin < SPIN_LIMIT; ++spin) {
+                    for (uint32_t spin = 0; spin < a.spin_limit; ++spin) {
                         v = __hip_atomic_load(&ready[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((v >> 32) == (tag & 0xffffffffull)) break;
                         __builtin_amdgcn_s_sleep(8);
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
                 uint32_t mask = (uint32_t)v;
                 const bool published = (v >> 32) == (tag & 0xffffffffull);
                 if (!published) {
-                    // never seen so far (SPIN_LIMIT polls): do the frame's resolution here; same maps, nothing is published
+                    // never seen so far (a.spin_limit polls): do the frame's resolution here; same maps, nothing is published
                     resolve(f, false);
                     uint32_t cnt = a.slots_per_frame;
                     if (a.packet_counts) cnt = min(a.packet_counts[f], a.slots_per_frame);

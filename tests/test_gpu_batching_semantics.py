@@ -214,3 +214,56 @@ def test_fuzz_against_the_sequential_reference(oracle, label, wide, seed):
     if fits:
         _decode_and_compare(O, cal, pf, fits, wide, False, f"fuzz {seed} slots")
     _decode_and_compare(O, cal, pf, frames, wide, True, f"fuzz {seed} compacted")
+
+
+def _damaged_batch(O, cal, n, seed):
+    """n frames, every fifth one damaged in turn: two packets swapped / compacted after a drop / a duplicate in a lost packet's
+    slot / one packet's ids shuffled."""
+    pf = cal.packet_format()
+    packets, _ = O.synth_packets(cal, n, seed=seed, with_window=True)
+    rng = np.random.default_rng(seed)
+    ppf = cal.w // cal.cpp
+    by_frame = []
+    for f in range(n):
+        pk = packets[f].copy()
+        kind = (f // 5) % 4 if f % 5 == 2 else -1
+        if kind == 0:
+            a, b = rng.choice(ppf, 2, replace=False)
+            pk[[a, b]] = pk[[b, a]]
+        elif kind == 1:
+            pk = np.delete(pk, int(rng.integers(0, ppf - 1)), axis=0)
+        elif kind == 2:
+            lost, src = rng.choice(ppf, 2, replace=False)
+            pk[lost] = pk[src]
+        elif kind == 3:
+            p = int(rng.integers(0, ppf))
+            for ic, m in enumerate(rng.permutation(cal.cpp)):
+                _set_mid(pf, pk[p], ic, p * cal.cpp + int(m))
+        by_frame.append(pk)
+    return pf, by_frame
+
+
+def test_fixup_workgroups_that_never_see_the_ready_word_resolve_the_frame_themselves(oracle):
+    """The hand-over between the fix-up pass's RESOLVE and REDO tickets is bounded: with the poll limit at zero EVERY REDO
+    ticket takes the fallback (resolve the frame itself, same maps) -- the bytes must not change."""
+    O = oracle
+    cal = O.synthetic_calib(h=64, w=1024, profile=PROFILE)
+    pf, by_frame = _damaged_batch(O, cal, 40, 7)
+    import os
+    for spin in (0, 1 << 16):
+        os.environ["OUSTER_HIP_FIXUP_SPIN"] = str(spin)   # read when the context is created (_decode_and_compare builds its own)
+        try:
+            hp = _decode_and_compare(O, cal, pf, by_frame, None, False, f"spin {spin}")
+        finally:
+            os.environ.pop("OUSTER_HIP_FIXUP_SPIN", None)
+        assert hp.ctx.last_decode_kernel() in ("k_decode_wide", "k_decode_stream", "k_decode_stream2", "k_decode")
+
+
+def test_more_frames_than_one_fixup_chunk(oracle):
+    """The fix-up pass lists flagged frames 512 at a time; tickets run on across the chunks.  700 small frames, damaged ones in
+    both chunks (and in the last, partial one)."""
+    O = oracle
+    cal = O.synthetic_calib(h=16, w=256, profile=PROFILE)
+    pf, by_frame = _damaged_batch(O, cal, 700, 11)
+    hp = _decode_and_compare(O, cal, pf, by_frame, None, False, "700 frames")
+    assert hp.ctx.last_decode_kernel() != ""
