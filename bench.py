@@ -18,7 +18,7 @@ prints ONE JSON line with the whole-job rate, the roofline of the dominant kerne
 restatement of the reference loops, timed on this box's host cores, rank 0 at N=1 only).
 
 Setup before the W warm-up steps (none of it inside the timed region, all of it reported in the JSON line):
-  * the library's kernel-variant tuner settles (first 16 calls of a workload shape);
+  * the library's kernel-variant tuner settles (first 20 calls of a workload shape);
   * buffer placement: `--placement first` (the default since round 4): the buffers as the first allocation put them, no
     search -- the headline is what any caller gets.  `--placement refine` is the opt-in search of
     ouster::sdk::hip::DeviceFrameBatch (BatchOptions::auto_placement): further copies of the output set are allocated and
@@ -266,7 +266,7 @@ def time_loss_paths(hp, packets, out, F, bytes_per_frame, steps=30):
     keep = keep[keep != lost.unsqueeze(1)].reshape(F, slots - 1)      # [F, slots-1] surviving packet indices, in order
 
     def clock(pk, counts):
-        for _ in range(20):                               # variant tuner of this shape + warm-up
+        for _ in range(24):                               # variant tuner of this shape + warm-up
             hp.decode(pk, out, packet_counts=counts)
         torch.cuda.synchronize()
         hp.ctx.timing(True)
@@ -380,7 +380,7 @@ def time_other_workloads(steps=12):
     res = {}
     for name, F in (("single", 256), ("batch512", 512), ("fused4", 256)):
         hp, packets, out, profile, shifts, lut_args, n_ret, label = _workload_setup(name, F)
-        for _ in range(20):
+        for _ in range(24):
             hp.decode(packets, out)
         torch.cuda.synchronize()
         inputs = [packets, packets.clone()]
@@ -562,9 +562,9 @@ def main():
             dist.barrier()
 
     # setup, like building the LUT: let the library's per-workload kernel-variant tuner finish
-    # (it times up to four kernel variants four times each on the first sixteen calls), so the W
+    # (it times up to five kernel variants four times each on the first twenty calls), so the W
     # warm-up steps and the K timed steps all run the variant it settled on
-    for _ in range(20):
+    for _ in range(24):
         hp.decode(packets, out)
     torch.cuda.synchronize()
     # setup, like sizing a memory pool: the physical placement of a buffer is drawn when it is allocated and

@@ -287,7 +287,7 @@ double DeviceFrameBatch::tune_placement(int tries, std::vector<double>* all_ms, 
     rejected_packets.clear();
     // the kernel variant was chosen on the first draw: let the tuner look again on the buffers that stay
     check(ouster_hip_ctx_set_knob(default_ctx(), "retune", 1));
-    for (int i = 0; i < 20; ++i) decode();
+    for (int i = 0; i < 24; ++i) decode();
     best = std::min(best, clock());
     return best * 1e-3;
 }
@@ -359,7 +359,7 @@ double DeviceFrameBatch::refine_placement(int draws, std::vector<double>* all_ms
             break;   // out of device memory: decide among what has been drawn
         }
     }
-    for (int i = 0; i < 20; ++i) decode();   // the library's variant tuner settles first
+    for (int i = 0; i < 24; ++i) decode();   // the library's variant tuner settles first
     double best = clock();
     if (all_ms) all_ms->push_back(best);
     for (size_t g = 0; g < groups.size(); ++g) {
@@ -376,7 +376,7 @@ double DeviceFrameBatch::refine_placement(int draws, std::vector<double>* all_ms
     copies.clear();
     ballast.clear();
     check(ouster_hip_ctx_set_knob(default_ctx(), "retune", 1));
-    for (int i = 0; i < 20; ++i) decode();
+    for (int i = 0; i < 24; ++i) decode();
     ctx_->sync();
     return best * 1e-3;
 }

@@ -125,9 +125,9 @@ struct ouster_hip_ctx {
     struct Tune {
         int best = -2;  // -2: still measuring; 0: narrow; 128 / 256: wide; 1000 + tile width: the persistent kernel
         int calls = 0;
-        static constexpr int ROUNDS = 4, NCAND = 4, SAMPLES = NCAND * ROUNDS;
-        hipEvent_t ev[SAMPLES][2] = {};  // up to four candidates x ROUNDS consecutive launches
-        float ms[NCAND] = {0, 0, 0, 0};  // fastest warm sample of each candidate
+        static constexpr int ROUNDS = 4, NCAND = 5, SAMPLES = NCAND * ROUNDS;
+        hipEvent_t ev[SAMPLES][2] = {};  // up to five candidates x ROUNDS consecutive launches
+        float ms[NCAND] = {0, 0, 0, 0, 0};  // fastest warm sample of each candidate
     };
     std::map<uint64_t, Tune> tune;
     int last_tile_cols = 0, last_tile_rows = 0;  // tile of the last k_decode launch
@@ -1009,6 +1009,8 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // 1.5 - 3 % ahead where the memory system is fastest and up to 10 % behind where it is slowest.
     int stream = 0, wide = 0;
     int stream_auto = 0;   // tile width of the persistent candidate (0: not eligible)
+    int stream_alt = 0;    // ... and of the other width, when that is eligible too (round 4: the 12 B/px profile's 256 x 16 tiles
+                           // beat its 128 x 32 ones by 3 - 4 % on some boxes, tools/ab/single_variants.py)
     // Small batches (one tick of a few sensors, a single frame): one launch, every wide tile resolves its frame's column maps
     // itself -- neither an optimistic pass nor a second launch, whatever the buffer looks like.
     // Measured (tools/ab/small_batch.py, 4 x 128 x 2048 dual return): optimistic wide tiles of 8 rows + the fix-up launch 27 us
@@ -1036,6 +1038,10 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         if (setup_stream(256) && sa.tr * g.channel_data_size >= 256) stream_auto = 256;
         else if (setup_stream(128)) stream_auto = 128;
         else if (setup_stream(256)) stream_auto = 256;
+        if (stream_auto) {
+            const int other = stream_auto == 256 ? 128 : 256;
+            if (setup_stream(other)) stream_alt = other;
+        }
     }
     ouster_hip_ctx::Tune* tuning = nullptr;
     int tune_slot = -1;
@@ -1065,7 +1071,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             }
             mix(pm); mix(dm);
             mix((da.xyz[0] ? 1u : 0u) | (da.xyz[1] ? 2u : 0u) | (da.gate_counts ? 4u : 0u) | (da.xyz_poses ? 8u : 0u));
-            mix((uint64_t)stream_auto);
+            mix((uint64_t)stream_auto); mix((uint64_t)stream_alt);
             if (ctx->tune.size() > 64 && !ctx->tune.count(key)) {  // bounded: forget everything, re-learn
                 for (auto& kv : ctx->tune)
                     for (auto& pr : kv.second.ev)
@@ -1074,8 +1080,8 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
                 ctx->tune.clear();
             }
             ouster_hip_ctx::Tune& t = ctx->tune[key];
-            const int cand[ouster_hip_ctx::Tune::NCAND] = {256, 128, 0, 1000 + stream_auto};
-            const int nc = stream_auto ? 4 : 3;
+            const int cand[ouster_hip_ctx::Tune::NCAND] = {256, 128, 0, 1000 + stream_auto, 1000 + stream_alt};
+            const int nc = stream_auto ? (stream_alt ? 5 : 4) : 3;
             // Four launches of each candidate, back to back (a launch that follows a different variant
             // is not representative of the steady state: alternating the candidates made the 64-column
             // kernel look 8 % faster than it then ran).  Single launches vary by ~10 %, mostly upwards,
@@ -1090,7 +1096,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
                 for (int i = 0; i < NS && all; ++i) all = hipEventQuery(t.ev[i][1]) == hipSuccess;
                 if (!all) (void)hipGetLastError();
                 else {
-                    float cold[ouster_hip_ctx::Tune::NCAND] = {0, 0, 0, 0};
+                    float cold[ouster_hip_ctx::Tune::NCAND] = {0, 0, 0, 0, 0};
                     for (int i = 0; i < NS; ++i) {
                         float ms = 0;
                         if (hipEventElapsedTime(&ms, t.ev[i][0], t.ev[i][1]) != hipSuccess || ms <= 0) continue;

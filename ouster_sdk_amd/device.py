@@ -183,7 +183,7 @@ class HotPath:
         except (capi.OusterHipError, AttributeError):   # an older A/B build of the library without that knob
             pass
         else:
-            for _ in range(20):
+            for _ in range(24):
                 self.decode(best_pk, best_out)
             torch.cuda.synchronize()
         return best_pk, best_out, {"tries": tries, "stride_gb": stride_gb, "output_sets_ms": out_ms,
@@ -265,7 +265,7 @@ class HotPath:
         except (capi.OusterHipError, AttributeError):
             pass
         else:
-            for _ in range(20):
+            for _ in range(24):
                 self.decode(packets, out)
             torch.cuda.synchronize()
         return out, report

@@ -545,7 +545,7 @@ def test_tuner_times_the_persistent_kernel_too(oracle):
     hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL", wide=None)
     out = hp.alloc_outputs(256, destagger=["RANGE", "RANGE2"], xyz=["RANGE", "RANGE2"])
     seen, first = set(), None
-    for call in range(20):
+    for call in range(24):
         for t in out.values():
             t.view(torch.uint8).fill_(0x77)
         hp.decode(d_pk, out)
