@@ -596,7 +596,7 @@ __device__ __forceinline__ ouster_hip_frame_meta frame_meta_general(const Decode
 // "the last slot whose live column carries that measurement_id", what rounds 1-3 computed.
 // Output, in LDS: s_pix[c] / s_hdr[c] = buffer slot (packet * cpp + column) that supplies destination column c's pixels /
 // its header, or -1 (zeros).  s_pkm[i] (may be nullptr) = last packet whose first column's m_id / cpp == i (packet-level
-// outputs, batch_lidar_packet :1534-1539).  Returns next_valid at the end of the frame.
+// outputs, batch_lidar_packet :1534-1539).  Returns next_valid at the end of the frame (0 on the common-case path).
 // Pixel columns the reference neither writes nor zeroes (BD < cpp and a block's ids not consecutive with the block before)
 // keep the previous contents of the caller's LidarFrame there; here they read as zeros (documented).
 // All NT threads call it; it ends with a barrier.
@@ -700,6 +700,51 @@ __device__ __forceinline__ uint32_t resolve_frame(const Geometry& g, const uint8
     if (s_pkm) for (uint32_t i = tid; i < npo; i += NT) s_pkm[i] = -1;
     __syncthreads();
     RSTAMP(9);
+    // ---- The common case, decided first.  The result is more than "the last live slot that carries the column's id" only
+    // when (i) the block path puts pixels somewhere else than their own ids -- an all-valid packet with non-consecutive ids --
+    // or (ii) a zeroed range or the end-of-frame zeroing reaches something already written.  A column-path write at c leaves
+    // next_valid > c, so (ii) needs a block-path packet that arrives when next_valid lies INSIDE its span (F < next_valid <
+    // F + cpp: it is written without moving next_valid, and the next jump zeroes its tail) -- e.g. a packet whose first copy
+    // ended in invalid columns, sent again complete.  When every packet that has live columns is "whole at its tail and
+    // aligned" -- its live columns carry ids base + ic with one base that is a multiple of cpp, and its last column is live --
+    // every value next_valid ever takes is a multiple of cpp and neither can happen: any order, loss, duplicates, packets of
+    // invalid columns.  Then one pass of atomicMax settles both maps and the bookkeeping below is skipped (18 -> 6 us per frame).
+    if (cpp <= 64 && (cpp & (cpp - 1)) == 0) {
+        const uint32_t lane_ = tid & 63u, ic_ = lane_ & (cpp - 1u);
+        const uint64_t gm = cpp >= 64 ? ~0ull : ((1ull << cpp) - 1ull);
+        bool odd = false;
+        for (uint32_t base = 0; base < nslots; base += NT * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t s = base + (uint32_t)u * NT + tid;
+                const bool in = s < nslots;
+                const uint32_t h = in ? s_hd[s] : 0u, m = h & 0xffffu;
+                const bool live = in && (h >> 16) && m < W;
+                const uint32_t mybase = m - ic_;                                                   // wraps for ids below ic: never equal to an aligned base then
+                const uint32_t ref = (uint32_t)__shfl((int)mybase, (int)(lane_ - ic_ + cpp - 1u));   // the packet's last column
+                const uint64_t lv = (__ballot(live) >> (lane_ - ic_)) & gm;
+                const uint64_t same = (__ballot(!live || mybase == ref) >> (lane_ - ic_)) & gm;
+                odd |= lv != 0 && !(((lv >> (cpp - 1u)) & 1ull) && same == gm && ref % cpp == 0u);
+            }
+        }
+        if (!__syncthreads_or(odd ? 1 : 0)) {
+            for (uint32_t base = 0; base < nslots; base += NT * U) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t s = base + (uint32_t)u * NT + tid;
+                    if (s >= nslots) continue;
+                    const uint32_t h = s_hd[s], m = h & 0xffffu;
+                    if ((h >> 16) && m < W) atomicMax(&s_pix[m], (int32_t)s);
+                    if (s_pkm && ic_ == 0 && m / cpp < npo) atomicMax(&s_pkm[m / cpp], (int32_t)(s / cpp));
+                }
+            }
+            __syncthreads();
+            for (uint32_t c = tid; c < W; c += NT) s_hdr[c] = s_pix[c];
+            __syncthreads();
+            RSTAMP(13);
+            return 0u;
+        }
+    }
     // ---- A: which path does the reference take for a packet, and what does the packet do to next_valid?
     //      s_pkt[2p] = block path: F | 1 << 31 (F = m_id of column 0); column path: M = max over live columns of m_id + 1
     // One lane per slot where a packet's columns are a power-of-two group of lanes (every sensor: 16): consecutive lanes

@@ -47,3 +47,15 @@ bufs = {k: make(k) for k in kinds}
 for rep in range(3):
     row = {k: round(clock(*bufs[k]), 1) for k in kinds}
     print({k: round(v - row["clean"], 1) for k, v in row.items()}, "clean", row["clean"], flush=True)
+
+# the same buffers through the general mapping of a second context (k_slotmap + k_decode_wide from the maps): every byte equal?
+hp2, _, out2, *_ = bench._workload_setup("dual", N, pool_frames=8)
+hp2.ctx.set_knob("fast", 0)
+for k in kinds:
+    d, c = bufs[k]
+    for t in out.values(): t.view(torch.uint8).fill_(0xCD)
+    for t in out2.values(): t.view(torch.uint8).fill_(0xEE)
+    hp.decode(d, out, packet_counts=c); hp2.decode(d, out2, packet_counts=c)
+    torch.cuda.synchronize()
+    bad = [n for n in out if n != "frame_meta" and not torch.equal(out[n].view(torch.uint8), out2[n].view(torch.uint8))]
+    print("check", k, "equal" if not bad else ("DIFFERENT: " + ",".join(bad)), hp2.ctx.last_decode_kernel(), flush=True)

@@ -16,9 +16,10 @@ CONFIGS = [
     ("wide256 rows8 optimistic, fixup=0", {"small": 0, "wide": 256, "wide_rows": 8, "wide_min_blocks": 0, "stream": 0, "fixup": 0}),
     ("wide256 rows16 optimistic, fixup=0", {"small": 0, "wide": 256, "wide_rows": 16, "wide_min_blocks": 0, "stream": 0, "fixup": 0}),
     ("wide128 rows8 optimistic, fixup=0", {"small": 0, "wide": 128, "wide_rows": 8, "wide_min_blocks": 0, "stream": 0, "fixup": 0}),
-    ("resolved rows8", {"wide_rows": 8}),
-    ("resolved rows16", {"wide_rows": 16}),
-    ("resolved rows32", {"wide_rows": 32}),
+    ("wide256 rows32 optimistic + fixup", {"small": 0, "wide": 256, "wide_rows": 32, "wide_min_blocks": 0, "stream": 0}),
+    ("wide256 rows16 optimistic + fixup", {"small": 0, "wide": 256, "wide_rows": 16, "wide_min_blocks": 0, "stream": 0}),
+    ("wide128 rows16 optimistic + fixup", {"small": 0, "wide": 128, "wide_rows": 16, "wide_min_blocks": 0, "stream": 0}),
+    ("one launch (small=2)", {"small": 2}),
 ]
 
 for n in [int(x) for x in sys.argv[1:]] or [1, 4]:
