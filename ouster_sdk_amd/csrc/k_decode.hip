@@ -483,12 +483,13 @@ __global__ __launch_bounds__(256) void k_decode_fixup(DecodeArgs a) {
 // under the tile image: they are read before the first barrier); otherwise a.slot_map / a.hdr_map in global memory, or none.
 template <class S, int TW, int XYZM, bool POSES, bool LMAPS>
 __device__ __forceinline__ void wide_tile(const DecodeArgs& a, uint32_t* smem, uint32_t f, uint32_t tile, uint32_t rc,
-                                          const int32_t* l_pix, const int32_t* l_hdr) {
+                                          const int32_t* l_pix, const int32_t* l_hdr, uint32_t TR, uint32_t nch) {
     constexpr int NT = 256;
     constexpr int NJ = (TW + NT - 1) / NT;        // columns per thread in the per-column phases
     static_assert(TW % 64 == 0 && TW / 4 <= NT * 4, "tile width");
 
-    const uint32_t TR = a.rows_per_tile, nch = a.row_chunks;
+    // TR rows per tile, nch row chunks per frame: a.rows_per_tile / a.row_chunks, or fewer rows (the fix-up pass with few
+    // flagged frames; the LDS column stride a.lds_col_slot stays that of the launch's tallest tile)
     const uint32_t tid = threadIdx.x;
     const uint32_t W = a.g.columns_per_frame, H = a.g.pixels_per_column;
     const uint32_t cpp = a.g.columns_per_packet, col_size = a.g.col_size;
@@ -804,7 +805,8 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
     // the column tiles of one row chunk are neighbouring blocks of an XCD: together they write whole
     // 8 KB rows at the same time (ordering the row chunks of a column tile next to each other instead
     // shares input cache lines but measured 6 % slower)
-    wide_tile<S, TW, XYZM, POSES, false>(a, smem, f, sub % a.tiles_per_frame, sub / a.tiles_per_frame, nullptr, nullptr);
+    wide_tile<S, TW, XYZM, POSES, false>(a, smem, f, sub % a.tiles_per_frame, sub / a.tiles_per_frame, nullptr, nullptr,
+                                         a.rows_per_tile, a.row_chunks);
 }
 
 // ------------------------------------------------------------------------------------
@@ -850,7 +852,8 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
     __shared__ unsigned long long s_ticket, s_ready;
     const uint32_t tid = threadIdx.x;
     const uint32_t W = a.g.columns_per_frame, cpp = a.g.columns_per_packet, npo = a.n_packets_out;
-    constexpr uint32_t SPLIT_MAX = 8;   // REDO tickets per (frame, row chunk): ticket s takes every SPLIT-th dirty column tile
+    constexpr uint32_t SPLIT_MAX = 16;   // REDO tickets per (frame, row chunk): ticket s takes every SPLIT-th dirty column tile
+    uint32_t TRd = a.rows_per_tile, nchd = a.row_chunks;
     const uint64_t tag = a.frame_state[FS_TAG];
     // One counter for the whole grid: a flagged frame's tiles go wherever a workgroup is free.  (Keeping a frame on one XCD
     // -- right for k_decode_fixup's 64-column tiles, whose partial cache lines must meet in one L2 -- limits ONE damaged frame
@@ -957,9 +960,16 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
         __syncthreads();
         const uint32_t n_flagged = s_n;
         const uint32_t my_frames = n_flagged > xcd ? (n_flagged - xcd + nx - 1u) / nx : 0u;   // flagged frames of my XCD
-        // few damaged frames: one ticket per dirty tile (the chip is idle, latency counts); many: fewer tickets that find no work
-        const uint32_t SPLIT = n_flagged <= 8u ? SPLIT_MAX : n_flagged <= 48u ? 4u : 2u;
-        const uint32_t bpf = a.row_chunks * SPLIT;
+        // few damaged frames: short tiles, one ticket per dirty tile (the chip is idle, latency counts); many: the launch's
+        // tall tiles (a workgroup moves 1.8 x the bytes per microsecond through a 32-row tile than through four 8-row ones)
+        // and fewer tickets that find no work
+        // (one ticket per dirty tile whatever the number of flagged frames: with two to four tiles behind one ticket the pass
+        // took as long as its unluckiest ticket -- 228 us for 64 compacted frames, tools/ab/fixup_kinds.py; a ticket that finds
+        // no work costs 2 us)
+        const uint32_t SPLIT = min(a.tiles_per_frame, SPLIT_MAX);
+        TRd = n_flagged <= 8u ? min(a.fix_rows_small, a.rows_per_tile) : a.rows_per_tile;
+        nchd = (a.g.pixels_per_column + TRd - 1u) / TRd;
+        const uint32_t bpf = nchd * SPLIT;
         const unsigned long long items = (unsigned long long)my_frames * (1u + bpf);
         if (items == 0) continue;
         while (ticket < done + items) {
@@ -972,7 +982,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
             } else {
                 const uint32_t j = it - my_frames;
                 const uint32_t f = base + s_list[(j / bpf) * nx + xcd], sub = j % bpf;
-                const uint32_t rc = sub % a.row_chunks, share = sub / a.row_chunks;
+                const uint32_t rc = sub % nchd, share = sub / nchd;
                 if (tid == 0) {
                     unsigned long long v = 0;
                     for (uint32_t spin = 0; spin < a.spin_limit; ++spin) {
@@ -1015,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
                 for (uint32_t m = mask; m; m &= m - 1u, ++rank) {
                     if (rank % SPLIT != share) continue;
                     const uint32_t tile = (uint32_t)__builtin_ctz(m);
-                    wide_tile<S, TW, XYZM, POSES, false>(a, smem, f, tile, rc, nullptr, nullptr);   // reads the maps with agent-scope loads
+                    wide_tile<S, TW, XYZM, POSES, false>(a, smem, f, tile, rc, nullptr, nullptr, TRd, nchd);   // reads the maps with agent-scope loads
                     __syncthreads();
                     ++ntl;
                 }
@@ -1232,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_resolved(DecodeArgs a) {
             }
         }
     }
-    wide_tile<S, TW, XYZM, POSES, true>(a, smem, f, tile, rc, L.pix, L.hdr);
+    wide_tile<S, TW, XYZM, POSES, true>(a, smem, f, tile, rc, L.pix, L.hdr, a.rows_per_tile, a.row_chunks);
 }
 
 template <class S, int TW, int XYZM>

@@ -904,7 +904,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             // about 16 KB of packet bytes per tile (8 rows of 256 dual-return columns, 16 rows of 128 single-return ones): smaller
             // tiles are all prologue (the 12 B/px profile's 128 x 8 tiles made its fix-up pass slower than r03's)
             const uint32_t rows = kn.fixup_rows > 0 ? (uint32_t)kn.fixup_rows : (16384u + (uint32_t)want * chan - 1u) / ((uint32_t)want * chan);
-            tr = std::max(rpp, std::min(tr, up(rows)));
+            da.fix_rows_small = std::max(rpp, std::min(tr, up(rows)));   // the launch keeps the tall tile; the kernel takes the short one for few flagged frames
             if (tiles > 32) return false;   // the frame's ready word carries one bit per column tile
         }
         if (kn.wide_rows > 0) tr = std::min((uint32_t)kn.wide_rows, H);
