@@ -267,3 +267,40 @@ def test_more_frames_than_one_fixup_chunk(oracle):
     pf, by_frame = _damaged_batch(O, cal, 700, 11)
     hp = _decode_and_compare(O, cal, pf, by_frame, None, False, "700 frames")
     assert hp.ctx.last_decode_kernel() != ""
+
+
+@pytest.mark.parametrize("h,w,cpp", [(64, 4096, 16), (32, 512, 8), (16, 384, 12), (20, 512, 16), (16, 256, 4)])
+def test_other_geometries_take_the_same_semantics(oracle, h, w, cpp):
+    """4096 columns (the column maps no longer fit under a wide tile: the fix-up pass falls back to 64-column tiles, each
+    resolving its frame), 8 and 4 columns per packet (other lane groups), 12 (not a power of two: the per-packet fallback of
+    resolve_frame), 20 rows (block_parsable() = 4 < columns_per_packet)."""
+    O = oracle
+    cal = O.synthetic_calib(h=h, w=w, cpp=cpp, profile=PROFILE)
+    pf = cal.packet_format()
+    packets, _ = O.synth_packets(cal, 6, seed=h + w + cpp, with_window=True)
+    ppf = w // cpp
+    rng = np.random.default_rng(h * w + cpp)
+    by_frame = [packets[f].copy() for f in range(6)]
+    a, b = rng.choice(ppf, 2, replace=False)
+    by_frame[1][[a, b]] = by_frame[1][[b, a]]                                        # two packets swapped
+    by_frame[2] = np.delete(by_frame[2], int(rng.integers(0, ppf - 1)), axis=0)       # compacted after a drop
+    p = int(rng.integers(0, ppf))
+    for ic, m in enumerate(rng.permutation(cpp)):                                     # ids shuffled inside an all-valid packet
+        _set_mid(pf, by_frame[3][p], ic, p * cpp + int(m))
+    q = int(rng.integers(1, ppf))
+    first = by_frame[4][q].copy()
+    for ic in range(cpp // 2, cpp):
+        _set_valid(pf, first, ic, False)                                             # a first copy that ends in invalid columns ...
+    by_frame[4] = np.concatenate([by_frame[4][:q], first[None], by_frame[4][q:]])[:ppf + 1]   # ... then the packet again, whole
+    # the same through the fix-up pass: the whole copy sits in the slot of the (lost) next packet.  The reference leaves
+    # next_valid inside the packet's span after the first copy, writes the second without moving it, and the next jump
+    # zeroes the second copy's tail again -- reproduced, not repaired
+    r = int(rng.integers(0, ppf - 2))
+    whole = by_frame[5][r].copy()
+    part = whole.copy()
+    for ic in range(cpp // 2, cpp):
+        _set_valid(pf, part, ic, False)
+    by_frame[5][r], by_frame[5][r + 1] = part, whole
+    for compacted in (False, True):
+        frames = by_frame if compacted else [fr for fr in by_frame if len(fr) <= ppf]
+        _decode_and_compare(O, cal, pf, frames, None, compacted, f"{h}x{w} cpp {cpp}")
