@@ -811,27 +811,30 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
 
 // ------------------------------------------------------------------------------------
 // k_decode_wide_fixup: the fix-up pass on wide tiles (round 4; k_decode_fixup's 64-column tiles remain for formats the wide
-// tiles cannot take).  A persistent grid as before: every workgroup lists the frames flagged with this call's tag; the
-// workgroups share the work out through a ticket counter.  Tickets, in this order:
-//   one per flagged frame      RESOLVE: resolve_frame gives the frame's real column maps (from the packed header words the
-//                              optimistic pass left behind); they go to a.slot_map / a.hdr_map, together with the mask of
+// tiles cannot take).  A persistent grid as before: every workgroup lists the frames flagged with this call's tag and the
+// workgroups share the work out through tickets.  Tickets, in this order:
+//   one per flagged frame      LEAD: resolve_frame gives the frame's real column maps (from the packed header words the
+//                              optimistic pass left behind); they go to a.slot_map / a.hdr_map together with the mask of
 //                              column tiles whose maps differ from what the optimistic pass assumed ("slot c holds column c,
-//                              anything else reads as zeros"), the frame's packet-level outputs, frame-level values and
-//                              valid-column count; then the frame's ready word is released (tag | mask).
-//   one per (frame, tile, row chunk)   REDO: waits for the frame's ready word, leaves at once when the tile is not in the
-//                              mask -- a frame with two packets swapped costs one column tile, not the frame (r03: every
-//                              flagged frame was redone whole) -- and decodes the tile from the maps otherwise.  Short tiles
-//                              (8 rows): the few flagged frames of a batch are spread over the whole XCD instead of keeping a
-//                              handful of workgroups busy for 50 us each.
-// RESOLVE tickets come first and never wait, so a REDO ticket normally waits for a workgroup that is making progress; the wait
-// is bounded all the same: after spin_limit polls the workgroup resolves the frame itself (the maps are a pure function of
-// the packets).  Maps and ready words are written and read with
-// agent-scope atomics: the XCDs' L2s are not coherent with each other for plain accesses.
-// The ticket counters live in frame_state behind the sequence words, one set per tag parity: this call's start at zero
-// (zeroed by the call before), the other set is zeroed for the next call; the ready words ([ready_off + f], the buffer's second half)
-// carry the tag and are never cleared.
+//                              anything else reads as zeros"), then the frame's ready word is published (tag | mask); then
+//                              the frame's packet-level outputs, frame-level values and valid-column count.
+//   one per (frame, row chunk, k)   REDO: decodes the k-th wrong column tile, if there is one -- a frame with two packets
+//                              swapped costs one column tile, not the frame (r03: every flagged frame was redone whole).
+//                              Where do the maps come from?  ONE look at the ready word: published -- a later round of
+//                              tickets -- they are read from global memory, for free; not yet -- the first round, whose LEAD
+//                              tickets started when this one did -- the workgroup resolves the frame itself (6 us for whole,
+//                              aligned packets) and decodes from its LDS copy.  Nobody ever waits for anybody: a version
+//                              that polled sat through the LEAD ticket's resolution, the write-through of the maps and a
+//                              poll interval (13 us, tools/ab/phase_fixup.py) and needed a bounded-wait fallback; a version
+//                              in which every ticket resolved for itself paid 6 us per ticket at scale (0.60 against 0.63).
+// Maps and ready words are written and read with agent-scope atomics: the XCDs' L2s are not coherent with each other for
+// plain accesses.  Few flagged frames: short tiles (fix_rows_small), so that the damage spreads over the chip; many: the
+// launch's tall tiles.  A workgroup's first ticket is its own number (no atomic on a clean batch: 512 workgroups adding to
+// one word are served one after the other, 4 us on every call); the counter hands out the tickets behind those, each asked
+// for when the item before it starts.  The counter lives in frame_state behind the sequence words, one per tag parity: this
+// call's starts at zero (zeroed by the call before), the other is zeroed for the next call; the ready words ([ready_off + f],
+// the buffer's second half) carry the tag and are never cleared.
 // ------------------------------------------------------------------------------------
-// polls of a frame's ready word before a REDO ticket gives up and resolves the frame itself: DecodeArgs::spin_limit (65536 x ~0.25 us)
 #ifdef OUSTER_PHASE_TIMING   // experiment builds (tools/ab/phase_timing.sh): per workgroup 64 words: [0] start, [1] events, then 4 per ticket
 #define FSTAMP_BEGIN() uint64_t fs0_ = __builtin_readcyclecounter(), fs1_ = 0
 #define FSTAMP_MID() do { fs1_ = __builtin_readcyclecounter(); } while (0)
@@ -862,11 +865,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
     unsigned long long* ctr = (unsigned long long*)&a.frame_state[FS_TICKET + (tag & 1u) * 8u + xcd];
     unsigned long long* ready = (unsigned long long*)&a.frame_state[a.ready_off];
     if (blockIdx.x < 8 && tid == 0) a.frame_state[FS_TICKET + ((tag + 1u) & 1u) * 8u + blockIdx.x] = 0;   // the next call's counters
-    // A workgroup's first ticket is its own number -- no atomic at all on a clean batch (512 workgroups adding to one word
-    // are served one after the other: 4 us on every call), no round trip before a flagged batch's work starts -- and the
-    // counter hands out the tickets behind those.  (A first ticket may thus belong to a workgroup that is not running yet;
-    // whoever waits for it gives up after spin_limit polls and resolves the frame itself.)
-    // The next ticket is asked for when an item starts and looked at when it ends: the round trip hides behind the item.
+    // first ticket = the workgroup's own number; the next one is asked for when an item starts and looked at when it ends
     unsigned long long ahead = 0;
     auto pull_ahead = [&]() { if (tid == 0) ahead = atomicAdd(ctr, 1ull) + gridDim.x; };
     auto take_ahead = [&]() -> unsigned long long {
@@ -886,14 +885,15 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
         if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
         if (tid == 0) { s_nvalid = 0; s_dirty = 0; }
         resolve_frame<NT>(a.g, fbase, a.packet_stride, count, npo, L, lead, a.hdr_words ? a.hdr_words + (size_t)f * W : nullptr);
-        if (!lead) return;
-        // the maps, and which column tiles the optimistic pass got wrong: it wrote slot c where that is live and at home,
-        // zeros otherwise
+        // which column tiles the optimistic pass got wrong: it wrote slot c where that is live and at home, zeros otherwise;
+        // the LEAD ticket also leaves the maps in global memory for the tickets of later rounds
         uint32_t n = 0, dm = 0;
         for (uint32_t c = tid; c < W; c += NT) {
             const int32_t px = L.pix[c], hd = L.hdr[c];
-            __hip_atomic_store(&a.slot_map[(size_t)f * W + c], px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.hdr_map[(size_t)f * W + c], hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lead) {
+                __hip_atomic_store(&a.slot_map[(size_t)f * W + c], px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.hdr_map[(size_t)f * W + c], hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             n += hd >= 0 ? 1u : 0u;
             int32_t expect = -1;
             if (c / cpp < count && L.hd[c] == (c | 0x10000u)) expect = (int32_t)c;
@@ -905,14 +905,15 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
             if (n) atomicAdd(&s_nvalid, n);
             if (dm) atomicOr(&s_dirty, dm);
         }
-        // The maps were stored with agent-scope atomics (written through to where the other XCDs can see them); every wave
-        // waits for its stores before the barrier, the word that announces them is stored behind it.  No cache-wide
+        // (LEAD) The maps were stored with agent-scope atomics (written through to where the other XCDs can see them); every
+        // wave waits for its stores before the barrier, the word that announces them is stored behind it.  No cache-wide
         // release: a buffer_wbl2 here would have to write back every tile the XCD has redone so far.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lead) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (!lead) return;
         if (tid == 0)
             __hip_atomic_store(&ready[f], (unsigned long long)((tag << 32) | s_dirty), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // Nobody waits for the rest: the frame's packet-level outputs (packet_timestamp is zeroed at frame start,
+        // Nobody needs the rest soon: the frame's packet-level outputs (packet_timestamp is zeroed at frame start,
         // lidar_frame.cpp:1719, alert_flags is not), frame-level values and valid-column count
         for (uint32_t i = tid; i < npo; i += NT) {
             const int32_t p = L.pkm[i];
@@ -983,49 +984,31 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
                 const uint32_t j = it - my_frames;
                 const uint32_t f = base + s_list[(j / bpf) * nx + xcd], sub = j % bpf;
                 const uint32_t rc = sub % nchd, share = sub / nchd;
-                if (tid == 0) {
-                    unsigned long long v = 0;
-                    for (uint32_t spin = 0; spin < a.spin_limit; ++spin) {
-                        v = __hip_atomic_load(&ready[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((v >> 32) == (tag & 0xffffffffull)) break;
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                    s_ready = v;
-                }
+                // ONE look at the frame's ready word.  There (a later round of tickets): the maps and the mask of wrong tiles are
+                // in global memory, nothing to compute.  Not there yet (the first round: the LEAD ticket started when this one
+                // did): resolve the frame here -- 6 us for whole, aligned packets -- instead of sitting through the LEAD
+                // ticket's resolution, its write-through of the maps and a poll interval (13 us, tools/ab/phase_fixup.py).
+                // Nobody ever waits for anybody.
+                if (tid == 0) s_ready = __hip_atomic_load(&ready[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
                 FSTAMP_MID();
                 const unsigned long long v = s_ready;
-                uint32_t mask = (uint32_t)v;
                 const bool published = (v >> 32) == (tag & 0xffffffffull);
+                uint32_t mask = (uint32_t)v;
                 if (!published) {
-                    // never seen so far (a.spin_limit polls): do the frame's resolution here; same maps, nothing is published
                     resolve(f, false);
-                    uint32_t cnt = a.slots_per_frame;
-                    if (a.packet_counts) cnt = min(a.packet_counts[f], a.slots_per_frame);
-                    uint32_t dm = 0;
-                    for (uint32_t c = tid; c < W; c += NT) {
-                        int32_t expect = -1;
-                        if (c / cpp < cnt && L.hd[c] == (c | 0x10000u)) expect = (int32_t)c;
-                        if (L.pix[c] != expect || L.hdr[c] != expect) dm |= 1u << (c / TW);
-                    }
-                    dm = wave_or(dm);
-                    if ((tid & 63u) == 0 && dm) atomicOr(&s_dirty, dm);
-                    __syncthreads();
                     mask = s_dirty;
-                    // the tiles below read the maps from global memory (the LDS copy lies under the tile image): store them, the same
-                    // values the RESOLVE ticket's workgroup stores
-                    for (uint32_t c = tid; c < W; c += NT) {
-                        __hip_atomic_store(&a.slot_map[(size_t)f * W + c], L.pix[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&a.hdr_map[(size_t)f * W + c], L.hdr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
                 }
                 uint32_t rank = 0, ntl = 0;
                 for (uint32_t m = mask; m; m &= m - 1u, ++rank) {
                     if (rank % SPLIT != share) continue;
                     const uint32_t tile = (uint32_t)__builtin_ctz(m);
-                    wide_tile<S, TW, XYZM, POSES, false>(a, smem, f, tile, rc, nullptr, nullptr, TRd, nchd);   // reads the maps with agent-scope loads
+                    if (published) {
+                        wide_tile<S, TW, XYZM, POSES, false>(a, smem, f, tile, rc, nullptr, nullptr, TRd, nchd);   // reads the maps with agent-scope loads
+                    } else {
+                        if (ntl) resolve(f, false);   // more than SPLIT_MAX column tiles: the maps lay under the tile before
+                        wide_tile<S, TW, XYZM, POSES, true>(a, smem, f, tile, rc, L.pix, L.hdr, TRd, nchd);
+                    }
                     __syncthreads();
                     ++ntl;
                 }

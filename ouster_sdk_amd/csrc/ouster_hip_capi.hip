@@ -82,7 +82,6 @@ struct Knobs {
     int fixup = 1;            // tests only: 0 skips the fix-up pass (flagged frames are then left undone)
     int small = 1;            // OUSTER_HIP_SMALL: small batches: 1 = wide tiles of few rows (optimistic pass + fix-up pass; any other buffer shape: the
                               //   one-launch k_decode_wide_resolved) | 2 = the one-launch form always | 0 = k_decode's narrow tiles as in r03
-    int fixup_spin = 1 << 16; // OUSTER_HIP_FIXUP_SPIN: polls of a frame's ready word before a fix-up workgroup resolves the frame itself (tests: 0)
     int fixup_rows = 0;       // OUSTER_HIP_FIXUP_ROWS: rows of a fix-up tile (0: 8)
     int hdr_words = 1;        // OUSTER_HIP_HDR_WORDS: 0 = the fix-up pass reads the column headers from the packets again (A/B)
     int fixup_wide = 1;       // OUSTER_HIP_FIXUP_WIDE: 1 = the fix-up pass on wide tiles where the format allows | 0 = 64-column tiles | 64 / 128 / 256 force
@@ -308,7 +307,6 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.small = env_int("OUSTER_HIP_SMALL", k.small);
         k.hdr_words = env_int("OUSTER_HIP_HDR_WORDS", k.hdr_words);
         k.fixup_rows = env_int("OUSTER_HIP_FIXUP_ROWS", k.fixup_rows);
-        k.fixup_spin = env_int("OUSTER_HIP_FIXUP_SPIN", k.fixup_spin);
     }
     if (stream == OUSTER_HIP_STREAM_NULL) {
         c->stream = nullptr;  // the null stream
@@ -385,7 +383,6 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "small") k.small = value;
     else if (n == "hdr_words") k.hdr_words = value;
     else if (n == "fixup_rows") k.fixup_rows = value;
-    else if (n == "fixup_spin") k.fixup_spin = value;
     else if (n == "beam_lds") k.beam_lds = value;
     else if (n == "dewarp_single_pass") k.dewarp_single_pass = value;
     else if (n == "stream") k.stream = value;
@@ -773,7 +770,6 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     da.packet_counts = d_counts;
     da.host_timestamps = host_timestamps;
     da.frame_state = (uint64_t*)ctx->state.p;
-    da.spin_limit = (uint32_t)std::max(kn.fixup_spin, 0);
     da.ready_off = FS_WORDS + (uint32_t)((ctx->state.cap / 8 - FS_WORDS) / 2);   // the second half of the buffer: moves only when it is reallocated (and zeroed)
     if (out->xyz_poses && xyzm == 3)
         return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "xyz_poses need LUTs with separable tables (ouster_hip_lut_create)");

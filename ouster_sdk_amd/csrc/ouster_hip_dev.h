@@ -92,7 +92,6 @@ struct DecodeArgs {
     int32_t* hdr_map;         // device [n_frames][W], with slot_map: the slot whose HEADER lands in destination column c (differs from
                               //   slot_map only for all-valid packets with non-consecutive ids: the reference's block path)
     uint32_t fix_rows_small;  // fix-up pass: rows of a tile when few frames are flagged (rows_per_tile otherwise)
-    uint32_t spin_limit;      // fix-up pass: polls of a frame's ready word before a REDO ticket resolves the frame itself
     uint32_t ready_off;       // frame_state word index of the fix-up pass's per-frame ready words (k_decode_wide_fixup)
     uint32_t* hdr_words;      // device [n_frames][W] or nullptr.  The optimistic pass leaves every slot's (measurement_id | valid << 16)
                               //   here, packed: the fix-up pass resolves a flagged frame from 8 KB of consecutive words instead of
