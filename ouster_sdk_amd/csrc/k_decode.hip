@@ -981,9 +981,12 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
                 resolve(base + s_list[it * nx + xcd], true);
                 FSTAMP_END(1u, 0u);
             } else {
-                const uint32_t j = it - my_frames;
-                const uint32_t f = base + s_list[(j / bpf) * nx + xcd], sub = j % bpf;
-                const uint32_t rc = sub % nchd, share = sub / nchd;
+                // ticket order: every frame's FIRST wrong tile (all its row chunks), then every frame's second, ... -- the
+                // tickets most likely to find work are handed out first, while every workgroup is still free; frame by frame,
+                // the last frames' tiles all fell into the second round behind workgroups that already had a tile to do
+                const uint32_t j = it - my_frames, per_share = my_frames * nchd;
+                const uint32_t share = j / per_share, rest = j % per_share;
+                const uint32_t f = base + s_list[(rest / nchd) * nx + xcd], rc = rest % nchd;
                 // ONE look at the frame's ready word.  There (a later round of tickets): the maps and the mask of wrong tiles are
                 // in global memory, nothing to compute.  Not there yet (the first round: the LEAD ticket started when this one
                 // did): resolve the frame here -- 6 us for whole, aligned packets -- instead of sitting through the LEAD
