@@ -19,12 +19,12 @@ restatement of the reference loops, timed on this box's host cores, rank 0 at N=
 
 Setup before the W warm-up steps (none of it inside the timed region, all of it reported in the JSON line):
   * the library's kernel-variant tuner settles (first 20 calls of a workload shape);
-  * buffer placement: `--placement first` (the default since round 4): the buffers as the first allocation put them, no
-    search -- the headline is what any caller gets.  `--placement refine` is the opt-in search of
-    ouster::sdk::hip::DeviceFrameBatch (BatchOptions::auto_placement): further copies of the output set are allocated and
-    every buffer group (XYZ pair, 32-bit planes, destaggered planes, narrow planes) is kept at the fastest of its
-    locations (~35 GB transient with 4 draws 8 GB apart, under a second; typically +1 ... +3 %); "placement" then reports the
-    first allocation's time next to the kept one.  `--placement draws` is the round-2 diagnostic (DESIGN.md 3.2c);
+  * buffer placement, `--placement refine` (default) in its FRUGAL form since round 4: two more copies of the output set are
+    allocated back to back (6.6 GB transient for 256 dual-return frames, 0.1 s; round 3: three copies 8 GB apart, 35 GB) and
+    every buffer group (XYZ pair, 32-bit planes, destaggered planes, narrow planes) is kept at the fastest of its three
+    locations -- what ouster::sdk::hip::DeviceFrameBatch does when BatchOptions::auto_placement is set (opt-in in the library).
+    "placement" and roofline.first_allocation_* report the first allocation's time next to the kept one (typically 3 - 9 %
+    slower).  `--placement first` takes the first allocation as it comes; `--placement draws` is the round-2 diagnostic;
   * after the K timed steps the outputs are compared with the oracle ("validated", "max_abs_dxyz_m").
 The timed steps rotate over `--rotate-inputs` copies of the packet batch (default 2: no step finds its input in the
 256 MB Infinity Cache).  After the timed region the paths the metric never touches are timed on the same buffers and
@@ -464,13 +464,16 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--rotate-inputs", type=int, default=2,
                     help="decode this many copies of the packet batch in turn (>= 2: cold input every step)")
-    ap.add_argument("--placement", default="first", choices=["first", "refine", "draws"],
-                    help="first (default since round 4): buffers as allocated, no search; refine: buffer groups re-drawn (what "
-                         "DeviceFrameBatch does at construction when BatchOptions::auto_placement is set; ~35 GB transient with "
-                         "the defaults below); draws: diagnostic, whole output sets drawn across the device memory")
-    ap.add_argument("--placement-draws", type=int, default=4, help="--placement refine: locations tried per buffer group")
-    ap.add_argument("--placement-ballast-gb", type=float, default=8.0,
-                    help="--placement refine: device memory held between two locations (0: back-to-back draws)")
+    ap.add_argument("--placement", default="refine", choices=["first", "refine", "draws"],
+                    help="refine (default): the frugal search -- two more copies of the output set, back to back (6.6 GB "
+                         "transient, 0.1 s), each buffer group kept at the fastest of its three locations; what "
+                         "DeviceFrameBatch does when BatchOptions::auto_placement is set.  The first allocation's time is "
+                         "printed beside the kept one.  first: buffers as allocated, no search; draws: diagnostic, whole "
+                         "output sets drawn across the device memory")
+    ap.add_argument("--placement-draws", type=int, default=3, help="--placement refine: locations tried per buffer group")
+    ap.add_argument("--placement-ballast-gb", type=float, default=0.0,
+                    help="--placement refine: device memory held between two locations (0: back-to-back draws; 8 with 4 draws "
+                         "is round 3's 35 GB form)")
     ap.add_argument("--placement-stride-gb", type=float, default=4.0,
                     help="--placement draws: ballast held between two draws (they scan the device memory)")
     ap.add_argument("--placement-tries", type=int, default=24,
