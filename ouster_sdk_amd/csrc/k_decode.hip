@@ -1304,19 +1304,19 @@ hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a_in, int tw, in
         const uint64_t items = (uint64_t)a.n_frames * bpf;
         uint32_t g = (uint32_t)std::min<uint64_t>(items, resident ? resident : 512u);
         const dim3 grid(g);
-        switch (tw) {
-            case 64: return launch_wide_fixup_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
+        switch (tw) {   // 128 or 256 columns (narrower frames take k_decode_fixup): every width is 12 more kernels per profile to compile
             case 128: return launch_wide_fixup_t<SpecT, 128>(a, xyzm, grid, lds, device, st);
-            default: return launch_wide_fixup_t<SpecT, 256>(a, xyzm, grid, lds, device, st);
+            case 256: return launch_wide_fixup_t<SpecT, 256>(a, xyzm, grid, lds, device, st);
+            default: return hipErrorInvalidValue;
         }
     }
     const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * bpf : a.n_frames * bpf;
     const dim3 grid(nblocks);
     if (resolved) {
         switch (tw) {
-            case 64: return launch_wide_resolved_t<SpecT, 64>(a, xyzm, grid, lds, device, st);
             case 128: return launch_wide_resolved_t<SpecT, 128>(a, xyzm, grid, lds, device, st);
-            default: return launch_wide_resolved_t<SpecT, 256>(a, xyzm, grid, lds, device, st);
+            case 256: return launch_wide_resolved_t<SpecT, 256>(a, xyzm, grid, lds, device, st);
+            default: return hipErrorInvalidValue;
         }
     }
     switch (tw) {

@@ -871,7 +871,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         if (!((fast || mapped_ok || small) && (want == 64 || want == 128 || want == 256 || want == 512) && chan && chan % 4 == 0 &&
               W >= (uint32_t)want))
             return false;
-        if ((for_fix || small) && (want == 512 || out->gate_counts || resolver_lds > 64 * 1024)) return false;
+        if ((for_fix || small) && (want == 512 || want == 64 || out->gate_counts || resolver_lds > 64 * 1024)) return false;
         if (da.xyz_poses && ((uintptr_t)da.xyz_poses & 15u)) return false;   // the wide tiles fetch the poses in 16 B pieces
         const uint32_t rpp = 1024u / (uint32_t)want;  // rows per pass of the 256-thread workgroup
         uint32_t budget = (uint32_t)(kn.wide_kb > 0 ? kn.wide_kb : 64) * 1024u;
@@ -1015,8 +1015,8 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // optimistic wide tiles, any other shape the one-launch form (kn.small = 2 forces it for both).
     bool resolved = false, small_wide = false;
     if (kn.small && kn.stream <= 0 && kn.wide < 0 && kn.tile == 0 && kn.fast) {
-        for (int tw : {256, 128, 64})
-            if (W >= (uint32_t)tw || tw == 64) {
+        for (int tw : {256, 128})
+            if (W >= (uint32_t)tw) {
                 if (setup_wide(tw, false, true)) {
                     wide = tw;
                     resolved = !fast || kn.small == 2;
