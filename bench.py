@@ -158,14 +158,29 @@ def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 12.0):
            "sample": f"{n} frames x {reps} passes, FrameBatcher(block path)+destagger x4+"
                      f"cartesianT<double> x2 (the reference's default single-threaded path), "
                      f"{t:.1f} s"}
-    if cores > 1:  # frames in parallel over the host cores (informational; 4 frames per thread)
-        threads = cores      # all host cores of this box (count stated in the line)
+    if cores > 1:  # frames in parallel over ALL host cores of this box (count stated in the line)
+        threads = cores
         nv = threads * 4
-        ta = run(1, threads, True, nv)
-        ra = max(1, int(6.0 / max(ta, 1e-3)))
-        ta = run(ra, threads, True, nv)
+
+        def run_all(reps_, flags):
+            return O.lib().ora_bench_hot_path2(C.byref(pf), 1, flat.ctypes.data, n, nv, W // CPP, sh.ctypes.data,
+                                               ldir.ctypes.data, lofs.ctypes.data, 1, reps_, threads, C.byref(cks), flags)
+        # flags 3: every thread on its own first-touched copy of the LUT / packets (NUMA-local pages), static schedule -- the
+        # round-4 harness (one shared 25 MB LUT on the node of the thread that built it, dynamic schedule) is quoted beside it
+        ta = run_all(1, 3)
+        ra = max(1, int(5.0 / max(ta, 1e-3)))
+        ta = run_all(ra, 3)
+        tb = run_all(max(1, ra // 2), 0)
+        bpp_all = algorithmic_bytes_per_frame("dual") / (H * W * 2)
+        cp_bytes, cp_reps = 64 << 20, 8
+        tcopy = O.lib().ora_bench_stream_copy(cp_bytes, cp_reps, threads)
         res["all_cores"] = {"value": nv * ra * H * W * 2 / ta / 1e6, "cores": threads, "host_cores": cores,
-                            "sample": f"{nv} frames x {ra} passes over {threads} OpenMP threads"}
+                            "sample": f"{nv} frames x {ra} passes over {threads} OpenMP threads, per-thread first-touched LUT "
+                                      "and packet copies, static schedule",
+                            "shared_lut_dynamic_schedule_value": round(nv * max(1, ra // 2) * H * W * 2 / tb / 1e6, 1),
+                            "stream_copy_GBps_same_threads": round(2.0 * cp_bytes * cp_reps * threads / tcopy / 1e9, 1),
+                            "note": "GBps (below) counts SURVEY 8(d)'s algorithmic bytes; the f64 path also reads 2 x 24 B of LUT "
+                                    "per point, so its memory traffic is about 3.5 x that"}
     rf = max(1, reps // 3)
     tf = run(rf, 1, False)
     res["f32_variant"] = {"value": n * rf * H * W * 2 / tf / 1e6, "cores": 1}
@@ -181,13 +196,34 @@ def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 12.0):
             td, tc = core_ref.bench_frame_legs(dst, rng, ldir, lofs, sh, 2)
             rr = max(2, int(3.0 / max(td + tc, 1e-3) * 2))
             td, tc = core_ref.bench_frame_legs(dst, rng, ldir, lofs, sh, rr)
+            decode_leg = {}
+            try:
+                from oracle import decode_ref
+                if decode_ref.available():
+                    rpf = decode_ref.RefPacketFormat(O, pf)
+                    planes = {nm: np.zeros((H, W), dtype=fr.plane(nm).dtype) for nm in rpf.names if nm in fr.plane_names()}
+                    tdec = rpf.bench_decode_frame(pool[0], planes, 16, 2)
+                    rd = max(2, int(3.0 / max(tdec, 1e-3) * 2))
+                    tdec = rpf.bench_decode_frame(pool[0], planes, 16, rd)
+                    same = all(np.array_equal(planes[nm], fr.plane(nm)) for nm in planes)
+                    decode_leg = {"decode_block_field_Mpixels_per_s": round(H * W * rd / tdec / 1e6, 1),
+                                  "decode_fields": len(planes), "decode_equals_oracle": bool(same),
+                                  "decode_what": "PacketFormat::block_field<T,16> of every plane for every packet of the frame "
+                                                 "(parse_by_block's loop, lidar_frame.cpp:1492-1528), the reference's own code "
+                                                 "(oracle/_ref/libdecode_ref.so: parsing.cpp:628-657 + field_decode_info.h:41-54)"}
+            except Exception as e:
+                decode_leg = {"decode_error": str(e)[:200]}
             res["reference_legs"] = {
+                **decode_leg,
                 "kind": "reference", "cores": 1, "sample": f"1 frame x {rr} passes",
                 "destagger_x4_Mpixels_per_s": round(4 * H * W * rr / td / 1e6, 1),
                 "cartesian_f64_x2_Mpoints_per_s": round(2 * H * W * rr / tc / 1e6, 1),
                 "destagger_plus_cartesian_Mpoints_per_s": round(2 * H * W * rr / (td + tc) / 1e6, 1),
-                "what": "destagger_into<T> x4 + cartesianT<double> x2 of the reference itself (oracle/_ref/libcore_ref.so); "
-                        "the packet decode leg of `value` above is the oracle's port of FrameBatcher"}
+                "what": "destagger_into<T> x4 + cartesianT<double> x2 of the reference itself (oracle/_ref/libcore_ref.so) and its "
+                        "block_field decode loop (libdecode_ref.so); `value` above is the oracle's port of the whole FrameBatcher path"}
+            if "decode_block_field_Mpixels_per_s" in res["reference_legs"]:   # all three legs by the reference's own code, one core
+                tt = 1.0 / (res["reference_legs"]["decode_block_field_Mpixels_per_s"] * 1e6) * H * W + (td + tc) / rr
+                res["reference_legs"]["all_three_legs_Mpoints_per_s"] = round(2 * H * W / tt / 1e6, 1)
     except Exception as e:   # the reference legs are optional evidence; the port's number stands on its own
         res["reference_legs"] = {"error": str(e)[:200]}
     # the same algorithmic byte count as the GPU leg: bytes/s next to points/s
@@ -461,6 +497,127 @@ def time_small_batches(calls=300):
     return res
 
 
+def time_standalone(n_images=128):
+    """The standalone kernels behind ouster_hip_destagger / _cartesian / _dewarp_frames_rows (SURVEY 8(a) rows a10, a13, f-2;
+    the reference's own three benchmarks: tests/benchmarks/core_benchmark.cpp:29-154) on resident data, each checked against
+    the oracle on one image, `frac` on SURVEY 8(d)'s per-kernel byte counts -- report rows, never `value`.  Every input
+    exists in 3 copies used in turn (a call must not find its input in the 256 MB Infinity Cache)."""
+    import torch
+    from ouster_sdk_amd.device import HotPath
+    from oracle import oracle as O
+    O.build()
+    N = n_images
+    alt, az, shifts, b2l, l2s = synth_calibration()
+    hp = HotPath(PROFILE, H, W, CPP)
+    hp.set_pixel_shift_by_row(shifts)
+    lut = hp.add_lut(b2l, l2s, az, alt)
+    d64, o64 = lut.export(W, H)
+    lut32 = hp.add_lut_arrays(d64.astype(np.float32), o64.astype(np.float32))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rng = torch.randint(0, 2 ** 19, (N, H, W), dtype=torch.int64, device="cuda", generator=g)
+    rng = (rng * (torch.rand(rng.shape, device="cuda", generator=g) >= 0.3)).to(torch.uint32)   # ~30 % no-return pixels
+
+    class Rot:
+        def __init__(self, t):
+            self.c, self.i = [t, t.clone(), t.clone()], 0
+
+        def __call__(self):
+            self.i += 1
+            return self.c[self.i % 3]
+
+    def clock(fn, reps=10):
+        fn(); fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e-3
+
+    res, npx = {}, N * H * W
+    for name, t, kern in (("destagger_u8", rng.to(torch.uint8), "k_destagger"), ("destagger_u16", rng.to(torch.uint16), "k_destagger"),
+                          ("destagger_u32", rng, "k_destagger")):
+        rt = Rot(t)
+        s = clock(lambda: hp.destagger(rt()))
+        ok = bool(np.array_equal(hp.destagger(t[:1].contiguous())[0].cpu().numpy(), O.destagger(t[0].cpu().numpy(), shifts)))
+        nbytes = 2 * t.numel() * t.element_size()
+        res[name] = {"kernel": kern, "ms": round(s * 1e3, 4), "algorithmic_bytes": int(nbytes),
+                     "frac": round(nbytes / s / 1e9 / HBM_PEAK_GBPS, 4), "validated": ok}
+    for name, l, bpp, ld, lo in (("cartesian_sep_f32", lut, 4 + 12, d64, o64),
+                                 ("cartesian_fullLUT_f32", lut32, 4 + 12 + 24.0 / N, d64.astype(np.float32), o64.astype(np.float32))):
+        rr = Rot(rng)
+        s = clock(lambda: hp.cartesian(rr(), lut=l, dtype=torch.float32))
+        got = hp.cartesian(rng[:1].contiguous(), lut=l, dtype=torch.float32)[0].cpu().numpy().astype(np.float64)
+        want = O.cartesian(rng[0].cpu().numpy(), ld.astype(np.float64), lo.astype(np.float64))
+        err = float(np.abs(got - want).max())
+        nbytes = npx * bpp
+        res[name] = {"kernel": "k_cartesian_tiled", "ms": round(s * 1e3, 4), "algorithmic_bytes": int(nbytes),
+                     "Mpoints_per_s": round(npx / s / 1e6, 1), "frac": round(nbytes / s / 1e9 / HBM_PEAK_GBPS, 4),
+                     "validated": bool(err <= 1e-4), "max_abs_dxyz_m": err}
+    # range-gated, compacting frame dewarp on the route DeviceFrameBatch::dewarp takes: the decode's gate counts + float
+    # pose rows (impl/dewarp_impl.h:23-81); bytes: range plane + 12 B per kept point + status, pose rows and gate counts per column
+    pk = torch.from_numpy(synth_packets(8)).cuda().repeat(N // 8, 1, 1).contiguous()
+    dout = hp.alloc_outputs(N, planes=["RANGE"], xyz=[])
+    hp.decode(pk, dout, gate=(0.5, 400.0))
+    drng, dst_, dgc = dout["RANGE"], dout["status"], dout["gate_counts"]
+    ang = torch.linspace(-0.2, 0.2, W, dtype=torch.float64, device="cuda")
+    poses = torch.eye(4, dtype=torch.float64, device="cuda").repeat(N, W, 1, 1).contiguous()
+    poses[..., 0, 0] = torch.cos(ang); poses[..., 0, 1] = -torch.sin(ang)
+    poses[..., 1, 0] = torch.sin(ang); poses[..., 1, 1] = torch.cos(ang)
+    poses[..., 0, 3] = 3.0
+    rows = HotPath.pose_rows(poses)
+    o = hp.dewarp_frames(drng, dst_, rows, 0.5, 400.0, provenance=False, luts=[lut], gate_counts=dgc)
+    kept = int(o["frame_offsets"][-1].item())
+    rr = Rot(drng)
+    s = clock(lambda: hp.dewarp_frames(rr(), dst_, rows, 0.5, 400.0, provenance=False, luts=[lut], gate_counts=dgc))
+    k1 = int(o["frame_offsets"][1].item())
+    want = O.dewarp_frame(drng[0].cpu().numpy(), dst_[0].cpu().numpy(), np.zeros(W, np.uint64), poses[0].cpu().numpy(),
+                          d64.astype(np.float32), o64.astype(np.float32), 0.5, 400.0)
+    got = o["points"][:k1].cpu().numpy().astype(np.float64)
+    ok = len(want[0]) == k1 and (k1 == 0 or float(np.abs(got - want[0].astype(np.float64)).max()) <= 1e-4)
+    nbytes = npx * 4 + kept * 12 + N * W * (48 + 4) + N * W * 2 * 8
+    res["dewarp_frames_rows_counted"] = {"kernel": "k_dwf_scan + k_dwf_frame_scan + k_dwf_emit", "ms": round(s * 1e3, 4),
+                                         "algorithmic_bytes": int(nbytes), "kept_fraction": round(kept / npx, 3),
+                                         "Mpixels_per_s": round(npx / s / 1e6, 1),
+                                         "frac": round(nbytes / s / 1e9 / HBM_PEAK_GBPS, 4), "validated": bool(ok)}
+    res["note"] = f"{N} images of {H}x{W}, inputs rotated over 3 copies; each row checked against the oracle on image 0"
+    return res
+
+
+def time_drop_in():
+    """What an UNMODIFIED caller of the reference's API gets through include/ouster/core/*.h (host containers in, host results
+    out, every call crosses PCIe): FrameBatcher::batch x128 + destagger<uint32_t> + XYZLut() per 128 x 2048 dual-return frame
+    (tools/bench_host_api.cpp), and FrameStream host-to-host (tools/bench_stream.cpp: pinned staging, H2D / decode / D2H
+    overlapped).  Both are small C++ programs built by `make` against libouster_core_amd.so; never `value`."""
+    import subprocess
+    res = {}
+    bdir = os.path.join(ROOT, "tests", "cpp", "_build")
+    for key, argv in (("host_api", ["bench_host_api", "12"]), ("frame_stream", ["bench_stream", "768", "32", "3", "xyz"])):
+        exe = os.path.join(bdir, argv[0])
+        try:
+            o = subprocess.run([exe] + argv[1:], capture_output=True, text=True, timeout=120)
+            res[key] = json.loads(o.stdout.strip().splitlines()[-1]) if o.returncode == 0 else {"error": (o.stderr or o.stdout)[-200:]}
+        except Exception as e:
+            res[key] = {"error": str(e)[:200]}
+    out = {"what": "ouster::sdk::core API on host containers, one 128x2048 dual-return frame per call (one PCIe round trip per call); "
+                   "FrameStream: host packets in, XYZ of both returns out, batches of 32 frames, 3 in flight"}
+    ha = res.get("host_api", {})
+    if "ms_per_frame" in ha:
+        out["frame_batcher_ms"] = ha["ms_per_frame"]["FrameBatcher_128_packets"]
+        out["destagger_ms"] = ha["ms_per_frame"]["destagger_u32"]
+        out["xyzlut_ms"] = ha["ms_per_frame"]["XYZLut_f64"]
+    else:
+        out["host_api_error"] = ha.get("error")
+    fs = res.get("frame_stream", {})
+    if "Mpoints_per_s" in fs:
+        out["frame_stream_Gpoints_s"] = round(fs["Mpoints_per_s"] / 1e3, 3)
+        out["frame_stream_H2D_GBps"] = fs.get("H2D_GBps")
+        out["frame_stream_D2H_GBps"] = fs.get("D2H_GBps")
+    else:
+        out["frame_stream_error"] = fs.get("error")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -469,6 +626,8 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="HIP events around every N-th decode kernel of the timed region (1: every launch)")
     ap.add_argument("--rotate-inputs", type=int, default=2,
                     help="decode this many copies of the packet batch in turn (>= 2: cold input every step)")
     ap.add_argument("--placement", default="refine", choices=["first", "refine", "draws"],
@@ -600,7 +759,7 @@ def main():
     # --rotate-inputs R > 1 (a diagnostic, not the metric): R copies of the packet batch are decoded in turn, so that
     # no step finds its input in the 256 MB Infinity Cache left there by the step before
     inputs = [packets] + [packets.clone() for _ in range(max(0, args.rotate_inputs - 1))]
-    hp.ctx.timing(True)
+    hp.ctx.timing(args.time_every)   # HIP events around every N-th decode kernel of the timed region (each pair costs the stream 2 - 3 us)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -663,31 +822,40 @@ def main():
         elapsed = float(t.item())
 
     exchange = None
-    if args.exchange and world > 1:
+    if args.exchange:
         # the only real exchange step of the path: the batch of all ranks' frames lives on
         # rank 0, every rank receives ITS shard (grouped point-to-point sends, one peer per xGMI link),
         # decodes it, and the XYZ clouds are gathered back.  Reported per stage, never part of `value`.
+        # `xyz_checksum` (sum of the gathered clouds' bit patterns) does not depend on the number of ranks: with one rank the
+        # same batch is decoded in place (tests/test_gpu_multirank.py compares the two).
         from ouster_sdk_amd import parallel
         xdev = "cuda" if backend == "nccl" else "cpu"
         total = F * world
         batch_all = packets.repeat(world, 1, 1).to(xdev) if rank == 0 else None
         ts = [0.0, 0.0, 0.0]
+        checksum = 0
         for rep in range(3):                       # rep 0 warms the RCCL channels
             torch.cuda.synchronize(); barrier()
             e0 = time.perf_counter()
-            mine = parallel.scatter_frames(batch_all, total, tuple(packets.shape[1:]), torch.uint8, xdev).cuda()
+            if world > 1:
+                mine = parallel.scatter_frames(batch_all, total, tuple(packets.shape[1:]), torch.uint8, xdev).cuda()
+            else:
+                mine = batch_all.cuda()
             torch.cuda.synchronize(); barrier()
             e1 = time.perf_counter()
             hp.decode(mine, out)
             torch.cuda.synchronize(); barrier()
             e2 = time.perf_counter()
+            gathered = []
             for n in xyz_names:
                 x = out["xyz:" + n]
-                parallel.gather_frames(x if backend == "nccl" else x.cpu(), total)
+                gathered.append(parallel.gather_frames(x if backend == "nccl" else x.cpu(), total) if world > 1 else x)
             torch.cuda.synchronize(); barrier()
             e3 = time.perf_counter()
             if rep:
                 ts = [ts[0] + e1 - e0, ts[1] + e2 - e1, ts[2] + e3 - e2]
+            if rep == 2 and rank == 0:
+                checksum = sum(int(g.contiguous().view(torch.int32).to(torch.int64).sum().item()) for g in gathered) & ((1 << 63) - 1)
         del batch_all
         pk_bytes = total * packets[0].numel() * (world - 1) / world
         xyz_bytes = len(xyz_names) * total * H * W * 12 * (world - 1) / world
@@ -696,7 +864,8 @@ def main():
                     "scatter_GBps": round(pk_bytes / (ts[0] / 2) / 1e9, 1),
                     "gather_GBps": round(xyz_bytes / (ts[2] / 2) / 1e9, 1),
                     "Mpoints_per_s_with_exchange": round(total * H * W * len(xyz_names) / (sum(ts) / 2) / 1e6, 1),
-                    "transport": "RCCL p2p (xGMI)" if backend == "nccl" else backend + " (test transport)"}
+                    "xyz_checksum": checksum,
+                    "transport": ("RCCL p2p (xGMI)" if backend == "nccl" else backend + " (test transport)") if world > 1 else "none (one rank)"}
 
     n_ret = len(xyz_names)
     points_per_step = F * H * W * n_ret * world
@@ -711,7 +880,7 @@ def main():
 
     # self-check of what the timed steps left in HBM (rank 0, outside the timed region)
     validated, max_dxyz, checked = None, None, None
-    if rank == 0 and not args.no_cpu and args.outputs == "full":
+    if rank == 0 and args.outputs == "full":     # (--no-cpu skips the CPU baseline leg only)
         validated, max_dxyz, checked = validate_against_oracle(
             hp, profile, packets, out, shifts, lut_args, len(lut_args), sorted({0, 7 % F, F // 2, F - 1}))
     # the paths the metric never touches, on the same output buffers, outside the timed region and
@@ -720,10 +889,14 @@ def main():
     if rank == 0 and not args.no_loss_paths and args.outputs == "full":
         loss_paths = time_loss_paths(hp, packets, out, F, algorithmic_bytes_per_frame(args.workload))
     # every other BASELINE config and the small-batch latency view, in the driver-visible line
-    other_workloads, latency = None, None
+    other_workloads, latency, standalone, drop_in = None, None, None, None
     if rank == 0 and world == 1 and args.workload == "dual" and args.outputs == "full" and not args.no_extras:
         other_workloads = time_other_workloads(placement="first" if args.placement == "first" else "refine")
         latency = time_small_batches()
+        torch.cuda.empty_cache()
+        standalone = time_standalone()
+        torch.cuda.empty_cache()
+        drop_in = time_drop_in()
     # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot wrap a run from inside):
     # only quoted when the committed profile is of exactly this workload and output set.
     traffic, traffic_src = None, None
@@ -799,6 +972,8 @@ def main():
             "loss_paths": loss_paths,
             "other_workloads": other_workloads,
             "latency": latency,
+            "standalone": standalone,
+            "drop_in": drop_in,
             "cpu_baseline": None,
         }
         if placement and "first_allocation_ms" in placement:   # the first allocation's fraction next to the kept draw's

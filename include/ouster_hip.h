@@ -373,7 +373,8 @@ int ouster_hip_osf_unpack(ouster_hip_ctx* ctx, const ouster_hip_osf_plane* plane
 /* ---- instrumentation ------------------------------------------------------ */
 /* Average duration in ms of the dominant decode kernel over the launches made
  * since the last reset, measured with HIP events on the context's stream
- * (enabled by ouster_hip_timing_enable; adds two event records per launch). */
+ * (enabled by ouster_hip_timing_enable; adds two event records per timed launch: on == 1 times every launch,
+ * on == N > 1 every N-th -- an event pair costs the stream 2 - 3 us, a caller inside a timed region samples). */
 int ouster_hip_timing_enable(ouster_hip_ctx* ctx, int on);
 int ouster_hip_timing_read(ouster_hip_ctx* ctx, double* avg_ms, uint32_t* n_launches);
 /* Tile (columns x rows) of the decode kernel variant the last ouster_hip_decode launched: 64/32/16

@@ -198,6 +198,10 @@ def lib():
     L.ora_bench_hot_path.argtypes = [C.POINTER(PF), C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    L.ora_bench_hot_path2.restype = C.c_double
+    L.ora_bench_hot_path2.argtypes = L.ora_bench_hot_path.argtypes + [C.c_int]
+    L.ora_bench_stream_copy.restype = C.c_double
+    L.ora_bench_stream_copy.argtypes = [C.c_size_t, C.c_int, C.c_int]
     _lib = L
     return L
 

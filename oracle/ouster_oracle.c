@@ -1207,24 +1207,29 @@ static double now_s(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-double ora_bench_hot_path(const ora_pf* pf, int with_window, const uint8_t* packets,
-                          uint32_t pool_frames, uint32_t n_frames, uint32_t ppf, const int32_t* shifts,
-                          const double* lut_dir, const double* lut_ofs, int xyz_f64,
-                          int reps, int threads, uint64_t* checksum_out) {
+/* flags: 1 = every thread works on ITS OWN copy of the LUT, the packet pool and the shifts, allocated and first touched by
+ * that thread (NUMA-local pages; the shared 25 MB f64 LUT otherwise lives on the node of the thread that built it);
+ * 2 = static schedule (frame f always on the same thread).  0 = the round-4 harness. */
+double ora_bench_hot_path2(const ora_pf* pf, int with_window, const uint8_t* packets,
+                           uint32_t pool_frames, uint32_t n_frames, uint32_t ppf, const int32_t* shifts,
+                           const double* lut_dir_shared, const double* lut_ofs_shared, int xyz_f64,
+                           int reps, int threads, uint64_t* checksum_out, int flags) {
     const uint32_t h = pf->pixels_per_column, w = pf->columns_per_frame;
     const size_t npx = (size_t)h * w;
     const size_t psz = pf->lidar_packet_size;
-    float *fdir = NULL, *fofs = NULL;
+    float *fdir_shared = NULL, *fofs_shared = NULL;
     if (!xyz_f64) { /* XYZLutT<float>: cast of the double LUT, xyzlut.h:119-124 */
-        fdir = (float*)malloc(npx * 3 * sizeof(float));
-        fofs = (float*)malloc(npx * 3 * sizeof(float));
-        for (size_t i = 0; i < npx * 3; ++i) { fdir[i] = (float)lut_dir[i]; fofs[i] = (float)lut_ofs[i]; }
+        fdir_shared = (float*)malloc(npx * 3 * sizeof(float));
+        fofs_shared = (float*)malloc(npx * 3 * sizeof(float));
+        for (size_t i = 0; i < npx * 3; ++i) { fdir_shared[i] = (float)lut_dir_shared[i]; fofs_shared[i] = (float)lut_ofs_shared[i]; }
     }
+    const uint8_t* packets_shared = packets;
     if (threads < 1) threads = 1;
     uint64_t checksum = 0;
     double t0 = 0, t1 = 0;
 #ifdef _OPENMP
     omp_set_num_threads(threads);
+    omp_set_schedule((flags & 2) ? omp_sched_static : omp_sched_dynamic, (flags & 2) ? 0 : 1);
 #endif
 #pragma omp parallel reduction(+ : checksum)
     {
@@ -1239,11 +1244,25 @@ double ora_bench_hot_path(const ora_pf* pf, int with_window, const uint8_t* pack
         }
         void* xyz1 = malloc(npx * 3 * (xyz_f64 ? 8 : 4));
         void* xyz2 = ora_frame_plane(fr, "RANGE2") ? malloc(npx * 3 * (xyz_f64 ? 8 : 4)) : NULL;
+        const double *lut_dir = lut_dir_shared, *lut_ofs = lut_ofs_shared;
+        const float *fdir = fdir_shared, *fofs = fofs_shared;
+        const uint8_t* packets = packets_shared;
+        void *own[3] = {0, 0, 0};
+        if (flags & 1) {   /* this thread's own, first-touched inputs */
+            const size_t es = xyz_f64 ? 8 : 4, lb = npx * 3 * es, pb = (size_t)pool_frames * ppf * psz;
+            own[0] = malloc(lb); own[1] = malloc(lb); own[2] = malloc(pb);
+            memcpy(own[0], xyz_f64 ? (const void*)lut_dir_shared : (const void*)fdir_shared, lb);
+            memcpy(own[1], xyz_f64 ? (const void*)lut_ofs_shared : (const void*)fofs_shared, lb);
+            memcpy(own[2], packets_shared, pb);
+            if (xyz_f64) { lut_dir = (const double*)own[0]; lut_ofs = (const double*)own[1]; }
+            else { fdir = (const float*)own[0]; fofs = (const float*)own[1]; }
+            packets = (const uint8_t*)own[2];
+        }
 #pragma omp barrier
 #pragma omp master
         t0 = now_s();
         for (int rep = 0; rep < reps; ++rep) {
-#pragma omp for schedule(dynamic, 1)
+#pragma omp for schedule(runtime)
             for (uint32_t f = 0; f < n_frames; ++f) {
                 ora_batcher_reset(b);
                 const uint8_t* fpk = packets + (size_t)(f % pool_frames) * ppf * psz;
@@ -1275,10 +1294,48 @@ double ora_bench_hot_path(const ora_pf* pf, int with_window, const uint8_t* pack
         t1 = now_s();
         for (int k = 0; k < 4; ++k) free(dst[k]);
         free(xyz1); free(xyz2);
+        free(own[0]); free(own[1]); free(own[2]);
         ora_batcher_free(b);
         ora_frame_free(fr);
     }
-    free(fdir); free(fofs);
+    free(fdir_shared); free(fofs_shared);
     if (checksum_out) *checksum_out = checksum;
+    return t1 - t0;
+}
+
+double ora_bench_hot_path(const ora_pf* pf, int with_window, const uint8_t* packets,
+                          uint32_t pool_frames, uint32_t n_frames, uint32_t ppf, const int32_t* shifts,
+                          const double* lut_dir, const double* lut_ofs, int xyz_f64,
+                          int reps, int threads, uint64_t* checksum_out) {
+    return ora_bench_hot_path2(pf, with_window, packets, pool_frames, n_frames, ppf, shifts, lut_dir, lut_ofs, xyz_f64, reps,
+                               threads, checksum_out, 0);
+}
+
+/* STREAM-style copy on the same cores: every thread copies its own first-touched `bytes_per_thread` array `reps` times.
+ * Returns seconds; the caller quotes 2 * bytes * threads * reps / seconds next to the hot path's byte rate. */
+double ora_bench_stream_copy(size_t bytes_per_thread, int reps, int threads) {
+    double t0 = 0, t1 = 0;
+    if (threads < 1) threads = 1;
+#ifdef _OPENMP
+    omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+    {
+        uint8_t* a = (uint8_t*)malloc(bytes_per_thread);
+        uint8_t* b = (uint8_t*)malloc(bytes_per_thread);
+        memset(a, 1, bytes_per_thread);
+        memset(b, 2, bytes_per_thread);
+#pragma omp barrier
+#pragma omp master
+        t0 = now_s();
+        for (int r = 0; r < reps; ++r) {
+            memcpy(b, a, bytes_per_thread);
+            __asm__ volatile("" : : "r"(b) : "memory");
+        }
+#pragma omp barrier
+#pragma omp master
+        t1 = now_s();
+        free(a); free(b);
+    }
     return t1 - t0;
 }

@@ -234,6 +234,12 @@ double ora_bench_hot_path(const ora_pf* pf, int with_window,
                           const double* lut_dir, const double* lut_ofs,
                           int xyz_f64, int reps, int threads,
                           uint64_t* checksum_out);
+/* flags: 1 = per-thread first-touched copies of LUT / packets, 2 = static schedule (see the .c file) */
+double ora_bench_hot_path2(const ora_pf* pf, int with_window, const uint8_t* packets,
+                           uint32_t pool_frames, uint32_t n_frames, uint32_t ppf, const int32_t* shifts,
+                           const double* lut_dir, const double* lut_ofs, int xyz_f64,
+                           int reps, int threads, uint64_t* checksum_out, int flags);
+double ora_bench_stream_copy(size_t bytes_per_thread, int reps, int threads);
 
 #ifdef __cplusplus
 }

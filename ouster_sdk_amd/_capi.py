@@ -248,7 +248,8 @@ class Context:
     def make_format(self, desc: FormatDesc) -> "Format":
         return Format(self, desc)
 
-    def timing(self, on: bool):
+    def timing(self, on):
+        """True / 1: HIP events around every decode kernel; N > 1: around every N-th (an event pair costs the stream 2 - 3 us)."""
         check(self.L.ouster_hip_timing_enable(self.h, int(on)))
 
     def last_decode_tile(self) -> Tuple[int, int]:

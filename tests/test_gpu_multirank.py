@@ -119,6 +119,23 @@ def test_bench_two_ranks_other_workloads_with_exchange(workload):
     assert (line["rccl_ranks"] == 2) == (backend == "nccl")
 
 
+def test_batch512_exchange_checksum_does_not_depend_on_the_number_of_ranks():
+    """`bench.py --gpus 2 --workload batch512 --exchange` -- configs[3]'s 512 frames scattered from rank 0,
+    decoded by two ranks, gathered back -- must leave the clouds one rank leaves (exchange.xyz_checksum).  With two or more
+    GPUs visible the two ranks run over RCCL, one per GPU, and anything else is a failure (no skip, no gloo)."""
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "batch512",
+                          "--no-cpu", "--exchange", "--placement", "first", "--no-loss-paths", "--no-extras"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a = _last_json(one.stdout)
+    b, backend = _two_ranks(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "batch512", "--no-cpu",
+                             "--exchange", "--placement", "first", "--no-loss-paths", "--no-extras"])
+    if _n_gpus() >= 2:
+        assert backend == "nccl" and b["rccl_ranks"] == 2, b
+    assert a["exchange"]["frames_total"] == b["exchange"]["frames_total"] == 512
+    assert a["exchange"]["xyz_checksum"] == b["exchange"]["xyz_checksum"] != 0, (a["exchange"], b["exchange"])
+
+
 def test_config4_recorded_frames_same_result_for_1_and_2_ranks():
     one = subprocess.run([sys.executable, "tools/config4_recorded.py", "--frames", "64", "--reps", "1"],
                          capture_output=True, text=True, cwd=ROOT, timeout=600)

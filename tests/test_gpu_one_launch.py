@@ -1,0 +1,204 @@
+"""GPU parity for the ONE-LAUNCH form of ouster_hip_decode (round 5): the optimistic pass's workgroups meet
+behind their last tile and are their own fix-up crew, so that a call is one kernel instead of two.
+
+  * the one-launch form (knob fused_tail = 1, the default) and the two-launch form (fused_tail = 0) leave the oracle's bytes,
+    on clean and on damaged batches, for small batches on wide tiles and for the persistent k_decode_stream2;
+  * what one batch() call must leave behind (ouster_core/src/lidar_frame.cpp:1530-1576) does not depend on the form: planes,
+    column headers, packet-level outputs, frame-level values and valid-column counts;
+  * one context may alternate the forms and the two fix-up kernels (the wide fix-up's ticket counter was only
+    zeroed by the wide fix-up of the call before), hundreds of calls in a row;
+  * two contexts that run damaged batches on two streams of one device at the same time finish (the rendezvous never makes
+    correctness depend on a workgroup that waits) and both leave the oracle's bytes.
+Mirrors tests/frame_batcher_test.cpp:73-303 of the reference (dropped / invalid / reordered packets).
+"""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = pytest.mark.gpu
+
+if has_gpu():
+    import torch
+    from ouster_sdk_amd.device import HotPath
+
+from test_gpu_parity import _np, _oracle_frames  # noqa: E402
+from test_gpu_fastpath import _compare, _hotpath  # noqa: E402
+
+
+def _damage(rng, packets, kinds):
+    """packets [n, P, bytes] -> per-frame packet lists with the damage of kinds[f] ('' = clean)."""
+    by_frame = []
+    for f, kind in enumerate(kinds):
+        pk = packets[f]
+        P = len(pk)
+        if kind == "drop":          # compacted after a lost packet
+            pk = np.delete(pk, [int(rng.integers(0, P))], axis=0)
+        elif kind == "shuffle":     # any order
+            pk = pk[rng.permutation(P)]
+        elif kind == "swap":        # two neighbours swapped
+            i = int(rng.integers(0, P - 1))
+            pk = pk.copy(); pk[[i, i + 1]] = pk[[i + 1, i]]
+        elif kind == "dup":         # one packet lost, another one sent twice
+            i, j = int(rng.integers(0, P)), int(rng.integers(0, P))
+            pk = np.concatenate([np.delete(pk, [i], axis=0), pk[j:j + 1]])
+        by_frame.append(pk)
+    return by_frame
+
+
+def _stage(pf, by_frame, slots):
+    host = np.zeros((len(by_frame), slots, pf.lidar_packet_size), np.uint8)
+    counts = np.zeros(len(by_frame), np.uint32)
+    for f, pk in enumerate(by_frame):
+        host[f, :len(pk)] = pk
+        counts[f] = len(pk)
+    return host, counts
+
+
+CASES = [
+    # label, profile, h, w, frames, forced variant, kinds of damage (cycled over the frames; '' = clean)
+    ("one_frame", "RNG15_RFL8_NIR8_DUAL", 128, 2048, 1, None, ["swap"]),
+    ("tick_of_four", "RNG15_RFL8_NIR8_DUAL", 128, 2048, 4, None, ["", "drop", "", "shuffle"]),
+    ("single_small", "RNG19_RFL8_SIG16_NIR16", 64, 1024, 3, None, ["dup", "", "swap"]),
+    ("stream256", "RNG15_RFL8_NIR8_DUAL", 64, 1024, 24, "s256", ["", "swap", "", "", "drop", "", "shuffle", "", "", "dup"]),
+    ("stream128", "RNG19_RFL8_SIG16_NIR16", 64, 1024, 19, "s128", ["", "", "drop", "", "swap"]),
+    ("stream_all_damaged", "RNG15_RFL8_NIR8_DUAL", 32, 512, 40, "s256", ["shuffle", "drop", "swap", "dup"]),
+]
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("label,profile,h,w,n,wide,kinds", CASES)
+def test_one_launch_and_two_launches_leave_the_oracles_bytes(oracle, label, profile, h, w, n, wide, kinds, fused):
+    O = oracle
+    cal = O.synthetic_calib(h=h, w=w, profile=profile)
+    pf = cal.packet_format()
+    packets, _ = O.synth_packets(cal, n, with_window=True)
+    rng = np.random.default_rng(17)
+    P = w // cal.cpp
+    hp = _hotpath(cal, profile, wide=wide)
+    hp.ctx.set_knob("fused_tail", fused)
+    names = [nm for nm, _ in hp.fields]
+    dst = [nm for nm in ("RANGE", "REFLECTIVITY") if nm in names]
+    xyz = [nm for nm in ("RANGE", "RANGE2") if nm in names]
+    out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
+    out["packet_timestamp"] = torch.empty((n, P), dtype=torch.uint64, device="cuda")
+    out["alert_flags"] = torch.empty((n, P), dtype=torch.uint8, device="cuda")
+    ts = torch.arange(1, n * P + 1, dtype=torch.int64).view(n, P).cuda() * 1000
+    # a clean batch, the damaged one, the clean one again: nothing of a call may leak into the next
+    for round_, kk in enumerate((["" for _ in kinds], kinds, ["" for _ in kinds])):
+        by_frame = _damage(rng, packets, [kk[f % len(kk)] for f in range(n)])
+        host, counts = _stage(pf, by_frame, P)
+        for t in out.values():
+            t.view(torch.uint8).fill_(0xCD)
+        hp.decode(torch.from_numpy(host).cuda(), out, packet_counts=counts, host_timestamps=ts)
+        hp.sync()
+        kernel = hp.ctx.last_decode_kernel()
+        if wide is not None:
+            assert kernel == ("k_decode_stream2+tail" if fused else "k_decode_stream2"), kernel
+        else:
+            assert kernel == ("k_decode_wide+tail" if fused else "k_decode_wide"), kernel
+        ref = _oracle_frames(O, cal, pf, by_frame, True)
+        _compare(O, cal, hp, out, ref, dst, xyz)
+        # packet-level outputs: the LAST buffered packet of each packet index (batch_lidar_packet, lidar_frame.cpp:1534-1539)
+        pts = _np(out["packet_timestamp"])
+        for f, pk in enumerate(by_frame):
+            want = np.zeros(P, np.uint64)
+            for i, p in enumerate(pk):
+                m0 = int(np.frombuffer(p[pf.packet_header_size + 8:pf.packet_header_size + 10].tobytes(), np.uint16)[0])
+                if m0 // cal.cpp < P:
+                    want[m0 // cal.cpp] = (1 + f * P + i) * 1000
+            assert np.array_equal(pts[f], want), (round_, f)
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_alternating_fixup_kernels_on_one_context(oracle, fused):
+    """one context alternating the wide and the 64-column fix-up kernel, each call with more flagged
+    frames than the wide fix-up hands out without its ticket counter -- and, round 5, alternating with the one-launch form."""
+    O = oracle
+    cal = O.synthetic_calib(h=64, w=1024, profile="RNG15_RFL8_NIR8_DUAL")
+    pf = cal.packet_format()
+    n, P = 48, 64
+    packets, _ = O.synth_packets(cal, n, with_window=True)
+    rng = np.random.default_rng(5)
+    hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL", wide=256)
+    dst, xyz = ["RANGE"], ["RANGE", "RANGE2"]
+    out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
+    for call in range(12):
+        kinds = [("drop", "swap", "shuffle", "dup")[int(rng.integers(0, 4))] if rng.random() < 0.6 else "" for _ in range(n)]
+        assert sum(k != "" for k in kinds) >= 8
+        by_frame = _damage(rng, packets, kinds)
+        host, counts = _stage(pf, by_frame, P)
+        hp.ctx.set_knob("fixup_wide", call % 2)                         # wide tiles / k_decode_fixup's 64-column tiles
+        hp.ctx.set_knob("fused_tail", fused if call % 3 == 0 else 0)    # (48 frames of wide tiles are resident at once)
+        for t in out.values():
+            t.view(torch.uint8).fill_(0xCD)
+        hp.decode(torch.from_numpy(host).cuda(), out, packet_counts=counts)
+        hp.sync()
+        _compare(O, cal, hp, out, _oracle_frames(O, cal, pf, by_frame, True), dst, xyz)
+
+
+def test_many_one_launch_calls_keep_the_rendezvous_words_clean(oracle):
+    """300 calls through one context, clean / damaged / clean ..., never synchronised in between: the counters of the
+    rendezvous are left at zero by every call's last workgroup, the sequence word advances, no flag survives a call."""
+    O = oracle
+    cal = O.synthetic_calib(h=32, w=512, profile="RNG15_RFL8_NIR8_DUAL")
+    pf = cal.packet_format()
+    n, P = 2, 32
+    packets, src = O.synth_packets(cal, n, with_window=True)
+    rng = np.random.default_rng(9)
+    hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL")
+    hp.ctx.set_knob("fused_tail", 1)
+    dst, xyz = ["RANGE"], ["RANGE"]
+    out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
+    clean_host, clean_counts = _stage(pf, [packets[f] for f in range(n)], P)
+    bad_by_frame = _damage(rng, packets, ["shuffle", "drop"])
+    bad_host, bad_counts = _stage(pf, bad_by_frame, P)
+    d_clean, d_bad = torch.from_numpy(clean_host).cuda(), torch.from_numpy(bad_host).cuda()
+    c_clean = torch.from_numpy(clean_counts.astype(np.int32)).cuda()
+    c_bad = torch.from_numpy(bad_counts.astype(np.int32)).cuda()
+    ref_clean = _oracle_frames(O, cal, pf, [packets[f] for f in range(n)], True)
+    ref_bad = _oracle_frames(O, cal, pf, bad_by_frame, True)
+    for call in range(300):
+        bad = call % 3 == 1
+        hp.decode(d_bad if bad else d_clean, out, packet_counts=c_bad if bad else c_clean)
+        assert hp.ctx.last_decode_kernel() == "k_decode_wide+tail"
+        if call < 6 or call % 41 == 0 or call >= 294:
+            hp.sync()
+            _compare(O, cal, hp, out, ref_bad if bad else ref_clean, dst, xyz)
+    hp.sync()
+
+
+@pytest.mark.parametrize("wide", [None, "s256"])
+def test_two_contexts_on_one_device_at_the_same_time(oracle, wide):
+    """Two contexts, two streams, damaged batches in flight together, many times: neither kernel may depend on workgroups that
+    wait for the other's (a volunteer's wait is bounded, the last arriver never waits) -- the calls finish and both contexts
+    leave the oracle's bytes."""
+    O = oracle
+    cal = O.synthetic_calib(h=64, w=1024, profile="RNG15_RFL8_NIR8_DUAL")
+    pf = cal.packet_format()
+    n, P = (4 if wide is None else 32), 64
+    packets, _ = O.synth_packets(cal, n, with_window=True)
+    rng = np.random.default_rng(23)
+    dst, xyz = ["RANGE"], ["RANGE", "RANGE2"]
+    ctxs = []
+    for k in range(2):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL", wide=wide)
+            hp.ctx.set_knob("fused_tail", 1)
+            by_frame = _damage(rng, packets, [("swap", "", "drop", "shuffle")[(f + k) % 4] for f in range(n)])
+            host, counts = _stage(pf, by_frame, P)
+            d = torch.from_numpy(host).cuda()
+            c = torch.from_numpy(counts.astype(np.int32)).cuda()
+            out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
+            hp.decode(d, out, packet_counts=c)   # warm-up: allocations
+            s.synchronize()
+        ctxs.append((s, hp, d, c, out, by_frame))
+    for rep in range(60):
+        for s, hp, d, c, out, _ in ctxs:
+            with torch.cuda.stream(s):
+                hp.decode(d, out, packet_counts=c)
+    torch.cuda.synchronize()
+    for s, hp, d, c, out, by_frame in ctxs:
+        assert hp.ctx.last_decode_kernel().endswith("+tail")
+        _compare(O, cal, hp, out, _oracle_frames(O, cal, pf, by_frame, True), dst, xyz)
