@@ -19,12 +19,13 @@ restatement of the reference loops, timed on this box's host cores, rank 0 at N=
 
 Setup before the W warm-up steps (none of it inside the timed region, all of it reported in the JSON line):
   * the library's kernel-variant tuner settles (first 20 calls of a workload shape);
-  * buffer placement, `--placement refine` (default) in its FRUGAL form since round 4: two more copies of the output set are
-    allocated back to back (6.6 GB transient for 256 dual-return frames, 0.1 s; round 3: three copies 8 GB apart, 35 GB) and
-    every buffer group (XYZ pair, 32-bit planes, destaggered planes, narrow planes) is kept at the fastest of its three
-    locations -- what ouster::sdk::hip::DeviceFrameBatch does when BatchOptions::auto_placement is set (opt-in in the library).
-    "placement" and roofline.first_allocation_* report the first allocation's time next to the kept one (typically 3 - 9 %
-    slower).  `--placement first` takes the first allocation as it comes; `--placement draws` is the round-2 diagnostic;
+  * buffer placement, `--placement refine` (default): the frugal search that ouster::sdk::hip::DeviceFrameBatch runs by itself
+    when it is constructed (BatchOptions::auto_placement = true, the library's default since round 5): two more copies of
+    the output set are allocated back to back (6.6 GB transient for 256 dual-return frames, 0.1 s) and every buffer group (XYZ
+    pair, 32-bit planes, destaggered planes, narrow planes) is kept at the fastest of its three locations.  "placement" and
+    roofline.first_allocation_* report the first allocation's time next to the kept one (1 - 9 % slower).  `--placement
+    first` takes the first allocation as it comes (auto_placement = false) and reports the search beside it
+    (roofline.searched_placement_*); `--placement draws` is the round-2 diagnostic;
   * after the K timed steps the outputs are compared with the oracle ("validated", "max_abs_dxyz_m").
 The timed steps rotate over `--rotate-inputs` copies of the packet batch (default 2: no step finds its input in the
 256 MB Infinity Cache).  After the timed region the paths the metric never touches are timed on the same buffers and
@@ -631,11 +632,12 @@ def main():
     ap.add_argument("--rotate-inputs", type=int, default=2,
                     help="decode this many copies of the packet batch in turn (>= 2: cold input every step)")
     ap.add_argument("--placement", default="refine", choices=["first", "refine", "draws"],
-                    help="refine (default): the frugal search -- two more copies of the output set, back to back (6.6 GB "
-                         "transient, 0.1 s), each buffer group kept at the fastest of its three locations; what "
-                         "DeviceFrameBatch does when BatchOptions::auto_placement is set.  The first allocation's time is "
-                         "printed beside the kept one.  first: buffers as allocated, no search; draws: diagnostic, whole "
-                         "output sets drawn across the device memory")
+                    help="refine (default): the frugal placement search that DeviceFrameBatch runs by itself when it is constructed "
+                         "(BatchOptions::auto_placement = true, the library's default since round 5): two more copies of the "
+                         "output set back to back (6.6 GB transient, 0.1 s), each buffer group kept at the fastest of its three "
+                         "locations; the first allocation's time is printed beside the kept one.  first: buffers as allocated "
+                         "(auto_placement = false); the search is then run AFTER the timed region and reported beside the "
+                         "headline.  draws: diagnostic, whole output sets drawn across the device memory")
     ap.add_argument("--placement-draws", type=int, default=3, help="--placement refine: locations tried per buffer group")
     ap.add_argument("--placement-ballast-gb", type=float, default=0.0,
                     help="--placement refine: device memory held between two locations (0: back-to-back draws; 8 with 4 draws "
@@ -883,6 +885,12 @@ def main():
     if rank == 0 and args.outputs == "full":     # (--no-cpu skips the CPU baseline leg only)
         validated, max_dxyz, checked = validate_against_oracle(
             hp, profile, packets, out, shifts, lut_args, len(lut_args), sorted({0, 7 % F, F // 2, F - 1}))
+    # what the opt-in placement search (BatchOptions::auto_placement / HotPath.refine_placement) would have
+    # given on this box: run AFTER the timed region and the self-check, reported beside the headline, never as `value`
+    if rank == 0 and world == 1 and args.placement == "first" and args.outputs == "full" and not args.no_extras:
+        t_setup = time.perf_counter()
+        out, rep = hp.refine_placement(packets, out, draws=args.placement_draws, ballast_gb=args.placement_ballast_gb)
+        placement = {"mode": "first", "search_after_timed_region": rep, "search_s": round(time.perf_counter() - t_setup, 3)}
     # the paths the metric never touches, on the same output buffers, outside the timed region and
     # after the self-check (they overwrite the outputs)
     loss_paths = None
@@ -891,7 +899,7 @@ def main():
     # every other BASELINE config and the small-batch latency view, in the driver-visible line
     other_workloads, latency, standalone, drop_in = None, None, None, None
     if rank == 0 and world == 1 and args.workload == "dual" and args.outputs == "full" and not args.no_extras:
-        other_workloads = time_other_workloads(placement="first" if args.placement == "first" else "refine")
+        other_workloads = time_other_workloads(placement="first" if args.placement == "first" else "refine")   # same default
         latency = time_small_batches()
         torch.cuda.empty_cache()
         standalone = time_standalone()
@@ -950,9 +958,11 @@ def main():
                        if args.outputs == "full" else "ABLATION:" + args.outputs,
                        "sharding": f"frames x{world}, no data-path collective",
                        "input_batches_rotated": args.rotate_inputs,
-                       "buffer_placement": ("first allocation" if not placement else
-                                            ("each buffer group at the fastest of %d locations %g GB apart (HotPath.refine_placement "
-                                             "= DeviceFrameBatch's construction-time default)"
+                       "buffer_placement": ("first allocation: the buffers as the allocator returned them "
+                                            "(BatchOptions::auto_placement = false)"
+                                            if (not placement or placement.get("mode") == "first") else
+                                            ("each buffer group at the fastest of %d locations %g GB apart (HotPath.refine_placement = what "
+                                             "DeviceFrameBatch does at construction with BatchOptions::auto_placement = true, the library's default)"
                                              % (placement["draws_per_group"], args.placement_ballast_gb)) if placement["mode"] == "refine" else
                                             "DIAGNOSTIC: best of %d allocations of the output set (%.0f GB of ballast between "
                                             "two draws) and of up to 10 of the packet buffer (HotPath.pick_placement)"
@@ -976,10 +986,14 @@ def main():
             "drop_in": drop_in,
             "cpu_baseline": None,
         }
-        if placement and "first_allocation_ms" in placement:   # the first allocation's fraction next to the kept draw's
+        if placement and "first_allocation_ms" in placement:   # --placement refine: the first allocation's fraction next to the kept draw's
             line["roofline"]["first_allocation_ms_per_call"] = placement["first_allocation_ms"]
             line["roofline"]["first_allocation_frac_step"] = round(
                 bytes_per_launch / (placement["first_allocation_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        if placement and "search_after_timed_region" in placement:   # default: what the opt-in search would have given
+            rep = placement["search_after_timed_region"]
+            line["roofline"]["searched_placement_ms_per_call"] = rep["kept_ms"]
+            line["roofline"]["searched_placement_frac_step"] = round(bytes_per_launch / (rep["kept_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         line["rccl_ranks"] = rccl_ranks
         line["collective_backend"] = coll
         if exchange:

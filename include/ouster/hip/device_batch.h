@@ -42,14 +42,16 @@ struct BatchOptions {
     /// the gated RANGE pixels per column (they are in registers there) and dewarp(min, max) with the same
     /// gate skips its counting pass over the RANGE planes.
     double gate_min_range = 0.0, gate_max_range = -1.0;
-    /// Opt-in (round 4: off by default -- a library object that transiently takes tens of GB of a shared GPU must be asked to):
-    /// batches of >= 64 frames settle WHERE their output buffers live when they are constructed, one
-    /// DeviceFrameBatch::refine_placement(placement_draws, nullptr, placement_ballast_bytes) on an all-zero packet
-    /// buffer (same store pattern): 0.1 - 0.6 s and a transient (draws - 1) x (output set + ballast) -- two more output
-    /// sets with the defaults, about 35 GB for 256 dual-return frames with 4 draws 8 GB apart (which finds a fast place
-    /// more often: DESIGN.md 3.2c).  A draw is skipped when it would take more than three quarters of the free device
-    /// memory.  Pointers handed out afterwards stay valid for the life of the batch.
-    bool auto_placement = false;
+    /// On by default in its FRUGAL form (round 5; round 4 had it opt-in): batches of >= 64 frames settle WHERE their output
+    /// buffers live when they are constructed, one DeviceFrameBatch::refine_placement(placement_draws, nullptr,
+    /// placement_ballast_bytes) on an all-zero packet buffer (same store pattern).  With the defaults below: two more copies
+    /// of the output set back to back, every buffer group kept at the fastest of its three locations -- 0.1 s and a transient
+    /// 2 x output set (6.6 GB for 256 dual-return frames); a draw is skipped when it would take more than three quarters of
+    /// the free device memory.  What it buys: the decode's store rate differs by 3 - 20 % between allocations of the same
+    /// buffers (+8.7 % on the box of profiles/r05).  Set it to false where construction time or the transient
+    /// memory matter more; placement_ballast_bytes > 0 / placement_draws = 4 is the thorough (tens of GB) form.
+    /// Pointers handed out afterwards stay valid for the life of the batch.
+    bool auto_placement = true;
     int placement_draws = 3;
     size_t placement_ballast_bytes = 0;
     int device = -1;                      ///< GPU to work on (-1: hip::current_device() of the constructing thread)

@@ -471,54 +471,21 @@ __global__ __launch_bounds__(256) void k_decode_wide(DecodeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// k_decode_wide_fixup: the fix-up crew on wide tiles (fixup_crew, wide_tile.h), in two forms:
-//   two launches (a.fused == 0)   a persistent grid behind an optimistic pass of any kind (k_decode's 64-column tiles, the
-//                                 persistent k_decode_stream, k_decode_wide on a grid too large to be resident at once)
-//   ONE launch (a.fused == 1)     grids that are resident at once (small batches: a tick of a few sensors, a single frame):
-//                                 every workgroup first decodes the optimistic tile its block index names, exactly as
-//                                 k_decode_wide would, then arrives at the rendezvous (tail_arrive).  Clean batch: everybody
-//                                 but the last arriver has left without waiting; dirty batch: the crew works the tickets.
+// k_decode_wide_fixup: the fix-up crew on wide tiles (fixup_crew, wide_tile.h): a persistent grid behind an optimistic pass of
+// any kind (k_decode's 64-column tiles, k_decode_wide, the persistent k_decode_stream*).  A clean batch -- nobody raised the
+// launch-wide word FS_ANY to this call's tag -- is two scalar loads and out (round 5; round 4: every workgroup read and listed
+// the frame words, 8 us of dependent round trips behind every optimistic pass).
 // ------------------------------------------------------------------------------------
 template <class S, int TW, int XYZM, bool POSES = false>
 __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
     constexpr int NT = 256;
     extern __shared__ __align__(16) uint32_t smem[];
     CrewLds* C = (CrewLds*)((uint8_t*)smem + a.crew_lds_off);
-    // (ONE call site of fixup_crew for both forms: with the crew's code inlined twice next to the optimistic tile the compiler
-    // gave up on keeping the kernel arguments in SGPRs and copied all 1.5 KB of them to scratch at entry -- every a.field a
-    // scratch load, the one-launch kernel three times slower than the two launches it replaces)
-    const bool fused = a.fused != 0;
-    uint64_t tag;
-    uint32_t role;
-    if (fused) {
-        tag = a.frame_state[FS_SEQ] + 1;
-        uint32_t f, sub;
-        if (block_to_frame(a, a.tiles_per_frame * a.row_chunks, f, sub))
-            wide_tile<S, TW, XYZM, POSES, false>(a, smem, f, sub % a.tiles_per_frame, sub / a.tiles_per_frame, nullptr, nullptr,
-                                                 a.rows_per_tile, a.row_chunks, false);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores are in this XCD's L2 (at least)
-        __syncthreads();
-        role = tail_arrive(a, tag, gridDim.x, C);
-        if (role == ROLE_LEAVE) return;
-    } else {
-        tag = a.frame_state[FS_TAG];
-        // the next call's ticket counters (tag parity; k_decode_fixup does the same)
-        if (blockIdx.x < 8 && threadIdx.x == 0) a.frame_state[FS_TICKET + ((tag + 1u) & 1u) * 8u + blockIdx.x] = 0;
-        // A clean batch (round 5): nobody raised the launch-wide word -- two scalar loads and out, instead of every workgroup
-        // reading and listing the frame words (8 us of dependent round trips behind every optimistic pass, profiles/r04)
-        role = a.frame_state[FS_ANY] == tag ? ROLE_DIRTY : ROLE_CLEAN;
-    }
-    if (role & ROLE_DIRTY) fixup_crew<S, TW, XYZM, POSES>(a, smem, C, tag, fused);
+    const uint64_t tag = a.frame_state[FS_TAG];
+    // the next call's ticket counters (tag parity; k_decode_fixup does the same)
+    if (blockIdx.x < 8 && threadIdx.x == 0) a.frame_state[FS_TICKET + ((tag + 1u) & 1u) * 8u + blockIdx.x] = 0;
+    if (a.frame_state[FS_ANY] == tag) fixup_crew<S, TW, XYZM, POSES>(a, smem, C, tag);
     // valid-column counts of the clean frames (flagged ones got theirs from their LEAD ticket), then the sequence word
-    if (fused) {
-        if (role & ROLE_LAST) {
-            sum_valid_columns<NT>(a, tag, 0u, 1u);
-            tail_finish(a, tag, C);
-        } else {
-            tail_leave_volunteer(a);
-        }
-        return;
-    }
     sum_valid_columns<NT>(a, tag, blockIdx.x, gridDim.x);
     if (blockIdx.x == 0 && threadIdx.x == 0) a.frame_state[FS_SEQ] = tag;  // the next call tags with tag + 1
 #ifdef OUSTER_PHASE_TIMING
@@ -778,29 +745,26 @@ static hipError_t launch_wide_fixup_t(const DecodeArgs& a, int xyzm, dim3 grid, 
 }
 
 // a.mode == MODE_FIXUP: the persistent fix-up grid (a.row_chunks etc. describe its tiles, a.fast_tiles the optimistic pass's
-// column tiles, `resident` the workgroups the device keeps resident); a.fused: the one-launch form (k_decode_wide_fixup on the
-// optimistic pass's own grid, which the caller has checked to be resident at once); otherwise one workgroup per tile
+// column tiles, `resident` the workgroups the device keeps resident); otherwise one workgroup per tile
 hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a_in, int tw, int xyzm, int device, hipStream_t st, uint32_t resident) {
     DecodeArgs a = a_in;
     const uint32_t bpf = a.tiles_per_frame * a.row_chunks;
-    const bool fix = a.mode == MODE_FIXUP, resolved = a.mode == MODE_RESOLVED, fused = a.fused != 0 && !fix;
+    const bool fix = a.mode == MODE_FIXUP, resolved = a.mode == MODE_RESOLVED;
     a.wide_img_words = (uint32_t)tw * (a.lds_col_slot >> 2) + 4u;
-    if (fix || resolved || fused)   // resolve_frame's scratch lies under the tile image
+    if (fix || resolved)   // resolve_frame's scratch lies under the tile image
         a.wide_img_words = std::max<uint32_t>(a.wide_img_words, (uint32_t)((slotmap_lds_bytes(a.g.columns_per_frame, a.g.columns_per_packet, a.slots_per_frame) / 4 + 3) & ~(size_t)3));
     size_t lds = (decode_wide_lds_bytes(tw, a.rows_per_tile, a.wide_img_words) + 15) & ~(size_t)15;
     a.pose_lds_off = (uint32_t)lds;
     lds += pose_lds_bytes(a, xyzm, tw);
-    if (fix || fused) {
+    if (fix) {
         lds = (lds + 15) & ~(size_t)15;
         a.crew_lds_off = (uint32_t)lds;
         lds += (sizeof(CrewLds) + 15) & ~(size_t)15;
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (fix || fused) {
+    if (fix) {
         const uint64_t items = (uint64_t)a.n_frames * bpf;
-        uint32_t g = (uint32_t)std::min<uint64_t>(items, resident ? resident : 512u);
-        if (fused) g = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * bpf : a.n_frames * bpf;   // the optimistic pass's grid
-        const dim3 grid(g);
+        const dim3 grid((uint32_t)std::min<uint64_t>(items, resident ? resident : 512u));
         switch (tw) {   // 128 or 256 columns (narrower frames take k_decode_fixup): every width is 12 more kernels per profile to compile
             case 128: return launch_wide_fixup_t<SpecT, 128>(a, xyzm, grid, lds, device, st);
             case 256: return launch_wide_fixup_t<SpecT, 256>(a, xyzm, grid, lds, device, st);

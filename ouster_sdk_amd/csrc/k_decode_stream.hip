@@ -30,7 +30,6 @@
 #include <atomic>
 
 #include "kernels_common.h"
-#include "wide_tile.h"
 
 #ifndef OUSTER_SPEC_ID
 #error "compile with -DOUSTER_SPEC_ID=1..5"
@@ -348,9 +347,7 @@ __global__ __launch_bounds__(512) void k_decode_stream(DecodeArgs a, StreamArgs 
 // when they are done with tile i-1's context; every lane classifies its own four columns from the fetched header
 // words (no shared validity table, hence no second barrier), invalid columns are zeroed per pixel.
 // ------------------------------------------------------------------------------------
-// TAIL: the one-launch form (sp.fused): the fix-up crew's code behind the tile loop.  Its own instantiation: the crew's code
-// costs the loader waves a spilled register (more SGPRs to spill into VGPR lanes, function-wide), the two-launch form keeps r04's code.
-template <class S, int TW, int XYZM, bool TAIL>
+template <class S, int TW, int XYZM>
 __global__ __launch_bounds__(768) void k_decode_stream2(DecodeArgs a, StreamArgs sp) {
     constexpr int NT = 512, QPR = TW / 4;          // decoding threads; thread 512.. = the loader wave
     constexpr uint32_t chan = S::chan;
@@ -366,14 +363,11 @@ __global__ __launch_bounds__(768) void k_decode_stream2(DecodeArgs a, StreamArgs
     const uint32_t xcd = blockIdx.x & 7u, kx = blockIdx.x >> 3;
     const uint32_t ct = kx % CT, grp = kx / CT, NG = sp.groups;
     const uint32_t c0 = ct * TW;
-    // (frame, row chunk) items of this XCD, and this group's share; a workgroup without any leaves at once -- in the one-launch
-    // form (sp.fused) through the rendezvous, where every workgroup of the launch is counted
-    const uint32_t items = xcd < a.n_frames ? ((a.n_frames - xcd + 7u) >> 3) * nch : 0u;
-    const uint32_t n_mine = grp < items ? (items - grp + NG - 1) / NG : 0u;
+    if (xcd >= a.n_frames) return;
+    const uint32_t items = ((a.n_frames - xcd + 7u) >> 3) * nch;
+    if (grp >= items) return;
+    const uint32_t n_mine = (items - grp + NG - 1) / NG;
     auto item = [&](uint32_t i) { return grp + NG * i; };
-    const uint64_t tag = a.frame_state[FS_SEQ] + 1;
-    if (n_mine == 0 && !TAIL) return;
-    if (n_mine != 0) {
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     uint32_t* s_colofs = (uint32_t*)((uint8_t*)smem + sp.fixed_off);   // [TW] byte offset of column c0+j in a frame buffer
@@ -392,6 +386,7 @@ __global__ __launch_bounds__(768) void k_decode_stream2(DecodeArgs a, StreamArgs
                                                        a.packet_stride, count);
         }
     }
+    const uint64_t tag = a.frame_state[FS_SEQ] + 1;
     __syncthreads();
 
     if (wave >= (uint32_t)(NT / 64)) {
@@ -564,27 +559,6 @@ __global__ __launch_bounds__(768) void k_decode_stream2(DecodeArgs a, StreamArgs
             a, s_pix, pxd, cc, s_off, nullptr, (XYZM == 1 || XYZM == 2) ? s_beam : nullptr, nullptr, lut, f, c0, r0, TR, vq,
             rc, nch, nullptr);
     }
-    }   // n_mine != 0
-
-    // ---- the one-launch form (wide_tile.h): behind its last tile the workgroup arrives at the rendezvous; waves 0..3 stay as
-    // potential fix-up crew (256 threads, the wide tiles of k_decode_wide_fixup in the LDS the tile contexts occupied), the
-    // other decoding waves leave (the loaders have left already, or leave here in a workgroup without items)
-    if constexpr (TAIL) {
-    if (wave >= (uint32_t)(NT / 64)) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores are in this XCD's L2 (at least)
-    __syncthreads();                                    // ... and nobody reads the tile contexts any more
-    if (wave >= 4u) return;
-    CrewLds* C = (CrewLds*)((uint8_t*)smem + a.crew_lds_off);
-    const uint32_t role = tail_arrive(a, tag, gridDim.x, C);
-    if (role == ROLE_LEAVE) return;
-    if (role & ROLE_DIRTY) fixup_crew<S, TW, XYZM, false>(a, smem, C, tag, true);
-    if (role & ROLE_LAST) {
-        sum_valid_columns<256>(a, tag, 0u, 1u);
-        tail_finish(a, tag, C);
-    } else {
-        tail_leave_volunteer(a);
-    }
-    }   // TAIL
 }
 
 // ------------------------------------------------------------------------------------
@@ -609,17 +583,17 @@ static hipError_t launch_stream_x(const DecodeArgs& a, const StreamArgs& sp, dim
     return hipGetLastError();
 }
 
-template <class S, int TW, int XYZM, bool TAIL>
+template <class S, int TW, int XYZM>
 static hipError_t launch_stream2_x(const DecodeArgs& a, const StreamArgs& sp, dim3 grid, int device, hipStream_t st) {
     static LdsGrantS done;
     std::atomic<uint32_t>& have = done.bytes[device & 15];
     if (sp.lds_bytes > 48 * 1024 && have.load(std::memory_order_acquire) < sp.lds_bytes) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_decode_stream2<S, TW, XYZM, TAIL>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_decode_stream2<S, TW, XYZM>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds_bytes);
         if (e != hipSuccess) return e;
         have.store(sp.lds_bytes, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_decode_stream2<S, TW, XYZM, TAIL>), grid, dim3(512u + 64u * sp.loader), sp.lds_bytes, st, a, sp);
+    hipLaunchKernelGGL((k_decode_stream2<S, TW, XYZM>), grid, dim3(512u + 64u * sp.loader), sp.lds_bytes, st, a, sp);
     return hipGetLastError();
 }
 
@@ -628,9 +602,9 @@ static hipError_t launch_stream_t(const DecodeArgs& a, const StreamArgs& sp, int
     if constexpr (TW == 128 || TW == 256) {
         if (sp.loader) {
             switch (xyzm) {
-                case 0: return sp.fused ? launch_stream2_x<S, TW, 0, true>(a, sp, grid, device, st) : launch_stream2_x<S, TW, 0, false>(a, sp, grid, device, st);
-                case 1: return sp.fused ? launch_stream2_x<S, TW, 1, true>(a, sp, grid, device, st) : launch_stream2_x<S, TW, 1, false>(a, sp, grid, device, st);
-                case 2: return sp.fused ? launch_stream2_x<S, TW, 2, true>(a, sp, grid, device, st) : launch_stream2_x<S, TW, 2, false>(a, sp, grid, device, st);
+                case 0: return launch_stream2_x<S, TW, 0>(a, sp, grid, device, st);
+                case 1: return launch_stream2_x<S, TW, 1>(a, sp, grid, device, st);
+                case 2: return launch_stream2_x<S, TW, 2>(a, sp, grid, device, st);
                 default: return hipErrorInvalidValue;
             }
         }

@@ -517,7 +517,16 @@ __device__ __forceinline__ void project_full(const LT* dir, const LT* ofs, size_
 //                   call uses a larger tag.  64 bits do not wrap.
 // ------------------------------------------------------------------------------------
 //   [FS_TICKET ..]  2 x 8 ticket counters of k_decode_wide_fixup (tag parity x XCD), see there
+//   [FS_ANY]        the launch-wide word: raised to the call's tag with the first frame word (round 5).  A clean batch is
+//                   "FS_ANY != tag": the fix-up kernel's workgroups leave after two scalar loads instead of reading and
+//                   listing every frame word (8 us behind every optimistic pass in round 4)
 // (the indices FS_* are in ouster_hip_dev.h: the host sizes the buffer)
+
+// a stray was seen in frame f: the frame's word and the launch-wide word are raised to this call's tag (nothing is ever cleared)
+__device__ __forceinline__ void flag_frame(const DecodeArgs& a, uint32_t f, uint64_t tag) {
+    atomicMax((unsigned long long*)&a.frame_state[FS_WORDS + f], (unsigned long long)tag);
+    atomicMax((unsigned long long*)&a.frame_state[FS_ANY], (unsigned long long)tag);
+}
 
 // (measurement_id, status) of a column header staged in LDS at byte offset cb
 __device__ __forceinline__ void col_header_lds(const Geometry& g, const uint32_t* s_tile, uint32_t cb,

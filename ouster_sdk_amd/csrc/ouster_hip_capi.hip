@@ -93,9 +93,6 @@ struct Knobs {
     int slotmap = 1;          // OUSTER_HIP_SLOTMAP: 0 = buffers without one slot per column go through k_decode's general tiles
                               //   (every tile scans the frame's headers) instead of k_slotmap + k_decode_wide
     int stream_loader = 4;    // OUSTER_HIP_STREAM_LOADER: loader waves of k_decode_stream2 (0 = k_decode_stream: every wave fetches)
-    int fused_tail = 0;       // OUSTER_HIP_FUSED_TAIL: 1 = ONE launch where the optimistic kernel can be its own fix-up crew (k_decode_stream2; wide
-                              //   tiles on a grid that is resident at once: small batches).  Built in round 5, bit-exact, and slower than the two
-                              //   launches it replaces once the fix-up kernel of a clean batch leaves after two scalar loads
 };
 
 struct ouster_hip_ctx {
@@ -306,7 +303,6 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.stream_min_tiles = env_int("OUSTER_HIP_STREAM_MIN_TILES", k.stream_min_tiles);
         k.stream_order = env_int("OUSTER_HIP_STREAM_ORDER", k.stream_order);
         k.stream_loader = env_int("OUSTER_HIP_STREAM_LOADER", k.stream_loader);
-        k.fused_tail = env_int("OUSTER_HIP_FUSED_TAIL", k.fused_tail);
         k.slotmap = env_int("OUSTER_HIP_SLOTMAP", k.slotmap);
         k.fixup_wide = env_int("OUSTER_HIP_FIXUP_WIDE", k.fixup_wide);
         k.small = env_int("OUSTER_HIP_SMALL", k.small);
@@ -396,7 +392,6 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "stream_min_tiles") k.stream_min_tiles = value;
     else if (n == "stream_order") k.stream_order = value;
     else if (n == "stream_loader") k.stream_loader = value;
-    else if (n == "fused_tail") k.fused_tail = value;
     else if (n == "slotmap") k.slotmap = value;
     else return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unknown knob '%s'", name);
     return OUSTER_HIP_OK;
@@ -1136,11 +1131,9 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
 
     // ---- the fix-up pass behind an optimistic pass: the tiles of the frames the optimistic pass flagged are looked at again
     // with the frame's real column maps and redone where those differ from "slot c holds column c".  Wide tiles
-    // (fixup_crew, wide_tile.h) where the format allows them, k_decode_fixup's 64-column tiles otherwise.
-    // ONE launch (round 5) where the optimistic kernel can be its own crew: k_decode_stream2 (persistent), and wide tiles on
-    // a grid that is resident at once (small batches) -- k_decode_wide_fixup with a.fused, every workgroup decodes its
-    // optimistic tile first.  Otherwise the fix-up kernel is launched behind the optimistic one, always: the workgroups
-    // of a clean batch leave after one read of the flags.
+    // (fixup_crew, wide_tile.h) where the format allows them, k_decode_fixup's 64-column tiles otherwise.  Always launched
+    // behind the optimistic kernel; the workgroups of a clean batch leave after two scalar loads (FS_ANY).  Its tile shape and
+    // every allocation of the call are settled here, before the first launch.
     struct Shape { uint32_t rows, chunks, slot, tiles, rows_small; };
     auto shape_now = [&]() { return Shape{da.rows_per_tile, da.row_chunks, da.lds_col_slot, da.tiles_per_frame, da.fix_rows_small}; };
     auto shape_set = [&](const Shape& sh) {
@@ -1150,7 +1143,6 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     const bool want_fix = fast && kn.fixup && !resolved;
     int fix_wide = 0;
     Shape fixs{};
-    bool fuse = false;
     if (want_fix) {
         auto try_fix = [&](int tw) {
             const bool ok = setup_wide(tw, true);
@@ -1159,57 +1151,17 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
             return ok;
         };
         if (kn.fixup_wide && kn.tile == 0) {
-            // the crew inside a one-launch kernel works on tiles of that kernel's width
-            const uint64_t opt_blocks = (uint64_t)(da.xcd_map ? (n_frames + 7) / 8 * 8 : n_frames) * opt.tiles * opt.chunks;
-            if (stream && kn.fused_tail && sa.loader && kn.fixup_wide == 1) try_fix(stream);
-            else if (!stream && (wide == 128 || wide == 256) && kn.fused_tail && kn.fixup_wide == 1 && opt_blocks <= ctx->resident_wgs) try_fix(wide);
-            if (!fix_wide) {
-                if (kn.fixup_wide > 1) try_fix(kn.fixup_wide);
-                else if (setup_wide(256, true) && da.rows_per_tile * g.channel_data_size >= 256) try_fix(256);
-                else if (!try_fix(128)) try_fix(256);
-                shape_set(opt);
-            }
+            if (kn.fixup_wide > 1) try_fix(kn.fixup_wide);
+            else if (setup_wide(256, true) && da.rows_per_tile * g.channel_data_size >= 256) try_fix(256);
+            else if (!try_fix(128)) try_fix(256);
+            shape_set(opt);
         }
-        // every allocation of this call happens before its first launch
         if (kn.hdr_words) {   // the optimistic pass leaves the packed column ids for the fix-up pass
             if (ctx->hdrw.ensure((size_t)n_frames * W * sizeof(uint32_t))) return fail(OUSTER_HIP_ERR_RUNTIME, "out of device memory (header words)");
             da.hdr_words = (uint32_t*)ctx->hdrw.p;
         }
         if (fix_wide && ctx->slotmap.ensure((size_t)n_frames * W * sizeof(int32_t) * 2)) fix_wide = 0;   // the 64-column fix-up needs no maps
-        const uint32_t resolver_words = (uint32_t)((resolver_lds / 4 + 3) & ~(size_t)3);
-        const size_t crew_bytes = (sizeof(CrewLds) + 15) & ~(size_t)15;
-        if (fix_wide && kn.fused_tail && stream && sa.loader && fix_wide == stream && !da.xyz_poses) {
-            // k_decode_stream2 + tail: the crew's wide tiles lie in the LDS the two tile contexts occupied
-            const uint32_t img = std::max<uint32_t>((uint32_t)stream * (fixs.slot >> 2) + 4u, resolver_words);
-            const size_t wl = (decode_wide_lds_bytes(stream, fixs.rows, img) + 15) & ~(size_t)15;
-            if (wl + crew_bytes <= 160u * 1024u) {
-                fuse = true;
-                shape_set(fixs);                    // the stream kernel takes its own tiles from `sa`; these describe the crew's
-                da.wide_img_words = img;
-                da.pose_lds_off = (uint32_t)wl;
-                da.crew_lds_off = (uint32_t)wl;
-                sa.lds_bytes = std::max<uint32_t>(sa.lds_bytes, (uint32_t)(wl + crew_bytes));
-                sa.fused = 1u;
-            }
-        } else if (fix_wide && kn.fused_tail && !stream && wide == fix_wide) {
-            // wide tiles on a grid that is resident at once (two workgroups per CU): k_decode_wide_fixup, one launch
-            const uint32_t bpf = opt.tiles * opt.chunks;
-            const uint64_t blocks = da.xcd_map ? (uint64_t)((n_frames + 7) / 8) * 8 * bpf : (uint64_t)n_frames * bpf;
-            const uint32_t img = std::max<uint32_t>((uint32_t)wide * (opt.slot >> 2) + 4u, resolver_words);
-            const size_t wl = ((decode_wide_lds_bytes(wide, opt.rows, img) + 15) & ~(size_t)15) + (size_t)wide * pose_per_col;
-            if (blocks <= ctx->resident_wgs && wl + crew_bytes + 16 <= 80u * 1024u) {
-                fuse = true;
-                Shape sh = opt;
-                sh.rows_small = std::max(1024u / (uint32_t)wide, std::min(fixs.rows_small, opt.rows));
-                shape_set(sh);
-            }
-        }
-        if (fix_wide) {
-            da.slot_map = (int32_t*)ctx->slotmap.p;
-            da.hdr_map = da.slot_map + (size_t)n_frames * W;
-        }
         da.fast_tiles = opt.tiles;    // column tiles of the optimistic pass (slots of tile_valid)
-        da.fused = fuse ? 1u : 0u;
     }
     if (wide && !fast && !resolved) {
         if (ctx->slotmap.ensure((size_t)n_frames * W * sizeof(int32_t) * 2)) return fail(OUSTER_HIP_ERR_RUNTIME, "out of device memory (slot map)");
@@ -1240,12 +1192,12 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
         HIP_TRY(launch_decode_stream(da, sa, spec, stream, xyzm, ctx->device, st));
         ctx->last_tile_cols = stream;
         ctx->last_tile_rows = (int)sa.tr;
-        ctx->last_kernel = sa.loader ? (fuse ? "k_decode_stream2+tail" : "k_decode_stream2") : "k_decode_stream";   // dedicated loader waves / every wave fetches
+        ctx->last_kernel = sa.loader ? "k_decode_stream2" : "k_decode_stream";   // dedicated loader waves / every wave fetches
     } else if (wide) {
         HIP_TRY(launch_decode_wide(da, spec, wide, xyzm, ctx->device, st));
         ctx->last_tile_cols = wide;
         ctx->last_tile_rows = (int)opt.rows;
-        ctx->last_kernel = resolved ? "k_decode_wide_resolved" : fuse ? "k_decode_wide+tail" : "k_decode_wide";
+        ctx->last_kernel = resolved ? "k_decode_wide_resolved" : "k_decode_wide";
     } else {
         HIP_TRY(launch_decode(da, spec, tile, xyzm, ctx->device, st));
         ctx->last_tile_cols = tile;
@@ -1254,13 +1206,15 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     }
     if (tuning) HIP_TRY(hipEventRecord(tuning->ev[tune_slot][1], st));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
-    if (want_fix && !fuse) {
+    if (want_fix) {
         da.mode = MODE_FIXUP;
 #ifdef OUSTER_PHASE_TIMING
         da.phase_times = phase_times_all;
 #endif
         if (fix_wide) {
             shape_set(fixs);
+            da.slot_map = (int32_t*)ctx->slotmap.p;
+            da.hdr_map = da.slot_map + (size_t)n_frames * W;
             HIP_TRY(launch_decode_wide(da, spec, fix_wide, xyzm, ctx->device, st, ctx->resident_wgs));
         } else {
             da.rows_per_tile = 0;

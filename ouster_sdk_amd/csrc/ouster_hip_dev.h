@@ -41,16 +41,16 @@ enum DecodeMode : uint32_t {
     MODE_RESOLVED = 3, // small batches, one launch: every wide tile resolves its frame's column maps itself (k_decode_wide_resolved)
 };
 
-// frame_state words (kernels_common.h): sequence, tag, 2 x 8 ticket counters, the rendezvous words of the one-launch form
-// (their own cache line: only ever touched by agent-scope atomics), then one word per frame (from a line boundary on)
-constexpr uint32_t FS_SEQ = 0, FS_TAG = 1, FS_TICKET = 2, FS_DONE = 18, FS_OUT = 19, FS_ANY = 20, FS_FTICKET = 21, FS_WORDS = 32;
+// frame_state words (kernels_common.h): sequence, tag, 2 x 8 ticket counters, the launch-wide "a frame was flagged" word
+// (its own cache line: only ever touched by atomics), then one word per frame (from a line boundary on)
+constexpr uint32_t FS_SEQ = 0, FS_TAG = 1, FS_TICKET = 2, FS_ANY = 20, FS_WORDS = 32;
 
 // fix-up crew (wide_tile.h): frames listed per round, and the crew's bookkeeping in dynamic LDS (DecodeArgs::crew_lds_off)
 constexpr uint32_t FIXUP_CHUNK = 512;
 struct CrewLds {
     uint16_t list[FIXUP_CHUNK];      // flagged frames of the chunk, in frame order
     uint32_t cnt[FIXUP_CHUNK / 64];
-    uint32_t n, nvalid, dirty, role, nvol, pad;
+    uint32_t n, nvalid, dirty, pad;
     unsigned long long ticket, ready;
 };
 
@@ -110,9 +110,6 @@ struct DecodeArgs {
     uint32_t fast_tiles;      // fix-up pass: column tiles of the optimistic pass before it (slots of tile_valid per frame)
     const double* xyz_poses;  // device [n_frames][W][16] or nullptr: per-column pose applied to the xyz outputs
     uint32_t pose_lds_off;    // byte offset of the tile's pose table in dynamic LDS (set by the launchers)
-    uint32_t fused;           // ONE launch: the optimistic pass's workgroups meet behind their last tile (FS_DONE) and are
-                              //   the fix-up crew themselves when a frame was flagged.  k_decode_wide_fixup: its workgroups first decode
-                              //   the optimistic tile their block index names (as k_decode_wide would); k_decode_stream2: StreamArgs::fused
     uint32_t crew_lds_off;    // byte offset of the crew's bookkeeping (CrewLds) in dynamic LDS (set by the launchers)
 #ifdef OUSTER_PHASE_TIMING
     uint64_t* phase_times;   // experiment builds only (tools/ab/phase_timing.sh): [workgroup][8] s_memtime stamps of k_decode_wide
@@ -142,8 +139,6 @@ struct StreamArgs {
     uint32_t lds_bytes;
     uint32_t order;            // how a group walks the XCD's (frame, row chunk) items, see the kernel
     uint32_t loader;           // > 0: k_decode_stream2 with that many loader waves behind the eight decoding ones (1..4)
-    uint32_t fused;            // k_decode_stream2: 1 = no fix-up launch follows; the workgroups meet behind their last tile and waves 0..3
-                               //   are the fix-up crew (DecodeArgs::rows_per_tile etc. describe the crew's wide tiles of the same width)
 };
 
 struct DestaggerArgs {

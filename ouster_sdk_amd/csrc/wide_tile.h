@@ -1,6 +1,5 @@
-// wide_tile.h -- device code shared by k_decode.hip and k_decode_stream.hip (both compiled once per packet profile):
+// wide_tile.h -- the wide-tile device code of k_decode.hip (compiled once per packet profile):
 //   wide_tile     one wide, short tile (TW columns x TR rows) of the fused decode + destagger + cartesian, 256 threads
-//   tail_arrive   the rendezvous of the ONE-LAUNCH form behind the optimistic pass's last tile
 //   fixup_crew    the fix-up pass: LEAD / REDO tickets over the frames the optimistic pass flagged
 // Reference semantics: FrameBatcher::batch_lidar_packet / parse_by_col / parse_by_block, ouster_core/src/lidar_frame.cpp:1422-1576;
 // what one batch() call must leave behind: lidar_frame.cpp:1530-1576.
@@ -8,22 +7,6 @@
 #include "kernels_common.h"
 
 namespace ouster_hip_dev {
-
-__device__ __forceinline__ unsigned long long fs_load(const uint64_t* p) {
-    return __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void fs_store(uint64_t* p, unsigned long long v) {
-    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long fs_add(uint64_t* p, unsigned long long v) {
-    return __hip_atomic_fetch_add((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// a stray was seen in frame f: the frame's word and the launch-wide word are raised to this call's tag (nothing is ever cleared)
-__device__ __forceinline__ void flag_frame(const DecodeArgs& a, uint32_t f, uint64_t tag) {
-    atomicMax((unsigned long long*)&a.frame_state[FS_WORDS + f], (unsigned long long)tag);
-    atomicMax((unsigned long long*)&a.frame_state[FS_ANY], (unsigned long long)tag);
-}
 
 // What the workgroup that owns column tile `tile` of frame f reports from the optimistic pass (one lane):
 // a stray raises the frame's word to this call's tag; the tile's valid-column count goes to its own
@@ -86,7 +69,7 @@ __device__ __forceinline__ void wide_tile(const DecodeArgs& a, uint32_t* smem, u
     uint32_t count = a.slots_per_frame;
     if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
 #ifdef OUSTER_PHASE_TIMING
-    uint64_t* pt_ = (a.phase_times && a.mode != MODE_FIXUP && !a.fused) ? a.phase_times + (size_t)blockIdx.x * 16 : nullptr;
+    uint64_t* pt_ = (a.phase_times && a.mode != MODE_FIXUP) ? a.phase_times + (size_t)blockIdx.x * 16 : nullptr;
 #define PHASE_STAMP(i) do { if (pt_ && tid == 0) pt_[i] = __builtin_readcyclecounter(); } while (0)
     if (pt_ && tid == 0) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); pt_[7] = xcc; }
 #else
@@ -372,86 +355,14 @@ __device__ __forceinline__ void wide_tile(const DecodeArgs& a, uint32_t* smem, u
 #endif
 }
 // ------------------------------------------------------------------------------------
-// The ONE-LAUNCH form (round 5).  A call used to be two launches: the optimistic pass and, always, the
-// fix-up pass behind it (8 us of kernel and a launch boundary even on a clean batch -- a quarter of a single frame's latency).
-// Now the optimistic pass's workgroups meet behind their last tile:
-//   * every workgroup ARRIVES: its waves wait for their stores, one lane releases them (agent scope: this XCD's L2 writes
-//     back, the crew may run on any XCD) and adds itself to FS_DONE.  Whoever completes the count is the LAST ARRIVER: it
-//     knows that the whole optimistic pass is in memory and it never waits for anybody.  On a clean batch it sums the
-//     frames' valid-column counts, advances the sequence word and the kernel is over: no workgroup has waited at all.
-//   * a workgroup that arrives while a frame is already flagged (FS_ANY == this call's tag) registers as a VOLUNTEER (the
-//     high half of its FS_DONE increment) and polls FS_DONE for the rest to arrive -- a BOUNDED wait: if two such kernels
-//     share the device (two contexts, two processes) and neither is fully resident, volunteers that hold CUs would
-//     deadlock them; a volunteer that runs out of patience leaves and the last arriver does the work with whoever is there.
-//   * the crew (last arriver + volunteers that saw the count complete) runs fixup_crew: tickets from one counter.
-//   * the last arriver waits for the registered volunteers to leave (they are running, never blocked), then resets the
-//     counters and advances the sequence word.
-// Correctness never depends on a volunteer; speed on a dirty batch does (flags are raised by a frame's first row chunk,
-// early in the launch, so practically every workgroup volunteers).
+// The fix-up pass behind an optimistic pass.  A ONE-LAUNCH form -- the optimistic pass's workgroups meeting
+// behind their last tile (arrival counter, release fence, the last arriver and bounded-wait volunteers as the fix-up crew) --
+// was built in round 5 (commit 34e94d7: bit-exact, 17 GPU tests, two contexts on one device included) and measured slower
+// than the two launches it replaces: the per-workgroup release fence (buffer_wbl2, served one workgroup after the other per
+// XCD) costs 6 - 30 us per call, while the second launch of a clean batch costs 0 - 1.5 us since its workgroups leave after
+// two scalar loads (FS_ANY below).  profiles/r05/one_launch_ab.json; removed again.
 // ------------------------------------------------------------------------------------
 // (CrewLds, the crew's bookkeeping in dynamic LDS, and FIXUP_CHUNK: ouster_hip_dev.h -- the launchers size the LDS)
-constexpr uint32_t ROLE_LEAVE = 0, ROLE_CLEAN = 1, ROLE_DIRTY = 2, ROLE_LAST = 4;
-constexpr uint32_t TAIL_SPINS = 1u << 10;   // a volunteer's patience: about 1 ms of polling (the normal wait is the launch's tail imbalance, microseconds)
-
-// Called by all threads of the (remaining) workgroup behind its last optimistic tile, after every wave has waited for its
-// stores (s_waitcnt vmcnt(0)) and a barrier.  total: workgroups of the launch.  Returns the workgroup's role.
-__device__ __forceinline__ uint32_t tail_arrive(const DecodeArgs& a, uint64_t tag, uint32_t total, CrewLds* C) {
-    if (threadIdx.x == 0) {
-        uint64_t* fs = a.frame_state;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const bool vol = fs_load(&fs[FS_ANY]) == tag;
-        const unsigned long long old = fs_add(&fs[FS_DONE], vol ? (1ull | (1ull << 32)) : 1ull);
-        uint32_t role = ROLE_LEAVE;
-        if ((uint32_t)old == total - 1u) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            role = ROLE_LAST | (fs_load(&fs[FS_ANY]) == tag ? ROLE_DIRTY : ROLE_CLEAN);
-            C->nvol = (uint32_t)(old >> 32);   // volunteers registered before me
-        } else if (vol) {
-            bool all = false;
-            for (uint32_t spins = 0; spins < TAIL_SPINS; ++spins) {
-                all = (uint32_t)fs_load(&fs[FS_DONE]) == total;
-                if (all) break;
-                __builtin_amdgcn_s_sleep(32);
-            }
-            if (all) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                role = ROLE_DIRTY;
-            } else {
-                fs_add(&fs[FS_OUT], 1ull);   // ran out of patience: leave, the last arriver manages without me
-            }
-        }
-        C->role = role;
-    }
-    __syncthreads();
-    return C->role;
-}
-
-// a volunteer that has worked its tickets leaves (all threads call; ends the workgroup's part)
-__device__ __forceinline__ void tail_leave_volunteer(const DecodeArgs& a) {
-    __syncthreads();
-    if (threadIdx.x == 0) fs_add(&a.frame_state[FS_OUT], 1ull);
-}
-
-// the last arriver, when everything of this call is done: wait for the registered volunteers (running, never blocked), then
-// leave the words as the next call expects them -- counters zero, sequence word = this call's tag
-__device__ __forceinline__ void tail_finish(const DecodeArgs& a, uint64_t tag, const CrewLds* C) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t* fs = a.frame_state;
-        const uint32_t nvol = C->nvol;
-        if (nvol) {
-            uint32_t spins = 0;
-            while ((uint32_t)fs_load(&fs[FS_OUT]) != nvol) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins == (1u << 28)) __builtin_trap();   // minutes: a volunteer died
-            }
-        }
-        fs_store(&fs[FS_OUT], 0ull);
-        fs_store(&fs[FS_FTICKET], 0ull);
-        fs_store(&fs[FS_DONE], 0ull);
-        fs_store(&fs[FS_SEQ], tag);
-    }
-}
 
 // valid-column counts of the clean frames, from the optimistic pass's per-tile counts (flagged frames get theirs from their
 // LEAD ticket).  Frames first, first + stride, ... x NT threads.
@@ -503,7 +414,7 @@ __device__ __forceinline__ void sum_valid_columns(const DecodeArgs& a, uint64_t 
 #define FSTAMP_END(kind, n) do {} while (0)
 #endif
 template <class S, int TW, int XYZM, bool POSES>
-__device__ __forceinline__ void fixup_crew(const DecodeArgs& a, uint32_t* smem, CrewLds* C, const uint64_t tag, const bool fused) {
+__device__ __forceinline__ void fixup_crew(const DecodeArgs& a, uint32_t* smem, CrewLds* C, const uint64_t tag) {
     constexpr int NT = 256;
     const uint32_t tid = threadIdx.x;
     const uint32_t W = a.g.columns_per_frame, cpp = a.g.columns_per_packet, npo = a.n_packets_out;
@@ -512,12 +423,11 @@ __device__ __forceinline__ void fixup_crew(const DecodeArgs& a, uint32_t* smem, 
     // One counter for the whole grid: a flagged frame's tiles go wherever a workgroup is free.  (Keeping a frame on one XCD
     // -- right for k_decode_fixup's 64-column tiles, whose partial cache lines must meet in one L2 -- limits ONE damaged frame
     // to an eighth of the chip's bandwidth: 115 us for a frame with eight dirty column tiles, tools/ab/fixup_kinds2.py.)
-    unsigned long long* ctr = (unsigned long long*)&a.frame_state[fused ? FS_FTICKET : FS_TICKET + (tag & 1u) * 8u];
+    unsigned long long* ctr = (unsigned long long*)&a.frame_state[FS_TICKET + (tag & 1u) * 8u];
     unsigned long long* ready = (unsigned long long*)&a.frame_state[a.ready_off];
-    // two-launch form: first ticket = the workgroup's own number (no atomic at all on a clean batch), the counter hands out the
-    // tickets behind those; one-launch form: the crew is whoever is there, every ticket comes from the counter.  The next
-    // ticket is asked for when an item starts and looked at when it ends.
-    const unsigned long long tick0 = fused ? 0ull : (unsigned long long)gridDim.x;
+    // first ticket = the workgroup's own number (no atomic at all where few frames are flagged), the counter hands out the tickets
+    // behind those.  The next ticket is asked for when an item starts and looked at when it ends.
+    const unsigned long long tick0 = (unsigned long long)gridDim.x;
     unsigned long long ahead = 0;
     auto pull_ahead = [&]() { if (tid == 0) ahead = atomicAdd(ctr, 1ull) + tick0; };
     auto take_ahead = [&]() -> unsigned long long {
@@ -584,10 +494,6 @@ __device__ __forceinline__ void fixup_crew(const DecodeArgs& a, uint32_t* smem, 
         }
     };
     unsigned long long ticket = blockIdx.x, done = 0;
-    if (fused) {
-        pull_ahead();
-        ticket = take_ahead();
-    }
     for (uint32_t base = 0; base < a.n_frames; base += FIXUP_CHUNK) {
         // The flagged frames of this chunk.  The list must come out in the SAME order in every workgroup -- the workgroups
         // share the items out by index -- so it is compacted in frame order (ballots + a prefix over the 64-frame groups),

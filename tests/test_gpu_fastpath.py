@@ -45,7 +45,7 @@ def _force_variant(hp, wide):
 
 def _assert_variant_ran(hp, wide):
     tc, _ = hp.ctx.last_decode_tile()
-    kernel = hp.ctx.last_decode_kernel().split("+")[0]   # "+tail": the one-launch form of the same kernel
+    kernel = hp.ctx.last_decode_kernel()
     if isinstance(wide, str):
         assert kernel in ("k_decode_stream", "k_decode_stream2") and tc == int(wide[1:]), (kernel, tc, wide)
     elif wide:
@@ -550,7 +550,7 @@ def test_tuner_times_the_persistent_kernel_too(oracle):
             t.view(torch.uint8).fill_(0x77)
         hp.decode(d_pk, out)
         hp.sync()
-        seen.add((hp.ctx.last_decode_kernel().split("+")[0],) + tuple(hp.ctx.last_decode_tile()))
+        seen.add((hp.ctx.last_decode_kernel(),) + tuple(hp.ctx.last_decode_tile()))
         snap = {k: v.clone() for k, v in out.items()}
         if first is None:
             first = snap
@@ -617,7 +617,7 @@ def test_general_mapping_on_wide_tiles(oracle, profile, slots, wide):
     ts = torch.arange(1, n * slots + 1, dtype=torch.int64).view(n, slots).cuda() * 1000
     hp.decode(torch.from_numpy(host).cuda(), out, packet_counts=counts, host_timestamps=ts)
     hp.sync()
-    kernel = hp.ctx.last_decode_kernel().split("+")[0]
+    kernel = hp.ctx.last_decode_kernel()
     assert kernel == ("k_decode" if wide == 0 else "k_decode_wide"), kernel
     _compare(O, cal, hp, out, ref, dst, xyz)
     # packet-level outputs: the LAST buffered packet of each packet index (batch_lidar_packet, lidar_frame.cpp:1534-1539)
@@ -686,7 +686,7 @@ def test_bench_size_loss_paths(oracle, path):
     hp.decode(torch.from_numpy(host).cuda(), out, packet_counts=counts)
     hp.sync()
     if path.startswith("general"):
-        assert hp.ctx.last_decode_kernel().split("+")[0] == ("k_decode" if path == "general_narrow" else "k_decode_wide")
+        assert hp.ctx.last_decode_kernel() == ("k_decode" if path == "general_narrow" else "k_decode_wide")
     ref = _oracle_frames(O, cal, pf, [by_frame[f] for f in check], True)
     worst = _compare(O, cal, hp, out, ref, dst, xyz, frames=list(zip(check, ref)))
     assert worst <= 4e-5

@@ -1,14 +1,13 @@
-"""GPU parity for the ONE-LAUNCH form of ouster_hip_decode (round 5): the optimistic pass's workgroups meet
-behind their last tile and are their own fix-up crew, so that a call is one kernel instead of two.
+"""GPU parity for the fix-up pass behind the optimistic decode pass, round 5: a clean batch's fix-up kernel
+leaves after two scalar loads (the launch-wide FS_ANY word), a damaged one runs the ticketed crew.
 
-  * the one-launch form (knob fused_tail = 1, the default) and the two-launch form (fused_tail = 0) leave the oracle's bytes,
-    on clean and on damaged batches, for small batches on wide tiles and for the persistent k_decode_stream2;
-  * what one batch() call must leave behind (ouster_core/src/lidar_frame.cpp:1530-1576) does not depend on the form: planes,
-    column headers, packet-level outputs, frame-level values and valid-column counts;
-  * one context may alternate the forms and the two fix-up kernels (the wide fix-up's ticket counter was only
-    zeroed by the wide fix-up of the call before), hundreds of calls in a row;
-  * two contexts that run damaged batches on two streams of one device at the same time finish (the rendezvous never makes
-    correctness depend on a workgroup that waits) and both leave the oracle's bytes.
+  * clean -> damaged -> clean batches through one context leave the oracle's bytes every time -- planes, column headers,
+    packet-level outputs, frame-level values and valid-column counts (what one batch() call must leave behind,
+    ouster_core/src/lidar_frame.cpp:1530-1576) -- for small batches on wide tiles and for the persistent k_decode_stream2;
+  * one context may alternate the wide and the 64-column fix-up kernel (the wide fix-up's ticket counter was only
+    zeroed by the wide fix-up of the call before), hundreds of calls in a row, never synchronised in between;
+  * two contexts that run damaged batches on two streams of one device at the same time both leave the oracle's bytes.
+(The ONE-launch form these cases were written for -- commit 34e94d7 -- passed them and was removed: slower, wide_tile.h.)
 Mirrors tests/frame_batcher_test.cpp:73-303 of the reference (dropped / invalid / reordered packets).
 """
 import numpy as np
@@ -66,9 +65,8 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("label,profile,h,w,n,wide,kinds", CASES)
-def test_one_launch_and_two_launches_leave_the_oracles_bytes(oracle, label, profile, h, w, n, wide, kinds, fused):
+def test_clean_damaged_clean_batches_leave_the_oracles_bytes(oracle, label, profile, h, w, n, wide, kinds):
     O = oracle
     cal = O.synthetic_calib(h=h, w=w, profile=profile)
     pf = cal.packet_format()
@@ -76,7 +74,6 @@ def test_one_launch_and_two_launches_leave_the_oracles_bytes(oracle, label, prof
     rng = np.random.default_rng(17)
     P = w // cal.cpp
     hp = _hotpath(cal, profile, wide=wide)
-    hp.ctx.set_knob("fused_tail", fused)
     names = [nm for nm, _ in hp.fields]
     dst = [nm for nm in ("RANGE", "REFLECTIVITY") if nm in names]
     xyz = [nm for nm in ("RANGE", "RANGE2") if nm in names]
@@ -93,10 +90,7 @@ def test_one_launch_and_two_launches_leave_the_oracles_bytes(oracle, label, prof
         hp.decode(torch.from_numpy(host).cuda(), out, packet_counts=counts, host_timestamps=ts)
         hp.sync()
         kernel = hp.ctx.last_decode_kernel()
-        if wide is not None:
-            assert kernel == ("k_decode_stream2+tail" if fused else "k_decode_stream2"), kernel
-        else:
-            assert kernel == ("k_decode_wide+tail" if fused else "k_decode_wide"), kernel
+        assert kernel == ("k_decode_stream2" if wide is not None else "k_decode_wide"), kernel
         ref = _oracle_frames(O, cal, pf, by_frame, True)
         _compare(O, cal, hp, out, ref, dst, xyz)
         # packet-level outputs: the LAST buffered packet of each packet index (batch_lidar_packet, lidar_frame.cpp:1534-1539)
@@ -110,10 +104,9 @@ def test_one_launch_and_two_launches_leave_the_oracles_bytes(oracle, label, prof
             assert np.array_equal(pts[f], want), (round_, f)
 
 
-@pytest.mark.parametrize("fused", [1, 0])
-def test_alternating_fixup_kernels_on_one_context(oracle, fused):
+def test_alternating_fixup_kernels_on_one_context(oracle):
     """one context alternating the wide and the 64-column fix-up kernel, each call with more flagged
-    frames than the wide fix-up hands out without its ticket counter -- and, round 5, alternating with the one-launch form."""
+    frames than the wide fix-up hands out without its ticket counter."""
     O = oracle
     cal = O.synthetic_calib(h=64, w=1024, profile="RNG15_RFL8_NIR8_DUAL")
     pf = cal.packet_format()
@@ -129,7 +122,6 @@ def test_alternating_fixup_kernels_on_one_context(oracle, fused):
         by_frame = _damage(rng, packets, kinds)
         host, counts = _stage(pf, by_frame, P)
         hp.ctx.set_knob("fixup_wide", call % 2)                         # wide tiles / k_decode_fixup's 64-column tiles
-        hp.ctx.set_knob("fused_tail", fused if call % 3 == 0 else 0)    # (48 frames of wide tiles are resident at once)
         for t in out.values():
             t.view(torch.uint8).fill_(0xCD)
         hp.decode(torch.from_numpy(host).cuda(), out, packet_counts=counts)
@@ -137,9 +129,9 @@ def test_alternating_fixup_kernels_on_one_context(oracle, fused):
         _compare(O, cal, hp, out, _oracle_frames(O, cal, pf, by_frame, True), dst, xyz)
 
 
-def test_many_one_launch_calls_keep_the_rendezvous_words_clean(oracle):
-    """300 calls through one context, clean / damaged / clean ..., never synchronised in between: the counters of the
-    rendezvous are left at zero by every call's last workgroup, the sequence word advances, no flag survives a call."""
+def test_many_calls_keep_the_frame_words_clean(oracle):
+    """300 calls through one context, clean / damaged / clean ..., never synchronised in between: the sequence word advances,
+    the launch-wide word and the frame words of a damaged call never reach the next one."""
     O = oracle
     cal = O.synthetic_calib(h=32, w=512, profile="RNG15_RFL8_NIR8_DUAL")
     pf = cal.packet_format()
@@ -147,7 +139,6 @@ def test_many_one_launch_calls_keep_the_rendezvous_words_clean(oracle):
     packets, src = O.synth_packets(cal, n, with_window=True)
     rng = np.random.default_rng(9)
     hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL")
-    hp.ctx.set_knob("fused_tail", 1)
     dst, xyz = ["RANGE"], ["RANGE"]
     out = hp.alloc_outputs(n, destagger=dst, xyz=xyz)
     clean_host, clean_counts = _stage(pf, [packets[f] for f in range(n)], P)
@@ -161,7 +152,6 @@ def test_many_one_launch_calls_keep_the_rendezvous_words_clean(oracle):
     for call in range(300):
         bad = call % 3 == 1
         hp.decode(d_bad if bad else d_clean, out, packet_counts=c_bad if bad else c_clean)
-        assert hp.ctx.last_decode_kernel() == "k_decode_wide+tail"
         if call < 6 or call % 41 == 0 or call >= 294:
             hp.sync()
             _compare(O, cal, hp, out, ref_bad if bad else ref_clean, dst, xyz)
@@ -170,9 +160,8 @@ def test_many_one_launch_calls_keep_the_rendezvous_words_clean(oracle):
 
 @pytest.mark.parametrize("wide", [None, "s256"])
 def test_two_contexts_on_one_device_at_the_same_time(oracle, wide):
-    """Two contexts, two streams, damaged batches in flight together, many times: neither kernel may depend on workgroups that
-    wait for the other's (a volunteer's wait is bounded, the last arriver never waits) -- the calls finish and both contexts
-    leave the oracle's bytes."""
+    """Two contexts, two streams, damaged batches in flight together, many times: the frame words, ticket counters and maps
+    are per context -- both leave the oracle's bytes."""
     O = oracle
     cal = O.synthetic_calib(h=64, w=1024, profile="RNG15_RFL8_NIR8_DUAL")
     pf = cal.packet_format()
@@ -185,7 +174,6 @@ def test_two_contexts_on_one_device_at_the_same_time(oracle, wide):
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
             hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL", wide=wide)
-            hp.ctx.set_knob("fused_tail", 1)
             by_frame = _damage(rng, packets, [("swap", "", "drop", "shuffle")[(f + k) % 4] for f in range(n)])
             host, counts = _stage(pf, by_frame, P)
             d = torch.from_numpy(host).cuda()
@@ -200,5 +188,4 @@ def test_two_contexts_on_one_device_at_the_same_time(oracle, wide):
                 hp.decode(d, out, packet_counts=c)
     torch.cuda.synchronize()
     for s, hp, d, c, out, by_frame in ctxs:
-        assert hp.ctx.last_decode_kernel().endswith("+tail")
         _compare(O, cal, hp, out, _oracle_frames(O, cal, pf, by_frame, True), dst, xyz)

@@ -3,6 +3,18 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/lottery_pmc; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp; cd /tmp
 i=0
+# round 5: LOTTERY_CHANNELS=1 records the per-channel write / read request counters (one CSV row per TCC
+# instance) instead: is a slow placement a channel imbalance?  LOTTERY_WORKLOAD=single LOTTERY_STREAM=128 for configs[1].
+if [ -n "$LOTTERY_CHANNELS" ]; then
+  i=0
+  for set in "TCC_EA0_WRREQ TCC_EA0_WRREQ_64B" "TCC_EA0_RDREQ TCC_EA0_WRREQ_STALL" "TCC_EA0_WRREQ_DRAM TCC_EA0_RDREQ_DRAM"; do
+    i=$((i+1))
+    timeout 150 rocprofv3 --pmc $set --kernel-include-regex "k_decode" --output-format json -d $O/c$i -o c -- python $R/tools/ab/lottery_pmc.py > $O/cout$i.txt 2> $O/cerr$i.txt || tail -3 $O/cerr$i.txt
+    tail -1 $O/cout$i.txt
+  done
+  python $R/tools/ab/lottery_pmc.py --channels $O
+  exit 0
+fi
 for set in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_PENDING_STALL_CYCLES_sum" \
            "TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_sum TCC_TAG_STALL_sum" \
            "GRBM_GUI_ACTIVE TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
