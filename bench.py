@@ -279,7 +279,7 @@ def kernel_sources_sha256() -> str:
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "ouster_sdk_amd", "csrc")
-    for name in ("kernels_common.h", "k_decode.hip", "k_decode_stream.hip", "ouster_hip_dev.h", "ouster_hip_capi.hip"):
+    for name in ("kernels_common.h", "wide_tile.h", "k_decode.hip", "k_decode_stream.hip", "ouster_hip_dev.h", "ouster_hip_capi.hip"):
         with open(os.path.join(base, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -498,7 +498,7 @@ def time_small_batches(calls=300):
     return res
 
 
-def time_standalone(n_images=128):
+def time_standalone(n_images=256):
     """The standalone kernels behind ouster_hip_destagger / _cartesian / _dewarp_frames_rows (SURVEY 8(a) rows a10, a13, f-2;
     the reference's own three benchmarks: tests/benchmarks/core_benchmark.cpp:29-154) on resident data, each checked against
     the oracle on one image, `frac` on SURVEY 8(d)'s per-kernel byte counts -- report rows, never `value`.  Every input

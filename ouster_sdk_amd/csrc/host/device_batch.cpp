@@ -102,6 +102,11 @@ DeviceFrameBatch::~DeviceFrameBatch() {
     if (fmt_) ouster_hip_format_destroy(fmt_);
 }
 
+// A packet that arrives twice is merged into its home slot in arrival order: the later copy's valid columns over the earlier's,
+// the later packet's header and footer.  That is what the reference ends up with except in one corner (DESIGN.md section 5 (ii):
+// a first copy that ends in invalid columns, re-sent whole before any later packet -- the reference's next_valid bookkeeping then
+// zeroes the second copy's tail again, the merged slot keeps it); a caller that needs that corner, or arrival-order semantics for
+// packets with rewritten ids, hands ouster_hip_decode the buffer in arrival order with packet counts (general mapping).
 void DeviceFrameBatch::stage_packet(uint8_t* slot, bool occupied, const uint8_t* pkt) const {
     if (!occupied) {
         std::memcpy(slot, pkt, pf_.lidar_packet_size);

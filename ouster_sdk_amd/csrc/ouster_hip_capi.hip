@@ -843,7 +843,12 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     if (!tile)
         for (int t : {64, 32, 16})
             if (decode_lds_bytes(g, t, true, false, slots_per_frame) + 2048 + t * pose_per_col <= 160 * 1024) { tile = t; break; }
-    if (!tile) return fail(OUSTER_HIP_ERR_UNSUPPORTED, "column of %u bytes does not fit in LDS", g.col_size);
+    if (!tile)   // the general mapping keeps resolve_frame's scratch ((2 + cpp) words per buffer slot) in LDS next to the tile
+        return fail(OUSTER_HIP_ERR_UNSUPPORTED,
+                    fast ? "column of %u bytes does not fit in LDS"
+                         : "column of %u bytes + the column maps of %u buffer slots per frame do not fit in LDS (general mapping: at most "
+                           "about 2000 slots of 16 columns; hand the frame over in fewer slots or in home slots)",
+                    g.col_size, slots_per_frame);
     // small batches: prefer narrower tiles so that at least ~2 workgroups per CU exist
     // (one 128x2048 frame is only 32 tiles of 64 columns -- latency, not bandwidth, bound)
     while (tile > 16 && (size_t)n_frames * ((W + tile - 1) / tile) < 512) tile /= 2;

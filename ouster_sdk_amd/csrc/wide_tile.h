@@ -378,7 +378,7 @@ __device__ __forceinline__ void sum_valid_columns(const DecodeArgs& a, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------
-// fixup_crew (k_decode_wide_fixup, and the tail of the one-launch kernels): the fix-up pass on wide tiles (round 4; k_decode_fixup's 64-column tiles remain for formats the wide
+// fixup_crew (k_decode_wide_fixup): the fix-up pass on wide tiles (round 4; k_decode_fixup's 64-column tiles remain for formats the wide
 // tiles cannot take).  A persistent grid as before: every workgroup lists the frames flagged with this call's tag and the
 // workgroups share the work out through tickets.  Tickets, in this order:
 //   one per flagged frame      LEAD: resolve_frame gives the frame's real column maps (from the packed header words the
