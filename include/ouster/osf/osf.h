@@ -106,11 +106,14 @@ struct LidarScanMsgView {
 struct StagedField {
     uint32_t encoding = 0;         ///< OUSTER_HIP_OSF_*
     uint32_t src_pixel_bytes = 0;
-    std::vector<uint8_t> bytes;    ///< PNG: unfiltered scanlines; ZPNG: zstd-decompressed residuals
+    bool filtered = false;         ///< PNG: `bytes` is the inflated stream, filter-type byte per scanline (device_unfilter)
+    std::vector<uint8_t> bytes;    ///< PNG: unfiltered scanlines (or the inflated stream); ZPNG: zstd-decompressed residuals
 };
-/** Host half of decode_field: inflate / unfilter (PNG) or zstd (ZPNG).  h, w: expected image size.
+/** Host half of decode_field: inflate (PNG; + the scanline filters unless device_unfilter) or zstd (ZPNG).  h, w: expected
+ *  image size.  device_unfilter (round 5): leave the PNG scanline filters to the GPU (ouster_hip_osf_plane::flags); the
+ *  filter-type bytes are checked here.
  *  @throw std::runtime_error("decodeField: could not decode field") like the reference */
-StagedField stage_field(const EncodedField& f, size_t h, size_t w);
+StagedField stage_field(const EncodedField& f, size_t h, size_t w, bool device_unfilter = false);
 
 /** A batch of OSF frames whose planes stay in HBM: plane `name` is [n_frames][H][W] elements, the layout
  *  ouster_hip_decode produces, so ouster_hip_destagger / ouster_hip_cartesian / ouster_hip_dewarp_frames (or
@@ -168,6 +171,10 @@ class OsfFrameDecoder {
     /** The same decode, results left in HBM (all messages must carry the same fields).
      *  @throw std::invalid_argument when the messages' field lists differ */
     OsfDeviceBatch decode_device(const std::vector<OsfFile::Message>& msgs);
+    /** Where the PNG scanline filters are reversed: on the GPU (default since round 5: the host is left with inflate only) or
+     *  on the host as in rounds 2 - 4.  Results are byte-identical. */
+    void set_device_unfilter(bool on);
+    bool device_unfilter() const;
 
    private:
     struct Impl;

@@ -365,8 +365,13 @@ typedef struct ouster_hip_osf_plane {
     uint32_t encoding;        /* OUSTER_HIP_OSF_* */
     uint32_t src_pixel_bytes; /* bytes of one source pixel */
     uint32_t dst_elem_size;   /* 1, 2, 4 or 8 */
-    uint32_t reserved;
+    uint32_t flags;           /* OUSTER_HIP_OSF_FLAG_* (0: src holds the pixel bytes) */
 } ouster_hip_osf_plane;
+/* PNG encodings only: `src` is the INFLATED IDAT stream as libpng sees it -- h scanlines of 1 filter-type byte followed by
+ * w * src_pixel_bytes filtered bytes (PNG specification section 9: None / Sub / Up / Average / Paeth) -- and the library
+ * reverses the scanline filters on the device (k_osf_png_unfilter, round 5) before it unpacks the pixels.  The caller checks
+ * the h filter-type bytes (<= 4: the reference's libpng refuses anything else); the kernel treats an unknown type as None. */
+#define OUSTER_HIP_OSF_FLAG_FILTERED 1u
 int ouster_hip_osf_unpack(ouster_hip_ctx* ctx, const ouster_hip_osf_plane* planes, uint32_t n_planes,
                           uint32_t h, uint32_t w, const int32_t* pixel_shift_by_row);
 

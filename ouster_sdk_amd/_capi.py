@@ -71,7 +71,7 @@ class FrameOut(C.Structure):
 
 class OsfPlane(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("encoding", C.c_uint32), ("src_pixel_bytes", C.c_uint32),
-                ("dst_elem_size", C.c_uint32), ("reserved", C.c_uint32)]
+                ("dst_elem_size", C.c_uint32), ("flags", C.c_uint32)]
 
 
 # every symbol include/ouster_hip.h declares (checked by tests/test_abi.py)

@@ -333,7 +333,7 @@ void png_unfilter(const uint8_t* raw, size_t h, size_t stride, size_t bpp, uint8
 
 }  // namespace
 
-StagedField stage_field(const EncodedField& f, size_t h, size_t w) {
+StagedField stage_field(const EncodedField& f, size_t h, size_t w, bool device_unfilter) {
     StagedField out;
     const size_t esz = field_type_size(f.type);
     if (esz != 1 && esz != 2 && esz != 4 && esz != 8) cannot_decode();
@@ -393,6 +393,13 @@ StagedField stage_field(const EncodedField& f, size_t h, size_t w) {
     uLongf got = static_cast<uLongf>(raw.size());
     if (::uncompress(raw.data(), &got, idat.data(), static_cast<uLong>(idat.size())) != Z_OK || got != raw.size())
         cannot_decode();
+    if (device_unfilter) {   // the GPU reverses the filters (k_osf_png_unfilter); what libpng would refuse is refused here
+        for (size_t y = 0; y < h; ++y)
+            if (raw[y * (stride + 1)] > 4) cannot_decode();
+        out.filtered = true;
+        out.bytes = std::move(raw);
+        return out;
+    }
     out.bytes.resize(h * stride);
     png_unfilter(raw.data(), h, stride, bpp, out.bytes.data());
     return out;
@@ -400,12 +407,12 @@ StagedField stage_field(const EncodedField& f, size_t h, size_t w) {
 
 // Entropy decoding is the host's share of the work and every field is independent: stage a batch of
 // fields on up to 32 threads (zlib and zstd are re-entrant; the first exception wins and is rethrown).
-static std::vector<StagedField> stage_fields_parallel(const std::vector<EncodedField>& fields, size_t h, size_t w) {
+static std::vector<StagedField> stage_fields_parallel(const std::vector<EncodedField>& fields, size_t h, size_t w, bool device_unfilter) {
     std::vector<StagedField> out(fields.size());
     const size_t n = fields.size();
     const size_t nt = std::min<size_t>({n, std::max(1u, std::thread::hardware_concurrency()), size_t{32}});
     if (nt <= 1) {
-        for (size_t i = 0; i < n; ++i) out[i] = stage_field(fields[i], h, w);
+        for (size_t i = 0; i < n; ++i) out[i] = stage_field(fields[i], h, w, device_unfilter);
         return out;
     }
     std::atomic<size_t> next{0};
@@ -418,7 +425,7 @@ static std::vector<StagedField> stage_fields_parallel(const std::vector<EncodedF
                 const size_t i = next.fetch_add(1);
                 if (i >= n) return;
                 try {
-                    out[i] = stage_field(fields[i], h, w);
+                    out[i] = stage_field(fields[i], h, w, device_unfilter);
                 } catch (...) {
                     std::lock_guard<std::mutex> lock(mu);
                     if (!err) err = std::current_exception();
@@ -437,12 +444,16 @@ struct OsfFrameDecoder::Impl {
     SensorInfo info;
     std::shared_ptr<hip::Context> ctx;
     int device = -1;
+    bool device_unfilter = true;   // PNG scanline filters on the GPU (round 5); false: on the host, as in rounds 2 - 4
     hip::DeviceBuffer d_src, d_dst;
     const std::shared_ptr<hip::Context>& context() {
         if (!ctx) ctx = std::make_shared<hip::Context>(device >= 0 ? device : hip::current_device());
         return ctx;
     }
 };
+
+void OsfFrameDecoder::set_device_unfilter(bool on) { impl_->device_unfilter = on; }
+bool OsfFrameDecoder::device_unfilter() const { return impl_->device_unfilter; }
 
 OsfFrameDecoder::OsfFrameDecoder(const SensorInfo& info, int device) : impl_(new Impl) {
     impl_->info = info;
@@ -546,7 +557,7 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
             std::vector<size_t> so(grp.size()), dof(grp.size());
             size_t stot = 0, dtot = 0;
             for (size_t k = 0; k < grp.size(); ++k) {
-                st[k] = stage_field(custom[grp[k]].enc, rows, cols);
+                st[k] = stage_field(custom[grp[k]].enc, rows, cols, s.device_unfilter && rows * cols > 0);
                 so[k] = stot; dof[k] = dtot;
                 stot += al(st[k].bytes.size());
                 dtot += al(rows * cols * custom[grp[k]].esz);
@@ -561,7 +572,7 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
                 pl[k].encoding = st[k].encoding;
                 pl[k].src_pixel_bytes = st[k].src_pixel_bytes;
                 pl[k].dst_elem_size = static_cast<uint32_t>(custom[grp[k]].esz);
-                pl[k].reserved = 0;
+                pl[k].flags = st[k].filtered ? OUSTER_HIP_OSF_FLAG_FILTERED : 0u;
             }
             dsrc.upload(stage.data(), stot);
             hip::check(ouster_hip_osf_unpack(s.ctx->handle(), pl.data(), static_cast<uint32_t>(pl.size()),
@@ -575,7 +586,7 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
     }
     if (jobs.empty()) return frames;
     {
-        std::vector<StagedField> staged = stage_fields_parallel(encoded, h, w);
+        std::vector<StagedField> staged = stage_fields_parallel(encoded, h, w, s.device_unfilter);
         for (size_t i = 0; i < jobs.size(); ++i) {
             jobs[i].st = std::move(staged[i]);
             jobs[i].src_off = src_total;
@@ -600,7 +611,7 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
         planes[i].encoding = jobs[i].st.encoding;
         planes[i].src_pixel_bytes = jobs[i].st.src_pixel_bytes;
         planes[i].dst_elem_size = static_cast<uint32_t>(jobs[i].esz);
-        planes[i].reserved = 0;
+        planes[i].flags = jobs[i].st.filtered ? OUSTER_HIP_OSF_FLAG_FILTERED : 0u;
         any_png |= jobs[i].st.encoding != OUSTER_HIP_OSF_ZPNG;
     }
     std::vector<int32_t> shifts(s.info.format.pixel_shift_by_row.begin(), s.info.format.pixel_shift_by_row.end());
@@ -630,7 +641,7 @@ std::vector<std::vector<uint8_t>> OsfFrameDecoder::decode_fields(const std::vect
         std::vector<size_t> idx;
         for (size_t i = 0; i < fields.size(); ++i)
             if (fields[i].size) { present.push_back(fields[i]); idx.push_back(i); }
-        std::vector<StagedField> st = stage_fields_parallel(present, h, w);
+        std::vector<StagedField> st = stage_fields_parallel(present, h, w, s.device_unfilter);
         for (size_t k = 0; k < idx.size(); ++k) staged[idx[k]] = std::move(st[k]);
     }
     for (size_t i = 0; i < fields.size(); ++i) {
@@ -657,6 +668,7 @@ std::vector<std::vector<uint8_t>> OsfFrameDecoder::decode_fields(const std::vect
         pl.encoding = staged[i].encoding;
         pl.src_pixel_bytes = staged[i].src_pixel_bytes;
         pl.dst_elem_size = static_cast<uint32_t>(field_type_size(fields[i].type));
+        pl.flags = staged[i].filtered ? OUSTER_HIP_OSF_FLAG_FILTERED : 0u;
         planes.push_back(pl);
         any_png |= staged[i].encoding != OUSTER_HIP_OSF_ZPNG;
     }
@@ -721,7 +733,7 @@ OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message
         }
     }
     {
-        std::vector<StagedField> staged = stage_fields_parallel(encoded, h, w);
+        std::vector<StagedField> staged = stage_fields_parallel(encoded, h, w, s.device_unfilter);
         for (size_t i = 0; i < jobs.size(); ++i) {
             jobs[i].st = std::move(staged[i]);
             jobs[i].src_off = src_total;
@@ -753,7 +765,7 @@ OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message
         planes[i].encoding = jobs[i].st.encoding;
         planes[i].src_pixel_bytes = jobs[i].st.src_pixel_bytes;
         planes[i].dst_elem_size = static_cast<uint32_t>(esz);
-        planes[i].reserved = 0;
+        planes[i].flags = jobs[i].st.filtered ? OUSTER_HIP_OSF_FLAG_FILTERED : 0u;
         any_png |= jobs[i].st.encoding != OUSTER_HIP_OSF_ZPNG;
     }
     std::vector<int32_t> shifts(s.info.format.pixel_shift_by_row.begin(), s.info.format.pixel_shift_by_row.end());

@@ -1296,6 +1296,87 @@ __device__ __forceinline__ uint32_t block_incl_scan_u8(uint32_t v, uint32_t* s_w
     return v + base;
 }
 
+// ------------------------------------------------------------------------------------
+// k_osf_png_unfilter (round 5; VERDICT r04 "missing" item 3): the PNG scanline filters of an OSF field reversed on the device
+// -- what libpng's png_read_row does behind decode_{8,16,24,32,64}bit_image (ouster_osf/src/png_tools.cpp:182-660; the filters:
+// PNG specification section 9, RFC 2083 6.2 - 6.6).  Sub is a prefix sum and Up is elementwise, but Average and Paeth are
+// recurrences in x AND depend on the row above, so a row cannot be split over lanes and rows cannot be done independently.
+// What is parallel is the ANTI-DIAGONAL: pixel (x, y) needs (x-1, y), (x, y-1), (x-1, y-1) only.  One wave per image, lane =
+// row of a 64-row band; at step t lane r reconstructs pixel x = t - r of its row.  Its left neighbour is its own result of
+// step t-1; the pixel above and the one above-left are lane r-1's results of steps t-1 and t-2: two wave shifts per step, no
+// memory.  A band's last row goes to LDS as it is produced (lane 63 is 63 pixels behind lane 0, so one row buffer serves both
+// the band that reads it and the band that writes it); W + 63 steps per band.  Every byte of a pixel is its own recurrence
+// (bpp = 1, 2, 3, 4 or 8 of them in one 64-bit register).  Input rows start at odd addresses (the filter byte), hence byte
+// loads; output pixels are stored whole.  2300 images of a 256-frame batch are 2300 independent waves: 9 per CU.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t shift_up_1(uint64_t v) {   // lane r receives lane r-1's value (lane 0: its own)
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, 64);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+__global__ __launch_bounds__(64) void k_osf_png_unfilter(OsfUnfilterArgs a) {
+    extern __shared__ __align__(16) uint8_t s_up[];   // [w * bpp]: the last row of the band above
+    const OsfUnfilterJob job = a.jobs[blockIdx.x];
+    const uint32_t H = a.h, W = a.w, bpp = job.bpp, lane = threadIdx.x;
+    const size_t stride = (size_t)W * bpp;
+    for (uint32_t band = 0; band < H; band += 64) {
+        const uint32_t row = band + lane;
+        const bool has_row = row < H;
+        const uint8_t* in = job.raw + (size_t)(has_row ? row : 0) * (stride + 1);
+        uint8_t* out = job.out + (size_t)(has_row ? row : 0) * stride;
+        const uint32_t ft = has_row ? in[0] : 0u;
+        ++in;
+        const bool first_row = row == 0;          // nothing above: b = c = 0
+        uint64_t res1 = 0, res2 = 0;              // my results of the two steps before (pixels x-1 and x-2 of my row)
+        uint64_t up_prev = 0;                     // lane 0: the pixel above-left (pixel x-1 of the band above's last row)
+        for (uint32_t t = 0; t < W + 63u; ++t) {
+            const int32_t x = (int32_t)t - (int32_t)lane;
+            const bool valid = has_row && x >= 0 && x < (int32_t)W;
+            // the row above: lane r-1 finished pixel x at step t-1 and pixel x-1 at step t-2
+            uint64_t b = shift_up_1(res1), c = shift_up_1(res2);
+            uint64_t raw = 0, up_here = 0;
+            if (valid) {
+                const uint8_t* px = in + (size_t)x * bpp;
+                for (uint32_t k = 0; k < bpp; ++k) raw |= (uint64_t)px[k] << (8u * k);
+            }
+            if (lane == 0) {   // the band's first row takes the row above from LDS (or has none)
+                if (band != 0 && valid)
+                    for (uint32_t k = 0; k < bpp; ++k) up_here |= (uint64_t)s_up[(size_t)x * bpp + k] << (8u * k);
+                b = up_here;
+                c = up_prev;
+                up_prev = up_here;
+            }
+            if (first_row) b = c = 0;
+            const uint64_t left = x > 0 ? res1 : 0ull;
+            if (x <= 0) c = 0;
+            uint64_t rec = 0;
+            for (uint32_t k = 0; k < bpp; ++k) {
+                const int32_t av = (int32_t)((left >> (8u * k)) & 0xffu), bv = (int32_t)((b >> (8u * k)) & 0xffu),
+                              cv = (int32_t)((c >> (8u * k)) & 0xffu), rv = (int32_t)((raw >> (8u * k)) & 0xffu);
+                int32_t pred = 0;
+                if (ft == 1u) pred = av;
+                else if (ft == 2u) pred = bv;
+                else if (ft == 3u) pred = (av + bv) >> 1;
+                else if (ft == 4u) {
+                    const int32_t p = av + bv - cv, pa = abs(p - av), pb = abs(p - bv), pc = abs(p - cv);
+                    pred = (pa <= pb && pa <= pc) ? av : (pb <= pc ? bv : cv);
+                }
+                rec |= (uint64_t)((uint32_t)(rv + pred) & 0xffu) << (8u * k);
+            }
+            if (valid) {
+                uint8_t* po = out + (size_t)x * bpp;
+                if (bpp == 3u) { po[0] = (uint8_t)rec; po[1] = (uint8_t)(rec >> 8); po[2] = (uint8_t)(rec >> 16); }
+                else store1(po, rec, bpp);
+                if (lane == 63u || row + 1u == H)   // the next band's row above (the last band writes it for nobody)
+                    for (uint32_t k = 0; k < bpp; ++k) s_up[(size_t)x * bpp + k] = (uint8_t)(rec >> (8u * k));
+            }
+            res2 = res1;
+            res1 = valid ? rec : 0ull;
+        }
+        __syncthreads();   // one wave: orders the band's LDS writes before the next band's reads
+    }
+}
+
 __global__ __launch_bounds__(256) void k_osf_unpack(OsfUnpackArgs a) {
     __shared__ uint32_t s_wave[4];
     const ouster_hip_osf_plane job = a.planes[blockIdx.y];
@@ -1632,6 +1713,17 @@ hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipSt
     };
     if (a.h > 64) emit(std::integral_constant<int, 128>{});
     else emit(std::integral_constant<int, 64>{});
+    return hipGetLastError();
+}
+
+hipError_t launch_osf_png_unfilter(const OsfUnfilterArgs& a, uint32_t n_jobs, uint32_t max_row_bytes, hipStream_t st) {
+    const size_t lds = ((size_t)max_row_bytes + 15) & ~(size_t)15;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_osf_png_unfilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_osf_png_unfilter, dim3(n_jobs), dim3(64), lds, st, a);
     return hipGetLastError();
 }
 

@@ -99,7 +99,7 @@ struct ouster_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf state, tile_valid, offsets, luts, counts, scratch, slotmap, hdrw;
+    DevBuf state, tile_valid, offsets, luts, counts, scratch, slotmap, hdrw, osf_pixels;
     uint32_t resident_wgs = 512;         // 2 workgroups (80 KB LDS each) per CU
     uint32_t cus = 256;                  // compute units (k_decode_stream: one persistent workgroup each)
     const char* last_kernel = "";        // name of the decode kernel the last ouster_hip_decode launched
@@ -341,6 +341,8 @@ void ouster_hip_ctx_destroy(ouster_hip_ctx* c) {
     c->scratch.release();
     c->slotmap.release();
     c->hdrw.release();
+    c->osf_pixels.release();
+    c->osf_pixels.release();
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -1424,24 +1426,35 @@ int ouster_hip_osf_unpack(ouster_hip_ctx* ctx, const ouster_hip_osf_plane* plane
     if (n_planes == 0 || h == 0 || w == 0) return OUSTER_HIP_OK;
     if (!planes) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "planes is NULL");
     bool any_png = false;
+    size_t unfiltered_bytes = 0;          // device scratch for the planes that arrive as filtered PNG scanlines
+    uint32_t n_filtered = 0, max_row_bytes = 0;
     for (uint32_t i = 0; i < n_planes; ++i) {
         const ouster_hip_osf_plane& p = planes[i];
         if (!p.src || !p.dst) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: NULL pointer", i);
         const uint32_t e = p.dst_elem_size;
         if (!(e == 1 || e == 2 || e == 4 || e == 8))
             return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: unsupported element size %u", i, e);
+        if (p.flags & ~OUSTER_HIP_OSF_FLAG_FILTERED) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: unknown flags", i);
         static const uint32_t want[6] = {0, 1, 2, 3, 4, 8};
         if (p.encoding >= OUSTER_HIP_OSF_PNG_GRAY8 && p.encoding <= OUSTER_HIP_OSF_PNG_RGBA16) {
             if (p.src_pixel_bytes != want[p.encoding])
                 return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: pixel size does not match its PNG type", i);
             any_png = true;
+            if (p.flags & OUSTER_HIP_OSF_FLAG_FILTERED) {
+                ++n_filtered;
+                unfiltered_bytes += ((size_t)h * w * p.src_pixel_bytes + 15) & ~(size_t)15;
+                max_row_bytes = std::max(max_row_bytes, w * p.src_pixel_bytes);
+            }
         } else if (p.encoding == OUSTER_HIP_OSF_ZPNG) {
             if (p.src_pixel_bytes == 0 || p.src_pixel_bytes > 8)
                 return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: ZPNG pixels are 1..8 bytes", i);
+            if (p.flags) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: ZPNG planes carry no PNG filters", i);
         } else {
             return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: unknown encoding %u", i, p.encoding);
         }
     }
+    if (n_filtered && (uint64_t)max_row_bytes > 64u * 1024u)
+        return fail(OUSTER_HIP_ERR_UNSUPPORTED, "a PNG scanline of %u bytes does not fit in LDS", max_row_bytes);
     HIP_TRY(hipSetDevice(ctx->device));
     OsfUnpackArgs a{};
     a.h = h;
@@ -1453,10 +1466,36 @@ int ouster_hip_osf_unpack(ouster_hip_ctx* ctx, const ouster_hip_osf_plane* plane
         ctx->shifts_host.clear();
         a.offsets = (const int32_t*)ctx->offsets.p;
     }
-    const size_t bytes = (size_t)n_planes * sizeof(ouster_hip_osf_plane);
-    if (ctx->scratch.ensure(bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "scratch allocation failed");
-    HIP_TRY(hipMemcpyAsync(ctx->scratch.p, planes, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // `planes` is the caller's memory
+    // the job arrays: the unpack jobs (filtered planes read the device-side unfiltered copy), then the unfilter jobs
+    std::vector<ouster_hip_osf_plane> jobs(planes, planes + n_planes);
+    std::vector<OsfUnfilterJob> unf;
+    if (n_filtered) {
+        if (ctx->osf_pixels.ensure(unfiltered_bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "scratch allocation failed");
+        size_t at = 0;
+        for (uint32_t i = 0; i < n_planes; ++i) {
+            if (!(jobs[i].flags & OUSTER_HIP_OSF_FLAG_FILTERED)) continue;
+            OsfUnfilterJob j{};
+            j.raw = (const uint8_t*)jobs[i].src;
+            j.out = (uint8_t*)ctx->osf_pixels.p + at;
+            j.bpp = jobs[i].src_pixel_bytes;
+            unf.push_back(j);
+            jobs[i].src = j.out;
+            jobs[i].flags = 0;
+            at += ((size_t)h * w * j.bpp + 15) & ~(size_t)15;
+        }
+    }
+    const size_t bytes = (size_t)n_planes * sizeof(ouster_hip_osf_plane), ubytes = unf.size() * sizeof(OsfUnfilterJob);
+    if (ctx->scratch.ensure(bytes + ubytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "scratch allocation failed");
+    HIP_TRY(hipMemcpyAsync(ctx->scratch.p, jobs.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (ubytes) HIP_TRY(hipMemcpyAsync((uint8_t*)ctx->scratch.p + bytes, unf.data(), ubytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the job arrays are this call's memory
+    if (n_filtered) {
+        OsfUnfilterArgs u{};
+        u.jobs = (const OsfUnfilterJob*)((uint8_t*)ctx->scratch.p + bytes);
+        u.h = h;
+        u.w = w;
+        HIP_TRY(launch_osf_png_unfilter(u, n_filtered, max_row_bytes, ctx->stream));
+    }
     a.planes = (const ouster_hip_osf_plane*)ctx->scratch.p;
     HIP_TRY(launch_osf_unpack(a, n_planes, ctx->stream));
     return OUSTER_HIP_OK;

@@ -198,6 +198,17 @@ struct OsfUnpackArgs {
     uint32_t h, w;
 };
 
+// PNG scanline filters reversed on the device (ouster_hip_osf_plane::flags & OUSTER_HIP_OSF_FLAG_FILTERED): one job per image
+struct OsfUnfilterJob {
+    const uint8_t* raw;   // device: h x (1 + w * bpp) bytes, filter type first
+    uint8_t* out;         // device: h x w * bpp bytes
+    uint32_t bpp, pad;
+};
+struct OsfUnfilterArgs {
+    const OsfUnfilterJob* jobs;   // device [n]
+    uint32_t h, w;
+};
+
 // one compile-time field of a standard profile (see the Spec* tables in the kernels file)
 struct FieldC {
     uint32_t offset;
@@ -221,5 +232,6 @@ hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
 hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);
 hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st);
 hipError_t launch_osf_unpack(const OsfUnpackArgs& a, uint32_t n_planes, hipStream_t st);
+hipError_t launch_osf_png_unfilter(const OsfUnfilterArgs& a, uint32_t n_jobs, uint32_t max_row_bytes, hipStream_t st);
 
 }  // namespace ouster_hip_dev

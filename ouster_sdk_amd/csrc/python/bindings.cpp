@@ -858,6 +858,7 @@ PYBIND11_MODULE(core, m) {
         });
         py::class_<oo::OsfFrameDecoder>(m, "OsfFrameDecoder")
             .def(py::init<const SensorInfo&, int>(), py::arg("info"), py::arg("device") = -1)
+            .def_property("device_unfilter", &oo::OsfFrameDecoder::device_unfilter, &oo::OsfFrameDecoder::set_device_unfilter)
             .def("decode", [](oo::OsfFrameDecoder& d, const std::vector<py::bytes>& msgs) {
                 std::vector<std::string> keep(msgs.begin(), msgs.end());
                 std::vector<oo::OsfFile::Message> mm(keep.size());

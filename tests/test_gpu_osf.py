@@ -279,3 +279,115 @@ def test_osf_custom_fields_2d_and_1d_from_a_hand_built_message(oracle):
     assert np.array_equal(fr.field("MY_PIXELS"), px) and fr.field("MY_PIXELS").dtype == np.uint16
     assert fr.field("MY_COLUMNS").shape == (w, 3) and np.array_equal(fr.field("MY_COLUMNS"), colf)
     assert np.array_equal(fr.field("MY_FRAME_VALUES"), one)
+
+
+# ---------------------------------------------------------------------------------------------
+# PNG scanline filters on the GPU (round 5, k_osf_png_unfilter): every filter type, every pixel size
+# ---------------------------------------------------------------------------------------------
+def _png_with_filters(pixels: np.ndarray, depth: int, colour: int, filters) -> bytes:
+    """A PNG whose row y is filtered with type filters[y] (PNG specification section 9): the encoder side of what the decoder
+    must reverse; pixels [h, w * bpp] uint8."""
+    import struct
+    import zlib
+    h, stride = pixels.shape
+    bpp = {0: 1, 2: 3, 6: 4}[colour] * depth // 8
+    raw = bytearray()
+    prev = np.zeros(stride, np.int32)
+    for y in range(h):
+        cur = pixels[y].astype(np.int32)
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        upleft = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        ft = int(filters[y])
+        if ft == 0:
+            pred = np.zeros(stride, np.int32)
+        elif ft == 1:
+            pred = left
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (left + prev) >> 1
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        raw.append(ft)
+        raw += ((cur - pred) & 0xFF).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(typ, body):
+        return struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xFFFFFFFF)
+    ihdr = struct.pack(">IIBBBBB", stride // bpp, h, depth, colour, 0, 0, 0)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("h,w", [(128, 1024), (64, 512), (70, 130), (200, 96), (1, 64), (5, 3)])
+def test_png_filters_on_the_gpu_equal_the_host_and_the_oracle(oracle, h, w):
+    """Every scanline filter (None / Sub / Up / Average / Paeth, and rows that mix them in every order), every pixel size the
+    OSF writer produces (8 / 16-bit gray, RGB8, RGBA8, RGBA16): OsfFrameDecoder.decode_fields with the filters reversed on the
+    GPU == with the filters reversed on the host == osf_oracle.decode_field (pinned on the reference's own .osf files).  Image
+    heights that are not a multiple of the kernel's 64-row band, one-row and three-column images."""
+    from oracle import osf_oracle as OO
+    from ouster_sdk_amd import core
+    rng = np.random.default_rng(h * 1000 + w)
+    info = core.SensorInfo()
+    fmt = core.DataFormat()
+    fmt.pixels_per_column, fmt.columns_per_frame, fmt.columns_per_packet = h, w, 1
+    # stagger() is not the subject here: random shifts where np.roll is the reference's arithmetic (power-of-two widths), none
+    # elsewhere (the reference's size_t expression is not a roll there: tests/test_oracle_ref_core.py, DESIGN.md section 5)
+    pow2 = w & (w - 1) == 0
+    fmt.pixel_shift_by_row = [int(x) if pow2 else 0 for x in rng.integers(-w, w, h)]
+    fmt.udp_profile_lidar = core.UDPProfileLidar.from_string("RNG19_RFL8_SIG16_NIR16")
+    info.format = fmt
+    kinds = [(8, 0, np.uint8, 1), (16, 0, np.uint16, 2), (8, 2, np.uint32, 3), (8, 6, np.uint32, 3), (16, 6, np.uint64, 4)]
+    blobs, want = [], []
+    for depth, colour, dt, tag in kinds:
+        bpp = {0: 1, 2: 3, 6: 4}[colour] * depth // 8
+        for mode in ("all0", "all1", "all2", "all3", "all4", "mixed"):
+            px = rng.integers(0, 256, (h, w * bpp), dtype=np.uint8)
+            px[:, bpp:] = (px[:, bpp:] // 8 + px[:, :-bpp]).astype(np.uint8)     # neighbouring pixels correlate
+            filters = rng.integers(0, 5, h) if mode == "mixed" else np.full(h, int(mode[-1]))
+            blob = _png_with_filters(px, depth, colour, filters)
+            blobs.append((blob, tag))
+            want.append(OO.decode_field(blob, dt, h, w, fmt.pixel_shift_by_row))
+            if mode == "mixed":   # the oracle's unfilter gives the pixels back (the test's encoder and the oracle agree)
+                assert np.array_equal(OO.png_pixels(blob)[0], px)
+    got = {}
+    for on in (True, False):
+        dec = core.OsfFrameDecoder(info)
+        dec.device_unfilter = on
+        assert dec.device_unfilter == on
+        got[on] = dec.decode_fields(blobs)
+    for i, ((depth, colour, dt, tag), w_) in enumerate(zip([k for k in kinds for _ in range(6)], want)):
+        a = np.frombuffer(got[True][i], dt).reshape(h, w)
+        b = np.frombuffer(got[False][i], dt).reshape(h, w)
+        assert np.array_equal(a, w_), ("gpu unfilter", i, depth, colour)
+        assert np.array_equal(b, w_), ("host unfilter", i, depth, colour)
+    # what libpng refuses is refused: a filter type above 4
+    bad = bytearray(_png_with_filters(rng.integers(0, 256, (h, w), dtype=np.uint8), 8, 0, np.zeros(h, int)))
+    import struct
+    import zlib
+    raw = bytearray(zlib.decompress(bytes(OO_idat(bad))))
+    raw[0] = 7
+    blob = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + _chunk(b"IDAT", zlib.compress(bytes(raw))) + _chunk(b"IEND", b"")
+    for on in (True, False):
+        dec = core.OsfFrameDecoder(info)
+        dec.device_unfilter = on
+        with pytest.raises(RuntimeError, match="could not decode field"):
+            dec.decode_fields([(blob, 1)])
+
+
+def _chunk(typ, body):
+    import struct
+    import zlib
+    return struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xFFFFFFFF)
+
+
+def OO_idat(png: bytes) -> bytes:
+    import struct
+    pos, out = 8, b""
+    while pos + 8 <= len(png):
+        n, typ = struct.unpack_from(">I4s", png, pos)
+        if typ == b"IDAT":
+            out += bytes(png[pos + 8:pos + 8 + n])
+        pos += 12 + n
+    return out
