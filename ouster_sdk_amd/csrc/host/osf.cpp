@@ -410,7 +410,7 @@ StagedField stage_field(const EncodedField& f, size_t h, size_t w, bool device_u
 static std::vector<StagedField> stage_fields_parallel(const std::vector<EncodedField>& fields, size_t h, size_t w, bool device_unfilter) {
     std::vector<StagedField> out(fields.size());
     const size_t n = fields.size();
-    const size_t nt = std::min<size_t>({n, std::max(1u, std::thread::hardware_concurrency()), size_t{32}});
+    const size_t nt = std::min<size_t>({n, std::max(1u, std::thread::hardware_concurrency()), size_t{128}});
     if (nt <= 1) {
         for (size_t i = 0; i < n; ++i) out[i] = stage_field(fields[i], h, w, device_unfilter);
         return out;

@@ -699,6 +699,14 @@ __device__ __forceinline__ void dwf_column_loop(const DewarpFramesArgs& a, const
         for (int hh = 0; hh < NR; ++hh) {
             if (!(keep[hh] && (roomy || rank[hh] < room))) continue;
             T pt[3];
+#ifdef OUSTER_ABLATE_DWF_MATH    // experiment builds only: every load and store stays, the projection and the pose do not
+            if constexpr (SEP) {
+                Pt3<T> o0;
+                o0.x = (T)r[hh]; o0.y = (T)rank[hh]; o0.z = (T)x;
+                ((Pt3<T>*)run)[rank[hh]] = o0;
+                continue;
+            }
+#endif
             if constexpr (SEP) {
                 const double rm = (double)r[hh] - lut.n;
 #pragma unroll
@@ -722,6 +730,9 @@ __device__ __forceinline__ void dwf_column_loop(const DewarpFramesArgs& a, const
             o.x = fma(ps[0], px, fma(ps[2], py, fma(ps[4], pz, ps[6])));
             o.y = fma(ps[1], px, fma(ps[3], py, fma(ps[5], pz, ps[7])));
             o.z = fma(ps[8], px, fma(ps[9], py, fma(ps[10], pz, ps[11])));
+#ifdef OUSTER_ABLATE_DWF_STORE   // experiment builds only: the arithmetic stays, (almost) nothing is stored
+            if (!(o.x == (T)-12345.678 && o.y == (T)8765.4321)) continue;
+#endif
 #if OUSTER_NT_STANDALONE
             {
                 T* pd = run + rank[hh] * 3u;
