@@ -585,6 +585,31 @@ def time_standalone(n_images=256):
     return res
 
 
+def time_latency_cpp(python_rows):
+    """The small-batch latency a C++ caller of the library sees (the product is a C++ library; Python is test plumbing):
+    tests/cpp/_build/bench_latency (tools/bench_latency.cpp, built by `make`) times hip::DeviceFrameBatch::decode() on 1, 4
+    (four sensors = one configs[4] tick) and 16 dual-return frames, full output set -- back to back, with a stream
+    synchronisation per call (median), and the host time of the call itself.  The same shapes are decoded and checked against
+    the oracle from Python (`latency_python`, whose `validated` flags are copied here)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_latency")
+    o = subprocess.run([exe, "1500"], capture_output=True, text=True, timeout=120)
+    if o.returncode != 0:
+        raise RuntimeError((o.stderr or o.stdout)[-200:])
+    rows = json.loads(o.stdout.strip().splitlines()[-1])
+    out = {"timed_by": "tests/cpp/_build/bench_latency (tools/bench_latency.cpp): hip::DeviceFrameBatch::decode() from C++; "
+                       "the Python-timed figures of the same calls are under latency_python"}
+    for k in ("1", "4", "16"):
+        r = dict(rows[k])
+        r["what"] = "one configs[4] tick: 4 sensors, per-sensor extrinsics" if k == "4" else f"{k} dual-return frame(s)"
+        r["Gpoints_per_s_pipelined"] = round(int(k) * H * W * 2 / (r["us_per_call_pipelined"] * 1e-6) / 1e9, 2)
+        if isinstance(python_rows, dict) and k in python_rows:
+            r["validated"] = python_rows[k].get("validated")
+            r["kernel"] = python_rows[k].get("kernel")
+        out[k] = r
+    return out
+
+
 def time_drop_in():
     """What an UNMODIFIED caller of the reference's API gets through include/ouster/core/*.h (host containers in, host results
     out, every call crosses PCIe): FrameBatcher::batch x128 + destagger<uint32_t> + XYZLut() per 128 x 2048 dual-return frame
@@ -913,10 +938,13 @@ def main():
     if rank == 0 and not args.no_loss_paths and args.outputs == "full":
         loss_paths = _report_row(time_loss_paths, hp, packets, out, F, algorithmic_bytes_per_frame(args.workload))
     # every other BASELINE config and the small-batch latency view, in the driver-visible line
-    other_workloads, latency, standalone, drop_in = None, None, None, None
+    other_workloads, latency, latency_python, standalone, drop_in = None, None, None, None, None
     if rank == 0 and world == 1 and args.workload == "dual" and args.outputs == "full" and not args.no_extras:
         other_workloads = _report_row(time_other_workloads, placement="first" if args.placement == "first" else "refine")   # same default
-        latency = _report_row(time_small_batches)
+        latency_python = _report_row(time_small_batches)
+        latency = _report_row(time_latency_cpp, latency_python)
+        if "error" in latency:      # the C++ helper is missing: the Python-timed rows are the only ones
+            latency = latency_python
         torch.cuda.empty_cache()
         standalone = _report_row(time_standalone)
         torch.cuda.empty_cache()
@@ -998,6 +1026,7 @@ def main():
             "loss_paths": loss_paths,
             "other_workloads": other_workloads,
             "latency": latency,
+            "latency_python": latency_python,
             "standalone": standalone,
             "drop_in": drop_in,
             "cpu_baseline": None,

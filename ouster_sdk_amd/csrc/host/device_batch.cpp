@@ -176,8 +176,11 @@ void DeviceFrameBatch::decode() {
             gate_valid_ = true;
         }
     }
+    // per-frame packet counts are only news when a frame has not been uploaded (count 0: it decodes as zeros); a batch whose
+    // frames are all there says "every slot counts" with a null pointer and spares the call an upload of the counts
+    const bool every_frame = std::all_of(counts_.begin(), counts_.end(), [&](uint32_t c) { return c == slots_; });
     check(ouster_hip_decode(default_ctx(), fmt_, static_cast<const uint8_t*>(d_packets_.data()), stride_,
-                            slots_, opt_.all_slots ? nullptr : counts_.data(), n_frames_, nullptr, &out,
+                            slots_, (opt_.all_slots || every_frame) ? nullptr : counts_.data(), n_frames_, nullptr, &out,
                             d_dst_.empty() ? nullptr : shifts_.data(), luts.empty() ? nullptr : luts.data(),
                             static_cast<uint32_t>(luts.size())));
 }
