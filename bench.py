@@ -582,7 +582,42 @@ def time_standalone(n_images=256):
                                          "Mpixels_per_s": round(npx / s / 1e6, 1),
                                          "frac": round(nbytes / s / 1e9 / HBM_PEAK_GBPS, 4), "validated": bool(ok)}
     res["note"] = f"{N} images of {H}x{W}, inputs rotated over 3 copies; each row checked against the oracle on image 0"
+    res["osf_decode_device"] = _report_row(time_osf)
     return res
+
+
+def time_osf(n_msgs=96):
+    """LidarScan messages of the reference's own OSF fixture (tests/golden/osf: PNG-encoded 128 x 1024 fields) ->
+    planes in HBM through OsfFrameDecoder.decode_device -- zlib inflate on the host, PNG scanline filters + unpack + stagger on
+    the GPU (k_osf_png_unfilter, k_osf_unpack); the first message is checked against the OSF oracle.  Host bound (inflate)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_osf as T
+    from oracle import osf_oracle as Z
+    from ouster_sdk_amd import core
+    path = T.LB
+    meta = list(Z.OsfFile(path).sensor_metadata().values())[0]
+    h, w, shifts = T._geometry(meta)
+    pf = core.OsfFile(path)
+    streams = pf.lidar_scan_streams()
+    msgs = [m for (_, sid, m) in pf.messages() if sid in streams]
+    batch = (msgs * (n_msgs // len(msgs) + 1))[:n_msgs]
+    info = T._sensor_info(core, meta)
+    out = {"messages": n_msgs, "h_w": [h, w], "fixture": os.path.relpath(path, ROOT)}
+    for on in (True, False):
+        dec = core.OsfFrameDecoder(info)
+        dec.device_unfilter = on
+        dec.decode_device(batch[:8])
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            dec.decode_device(batch)
+            best = min(best, time.perf_counter() - t0)
+        out["ms_gpu_unfilter" if on else "ms_host_unfilter"] = round(best * 1e3, 2)
+    fr = core.OsfFrameDecoder(info).decode([msgs[0]])[0]
+    want = Z.decode_lidar_scan_msg(msgs[0], h, w, shifts)
+    out["validated"] = bool(all(np.array_equal(fr.field(n), v) for n, v in want["fields"].items()))
+    out["frames_per_s"] = round(n_msgs / (out["ms_gpu_unfilter"] * 1e-3), 1)
+    return out
 
 
 def time_latency_cpp(python_rows):
