@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <fstream>
+#include <functional>
 #include <atomic>
 #include <exception>
 #include <mutex>
@@ -333,8 +335,22 @@ void png_unfilter(const uint8_t* raw, size_t h, size_t stride, size_t bpp, uint8
 
 }  // namespace
 
-StagedField stage_field(const EncodedField& f, size_t h, size_t w, bool device_unfilter) {
-    StagedField out;
+namespace {
+
+// What the header of one encoded field says, before any entropy decoding: how many bytes its staged form takes, so that a
+// whole batch can be laid out first and every field inflated straight to its place in ONE pinned staging buffer (round 5:
+// the staged bytes used to go through a vector per field, a second vector for the batch and a pageable copy to the GPU --
+// three passes over ~0.9 MB per frame that cost more than the inflate itself).
+struct FieldPlan {
+    uint32_t encoding = 0, src_pixel_bytes = 0;
+    bool filtered = false;
+    size_t staged_bytes = 0;
+    size_t h = 0, stride = 0, bpp = 0;                          // PNG
+    std::vector<std::pair<const uint8_t*, size_t>> chunks;      // PNG: the IDAT bodies; ZPNG: the zstd frame
+};
+
+FieldPlan plan_field(const EncodedField& f, size_t h, size_t w, bool device_unfilter) {
+    FieldPlan out;
     const size_t esz = field_type_size(f.type);
     if (esz != 1 && esz != 2 && esz != 4 && esz != 8) cannot_decode();
     // ZPNG first, as decode_field does (png_tools.cpp:688-706)
@@ -344,9 +360,8 @@ StagedField stage_field(const EncodedField& f, size_t h, size_t w, bool device_u
         if (zw != w || zh != h || pixel_bytes != esz) throw std::runtime_error("Invalid allocation");
         out.encoding = OUSTER_HIP_OSF_ZPNG;
         out.src_pixel_bytes = static_cast<uint32_t>(pixel_bytes);
-        out.bytes.resize(w * h * pixel_bytes);
-        const size_t n = ZSTD_decompress(out.bytes.data(), out.bytes.size(), f.data + 8, f.size - 8);
-        if (ZSTD_isError(n) || n != out.bytes.size()) cannot_decode();
+        out.staged_bytes = w * h * pixel_bytes;
+        out.chunks.emplace_back(f.data + 8, f.size - 8);
         return out;
     }
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
@@ -354,7 +369,6 @@ StagedField stage_field(const EncodedField& f, size_t h, size_t w, bool device_u
     size_t pos = 8;
     uint32_t pw = 0, ph = 0;
     int depth = 0, colour = -1, interlace = 0;
-    std::vector<uint8_t> idat;
     while (pos + 12 <= f.size) {
         const uint32_t n = be32(f.data + pos);
         const uint8_t* typ = f.data + pos + 4;
@@ -367,7 +381,7 @@ StagedField stage_field(const EncodedField& f, size_t h, size_t w, bool device_u
             colour = body[9];
             interlace = body[12];
         } else if (!std::memcmp(typ, "IDAT", 4)) {
-            idat.insert(idat.end(), body, body + n);
+            out.chunks.emplace_back(body, n);
         } else if (!std::memcmp(typ, "IEND", 4)) {
             break;
         }
@@ -388,52 +402,142 @@ StagedField stage_field(const EncodedField& f, size_t h, size_t w, bool device_u
                     (esz == 8 && bpp == 8);
     if (!ok) cannot_decode();
     out.src_pixel_bytes = static_cast<uint32_t>(bpp);
-    const size_t stride = w * bpp;
-    std::vector<uint8_t> raw(h * (stride + 1));
-    uLongf got = static_cast<uLongf>(raw.size());
-    if (::uncompress(raw.data(), &got, idat.data(), static_cast<uLong>(idat.size())) != Z_OK || got != raw.size())
-        cannot_decode();
-    if (device_unfilter) {   // the GPU reverses the filters (k_osf_png_unfilter); what libpng would refuse is refused here
-        for (size_t y = 0; y < h; ++y)
-            if (raw[y * (stride + 1)] > 4) cannot_decode();
-        out.filtered = true;
-        out.bytes = std::move(raw);
-        return out;
-    }
-    out.bytes.resize(h * stride);
-    png_unfilter(raw.data(), h, stride, bpp, out.bytes.data());
+    out.h = h;
+    out.bpp = bpp;
+    out.stride = w * bpp;
+    out.filtered = device_unfilter;   // the GPU reverses the filters (k_osf_png_unfilter)
+    out.staged_bytes = device_unfilter ? h * (out.stride + 1) : h * out.stride;
     return out;
 }
 
-// Entropy decoding is the host's share of the work and every field is independent: stage a batch of
-// fields on up to 32 threads (zlib and zstd are re-entrant; the first exception wins and is rethrown).
-static std::vector<StagedField> stage_fields_parallel(const std::vector<EncodedField>& fields, size_t h, size_t w, bool device_unfilter) {
-    std::vector<StagedField> out(fields.size());
-    const size_t n = fields.size();
-    const size_t nt = std::min<size_t>({n, std::max(1u, std::thread::hardware_concurrency()), size_t{128}});
-    if (nt <= 1) {
-        for (size_t i = 0; i < n; ++i) out[i] = stage_field(fields[i], h, w, device_unfilter);
-        return out;
+// inflate a zlib stream that may be split over several IDAT chunks into exactly `want` bytes
+void inflate_chunks(const std::vector<std::pair<const uint8_t*, size_t>>& chunks, uint8_t* dst, size_t want) {
+    z_stream z{};
+    if (inflateInit(&z) != Z_OK) cannot_decode();
+    z.next_out = dst;
+    z.avail_out = static_cast<uInt>(want);
+    int rc = Z_OK;
+    for (size_t i = 0; i < chunks.size() && rc == Z_OK; ++i) {
+        z.next_in = const_cast<Bytef*>(chunks[i].first);
+        z.avail_in = static_cast<uInt>(chunks[i].second);
+        while (z.avail_in && rc == Z_OK) rc = inflate(&z, Z_NO_FLUSH);   // more pixels than the header said: Z_BUF_ERROR
     }
-    std::atomic<size_t> next{0};
-    std::exception_ptr err;
-    std::mutex mu;
-    std::vector<std::thread> pool;
-    for (size_t t = 0; t < nt; ++t)
-        pool.emplace_back([&] {
-            for (;;) {
-                const size_t i = next.fetch_add(1);
-                if (i >= n) return;
-                try {
-                    out[i] = stage_field(fields[i], h, w, device_unfilter);
-                } catch (...) {
-                    std::lock_guard<std::mutex> lock(mu);
-                    if (!err) err = std::current_exception();
-                }
-            }
-        });
-    for (auto& th : pool) th.join();
-    if (err) std::rethrow_exception(err);
+    const bool ok = rc == Z_STREAM_END && z.total_out == want;
+    inflateEnd(&z);
+    if (!ok) cannot_decode();
+}
+
+// entropy decoding of one planned field into its staged_bytes at dst
+void stage_into(const FieldPlan& p, uint8_t* dst) {
+    if (p.encoding == OUSTER_HIP_OSF_ZPNG) {
+        const size_t n = ZSTD_decompress(dst, p.staged_bytes, p.chunks[0].first, p.chunks[0].second);
+        if (ZSTD_isError(n) || n != p.staged_bytes) cannot_decode();
+        return;
+    }
+    if (p.filtered) {   // what libpng would refuse is refused here
+        inflate_chunks(p.chunks, dst, p.staged_bytes);
+        for (size_t y = 0; y < p.h; ++y)
+            if (dst[y * (p.stride + 1)] > 4) cannot_decode();
+        return;
+    }
+    std::vector<uint8_t> raw(p.h * (p.stride + 1));
+    inflate_chunks(p.chunks, raw.data(), raw.size());
+    png_unfilter(raw.data(), p.h, p.stride, p.bpp, dst);
+}
+
+// A few parked threads for the entropy decoding (zlib and zstd are re-entrant; every field is independent).  Started on first
+// use and kept: spawning 128 threads per batch cost about as much as one round of inflates.
+class Crew {
+   public:
+    ~Crew() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // fn(i) for i in [0, n) on up to `want` threads (the caller is one of them); fn must not throw
+    void run(size_t n, size_t want, const std::function<void(size_t)>& fn) {
+        if (want <= 1 || n <= 1) {
+            for (size_t i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        while (th_.size() + 1 < want) th_.emplace_back([this] { worker(); });
+        fn_ = &fn;
+        n_ = n;
+        next_.store(0);
+        active_ = th_.size();
+        ++gen_;
+        lk.unlock();
+        wake_.notify_all();
+        for (size_t i; (i = next_.fetch_add(1)) < n;) fn(i);
+        lk.lock();
+        done_.wait(lk, [&] { return active_ == 0; });
+    }
+
+   private:
+    void worker() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            wake_.wait(lk, [&] { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
+            const std::function<void(size_t)>* fn = fn_;
+            const size_t n = n_;
+            lk.unlock();
+            for (size_t i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
+            lk.lock();
+            if (--active_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable wake_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0, active_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+// host memory the copy engine reads and writes directly; grows, never shrinks
+struct PinnedBytes {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    PinnedBytes() = default;
+    PinnedBytes(const PinnedBytes&) = delete;
+    PinnedBytes& operator=(const PinnedBytes&) = delete;
+    ~PinnedBytes() {
+        if (p) (void)hipHostFree(p);
+    }
+    uint8_t* need(size_t n) {
+        if (n > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            cap = 0;
+            const size_t want = n + n / 4;
+            void* q = nullptr;
+            if (hipHostMalloc(&q, want, hipHostMallocPortable) != hipSuccess) throw std::runtime_error("ouster_hip: hipHostMalloc failed");
+            p = static_cast<uint8_t*>(q);
+            cap = want;
+        }
+        return p;
+    }
+};
+
+}  // namespace
+
+StagedField stage_field(const EncodedField& f, size_t h, size_t w, bool device_unfilter) {
+    const FieldPlan p = plan_field(f, h, w, device_unfilter);
+    StagedField out;
+    out.encoding = p.encoding;
+    out.src_pixel_bytes = p.src_pixel_bytes;
+    out.filtered = p.filtered;
+    out.bytes.resize(p.staged_bytes);
+    stage_into(p, out.bytes.data());
     return out;
 }
 
@@ -446,6 +550,23 @@ struct OsfFrameDecoder::Impl {
     int device = -1;
     bool device_unfilter = true;   // PNG scanline filters on the GPU (round 5); false: on the host, as in rounds 2 - 4
     hip::DeviceBuffer d_src, d_dst;
+    PinnedBytes h_src, h_dst;
+    Crew crew;
+    // every planned field inflated to base + off[i], in parallel; the first exception wins and is rethrown
+    void stage_all(const std::vector<FieldPlan>& plans, const std::vector<size_t>& off, uint8_t* base) {
+        std::exception_ptr err;
+        std::mutex mu;
+        const size_t nt = std::min<size_t>({plans.size(), std::max(1u, std::thread::hardware_concurrency()), size_t{128}});
+        crew.run(plans.size(), nt, [&](size_t i) {
+            try {
+                stage_into(plans[i], base + off[i]);
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(mu);
+                if (!err) err = std::current_exception();
+            }
+        });
+        if (err) std::rethrow_exception(err);
+    }
     const std::shared_ptr<hip::Context>& context() {
         if (!ctx) ctx = std::make_shared<hip::Context>(device >= 0 ? device : hip::current_device());
         return ctx;
@@ -465,7 +586,7 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
     Impl& s = *impl_;
     const size_t h = s.info.format.pixels_per_column, w = s.info.format.columns_per_frame;
     std::vector<LidarFrame> frames;
-    struct Job { size_t frame; std::string name; size_t esz; StagedField st; size_t src_off, dst_off; };
+    struct Job { size_t frame; std::string name; size_t esz; size_t dst_off; };
     struct CustomJob { size_t frame; std::string name; size_t esz, rows, cols; EncodedField enc; };
     std::vector<Job> jobs;
     std::vector<CustomJob> custom;
@@ -585,34 +706,32 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
         }
     }
     if (jobs.empty()) return frames;
-    {
-        std::vector<StagedField> staged = stage_fields_parallel(encoded, h, w, s.device_unfilter);
-        for (size_t i = 0; i < jobs.size(); ++i) {
-            jobs[i].st = std::move(staged[i]);
-            jobs[i].src_off = src_total;
-            jobs[i].dst_off = dst_total;
-            src_total += al(jobs[i].st.bytes.size());
-            dst_total += al(h * w * jobs[i].esz);
-        }
+    std::vector<FieldPlan> plans(jobs.size());
+    std::vector<size_t> src_off(jobs.size());
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        plans[i] = plan_field(encoded[i], h, w, s.device_unfilter);
+        src_off[i] = src_total;
+        jobs[i].dst_off = dst_total;
+        src_total += al(plans[i].staged_bytes);
+        dst_total += al(h * w * jobs[i].esz);
     }
 
     hip::ScopedContext on_my_context(s.context());
     s.d_src.resize(src_total);
     s.d_dst.resize(dst_total);
-    // one staging buffer, one copy in; one launch over every (frame, field); one copy out
-    std::vector<uint8_t> staging(src_total);
-    for (const auto& j : jobs) std::memcpy(staging.data() + j.src_off, j.st.bytes.data(), j.st.bytes.size());
-    s.d_src.upload(staging.data(), src_total);
+    // one pinned staging buffer every field is inflated into, one copy in; one launch over every (frame, field); one copy out
+    s.stage_all(plans, src_off, s.h_src.need(src_total));
+    s.d_src.upload(s.h_src.p, src_total);
     std::vector<ouster_hip_osf_plane> planes(jobs.size());
     bool any_png = false;
     for (size_t i = 0; i < jobs.size(); ++i) {
-        planes[i].src = static_cast<const uint8_t*>(s.d_src.data()) + jobs[i].src_off;
+        planes[i].src = static_cast<const uint8_t*>(s.d_src.data()) + src_off[i];
         planes[i].dst = static_cast<uint8_t*>(s.d_dst.data()) + jobs[i].dst_off;
-        planes[i].encoding = jobs[i].st.encoding;
-        planes[i].src_pixel_bytes = jobs[i].st.src_pixel_bytes;
+        planes[i].encoding = plans[i].encoding;
+        planes[i].src_pixel_bytes = plans[i].src_pixel_bytes;
         planes[i].dst_elem_size = static_cast<uint32_t>(jobs[i].esz);
-        planes[i].flags = jobs[i].st.filtered ? OUSTER_HIP_OSF_FLAG_FILTERED : 0u;
-        any_png |= jobs[i].st.encoding != OUSTER_HIP_OSF_ZPNG;
+        planes[i].flags = plans[i].filtered ? OUSTER_HIP_OSF_FLAG_FILTERED : 0u;
+        any_png |= plans[i].encoding != OUSTER_HIP_OSF_ZPNG;
     }
     std::vector<int32_t> shifts(s.info.format.pixel_shift_by_row.begin(), s.info.format.pixel_shift_by_row.end());
     if (any_png && !shifts.empty() && shifts.size() != h)
@@ -620,10 +739,10 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
     hip::check(ouster_hip_osf_unpack(s.ctx->handle(), planes.data(), static_cast<uint32_t>(planes.size()),
                                      static_cast<uint32_t>(h), static_cast<uint32_t>(w),
                                      shifts.empty() ? nullptr : shifts.data()));
-    std::vector<uint8_t> host(dst_total);
-    s.d_dst.download(host.data(), dst_total);
+    const uint8_t* host = s.h_dst.need(dst_total);
+    s.d_dst.download(s.h_dst.p, dst_total);
     for (const auto& j : jobs)
-        std::memcpy(frames[j.frame].field(j.name).get(), host.data() + j.dst_off, h * w * j.esz);
+        std::memcpy(frames[j.frame].field(j.name).get(), host + j.dst_off, h * w * j.esz);
     return frames;
 }
 
@@ -632,57 +751,48 @@ std::vector<std::vector<uint8_t>> OsfFrameDecoder::decode_fields(const std::vect
     const size_t h = s.info.format.pixels_per_column, w = s.info.format.columns_per_frame;
     auto al = [](size_t x) { return (x + 255) & ~size_t{255}; };
     std::vector<std::vector<uint8_t>> out(fields.size());
-    std::vector<StagedField> staged(fields.size());
-    std::vector<size_t> src_off(fields.size()), dst_off(fields.size());
+    std::vector<FieldPlan> plans;        // the fields that carry data, in order
+    std::vector<size_t> src_off, dst_off, idx;
     std::vector<ouster_hip_osf_plane> planes;
     size_t src_total = 0, dst_total = 0;
-    {
-        std::vector<EncodedField> present;
-        std::vector<size_t> idx;
-        for (size_t i = 0; i < fields.size(); ++i)
-            if (fields[i].size) { present.push_back(fields[i]); idx.push_back(i); }
-        std::vector<StagedField> st = stage_fields_parallel(present, h, w, s.device_unfilter);
-        for (size_t k = 0; k < idx.size(); ++k) staged[idx[k]] = std::move(st[k]);
-    }
     for (size_t i = 0; i < fields.size(); ++i) {
         const size_t esz = field_type_size(fields[i].type);
         out[i].assign(h * w * esz, 0);
         if (fields[i].size == 0) continue;
-        src_off[i] = src_total;
-        dst_off[i] = dst_total;
-        src_total += al(staged[i].bytes.size());
+        plans.push_back(plan_field(fields[i], h, w, s.device_unfilter));
+        idx.push_back(i);
+        src_off.push_back(src_total);
+        dst_off.push_back(dst_total);
+        src_total += al(plans.back().staged_bytes);
         dst_total += al(h * w * esz);
     }
     if (!src_total) return out;
     hip::ScopedContext on_my_context(s.context());
     s.d_src.resize(src_total);
     s.d_dst.resize(dst_total);
-    std::vector<uint8_t> staging(src_total);
+    s.stage_all(plans, src_off, s.h_src.need(src_total));
     bool any_png = false;
-    for (size_t i = 0; i < fields.size(); ++i) {
-        if (fields[i].size == 0) continue;
-        std::memcpy(staging.data() + src_off[i], staged[i].bytes.data(), staged[i].bytes.size());
+    for (size_t k = 0; k < plans.size(); ++k) {
         ouster_hip_osf_plane pl{};
-        pl.src = static_cast<const uint8_t*>(s.d_src.data()) + src_off[i];
-        pl.dst = static_cast<uint8_t*>(s.d_dst.data()) + dst_off[i];
-        pl.encoding = staged[i].encoding;
-        pl.src_pixel_bytes = staged[i].src_pixel_bytes;
-        pl.dst_elem_size = static_cast<uint32_t>(field_type_size(fields[i].type));
-        pl.flags = staged[i].filtered ? OUSTER_HIP_OSF_FLAG_FILTERED : 0u;
+        pl.src = static_cast<const uint8_t*>(s.d_src.data()) + src_off[k];
+        pl.dst = static_cast<uint8_t*>(s.d_dst.data()) + dst_off[k];
+        pl.encoding = plans[k].encoding;
+        pl.src_pixel_bytes = plans[k].src_pixel_bytes;
+        pl.dst_elem_size = static_cast<uint32_t>(field_type_size(fields[idx[k]].type));
+        pl.flags = plans[k].filtered ? OUSTER_HIP_OSF_FLAG_FILTERED : 0u;
         planes.push_back(pl);
-        any_png |= staged[i].encoding != OUSTER_HIP_OSF_ZPNG;
+        any_png |= plans[k].encoding != OUSTER_HIP_OSF_ZPNG;
     }
-    s.d_src.upload(staging.data(), src_total);
+    s.d_src.upload(s.h_src.p, src_total);
     std::vector<int32_t> shifts(s.info.format.pixel_shift_by_row.begin(), s.info.format.pixel_shift_by_row.end());
     if (any_png && !shifts.empty() && shifts.size() != h)
         throw std::invalid_argument("image height does not match shifts size");
     hip::check(ouster_hip_osf_unpack(s.ctx->handle(), planes.data(), static_cast<uint32_t>(planes.size()),
                                      static_cast<uint32_t>(h), static_cast<uint32_t>(w),
                                      shifts.empty() ? nullptr : shifts.data()));
-    std::vector<uint8_t> host(dst_total);
-    s.d_dst.download(host.data(), dst_total);
-    for (size_t i = 0; i < fields.size(); ++i)
-        if (fields[i].size) std::memcpy(out[i].data(), host.data() + dst_off[i], out[i].size());
+    const uint8_t* host = s.h_dst.need(dst_total);
+    s.d_dst.download(s.h_dst.p, dst_total);
+    for (size_t k = 0; k < plans.size(); ++k) std::memcpy(out[idx[k]].data(), host + dst_off[k], out[idx[k]].size());
     return out;
 }
 
@@ -707,7 +817,7 @@ OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message
     if (msgs.empty()) return b;
     const size_t h = b.h_, w = b.w_, n = msgs.size();
     auto al = [](size_t x) { return (x + 255) & ~size_t{255}; };
-    struct Job { size_t frame, field; StagedField st; size_t src_off; };
+    struct Job { size_t frame, field; };
     std::vector<Job> jobs;
     std::vector<EncodedField> encoded;   // parallel to jobs
     size_t src_total = 0;
@@ -729,16 +839,15 @@ OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message
         for (size_t i = 0; i < v.fields.size(); ++i) {
             if (v.fields[i].size == 0) continue;
             encoded.push_back(v.fields[i]);
-            jobs.push_back(Job{m, i, StagedField{}, 0});
+            jobs.push_back(Job{m, i});
         }
     }
-    {
-        std::vector<StagedField> staged = stage_fields_parallel(encoded, h, w, s.device_unfilter);
-        for (size_t i = 0; i < jobs.size(); ++i) {
-            jobs[i].st = std::move(staged[i]);
-            jobs[i].src_off = src_total;
-            src_total += al(jobs[i].st.bytes.size());
-        }
+    std::vector<FieldPlan> plans(jobs.size());
+    std::vector<size_t> src_off(jobs.size());
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        plans[i] = plan_field(encoded[i], h, w, s.device_unfilter);
+        src_off[i] = src_total;
+        src_total += al(plans[i].staged_bytes);
     }
     hip::ScopedContext on_my_context(s.context());
     b.ctx_ = s.ctx;
@@ -752,21 +861,20 @@ OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message
     if (hipMemsetAsync(b.planes_.get(), 0, dst_total, st) != hipSuccess) throw std::runtime_error("ouster_hip: memset failed");
     if (jobs.empty()) return b;
     s.d_src.resize(src_total);
-    std::vector<uint8_t> staging(src_total);
-    for (const auto& j : jobs) std::memcpy(staging.data() + j.src_off, j.st.bytes.data(), j.st.bytes.size());
-    s.d_src.upload(staging.data(), src_total);
+    s.stage_all(plans, src_off, s.h_src.need(src_total));
+    s.d_src.upload(s.h_src.p, src_total);
     std::vector<ouster_hip_osf_plane> planes(jobs.size());
     bool any_png = false;
     for (size_t i = 0; i < jobs.size(); ++i) {
         const auto& f = b.fields_[jobs[i].field];
         const size_t esz = field_type_size(f.second);
-        planes[i].src = static_cast<const uint8_t*>(s.d_src.data()) + jobs[i].src_off;
+        planes[i].src = static_cast<const uint8_t*>(s.d_src.data()) + src_off[i];
         planes[i].dst = static_cast<uint8_t*>(b.planes_.get()) + b.plane_off_[f.first] + jobs[i].frame * h * w * esz;
-        planes[i].encoding = jobs[i].st.encoding;
-        planes[i].src_pixel_bytes = jobs[i].st.src_pixel_bytes;
+        planes[i].encoding = plans[i].encoding;
+        planes[i].src_pixel_bytes = plans[i].src_pixel_bytes;
         planes[i].dst_elem_size = static_cast<uint32_t>(esz);
-        planes[i].flags = jobs[i].st.filtered ? OUSTER_HIP_OSF_FLAG_FILTERED : 0u;
-        any_png |= jobs[i].st.encoding != OUSTER_HIP_OSF_ZPNG;
+        planes[i].flags = plans[i].filtered ? OUSTER_HIP_OSF_FLAG_FILTERED : 0u;
+        any_png |= plans[i].encoding != OUSTER_HIP_OSF_ZPNG;
     }
     std::vector<int32_t> shifts(s.info.format.pixel_shift_by_row.begin(), s.info.format.pixel_shift_by_row.end());
     if (any_png && !shifts.empty() && shifts.size() != h)

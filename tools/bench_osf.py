@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """OSF LidarScan messages -> planes in HBM (OsfFrameDecoder.decode_device) with the PNG scanline filters reversed on the GPU
 (k_osf_png_unfilter, the default since round 5) and on the host (rounds 2 - 4): milliseconds per batch of 96 messages of the
-reference's fixtures.  The host half (zlib inflate on up to 32 threads) dominates either way."""
+reference's fixtures.  The host half (zlib inflate on a parked crew of up to 128 threads, straight into one pinned buffer)
+dominates either way."""
 import sys, time, json, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
