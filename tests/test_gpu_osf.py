@@ -374,6 +374,27 @@ def test_png_filters_on_the_gpu_equal_the_host_and_the_oracle(oracle, h, w):
         dec.device_unfilter = on
         with pytest.raises(RuntimeError, match="could not decode field"):
             dec.decode_fields([(blob, 1)])
+        # ... also in the middle of a batch staged by the decoder's crew of threads, which then serves the next call: a stream
+        # cut short, one split over several IDAT chunks, and the decoder's staging buffers growing between calls
+        good = blobs[:7]
+        cut = _rechunk(blobs[0][0], lambda z: [z[:len(z) // 2]])
+        with pytest.raises(RuntimeError, match="could not decode field"):
+            dec.decode_fields(good + [(blob, 1)] + good)
+        with pytest.raises(RuntimeError, match="could not decode field"):
+            dec.decode_fields(good + [(cut, blobs[0][1])])
+        split = _rechunk(blobs[5][0], lambda z: [z[:1], z[1:len(z) // 3], z[len(z) // 3:]])
+        again = dec.decode_fields([(split, blobs[5][1])] + blobs * 2)
+        assert bytes(again[0]) == bytes(got[on][5])
+        for i in range(len(blobs)):
+            assert bytes(again[1 + i]) == bytes(got[on][i]) and bytes(again[1 + len(blobs) + i]) == bytes(got[on][i])
+
+
+def _rechunk(png, parts):
+    """The same PNG with its zlib stream cut into the IDAT chunks parts(stream) returns."""
+    import struct
+    z = bytes(OO_idat(bytearray(png)))
+    ihdr = png[8:8 + 25]
+    return png[:8] + ihdr + b"".join(_chunk(b"IDAT", p) for p in parts(z)) + _chunk(b"IEND", b"")
 
 
 def _chunk(typ, body):
