@@ -1329,8 +1329,9 @@ __device__ __forceinline__ uint64_t shift_up_1(uint64_t v) {   // lane r receive
 // from global memory into registers when window m (64 steps) starts and copied to the ring when it ends; a step reads its raw
 // pixel from the ring and writes the reconstructed one over it; block m-2 -- finished by every row -- leaves for global memory
 // when window m starts.  16 bytes per lane per access on both sides.  (The first form loaded and stored inside the step: 2.9 ms
-// per image whatever the batch, ~1.3 us a step -- on gfx9 a load's wait also waits for the stores before it.)
-constexpr uint32_t UF_BLK = 64, UF_RING = 3 * UF_BLK, UF_G = 8;
+// per image whatever the batch, ~1.3 us a step -- on gfx9 a load's wait also waits for the stores before it.  With the ring
+// 1.95 ms, then the step itself made branch free -- uf_byte -- 0.64 ms per 128 x 1024 image: 0.29 us a step.)
+constexpr uint32_t UF_BLK = 64, UF_RING = 3 * UF_BLK, UF_G = 8;   // UF_G steps share their LDS reads (2, 4, 16: within 2 %)
 typedef uint32_t uf_v4 __attribute__((ext_vector_type(4)));   // a plain vector: HIP's uint4 is a class and cannot live in an address space
 typedef uf_v4 __attribute__((aligned(1))) uf_chunk_u;   // rows start where they start: the hardware takes unaligned 16-byte accesses
 // explicit address spaces: the job's pointers were loaded from memory and the ring is reached through a lambda -- as generic
@@ -1363,6 +1364,20 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {   // lane r receives
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
+// One byte of one pixel, every filter computed and the row's one picked by masks (m1..m4: all ones for the lane's filter type,
+// zero otherwise).  Written as branches (if ft == 1 ... else if ...) the step compiled to ~260 VALU + ~400 SALU instructions of
+// exec-mask juggling, 0.9 us a step; this is ~25 VALU per byte and no branch.
+__device__ __forceinline__ uint32_t uf_byte(uint32_t a, uint32_t b, uint32_t c, uint32_t raw, uint32_t m1, uint32_t m2,
+                                            uint32_t m3, uint32_t m4) {
+    const uint32_t avg = (a + b) >> 1;
+    const uint32_t pa = __usad(b, c, 0u), pb = __usad(a, c, 0u), pc = __usad(a + b, 2u * c, 0u);   // |p - a|, |p - b|, |p - c|
+    const uint32_t paeth = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+    const uint32_t pred = (a & m1) | (b & m2) | (avg & m3) | (paeth & m4);
+    return (raw + pred) & 0xffu;
+}
+template <uint32_t K, class P>
+__device__ __forceinline__ uint32_t uf_get(P v) { return (uint32_t)(v >> (8u * K)) & 0xffu; }
+
 template <uint32_t BPP>
 __device__ __forceinline__ void unfilter_band(const OsfUnfilterJob& job, uint32_t H, uint32_t W, uint32_t band, l_u8* smem) {
     constexpr uint32_t BLKB = UF_BLK * BPP, NCH = BLKB / 16u;
@@ -1381,22 +1396,22 @@ __device__ __forceinline__ void unfilter_band(const OsfUnfilterJob& job, uint32_
     const bool feeds_next = lane == 63u || row + 1u == H;   // the next band's row above (the last band writes it for nobody)
     const uint32_t nblk = (W + UF_BLK - 1) / UF_BLK, steps = W + 63u, nwin = (steps + UF_BLK - 1) / UF_BLK;
 
+    // A full block travels as 16-byte pieces through registers (fetch at the start of a window, commit at its end); the last,
+    // partial block of a row goes byte by byte straight between memory and the ring (nothing is read or written past a row).
+    // Lanes without a row read row 0's bytes (harmless) and store nothing.
     uf_v4 stage[NCH];
-    auto fetch = [&](uint32_t blk) {    // global -> registers
+    auto fetch = [&](uint32_t blk) -> bool {    // global -> registers; false: the block already lies in the ring
         const uint32_t nb = min(UF_BLK, W - blk * UF_BLK) * BPP;
         const g_u8* src = in + (size_t)blk * BLKB;
+        if (nb == BLKB) {
 #pragma unroll
-        for (uint32_t c = 0; c < NCH; ++c) {
-            uf_v4 v = {0u, 0u, 0u, 0u};
-            if (has_row && (c + 1) * 16u <= nb) {
-                v = *reinterpret_cast<const g_chunk_u*>(src + c * 16u);
-            } else if (has_row && c * 16u < nb) {   // a row's last bytes: nothing is read past them
-                uint32_t d[4] = {0, 0, 0, 0};
-                for (uint32_t j = 0; j < 16u && c * 16u + j < nb; ++j) d[j >> 2] |= (uint32_t)src[c * 16u + j] << (8u * (j & 3u));
-                v = uf_v4{d[0], d[1], d[2], d[3]};
-            }
-            stage[c] = v;
+            for (uint32_t c = 0; c < NCH; ++c) stage[c] = *reinterpret_cast<const g_chunk_u*>(src + c * 16u);
+            return true;
         }
+        l_u8* d = ring + (blk % 3u) * BLKB;
+#pragma nounroll
+        for (uint32_t i = 0; i < nb; ++i) d[i] = src[i];
+        return false;
     };
     auto commit = [&](uint32_t blk) {   // registers -> my ring
         l_uint4* d = reinterpret_cast<l_uint4*>(ring + (blk % 3u) * BLKB);
@@ -1404,93 +1419,89 @@ __device__ __forceinline__ void unfilter_band(const OsfUnfilterJob& job, uint32_
         for (uint32_t c = 0; c < NCH; ++c) d[c] = stage[c];
     };
     auto flush = [&](uint32_t blk) {    // my ring -> global
+        if (!has_row) return;
         const uint32_t nb = min(UF_BLK, W - blk * UF_BLK) * BPP;
         g_u8* dst = out + (size_t)blk * BLKB;
-        const l_uint4* sp = reinterpret_cast<const l_uint4*>(ring + (blk % 3u) * BLKB);
+        if (nb == BLKB) {
+            const l_uint4* sp = reinterpret_cast<const l_uint4*>(ring + (blk % 3u) * BLKB);
 #pragma unroll
-        for (uint32_t c = 0; c < NCH; ++c) {
-            const uf_v4 v = sp[c];
-            if (has_row && (c + 1) * 16u <= nb) {
-                *reinterpret_cast<g_chunk_u*>(dst + c * 16u) = v;
-            } else if (has_row && c * 16u < nb) {
-                const uint32_t d[4] = {v[0], v[1], v[2], v[3]};
-                for (uint32_t j = 0; j < 16u && c * 16u + j < nb; ++j) dst[c * 16u + j] = (uint8_t)(d[j >> 2] >> (8u * (j & 3u)));
-            }
+            for (uint32_t c = 0; c < NCH; ++c) *reinterpret_cast<g_chunk_u*>(dst + c * 16u) = sp[c];
+            return;
         }
+        const l_u8* sp = ring + (blk % 3u) * BLKB;
+#pragma nounroll
+        for (uint32_t i = 0; i < nb; ++i) dst[i] = sp[i];
     };
 
-    fetch(0);
-    commit(0);
-    uint64_t res1 = 0, res2 = 0;              // my results of the two steps before (pixels x-1 and x-2 of my row)
-    uint64_t up_prev = 0;                     // lane 0: the pixel above-left (pixel x-1 of the band above's last row)
+    if (fetch(0)) commit(0);
+    using P = typename std::conditional<(BPP <= 4u), uint32_t, uint64_t>::type;   // a pixel's bytes in one register
+    const uint32_t m1 = ft == 1u ? ~0u : 0u, m2 = ft == 2u ? ~0u : 0u, m3 = ft == 3u ? ~0u : 0u, m4 = ft == 4u ? ~0u : 0u;
+    P res1 = 0, res2 = 0;                     // my results of the two steps before (pixels x-1 and x-2 of my row)
+    P up_prev = 0;                            // lane 0: the pixel above-left (pixel x-1 of the band above's last row)
     uint32_t pos = (UF_RING - lane) % UF_RING;   // ring position of pixel x = t - lane (meaningful once x >= 0)
     for (uint32_t m = 0; m < nwin; ++m) {
-        if (m + 1 < nblk) fetch(m + 1);
-        if (m >= 2 && m - 2 < nblk) flush(m - 2);
+        if (m >= 2 && m - 2 < nblk) flush(m - 2);                    // its ring slot is the one block m + 1 goes to
+        const bool staged = m + 1 < nblk && fetch(m + 1);
         for (uint32_t g = 0; g < UF_BLK / UF_G; ++g) {
             const uint32_t t0 = m * UF_BLK + g * UF_G;
-            uint64_t raw[UF_G], up[UF_G];
+            P raw[UF_G], up[UF_G], rec_g[UF_G];
             uint32_t at[UF_G];
 #pragma unroll
             for (uint32_t j = 0; j < UF_G; ++j) {
-                const int32_t x = (int32_t)(t0 + j) - (int32_t)lane;
-                const bool valid = has_row && x >= 0 && x < (int32_t)W;
+                const uint32_t x = t0 + j - lane;                       // "negative" before the lane's first pixel: huge
                 uint32_t q = pos + j;
                 if (q >= UF_RING) q -= UF_RING;
                 at[j] = q * BPP;
-                raw[j] = valid ? uf_px_load<BPP>(ring + at[j]) : 0ull;
-                up[j] = (valid && from_lds) ? uf_px_load<BPP>(s_up + (size_t)x * BPP) : 0ull;   // rewritten 63 steps from now at the earliest
+                // unguarded LDS reads (a guard is a branch): what a lane without a pixel reads is never used
+                raw[j] = (P)uf_px_load<BPP>(ring + at[j]);
+                up[j] = (P)uf_px_load<BPP>(s_up + min(x, W - 1u) * BPP);   // lane 0's; rewritten 63 steps from now at the earliest
             }
-            uint64_t rec_g[UF_G];
 #pragma unroll
             for (uint32_t j = 0; j < UF_G; ++j) {
-                const int32_t x = (int32_t)(t0 + j) - (int32_t)lane;
-                const bool valid = has_row && x >= 0 && x < (int32_t)W;   // steps past W + 62 are valid for nobody
+                const uint32_t x = t0 + j - lane;
+                const bool valid = has_row && x < W;   // steps past W + 62 are valid for nobody
                 // the row above: lane r-1 finished pixel x at step t-1 and pixel x-1 at step t-2
-                uint64_t b = wave_shr1((uint32_t)res1), c = wave_shr1((uint32_t)res2);
-                if (BPP > 4u) {
-                    b |= (uint64_t)wave_shr1((uint32_t)(res1 >> 32)) << 32;
-                    c |= (uint64_t)wave_shr1((uint32_t)(res2 >> 32)) << 32;
+                P b, c;
+                if constexpr (BPP <= 4u) {
+                    b = wave_shr1(res1);
+                    c = wave_shr1(res2);
+                } else {
+                    b = (uint64_t)wave_shr1((uint32_t)res1) | ((uint64_t)wave_shr1((uint32_t)(res1 >> 32)) << 32);
+                    c = (uint64_t)wave_shr1((uint32_t)res2) | ((uint64_t)wave_shr1((uint32_t)(res2 >> 32)) << 32);
                 }
                 if (lane == 0) {   // the band's first row takes the row above from LDS (or has none)
-                    b = up[j];
+                    b = from_lds ? up[j] : (P)0;
                     c = up_prev;
-                    up_prev = up[j];
+                    up_prev = b;
                 }
                 if (first_row) b = c = 0;
-                const uint64_t left = x > 0 ? res1 : 0ull;
-                if (x <= 0) c = 0;
-                uint64_t rec = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < BPP; ++k) {
-                    const int32_t av = (int32_t)((left >> (8u * k)) & 0xffu), bv = (int32_t)((b >> (8u * k)) & 0xffu),
-                                  cv = (int32_t)((c >> (8u * k)) & 0xffu), rv = (int32_t)((raw[j] >> (8u * k)) & 0xffu);
-                    int32_t pred = 0;
-                    if (ft == 1u) pred = av;
-                    else if (ft == 2u) pred = bv;
-                    else if (ft == 3u) pred = (av + bv) >> 1;
-                    else if (ft == 4u) {
-                        const int32_t pp = av + bv - cv, pa = abs(pp - av), pb = abs(pp - bv), pc = abs(pp - cv);
-                        pred = (pa <= pb && pa <= pc) ? av : (pb <= pc ? bv : cv);
-                    }
-                    rec |= (uint64_t)((uint32_t)(rv + pred) & 0xffu) << (8u * k);
-                }
+                const P left = (x != 0u) ? res1 : (P)0;   // res1 is zero while the lane has not started
+                if (x == 0u) c = 0;
+                P rec = 0;
+                [&]<uint32_t... K>(std::integer_sequence<uint32_t, K...>) {
+                    ((rec |= (P)uf_byte(uf_get<K>(left), uf_get<K>(b), uf_get<K>(c), uf_get<K>(raw[j]), m1, m2, m3, m4) << (8u * K)), ...);
+                }(std::make_integer_sequence<uint32_t, BPP>{});
                 rec_g[j] = rec;
                 res2 = res1;
-                res1 = valid ? rec : 0ull;
+                res1 = valid ? rec : (P)0;
             }
 #pragma unroll
             for (uint32_t j = 0; j < UF_G; ++j) {
-                const int32_t x = (int32_t)(t0 + j) - (int32_t)lane;
-                if (has_row && x >= 0 && x < (int32_t)W) {
-                    uf_px_store<BPP>(ring + at[j], rec_g[j]);
-                    if (feeds_next) uf_px_store<BPP>(s_up + (size_t)x * BPP, rec_g[j]);
+                // the ring takes every lane's result: what a lane without a pixel writes lands in a slot that is free (before its
+                // first pixel: block 2's, committed at the end of window 1; behind its last: a flushed block's or past the row's end)
+                uf_px_store<BPP>(ring + at[j], rec_g[j]);
+            }
+            if (feeds_next) {
+#pragma unroll
+                for (uint32_t j = 0; j < UF_G; ++j) {
+                    const uint32_t x = t0 + j - lane;
+                    if (has_row && x < W) uf_px_store<BPP>(s_up + (size_t)x * BPP, rec_g[j]);
                 }
             }
             pos += UF_G;
             if (pos >= UF_RING) pos -= UF_RING;
         }
-        if (m + 1 < nblk) commit(m + 1);
+        if (staged) commit(m + 1);
     }
     for (uint32_t blk = nwin >= 2 ? nwin - 2 : 0; blk < nblk; ++blk) flush(blk);
 }
