@@ -10,6 +10,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <fstream>
+#include <memory>
 #include <functional>
 #include <atomic>
 #include <exception>
@@ -457,10 +458,12 @@ class Crew {
         wake_.notify_all();
         for (auto& t : th_) t.join();
     }
-    // fn(i) for i in [0, n) on up to `want` threads (the caller is one of them); fn must not throw
-    void run(size_t n, size_t want, const std::function<void(size_t)>& fn) {
+    // fn(i) for i in [0, n) on up to `want` threads; fn must not throw.  The caller is one of them -- or, given `meanwhile`,
+    // runs that instead while the others work (it may wait for items to finish: they are handed out in index order)
+    void run(size_t n, size_t want, const std::function<void(size_t)>& fn, const std::function<void()>* meanwhile = nullptr) {
         if (want <= 1 || n <= 1) {
             for (size_t i = 0; i < n; ++i) fn(i);
+            if (meanwhile) (*meanwhile)();
             return;
         }
         std::unique_lock<std::mutex> lk(mu_);
@@ -472,7 +475,9 @@ class Crew {
         ++gen_;
         lk.unlock();
         wake_.notify_all();
-        for (size_t i; (i = next_.fetch_add(1)) < n;) fn(i);
+        if (meanwhile) (*meanwhile)();
+        else
+            for (size_t i; (i = next_.fetch_add(1)) < n;) fn(i);
         lk.lock();
         done_.wait(lk, [&] { return active_ == 0; });
     }
@@ -552,20 +557,46 @@ struct OsfFrameDecoder::Impl {
     hip::DeviceBuffer d_src, d_dst;
     PinnedBytes h_src, h_dst;
     Crew crew;
-    // every planned field inflated to base + off[i], in parallel; the first exception wins and is rethrown
-    void stage_all(const std::vector<FieldPlan>& plans, const std::vector<size_t>& off, uint8_t* base) {
+    // Every planned field inflated to base + off[i] by the crew while this thread sends what is finished to dev + off[i]: the
+    // fields are handed out in order, so the batch is uploaded as (up to) eight consecutive pieces, each as soon as its last
+    // field is there -- the copy engine works under the inflate instead of behind it.  Stream-ordered: the caller's next
+    // launch on `st` sees all of it.  The first exception wins and is rethrown.
+    void stage_and_upload(const std::vector<FieldPlan>& plans, const std::vector<size_t>& off, size_t total, uint8_t* base,
+                          void* dev, hipStream_t st) {
+        const size_t n = plans.size(), G = std::min<size_t>(8, n);
+        if (!n) return;
+        std::vector<uint32_t> grp(n);
+        std::vector<size_t> first(G + 1);
+        std::unique_ptr<std::atomic<uint32_t>[]> left(new std::atomic<uint32_t>[G]);
+        for (size_t g = 0; g <= G; ++g) first[g] = g * n / G;
+        for (size_t g = 0; g < G; ++g) {
+            left[g].store(static_cast<uint32_t>(first[g + 1] - first[g]));
+            for (size_t i = first[g]; i < first[g + 1]; ++i) grp[i] = static_cast<uint32_t>(g);
+        }
         std::exception_ptr err;
         std::mutex mu;
-        const size_t nt = std::min<size_t>({plans.size(), std::max(1u, std::thread::hardware_concurrency()), size_t{128}});
-        crew.run(plans.size(), nt, [&](size_t i) {
+        hipError_t copy_err = hipSuccess;
+        const std::function<void(size_t)> work = [&](size_t i) {
             try {
                 stage_into(plans[i], base + off[i]);
             } catch (...) {
                 std::lock_guard<std::mutex> lock(mu);
                 if (!err) err = std::current_exception();
             }
-        });
+            left[grp[i]].fetch_sub(1, std::memory_order_release);
+        };
+        const std::function<void()> uploads = [&] {
+            for (size_t g = 0; g < G; ++g) {
+                while (left[g].load(std::memory_order_acquire) != 0) std::this_thread::yield();
+                const size_t b0 = off[first[g]], b1 = g + 1 < G ? off[first[g + 1]] : total;
+                const hipError_t e = hipMemcpyAsync(static_cast<uint8_t*>(dev) + b0, base + b0, b1 - b0, hipMemcpyHostToDevice, st);
+                if (e != hipSuccess) copy_err = e;
+            }
+        };
+        const size_t nt = std::min<size_t>({n, std::max(1u, std::thread::hardware_concurrency()), size_t{128}});
+        crew.run(n, nt + 1, work, &uploads);
         if (err) std::rethrow_exception(err);
+        if (copy_err != hipSuccess) throw std::runtime_error("ouster_hip: upload failed");
     }
     const std::shared_ptr<hip::Context>& context() {
         if (!ctx) ctx = std::make_shared<hip::Context>(device >= 0 ? device : hip::current_device());
@@ -720,8 +751,7 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
     s.d_src.resize(src_total);
     s.d_dst.resize(dst_total);
     // one pinned staging buffer every field is inflated into, one copy in; one launch over every (frame, field); one copy out
-    s.stage_all(plans, src_off, s.h_src.need(src_total));
-    s.d_src.upload(s.h_src.p, src_total);
+    s.stage_and_upload(plans, src_off, src_total, s.h_src.need(src_total), s.d_src.data(), static_cast<hipStream_t>(s.ctx->stream()));
     std::vector<ouster_hip_osf_plane> planes(jobs.size());
     bool any_png = false;
     for (size_t i = 0; i < jobs.size(); ++i) {
@@ -770,7 +800,7 @@ std::vector<std::vector<uint8_t>> OsfFrameDecoder::decode_fields(const std::vect
     hip::ScopedContext on_my_context(s.context());
     s.d_src.resize(src_total);
     s.d_dst.resize(dst_total);
-    s.stage_all(plans, src_off, s.h_src.need(src_total));
+    s.stage_and_upload(plans, src_off, src_total, s.h_src.need(src_total), s.d_src.data(), static_cast<hipStream_t>(s.ctx->stream()));
     bool any_png = false;
     for (size_t k = 0; k < plans.size(); ++k) {
         ouster_hip_osf_plane pl{};
@@ -783,7 +813,6 @@ std::vector<std::vector<uint8_t>> OsfFrameDecoder::decode_fields(const std::vect
         planes.push_back(pl);
         any_png |= plans[k].encoding != OUSTER_HIP_OSF_ZPNG;
     }
-    s.d_src.upload(s.h_src.p, src_total);
     std::vector<int32_t> shifts(s.info.format.pixel_shift_by_row.begin(), s.info.format.pixel_shift_by_row.end());
     if (any_png && !shifts.empty() && shifts.size() != h)
         throw std::invalid_argument("image height does not match shifts size");
@@ -861,8 +890,7 @@ OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message
     if (hipMemsetAsync(b.planes_.get(), 0, dst_total, st) != hipSuccess) throw std::runtime_error("ouster_hip: memset failed");
     if (jobs.empty()) return b;
     s.d_src.resize(src_total);
-    s.stage_all(plans, src_off, s.h_src.need(src_total));
-    s.d_src.upload(s.h_src.p, src_total);
+    s.stage_and_upload(plans, src_off, src_total, s.h_src.need(src_total), s.d_src.data(), static_cast<hipStream_t>(s.ctx->stream()));
     std::vector<ouster_hip_osf_plane> planes(jobs.size());
     bool any_png = false;
     for (size_t i = 0; i < jobs.size(); ++i) {
