@@ -771,8 +771,11 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
                                      shifts.empty() ? nullptr : shifts.data()));
     const uint8_t* host = s.h_dst.need(dst_total);
     s.d_dst.download(s.h_dst.p, dst_total);
-    for (const auto& j : jobs)
-        std::memcpy(frames[j.frame].field(j.name).get(), host + j.dst_off, h * w * j.esz);
+    // into the frames' own planes, on the crew: ~1 MB per frame from one thread was two thirds of this function's time
+    std::vector<void*> dst(jobs.size());
+    for (size_t i = 0; i < jobs.size(); ++i) dst[i] = frames[jobs[i].frame].field(jobs[i].name).get();
+    s.crew.run(jobs.size(), std::min<size_t>({jobs.size(), std::max(1u, std::thread::hardware_concurrency()), size_t{32}}),
+               [&](size_t i) { std::memcpy(dst[i], host + jobs[i].dst_off, h * w * jobs[i].esz); });
     return frames;
 }
 

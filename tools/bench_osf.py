@@ -27,5 +27,11 @@ for label, path in (("png16_lb", T.LB), ("png8", T.PNG8)):
         for _ in range(3):
             t0 = time.perf_counter(); b = dec.decode_device(batch); best = min(best, time.perf_counter() - t0)
         r["device_unfilter" if on else "host_unfilter"] = round(best * 1e3, 2)
+        if on:   # the same batch back on the host as LidarFrames (OsfFrameDecoder.decode)
+            dec.decode(batch[:8])
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter(); fr = dec.decode(batch); best = min(best, time.perf_counter() - t0)
+            r["decode_to_host_frames"] = round(best * 1e3, 2)
     res[label] = r
 print(json.dumps(res))
