@@ -546,6 +546,23 @@ StagedField stage_field(const EncodedField& f, size_t h, size_t w, bool device_u
     return out;
 }
 
+// Where every planned field goes in the staging buffer, biggest first (256-byte aligned): the crew takes the fields in that
+// order -- a 24-bit range image inflates three times as long as an 8-bit plane, and handed out as they come the last thread
+// to finish decides the batch -- and the buffer fills front to back, so that finished pieces can be uploaded while the rest
+// is inflated.  Returns the order; off[i] = offset of field i; total = bytes.
+static std::vector<size_t> lay_out(const std::vector<FieldPlan>& plans, std::vector<size_t>& off, size_t& total) {
+    std::vector<size_t> order(plans.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return plans[a].staged_bytes > plans[b].staged_bytes; });
+    off.assign(plans.size(), 0);
+    total = 0;
+    for (size_t i : order) {
+        off[i] = total;
+        total += (plans[i].staged_bytes + 255) & ~size_t{255};
+    }
+    return order;
+}
+
 // ---------------------------------------------------------------------------------------
 // OsfFrameDecoder
 // ---------------------------------------------------------------------------------------
@@ -558,11 +575,11 @@ struct OsfFrameDecoder::Impl {
     PinnedBytes h_src, h_dst;
     Crew crew;
     // Every planned field inflated to base + off[i] by the crew while this thread sends what is finished to dev + off[i]: the
-    // fields are handed out in order, so the batch is uploaded as (up to) eight consecutive pieces, each as soon as its last
-    // field is there -- the copy engine works under the inflate instead of behind it.  Stream-ordered: the caller's next
+    // fields are handed out in lay_out's order, so the batch is uploaded as (up to) eight consecutive pieces, each as soon as
+    // its last field is there -- the copy engine works under the inflate instead of behind it.  Stream-ordered: the caller's next
     // launch on `st` sees all of it.  The first exception wins and is rethrown.
-    void stage_and_upload(const std::vector<FieldPlan>& plans, const std::vector<size_t>& off, size_t total, uint8_t* base,
-                          void* dev, hipStream_t st) {
+    void stage_and_upload(const std::vector<FieldPlan>& plans, const std::vector<size_t>& order, const std::vector<size_t>& off,
+                          size_t total, uint8_t* base, void* dev, hipStream_t st) {
         const size_t n = plans.size(), G = std::min<size_t>(8, n);
         if (!n) return;
         std::vector<uint32_t> grp(n);
@@ -576,9 +593,9 @@ struct OsfFrameDecoder::Impl {
         std::exception_ptr err;
         std::mutex mu;
         hipError_t copy_err = hipSuccess;
-        const std::function<void(size_t)> work = [&](size_t i) {
+        const std::function<void(size_t)> work = [&](size_t i) {   // i: position in the order
             try {
-                stage_into(plans[i], base + off[i]);
+                stage_into(plans[order[i]], base + off[order[i]]);
             } catch (...) {
                 std::lock_guard<std::mutex> lock(mu);
                 if (!err) err = std::current_exception();
@@ -588,7 +605,7 @@ struct OsfFrameDecoder::Impl {
         const std::function<void()> uploads = [&] {
             for (size_t g = 0; g < G; ++g) {
                 while (left[g].load(std::memory_order_acquire) != 0) std::this_thread::yield();
-                const size_t b0 = off[first[g]], b1 = g + 1 < G ? off[first[g + 1]] : total;
+                const size_t b0 = off[order[first[g]]], b1 = g + 1 < G ? off[order[first[g + 1]]] : total;
                 const hipError_t e = hipMemcpyAsync(static_cast<uint8_t*>(dev) + b0, base + b0, b1 - b0, hipMemcpyHostToDevice, st);
                 if (e != hipSuccess) copy_err = e;
             }
@@ -738,20 +755,19 @@ std::vector<LidarFrame> OsfFrameDecoder::decode(const std::vector<OsfFile::Messa
     }
     if (jobs.empty()) return frames;
     std::vector<FieldPlan> plans(jobs.size());
-    std::vector<size_t> src_off(jobs.size());
+    std::vector<size_t> src_off;
     for (size_t i = 0; i < jobs.size(); ++i) {
         plans[i] = plan_field(encoded[i], h, w, s.device_unfilter);
-        src_off[i] = src_total;
         jobs[i].dst_off = dst_total;
-        src_total += al(plans[i].staged_bytes);
         dst_total += al(h * w * jobs[i].esz);
     }
+    const std::vector<size_t> order = lay_out(plans, src_off, src_total);
 
     hip::ScopedContext on_my_context(s.context());
     s.d_src.resize(src_total);
     s.d_dst.resize(dst_total);
     // one pinned staging buffer every field is inflated into, one copy in; one launch over every (frame, field); one copy out
-    s.stage_and_upload(plans, src_off, src_total, s.h_src.need(src_total), s.d_src.data(), static_cast<hipStream_t>(s.ctx->stream()));
+    s.stage_and_upload(plans, order, src_off, src_total, s.h_src.need(src_total), s.d_src.data(), static_cast<hipStream_t>(s.ctx->stream()));
     std::vector<ouster_hip_osf_plane> planes(jobs.size());
     bool any_png = false;
     for (size_t i = 0; i < jobs.size(); ++i) {
@@ -794,16 +810,16 @@ std::vector<std::vector<uint8_t>> OsfFrameDecoder::decode_fields(const std::vect
         if (fields[i].size == 0) continue;
         plans.push_back(plan_field(fields[i], h, w, s.device_unfilter));
         idx.push_back(i);
-        src_off.push_back(src_total);
         dst_off.push_back(dst_total);
-        src_total += al(plans.back().staged_bytes);
         dst_total += al(h * w * esz);
     }
+    if (plans.empty()) return out;
+    const std::vector<size_t> order = lay_out(plans, src_off, src_total);
     if (!src_total) return out;
     hip::ScopedContext on_my_context(s.context());
     s.d_src.resize(src_total);
     s.d_dst.resize(dst_total);
-    s.stage_and_upload(plans, src_off, src_total, s.h_src.need(src_total), s.d_src.data(), static_cast<hipStream_t>(s.ctx->stream()));
+    s.stage_and_upload(plans, order, src_off, src_total, s.h_src.need(src_total), s.d_src.data(), static_cast<hipStream_t>(s.ctx->stream()));
     bool any_png = false;
     for (size_t k = 0; k < plans.size(); ++k) {
         ouster_hip_osf_plane pl{};
@@ -875,12 +891,9 @@ OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message
         }
     }
     std::vector<FieldPlan> plans(jobs.size());
-    std::vector<size_t> src_off(jobs.size());
-    for (size_t i = 0; i < jobs.size(); ++i) {
-        plans[i] = plan_field(encoded[i], h, w, s.device_unfilter);
-        src_off[i] = src_total;
-        src_total += al(plans[i].staged_bytes);
-    }
+    std::vector<size_t> src_off;
+    for (size_t i = 0; i < jobs.size(); ++i) plans[i] = plan_field(encoded[i], h, w, s.device_unfilter);
+    const std::vector<size_t> order = lay_out(plans, src_off, src_total);
     hip::ScopedContext on_my_context(s.context());
     b.ctx_ = s.ctx;
     size_t dst_total = 0;
@@ -893,7 +906,7 @@ OsfDeviceBatch OsfFrameDecoder::decode_device(const std::vector<OsfFile::Message
     if (hipMemsetAsync(b.planes_.get(), 0, dst_total, st) != hipSuccess) throw std::runtime_error("ouster_hip: memset failed");
     if (jobs.empty()) return b;
     s.d_src.resize(src_total);
-    s.stage_and_upload(plans, src_off, src_total, s.h_src.need(src_total), s.d_src.data(), static_cast<hipStream_t>(s.ctx->stream()));
+    s.stage_and_upload(plans, order, src_off, src_total, s.h_src.need(src_total), s.d_src.data(), static_cast<hipStream_t>(s.ctx->stream()));
     std::vector<ouster_hip_osf_plane> planes(jobs.size());
     bool any_png = false;
     for (size_t i = 0; i < jobs.size(); ++i) {
