@@ -115,7 +115,7 @@ void DeviceFrameBatch::stage_packet(uint8_t* slot, bool occupied, const uint8_t*
     const size_t cols_end = pf_.packet_header_size + static_cast<size_t>(pf_.columns_per_packet) * pf_.col_size;
     std::memcpy(slot, pkt, pf_.packet_header_size);
     std::memcpy(slot + cols_end, pkt + cols_end, pf_.lidar_packet_size - cols_end);
-    for (int ic = 0; ic < pf_.columns_per_packet; ++ic) {
+    for (uint32_t ic = 0; ic < pf_.columns_per_packet; ++ic) {
         const uint8_t* col = pf_.nth_col(ic, pkt);
         if ((pf_.col_status(col) & 0x01) != 0u && pf_.col_measurement_id(col) < w_)
             std::memcpy(slot + (col - pkt), col, pf_.col_size);
