@@ -12,8 +12,8 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result
 OBJ := $(CSRC)/_build
 SPEC_IDS := 0 1 2 3 4 5
 STREAM_IDS := 1 2 3 4 5
-HIP_OBJS := $(foreach i,$(SPEC_IDS),$(OBJ)/k_decode_$(i).o) $(foreach i,$(STREAM_IDS),$(OBJ)/k_decode_stream_$(i).o) $(OBJ)/k_standalone.o $(OBJ)/ouster_hip_capi.o
-HIP_HDRS := $(CSRC)/ouster_hip_dev.h $(CSRC)/kernels_common.h $(CSRC)/wide_tile.h include/ouster_hip.h
+HIP_OBJS := $(foreach i,$(SPEC_IDS),$(OBJ)/k_decode_$(i).o) $(foreach i,$(STREAM_IDS),$(OBJ)/k_decode_stream_$(i).o) $(OBJ)/k_standalone.o $(OBJ)/ouster_hip_capi.o $(OBJ)/host_pool.o
+HIP_HDRS := $(CSRC)/ouster_hip_dev.h $(CSRC)/host_pool.h $(CSRC)/kernels_common.h $(CSRC)/wide_tile.h include/ouster_hip.h
 ROCM ?= /opt/rocm
 CXXFLAGS := -O2 -std=c++17 -fPIC -pthread -Wall -Wextra -Iinclude -I$(CSRC)/host -I$(ROCM)/include -D__HIP_PLATFORM_AMD__
 

@@ -405,7 +405,8 @@ inline void destagger_into(const ConstArrayView<T, static_cast<size_t>(ndim)>& i
 template <typename T>
 inline img_t<T> destagger(const ImgRef<const T>& img, const std::vector<int>& pixel_shift_by_row,
                           bool inverse = false) {
-    img_t<T> out(img.rows(), img.cols());
+    if (pixel_shift_by_row.size() != img.rows()) throw std::invalid_argument{"image height does not match shifts size"};
+    img_t<T> out(img.rows(), img.cols(), impl::uninitialized);   // every element is written; pool memory, filled in place
     destagger_into<T>(img, pixel_shift_by_row, inverse, ImgRef<T>(out));
     return out;
 }

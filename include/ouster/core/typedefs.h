@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstring>
 #include <initializer_list>
+#include <new>
 #include <stdexcept>
 #include <type_traits>
 #include <vector>
@@ -48,6 +49,64 @@ using EigenX3R = Eigen::Array<T, Eigen::Dynamic, 3, Eigen::RowMajor>;
 template <typename T> class ImgRef;
 template <typename T> class VecRef;
 
+namespace impl {
+/** Host memory of the containers below and of Field.  From OUSTER_HIP_HOST_POOL_MIN bytes on it comes from the library's
+ *  pool of page-locked blocks (include/ouster_hip.h, ouster_hip_host_alloc): the GPU reads and writes such memory in place,
+ *  so destagger / XYZLut() / FrameBatcher on these containers are one kernel launch with no staging copy, and a block that
+ *  is freed is handed out again instead of being returned to the system.  Smaller requests, and every request on a machine
+ *  without a GPU, are plain heap memory. */
+void* host_alloc(size_t bytes, bool zero);
+void host_free(void* p, size_t bytes) noexcept;
+/** Tag: allocate without clearing (the caller overwrites every element). */
+struct uninitialized_t {};
+constexpr uninitialized_t uninitialized{};
+
+/** The storage of ArrayXXR: a fixed-size run of trivially copyable elements in host_alloc memory. */
+template <typename T>
+class HostArray {
+    static_assert(std::is_trivially_copyable<T>::value, "HostArray holds plain data");
+
+   public:
+    HostArray() = default;
+    explicit HostArray(size_t n) : p_(n ? static_cast<T*>(host_alloc(n * sizeof(T), true)) : nullptr), n_(n) { check(); }
+    HostArray(size_t n, uninitialized_t) : p_(n ? static_cast<T*>(host_alloc(n * sizeof(T), false)) : nullptr), n_(n) { check(); }
+    HostArray(const HostArray& o) : HostArray(o.n_, uninitialized) {
+        if (n_) std::memcpy(static_cast<void*>(p_), o.p_, n_ * sizeof(T));
+    }
+    HostArray(HostArray&& o) noexcept : p_(o.p_), n_(o.n_) {
+        o.p_ = nullptr;
+        o.n_ = 0;
+    }
+    HostArray& operator=(HostArray o) noexcept {
+        std::swap(p_, o.p_);
+        std::swap(n_, o.n_);
+        return *this;
+    }
+    ~HostArray() { host_free(p_, n_ * sizeof(T)); }
+    size_t size() const { return n_; }
+    T* data() { return p_; }
+    const T* data() const { return p_; }
+    T* begin() { return p_; }
+    T* end() { return p_ + n_; }
+    const T* begin() const { return p_; }
+    const T* end() const { return p_ + n_; }
+    T& operator[](size_t i) { return p_[i]; }
+    const T& operator[](size_t i) const { return p_[i]; }
+    void assign(size_t n, const T& v) {
+        if (n != n_) *this = HostArray(n, uninitialized);
+        std::fill(p_, p_ + n_, v);
+    }
+    bool operator==(const HostArray& o) const { return n_ == o.n_ && std::equal(p_, p_ + n_, o.p_); }
+
+   private:
+    void check() const {
+        if (n_ && !p_) throw std::bad_alloc();
+    }
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+}  // namespace impl
+
 /** Dense row-major 2-D array owning its storage (zero initialised). */
 template <typename T>
 class ArrayXXR {
@@ -55,6 +114,8 @@ class ArrayXXR {
     using Scalar = T;
     ArrayXXR() = default;
     ArrayXXR(size_t rows, size_t cols) : rows_(rows), cols_(cols), d_(rows * cols) {}
+    /** Not cleared: for results that are overwritten in full (what the library's own calls return). */
+    ArrayXXR(size_t rows, size_t cols, impl::uninitialized_t) : rows_(rows), cols_(cols), d_(rows * cols, impl::uninitialized) {}
     size_t rows() const { return rows_; }
     size_t cols() const { return cols_; }
     size_t size() const { return d_.size(); }
@@ -154,7 +215,7 @@ class ArrayXXR {
         return static_cast<T>(z);
     }
     size_t rows_ = 0, cols_ = 0;
-    std::vector<T> d_;
+    impl::HostArray<T> d_;
 };
 
 template <typename T>
@@ -166,6 +227,7 @@ class ArrayX3R : public ArrayXXR<T> {
    public:
     ArrayX3R() = default;
     explicit ArrayX3R(size_t rows) : ArrayXXR<T>(rows, 3) {}
+    ArrayX3R(size_t rows, impl::uninitialized_t) : ArrayXXR<T>(rows, 3, impl::uninitialized) {}
     ArrayX3R(size_t rows, size_t cols) : ArrayXXR<T>(rows, cols) {
         if (cols != 3) throw std::invalid_argument("ArrayX3R needs 3 columns");
     }

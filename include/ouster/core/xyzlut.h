@@ -72,7 +72,7 @@ PointCloudXYZ<T> cartesianT(const ImgRef<const uint32_t>& range, const ArrayX3R<
                             const ArrayX3R<T>& offset) {
     if (range.cols() * range.rows() != direction.rows())
         throw std::invalid_argument("unexpected image dimensions");
-    PointCloudXYZ<T> points(direction.rows());
+    PointCloudXYZ<T> points(direction.rows(), impl::uninitialized);
     cartesianT<T>(ImgRef<T>(points), range, direction, offset);
     return points;
 }
@@ -108,7 +108,7 @@ class XYZLutT {
     PointCloudXYZ<T> operator()(const ImgRef<const uint32_t>& range) const {
         if (range.rows() * range.cols() != static_cast<size_t>(direction.rows()))
             throw std::invalid_argument("unexpected image dimensions");
-        PointCloudXYZ<T> points(range.rows() * range.cols());
+        PointCloudXYZ<T> points(range.rows() * range.cols(), impl::uninitialized);   // pool memory: the kernel writes it in place
         impl::cartesian_device(device(), range.data(), range.size(), points.data(), sizeof(T) == 8);
         return points;
     }

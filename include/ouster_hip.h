@@ -375,6 +375,65 @@ typedef struct ouster_hip_osf_plane {
 int ouster_hip_osf_unpack(ouster_hip_ctx* ctx, const ouster_hip_osf_plane* planes, uint32_t n_planes,
                           uint32_t h, uint32_t w, const int32_t* pixel_shift_by_row);
 
+/* ---- host containers: memory the GPU reaches in place, frame-at-a-time calls -------------------- */
+/* The reference's callers work one frame at a time on HOST containers: destagger<T>(img, shifts)
+ * (ouster_core/include/ouster/core/lidar_frame.h:917-919), XYZLutT<T>::operator()(range)
+ * (xyzlut.h:139-150), dewarp<T>(points, poses) (pose_util.h:38-56), FrameBatcher::batch(packet, frame)
+ * (lidar_frame.h:1043-1144).  For those the cost is the PCIe crossing, not the kernel, so this
+ * group removes everything else from it:
+ *   - ouster_hip_host_alloc hands out page-locked host memory from a process-wide pool (freed
+ *     blocks are kept and handed out again: no hipHostMalloc in steady state).  The GPU reads
+ *     and writes such memory IN PLACE: every "device pointer" of this header may be a pointer into a
+ *     pool block, and a kernel launched on it moves its input and its output over the full-duplex
+ *     link at the same time, in one launch, with no staging copy on either side.  The C++ mirror's
+ *     containers (Field, img_t<T>, PointCloudXYZ<T>) allocate from it.
+ *   - the *_host entry points take HOST pointers of any provenance and return when the result is
+ *     in place: pool memory is used where it lies; other memory (a caller's own Eigen array, a
+ *     numpy buffer) goes through grow-only device scratch of the context with asynchronous copies
+ *     and ONE stream synchronisation.  Neither route allocates once the context has seen the size.
+ * Without a GPU ouster_hip_host_alloc returns plain calloc'd memory (containers still work; every
+ * compute entry point fails with OUSTER_HIP_ERR_NO_DEVICE as before). */
+#define OUSTER_HIP_HOST_POOL_MIN 2048 /* smaller requests are plain malloc / calloc memory (free() or host_free) */
+void* ouster_hip_host_alloc(size_t bytes, int zero);
+void ouster_hip_host_free(void* p);
+/* 1 when [p, p + bytes) lies inside one live block of the pool (device-accessible), else 0 */
+int ouster_hip_host_is_pinned(const void* p, size_t bytes);
+/* give cached (free) pool blocks back to the system until at most keep_bytes stay cached */
+void ouster_hip_host_pool_trim(size_t keep_bytes);
+
+/* Process-wide allocation counters of this library (device memory: every hipMalloc / hipFree it makes,
+ * ouster_hip_device_alloc included; pinned: the pool's hipHostMalloc / hipHostFree calls).  The
+ * steady-state contract of the frame-at-a-time calls -- no allocation once the shapes have been
+ * seen -- is checked by reading these before and after (tests/test_gpu_dropin.py). */
+typedef struct ouster_hip_alloc_stats {
+    uint64_t device_allocs, device_frees;
+    uint64_t pinned_allocs, pinned_frees;
+    uint64_t pool_requests, pool_hits;       /* host_alloc calls at pool sizes / served from cached blocks */
+    uint64_t pool_live_bytes, pool_cached_bytes;
+} ouster_hip_alloc_stats;
+void ouster_hip_alloc_stats_read(ouster_hip_alloc_stats* out);
+/* counted hipMalloc / hipFree on the context's device, for bindings that keep their own device buffers */
+int ouster_hip_device_alloc(ouster_hip_ctx* ctx, size_t bytes, void** out);
+void ouster_hip_device_free(void* p);
+
+/* destagger_into<T> on host images (impl/lidar_frame_impl.h:733-760): src / dst are HOST pointers. */
+int ouster_hip_destagger_host(ouster_hip_ctx* ctx, const void* src, void* dst, uint32_t h, uint32_t w,
+                              uint32_t elem_bytes, const int32_t* shifts, uint32_t n_shifts, int inverse);
+/* XYZLutT<T>::operator()(range) / cartesianT<T> on host arrays (xyzlut.h:139-150, impl/cartesian.h:36-66) */
+int ouster_hip_cartesian_host(ouster_hip_ctx* ctx, const ouster_hip_lut* lut, const uint32_t* range,
+                              void* xyz, int xyz_dtype);
+/* dewarp<T>(dewarped, points, poses) on host arrays (pose_util.h:38-56); poses [w][16] f64 */
+int ouster_hip_dewarp_host(ouster_hip_ctx* ctx, const void* points, const double* poses, void* dewarped,
+                           int dtype, uint32_t h, uint32_t w);
+/* Asynchronous copies between host memory of any provenance and device memory, ordered on the context's
+ * stream; complete after ouster_hip_sync.  (Pool memory: one DMA.  Other memory: the runtime's
+ * pageable route, which tools/copybench measures at the pinned rate from 2 MB on.) */
+int ouster_hip_copy_in(ouster_hip_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+int ouster_hip_copy_out(ouster_hip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+/* Grow-only device scratch owned by the context (slot 0..7; contents undefined; valid until the same slot is
+ * asked for more).  What the *_host calls stage through; bindings that stage themselves use slots 4..7. */
+int ouster_hip_ctx_scratch(ouster_hip_ctx* ctx, uint32_t slot, size_t bytes, void** out);
+
 /* ---- instrumentation ------------------------------------------------------ */
 /* Average duration in ms of the dominant decode kernel over the launches made
  * since the last reset, measured with HIP events on the context's stream

@@ -75,6 +75,12 @@ class OsfPlane(C.Structure):
 
 
 # every symbol include/ouster_hip.h declares (checked by tests/test_abi.py)
+class AllocStats(C.Structure):
+    """ouster_hip_alloc_stats (include/ouster_hip.h)"""
+    _fields_ = [(n, C.c_uint64) for n in ("device_allocs", "device_frees", "pinned_allocs", "pinned_frees", "pool_requests",
+                                          "pool_hits", "pool_live_bytes", "pool_cached_bytes")]
+
+
 ABI_SYMBOLS = [
     "ouster_hip_ctx_create", "ouster_hip_ctx_destroy", "ouster_hip_ctx_stream", "ouster_hip_ctx_device",
     "ouster_hip_ctx_set_knob", "ouster_hip_sync",
@@ -82,6 +88,11 @@ ABI_SYMBOLS = [
     "ouster_hip_format_destroy", "ouster_hip_lut_create", "ouster_hip_lut_create_from_arrays",
     "ouster_hip_lut_export", "ouster_hip_lut_destroy", "ouster_hip_decode", "ouster_hip_destagger",
     "ouster_hip_cartesian", "ouster_hip_osf_unpack", "ouster_hip_dewarp", "ouster_hip_dewarp_frames", "ouster_hip_dewarp_frames_counted", "ouster_hip_dewarp_frames_rows", "ouster_hip_range_gate", "ouster_hip_timing_enable", "ouster_hip_timing_read", "ouster_hip_last_decode_tile", "ouster_hip_last_decode_kernel",
+    # host containers (round 6): pooled page-locked memory the GPU works on in place, frame-at-a-time calls on host arrays
+    "ouster_hip_host_alloc", "ouster_hip_host_free", "ouster_hip_host_is_pinned", "ouster_hip_host_pool_trim",
+    "ouster_hip_alloc_stats_read", "ouster_hip_device_alloc", "ouster_hip_device_free",
+    "ouster_hip_destagger_host", "ouster_hip_cartesian_host", "ouster_hip_dewarp_host",
+    "ouster_hip_copy_in", "ouster_hip_copy_out", "ouster_hip_ctx_scratch",
 ]
 
 _hip = None
@@ -152,9 +163,35 @@ def load_hip(private_path: Optional[str] = None):
     if hasattr(L, "ouster_hip_last_decode_kernel"):   # absent only in older A/B builds loaded via OUSTER_HIP_SO
         L.ouster_hip_last_decode_kernel.restype = C.c_char_p
         L.ouster_hip_last_decode_kernel.argtypes = [vp]
+    if hasattr(L, "ouster_hip_host_alloc"):   # absent only in older A/B builds loaded via OUSTER_HIP_SO
+        L.ouster_hip_host_alloc.restype = vp
+        L.ouster_hip_host_alloc.argtypes = [C.c_size_t, C.c_int]
+        L.ouster_hip_host_free.argtypes = [vp]
+        L.ouster_hip_host_free.restype = None
+        L.ouster_hip_host_is_pinned.argtypes = [vp, C.c_size_t]
+        L.ouster_hip_host_pool_trim.argtypes = [C.c_size_t]
+        L.ouster_hip_host_pool_trim.restype = None
+        L.ouster_hip_alloc_stats_read.argtypes = [C.POINTER(AllocStats)]
+        L.ouster_hip_alloc_stats_read.restype = None
+        L.ouster_hip_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.ouster_hip_device_free.argtypes = [vp]
+        L.ouster_hip_device_free.restype = None
+        L.ouster_hip_destagger_host.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_int]
+        L.ouster_hip_cartesian_host.argtypes = [vp, vp, vp, vp, C.c_int]
+        L.ouster_hip_dewarp_host.argtypes = [vp, vp, vp, vp, C.c_int, C.c_uint32, C.c_uint32]
+        L.ouster_hip_copy_in.argtypes = [vp, vp, vp, C.c_size_t]
+        L.ouster_hip_copy_out.argtypes = [vp, vp, vp, C.c_size_t]
+        L.ouster_hip_ctx_scratch.argtypes = [vp, C.c_uint32, C.c_size_t, C.POINTER(vp)]
     if private_path is None:
         _hip = L
     return L
+
+
+def alloc_stats() -> dict:
+    """ouster_hip_alloc_stats_read as a dict (the library's hipMalloc / hipHostMalloc calls and the pool's hit count)."""
+    st = AllocStats()
+    load_hip().ouster_hip_alloc_stats_read(C.byref(st))
+    return {n: int(getattr(st, n)) for n, _ in AllocStats._fields_}
 
 
 def load_core():

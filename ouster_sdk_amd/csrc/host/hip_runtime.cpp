@@ -102,9 +102,7 @@ static void hip_ok(hipError_t e, const char* what) {
 }
 
 DeviceBuffer::DeviceBuffer(size_t bytes) { resize(bytes); }
-DeviceBuffer::~DeviceBuffer() {
-    if (p_) (void)hipFree(p_);
-}
+DeviceBuffer::~DeviceBuffer() { ouster_hip_device_free(p_); }
 DeviceBuffer::DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) {
     o.p_ = nullptr;
     o.n_ = o.cap_ = 0;
@@ -116,32 +114,50 @@ DeviceBuffer& DeviceBuffer::operator=(DeviceBuffer&& o) noexcept {
     return *this;
 }
 void DeviceBuffer::resize(size_t bytes) {
-    default_ctx();  // selects the device
+    ouster_hip_ctx* ctx = default_ctx();  // selects the device
     if (bytes > cap_) {
-        if (p_) (void)hipFree(p_);
+        ouster_hip_device_free(p_);
         p_ = nullptr;
-        hip_ok(hipMalloc(&p_, bytes ? bytes : 1), "hipMalloc");
+        cap_ = 0;
+        check(ouster_hip_device_alloc(ctx, bytes ? bytes : 1, &p_));
         cap_ = bytes;
     }
     n_ = bytes;
 }
+void DeviceBuffer::upload_async(const void* src, size_t bytes, size_t offset) {
+    check(ouster_hip_copy_in(default_ctx(), static_cast<uint8_t*>(p_) + offset, src, bytes));
+}
+void DeviceBuffer::download_async(void* dst, size_t bytes, size_t offset) const {
+    check(ouster_hip_copy_out(default_ctx(), dst, static_cast<const uint8_t*>(p_) + offset, bytes));
+}
 void DeviceBuffer::upload(const void* src, size_t bytes, size_t offset) {
-    auto st = static_cast<hipStream_t>(ouster_hip_ctx_stream(default_ctx()));
-    hip_ok(hipMemcpyAsync(static_cast<uint8_t*>(p_) + offset, src, bytes, hipMemcpyHostToDevice, st),
-           "hipMemcpyAsync(H2D)");
-    hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
+    upload_async(src, bytes, offset);
+    check(ouster_hip_sync(default_ctx()));
 }
 void DeviceBuffer::download(void* dst, size_t bytes, size_t offset) const {
-    auto st = static_cast<hipStream_t>(ouster_hip_ctx_stream(default_ctx()));
-    hip_ok(hipMemcpyAsync(dst, static_cast<const uint8_t*>(p_) + offset, bytes,
-                          hipMemcpyDeviceToHost, st),
-           "hipMemcpyAsync(D2H)");
-    hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
+    download_async(dst, bytes, offset);
+    check(ouster_hip_sync(default_ctx()));
 }
 void DeviceBuffer::fill(int byte_value) {
     auto st = static_cast<hipStream_t>(ouster_hip_ctx_stream(default_ctx()));
     hip_ok(hipMemsetAsync(p_, byte_value, n_, st), "hipMemsetAsync");
 }
+
+AllocStats alloc_stats() {
+    ouster_hip_alloc_stats c{};
+    ouster_hip_alloc_stats_read(&c);
+    AllocStats s;
+    s.device_allocs = c.device_allocs;
+    s.device_frees = c.device_frees;
+    s.pinned_allocs = c.pinned_allocs;
+    s.pinned_frees = c.pinned_frees;
+    s.pool_requests = c.pool_requests;
+    s.pool_hits = c.pool_hits;
+    s.pool_live_bytes = c.pool_live_bytes;
+    s.pool_cached_bytes = c.pool_cached_bytes;
+    return s;
+}
+bool is_device_accessible(const void* p, size_t bytes) { return ouster_hip_host_is_pinned(p, bytes) != 0; }
 
 }  // namespace hip
 
@@ -151,21 +167,26 @@ namespace core {
 // destagger (impl/lidar_frame_impl.h:733-811)
 // ---------------------------------------------------------------------------------------
 namespace impl {
+void* host_alloc(size_t bytes, bool zero) { return ouster_hip_host_alloc(bytes, zero ? 1 : 0); }
+void host_free(void* p, size_t bytes) noexcept {
+    if (!p) return;
+    if (bytes < OUSTER_HIP_HOST_POOL_MIN) std::free(p);   // never a pool block: skip the registry
+    else ouster_hip_host_free(p);
+}
+
+// One launch on the images where they lie when they are pool memory (Field, img_t: one pass over the link in each
+// direction, at the same time); any other memory goes through the context's grow-only scratch (ouster_hip_destagger_host).
 void destagger_bytes(const void* img, void* out, size_t h, size_t w, size_t elem_bytes,
                      const std::vector<int>& shifts, bool inverse, size_t out_h, size_t out_w) {
     if (shifts.size() != h) throw std::invalid_argument{"image height does not match shifts size"};
     if (h != out_h || w != out_w)
         throw std::invalid_argument{"image and destaggered must have the same shape"};
     if (h == 0 || w == 0) return;
-    const size_t bytes = h * w * elem_bytes;
-    hip::DeviceBuffer src(bytes), dst(bytes);
-    src.upload(img, bytes);
-    std::vector<int32_t> sh(shifts.begin(), shifts.end());
-    hip::check(ouster_hip_destagger(hip::default_ctx(), src.data(), dst.data(),
-                                    static_cast<uint32_t>(h), static_cast<uint32_t>(w),
-                                    static_cast<uint32_t>(elem_bytes), sh.data(),
-                                    static_cast<uint32_t>(sh.size()), inverse ? 1 : 0, 1));
-    dst.download(out, bytes);
+    static_assert(sizeof(int) == sizeof(int32_t), "pixel_shift_by_row is handed over as int32");
+    hip::check(ouster_hip_destagger_host(hip::default_ctx(), img, out, static_cast<uint32_t>(h),
+                                         static_cast<uint32_t>(w), static_cast<uint32_t>(elem_bytes),
+                                         reinterpret_cast<const int32_t*>(shifts.data()),
+                                         static_cast<uint32_t>(shifts.size()), inverse ? 1 : 0));
 }
 }  // namespace impl
 
@@ -258,37 +279,25 @@ XYZLut make_xyz_lut(const SensorInfo& sensor, bool use_extrinsics) {
 void cartesian_device(const DeviceLut& dev, const uint32_t* range, size_t n, void* points,
                       bool points_f64) {
     if (n == 0) return;
-    const size_t pbytes = n * 3 * (points_f64 ? 8 : 4);
     hip::ScopedContext on_lut_device(hip::Context::current()->device() == dev.device
                                          ? hip::Context::current() : hip::Context::for_device(dev.device));
-    hip::DeviceBuffer d_range(n * 4), d_xyz(pbytes);
-    d_range.upload(range, n * 4);
-    hip::check(ouster_hip_cartesian(hip::default_ctx(), dev.handle,
-                                    static_cast<const uint32_t*>(d_range.data()), d_xyz.data(),
-                                    points_f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32, 1));
-    d_xyz.download(points, pbytes);
+    hip::check(ouster_hip_cartesian_host(hip::default_ctx(), dev.handle, range, points,
+                                         points_f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32));
 }
 
 }  // namespace impl
 
 namespace impl {
 void dewarp_device(const void* points, const double* poses, void* out, bool f64, size_t h, size_t w) {
-    const size_t pbytes = h * w * 3 * (f64 ? 8 : 4);
-    hip::DeviceBuffer d_pts(pbytes), d_poses(w * 16 * 8);
-    d_pts.upload(points, pbytes);
-    d_poses.upload(poses, w * 16 * 8);
-    hip::check(ouster_hip_dewarp(hip::default_ctx(), d_pts.data(),
-                                 static_cast<const double*>(d_poses.data()), d_pts.data(),
-                                 f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32, static_cast<uint32_t>(h),
-                                 static_cast<uint32_t>(w), 1));
-    d_pts.download(out, pbytes);
+    hip::check(ouster_hip_dewarp_host(hip::default_ctx(), points, poses, out, f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32,
+                                      static_cast<uint32_t>(h), static_cast<uint32_t>(w)));
 }
 }  // namespace impl
 
 namespace impl {
 // dewarp(LidarFrame | FrameSet, ...) (impl/dewarp_impl.h:23-115): stage RANGE / status /
 // timestamp / body_to_world of the frames, one ouster_hip_dewarp_frames per run of frames with
-// equal dimensions, append the compacted results.
+// equal dimensions, append the compacted results.  The buffers are the thread's and only grow.
 void dewarp_frames_device(const std::vector<const LidarFrame*>& frames,
                           const std::vector<const DeviceLut*>& luts,
                           const std::vector<uint32_t>& frame_index, double min_range,
@@ -296,50 +305,67 @@ void dewarp_frames_device(const std::vector<const LidarFrame*>& frames,
                           std::vector<uint32_t>* frame_idxs, std::vector<uint32_t>* col_idxs,
                           std::vector<uint64_t>* timestamps_ns) {
     const size_t esz = f64 ? 24 : 12;
+    ouster_hip_ctx* ctx = hip::default_ctx();
+    struct Bufs {
+        hip::DeviceBuffer d_rng, d_st, d_ts, d_po, d_off, d_pts, d_ci, d_tn;
+        int device = -1;
+    };
+    static thread_local Bufs tl;
+    if (tl.device != ouster_hip_ctx_device(ctx)) {   // the thread moved to another GPU: fresh buffers there
+        tl = Bufs();
+        tl.device = ouster_hip_ctx_device(ctx);
+    }
     size_t i = 0;
     while (i < frames.size()) {
         const size_t h = frames[i]->h, w = frames[i]->w;
         size_t j = i;
         while (j < frames.size() && frames[j]->h == h && frames[j]->w == w) ++j;
         const size_t n = j - i, npx = h * w;
-        hip::DeviceBuffer d_rng(n * npx * 4), d_st(n * w * 4), d_ts(n * w * 8), d_po(n * w * 128),
-            d_off((n + 1) * 8), d_pts(n * npx * esz), d_ci, d_tn;
+        hip::DeviceBuffer &d_rng = tl.d_rng, &d_st = tl.d_st, &d_ts = tl.d_ts, &d_po = tl.d_po, &d_off = tl.d_off,
+                          &d_pts = tl.d_pts, &d_ci = tl.d_ci, &d_tn = tl.d_tn;
+        d_rng.resize(n * npx * 4);
+        d_st.resize(n * w * 4);
+        d_ts.resize(n * w * 8);
+        d_po.resize(n * w * 128);
+        d_off.resize((n + 1) * 8);
+        d_pts.resize(n * npx * esz);
         if (col_idxs) d_ci.resize(n * npx * 4);
         if (timestamps_ns) d_tn.resize(n * npx * 8);
         std::vector<const ouster_hip_lut*> handles(n);
         for (size_t k = 0; k < n; ++k) {
             const LidarFrame& fr = *frames[i + k];
             const auto range = fr.field<uint32_t>(ChanField::RANGE);
-            d_rng.upload(range.data(), npx * 4, k * npx * 4);
-            d_st.upload(fr.status().data(), w * 4, k * w * 4);
-            d_ts.upload(fr.timestamp().data(), w * 8, k * w * 8);
-            d_po.upload(fr.body_to_world().get<double>(), w * 128, k * w * 128);
+            d_rng.upload_async(range.data(), npx * 4, k * npx * 4);
+            d_st.upload_async(fr.status().data(), w * 4, k * w * 4);
+            d_ts.upload_async(fr.timestamp().data(), w * 8, k * w * 8);
+            d_po.upload_async(fr.body_to_world().get<double>(), w * 128, k * w * 128);
             handles[k] = luts[i + k]->handle;
         }
         hip::check(ouster_hip_dewarp_frames(
-            hip::default_ctx(), handles.data(), static_cast<uint32_t>(n),
+            ctx, handles.data(), static_cast<uint32_t>(n),
             static_cast<const uint32_t*>(d_rng.data()), static_cast<const uint32_t*>(d_st.data()),
             static_cast<const uint64_t*>(d_ts.data()), static_cast<const double*>(d_po.data()),
             static_cast<uint32_t>(n), min_range, max_range, f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32,
-            d_pts.data(), nullptr, static_cast<uint32_t*>(d_ci.data()),
-            static_cast<uint64_t*>(d_tn.data()), n * npx, static_cast<uint64_t*>(d_off.data())));
+            d_pts.data(), nullptr, col_idxs ? static_cast<uint32_t*>(d_ci.data()) : nullptr,
+            timestamps_ns ? static_cast<uint64_t*>(d_tn.data()) : nullptr, n * npx, static_cast<uint64_t*>(d_off.data())));
         std::vector<uint64_t> off(n + 1);
         d_off.download(off.data(), (n + 1) * 8);
         const size_t total = off[n];
         if (total) {
             const size_t p0 = points.size();
             points.resize(p0 + total * esz);
-            d_pts.download(points.data() + p0, total * esz);
+            d_pts.download_async(points.data() + p0, total * esz);
             if (col_idxs) {
                 const size_t c0 = col_idxs->size();
                 col_idxs->resize(c0 + total);
-                d_ci.download(col_idxs->data() + c0, total * 4);
+                d_ci.download_async(col_idxs->data() + c0, total * 4);
             }
             if (timestamps_ns) {
                 const size_t t0 = timestamps_ns->size();
                 timestamps_ns->resize(t0 + total);
-                d_tn.download(timestamps_ns->data() + t0, total * 8);
+                d_tn.download_async(timestamps_ns->data() + t0, total * 8);
             }
+            hip::check(ouster_hip_sync(ctx));
             if (frame_idxs) {  // batch-local index -> caller's FrameSet index
                 const size_t f0 = frame_idxs->size();
                 frame_idxs->resize(f0 + total);
@@ -381,15 +407,19 @@ void decode_one_packet(const PacketFormat& pf, const std::string& name, size_t e
     hip::check(ouster_hip_format_create(ctx, &d, &fmt));
     const size_t H = pf.pixels_per_column, plane_bytes = H * static_cast<size_t>(cols) * elem;
     try {
-        hip::DeviceBuffer d_pkt((pf.lidar_packet_size + 15) & ~size_t{15}), d_plane(plane_bytes);
-        d_pkt.upload(lidar_buf, pf.lidar_packet_size);
+        const size_t stride = (pf.lidar_packet_size + 15) & ~size_t{15};
+        void *d_pkt = nullptr, *d_plane = nullptr;   // the context's scratch: nothing is allocated per call
+        hip::check(ouster_hip_ctx_scratch(ctx, 4, stride, &d_pkt));
+        hip::check(ouster_hip_ctx_scratch(ctx, 5, plane_bytes, &d_plane));
+        hip::check(ouster_hip_copy_in(ctx, d_pkt, lidar_buf, pf.lidar_packet_size));
         ouster_hip_frame_out out{};
-        out.planes[0] = d_plane.data();
+        out.planes[0] = d_plane;
         out.xyz_field[0] = out.xyz_field[1] = -1;
-        hip::check(ouster_hip_decode(ctx, fmt, static_cast<const uint8_t*>(d_pkt.data()),
-                                     d_pkt.size(), 1, nullptr, 1, nullptr, &out, nullptr, nullptr, 0));
+        hip::check(ouster_hip_decode(ctx, fmt, static_cast<const uint8_t*>(d_pkt), stride, 1, nullptr, 1, nullptr, &out,
+                                     nullptr, nullptr, 0));
         std::vector<uint8_t> host(plane_bytes);
-        d_plane.download(host.data(), plane_bytes);
+        hip::check(ouster_hip_copy_out(ctx, host.data(), d_plane, plane_bytes));
+        hip::check(ouster_hip_sync(ctx));
         for (uint32_t icol = 0; icol < pf.columns_per_packet; ++icol) {
             const uint8_t* col = pf.nth_col(icol, lidar_buf);
             const uint16_t m_id = pf.col_measurement_id(col);

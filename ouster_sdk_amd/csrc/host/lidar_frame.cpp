@@ -32,13 +32,13 @@ Field::Field(ChanFieldType tag, std::vector<size_t> shape, FieldClass c)
     for (size_t d : shape_) count_ *= d;
     if (shape_.empty()) count_ = 1;
     const size_t b = count_ * field_type_size(tag_);
-    ptr_ = b ? std::calloc(b, 1) : nullptr;
+    ptr_ = b ? impl::host_alloc(b, true) : nullptr;   // planes come from the pinned pool: the GPU writes them in place
     if (b && !ptr_) throw std::runtime_error("Field: host memory allocation failed");
 }
 Field::Field(const Field& o) : tag_(o.tag_), shape_(o.shape_), class_(o.class_), count_(o.count_) {
     const size_t b = o.bytes();
     if (b) {
-        ptr_ = std::malloc(b);
+        ptr_ = impl::host_alloc(b, false);
         if (!ptr_) throw std::runtime_error("Field: host memory allocation failed");
         std::memcpy(ptr_, o.ptr_, b);
     }
@@ -57,7 +57,7 @@ Field& Field::operator=(Field o) noexcept {
     std::swap(ptr_, o.ptr_);
     return *this;
 }
-Field::~Field() { std::free(ptr_); }
+Field::~Field() { impl::host_free(ptr_, bytes()); }
 void Field::set_zero() {
     if (ptr_) std::memset(ptr_, 0, bytes());
 }
@@ -569,8 +569,9 @@ struct FrameBatcher::State : std::enable_shared_from_this<FrameBatcher::State> {
     uint32_t next_valid_m_id = 0, next_headers_m_id = 0;
     std::weak_ptr<impl::PendingDecode> pending;     // what frames being assembled are told to call (they own it, and through it this state)
 
-    // packets of the frame being assembled, in arrival order
-    std::vector<uint8_t> staged;
+    // packets of the frame being assembled, in arrival order -- in pool (page-locked) memory: the decode kernel reads them
+    // where they were staged, no upload (include/ouster_hip.h, "host containers")
+    impl::HostArray<uint8_t> staged;
     size_t staged_count = 0;
     size_t stride = 0;
 
@@ -664,11 +665,16 @@ struct BatcherOps {
             frame.packet_timestamp()[packet_id] = host_ts;
             frame.alert_flags()[packet_id] = pf.alert_flags(buf);
         }
-        if ((s.staged_count + 1) * s.stride > s.staged.size())
-            s.staged.resize(std::max<size_t>(s.staged.size() * 2, (s.staged_count + 8) * s.stride));
+        if ((s.staged_count + 1) * s.stride > s.staged.size()) {   // first packet: room for a whole frame; more only for duplicates
+            impl::HostArray<uint8_t> grown(std::max<size_t>({s.staged.size() * 2, (s.staged_count + 8) * s.stride,
+                                                             (s.expected_lidar_packets + 4) * s.stride}),
+                                           impl::uninitialized);
+            if (s.staged_count) std::memcpy(grown.data(), s.staged.data(), s.staged_count * s.stride);
+            s.staged = std::move(grown);
+        }
         uint8_t* dst = s.staged.data() + s.staged_count * s.stride;
         std::memcpy(dst, buf, std::min(len, pf.lidar_packet_size));
-        if (len < pf.lidar_packet_size) std::memset(dst + len, 0, pf.lidar_packet_size - len);
+        if (len < s.stride) std::memset(dst + std::min(len, pf.lidar_packet_size), 0, s.stride - std::min(len, pf.lidar_packet_size));
         s.staged_count++;
         s.batched_lidar_packets++;
         track_columns(s, pf, dst, frame);
@@ -788,7 +794,35 @@ struct BatcherOps {
             s.fmt_elems = elems;
         }
         const size_t W = frame.w, H = frame.h;
-        // device output block: planes, then timestamp / status / measurement_id (16 B aligned)
+        const uint32_t count = static_cast<uint32_t>(s.staged_count);
+        const size_t slots = std::max<size_t>(s.staged_count, 1);
+        ouster_hip_frame_out out{};
+        out.xyz_field[0] = out.xyz_field[1] = -1;
+        void* h_ts = frame.timestamp().data();
+        void* h_st = frame.status().data();
+        void* h_mid = frame.measurement_id().data();
+
+        // (1) The frame's planes and headers and the staged packets are pool memory (what LidarFrame and this batcher
+        // allocate): ONE launch that reads the packets and writes the frame where they lie.  Input and output cross the link
+        // at the same time; nothing is copied, nothing is allocated.
+        bool in_place = col_limit >= W && s.staged_count && hip::is_device_accessible(s.staged.data(), s.staged_count * s.stride) &&
+                        hip::is_device_accessible(h_ts, W * 8) && hip::is_device_accessible(h_st, W * 4) &&
+                        hip::is_device_accessible(h_mid, W * 2);
+        for (size_t i = 0; i < dst.size() && in_place; ++i) in_place = hip::is_device_accessible(dst[i]->get(), H * W * elems[i]);
+        if (in_place) {
+            for (size_t i = 0; i < dst.size(); ++i) out.planes[i] = dst[i]->get();
+            out.timestamp = static_cast<uint64_t*>(h_ts);
+            out.status = static_cast<uint32_t*>(h_st);
+            out.measurement_id = static_cast<uint16_t*>(h_mid);
+            hip::check(ouster_hip_decode(ctx, s.fmt, s.staged.data(), s.stride, static_cast<uint32_t>(slots), &count, 1, nullptr,
+                                         &out, nullptr, nullptr, 0));
+            hip::check(ouster_hip_sync(ctx));
+            return;
+        }
+
+        // (2) Anything else (a frame whose fields the caller adopted from foreign memory, a tiny frame below the pool's block
+        // size, a look at a frame under assembly): device block -- planes, then timestamp / status / measurement_id -- in this
+        // batcher's grow-only buffers, asynchronous copies, one synchronisation.
         auto al = [](size_t x) { return (x + 255) & ~size_t{255}; };
         std::vector<size_t> off(dst.size());
         size_t total = 0;
@@ -803,23 +837,24 @@ struct BatcherOps {
         const size_t off_mid = total;
         total += al(W * 2);
         s.d_out.resize(total);
-        const size_t slots = std::max<size_t>(s.staged_count, 1);
         s.d_packets.resize(slots * s.stride);
-        if (s.staged_count) s.d_packets.upload(s.staged.data(), s.staged_count * s.stride);
-        ouster_hip_frame_out out{};
+        if (s.staged_count) s.d_packets.upload_async(s.staged.data(), s.staged_count * s.stride);
         uint8_t* base = static_cast<uint8_t*>(s.d_out.data());
         for (size_t i = 0; i < dst.size(); ++i) out.planes[i] = base + off[i];
         out.timestamp = reinterpret_cast<uint64_t*>(base + off_ts);
         out.status = reinterpret_cast<uint32_t*>(base + off_st);
         out.measurement_id = reinterpret_cast<uint16_t*>(base + off_mid);
-        out.xyz_field[0] = out.xyz_field[1] = -1;
-        const uint32_t count = static_cast<uint32_t>(s.staged_count);
         hip::check(ouster_hip_decode(ctx, s.fmt, static_cast<const uint8_t*>(s.d_packets.data()),
                                      s.stride, static_cast<uint32_t>(slots), &count, 1, nullptr, &out,
                                      nullptr, nullptr, 0));
+        s.d_out.download_async(h_ts, W * 8, off_ts);
+        s.d_out.download_async(h_st, W * 4, off_st);
+        s.d_out.download_async(h_mid, W * 2, off_mid);
         if (col_limit >= W) {
-            for (size_t i = 0; i < dst.size(); ++i) s.d_out.download(dst[i]->get(), H * W * elems[i], off[i]);
+            for (size_t i = 0; i < dst.size(); ++i) s.d_out.download_async(dst[i]->get(), H * W * elems[i], off[i]);
+            hip::check(ouster_hip_sync(ctx));
         } else if (col_limit > 0) {
+            hip::check(ouster_hip_sync(ctx));
             std::vector<uint8_t> tmp;
             for (size_t i = 0; i < dst.size(); ++i) {
                 tmp.resize(H * W * elems[i]);
@@ -828,10 +863,9 @@ struct BatcherOps {
                 for (size_t r = 0; r < H; ++r)
                     std::memcpy(out_plane + r * W * elems[i], tmp.data() + r * W * elems[i], col_limit * elems[i]);
             }
+        } else {
+            hip::check(ouster_hip_sync(ctx));
         }
-        s.d_out.download(frame.timestamp().data(), W * 8, off_ts);
-        s.d_out.download(frame.status().data(), W * 4, off_st);
-        s.d_out.download(frame.measurement_id().data(), W * 2, off_mid);
     }
 
     static int top_of_cache(const FrameBatcher::State& s, const PacketFormat& pf) {

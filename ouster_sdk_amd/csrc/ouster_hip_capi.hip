@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "host_pool.h"
 #include "ouster_hip_dev.h"
 
 using namespace ouster_hip_dev;
@@ -46,11 +47,11 @@ struct DevBuf {
     size_t cap = 0;
     int ensure(size_t n) {
         if (n <= cap) return 0;
-        if (p) (void)hipFree(p);
+        counted_free(p);
         p = nullptr;
         cap = 0;
         size_t want = n + n / 2;
-        if (hipMalloc(&p, want) != hipSuccess) {
+        if (counted_malloc(&p, want) != hipSuccess) {
             p = nullptr;
             return -1;
         }
@@ -58,7 +59,7 @@ struct DevBuf {
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        counted_free(p);
         p = nullptr;
         cap = 0;
     }
@@ -100,6 +101,7 @@ struct ouster_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevBuf state, tile_valid, offsets, luts, counts, scratch, slotmap, hdrw, osf_pixels;
+    DevBuf user_scratch[8];              // ouster_hip_ctx_scratch: what the *_host calls and bindings stage through
     uint32_t resident_wgs = 512;         // 2 workgroups (80 KB LDS each) per CU
     uint32_t cus = 256;                  // compute units (k_decode_stream: one persistent workgroup each)
     const char* last_kernel = "";        // name of the decode kernel the last ouster_hip_decode launched
@@ -342,7 +344,7 @@ void ouster_hip_ctx_destroy(ouster_hip_ctx* c) {
     c->slotmap.release();
     c->hdrw.release();
     c->osf_pixels.release();
-    c->osf_pixels.release();
+    for (auto& b : c->user_scratch) b.release();
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -475,7 +477,7 @@ void ouster_hip_format_destroy(ouster_hip_format* f) { delete f; }
 
 // ---- lut -------------------------------------------------------------------------------
 static int upload(void** dptr, const void* src, size_t bytes, hipStream_t st) {
-    if (hipMalloc(dptr, bytes) != hipSuccess) return -1;
+    if (counted_malloc(dptr, bytes) != hipSuccess) return -1;
     if (hipMemcpyAsync(*dptr, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     return hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
 }
@@ -567,10 +569,10 @@ int ouster_hip_lut_export(const ouster_hip_lut* L, double* direction, double* of
 void ouster_hip_lut_destroy(ouster_hip_lut* L) {
     if (!L) return;
     (void)hipSetDevice(L->device);
-    if (L->d_beam) (void)hipFree(L->d_beam);
-    if (L->d_col) (void)hipFree(L->d_col);
-    if (L->d_dir) (void)hipFree(L->d_dir);
-    if (L->d_ofs) (void)hipFree(L->d_ofs);
+    counted_free((void*)L->d_beam);
+    counted_free((void*)L->d_col);
+    counted_free((void*)L->d_dir);
+    counted_free((void*)L->d_ofs);
     delete L;
 }
 
@@ -1304,6 +1306,127 @@ int ouster_hip_dewarp(ouster_hip_ctx* ctx, const void* points, const double* pos
     a.dtype = dtype;
     HIP_TRY(launch_dewarp(a, ctx->stream));
     return OUSTER_HIP_OK;
+}
+
+// ---- host containers (include/ouster_hip.h, "host containers") -----------------------------------
+int ouster_hip_device_alloc(ouster_hip_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    *out = nullptr;
+    const hipError_t e = counted_malloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(OUSTER_HIP_ERR_RUNTIME, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    return OUSTER_HIP_OK;
+}
+void ouster_hip_device_free(void* p) { counted_free(p); }
+
+int ouster_hip_ctx_scratch(ouster_hip_ctx* ctx, uint32_t slot, size_t bytes, void** out) {
+    if (!ctx || !out || slot >= 8) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "bad scratch request");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->user_scratch[slot].ensure(bytes ? bytes : 1)) return fail(OUSTER_HIP_ERR_RUNTIME, "out of device memory (scratch %u, %zu bytes)", slot, bytes);
+    *out = ctx->user_scratch[slot].p;
+    return OUSTER_HIP_OK;
+}
+
+int ouster_hip_copy_in(ouster_hip_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+    if (!ctx || (bytes && (!dev_dst || !host_src))) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (bytes) HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return OUSTER_HIP_OK;
+}
+int ouster_hip_copy_out(ouster_hip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+    if (!ctx || (bytes && (!host_dst || !dev_src))) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (bytes) HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return OUSTER_HIP_OK;
+}
+
+namespace {
+// One host array of a *_host call: pool memory is handed to the kernel as it is, anything else gets a slot of the context's
+// grow-only scratch (inputs copied in now, outputs copied out by finish()).
+struct HostArg {
+    void* dev = nullptr;
+    void* host = nullptr;
+    size_t bytes = 0;
+    bool staged = false;
+};
+int host_arg(ouster_hip_ctx* ctx, const void* host, size_t bytes, uint32_t slot, bool is_input, HostArg& a) {
+    a.host = const_cast<void*>(host);
+    a.bytes = bytes;
+    if (ouster_hip_host_is_pinned(host, bytes)) {
+        a.dev = a.host;
+        return OUSTER_HIP_OK;
+    }
+    a.staged = true;
+    if (ctx->user_scratch[slot].ensure(bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "out of device memory (scratch %u, %zu bytes)", slot, bytes);
+    a.dev = ctx->user_scratch[slot].p;
+    if (is_input) HIP_TRY(hipMemcpyAsync(a.dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return OUSTER_HIP_OK;
+}
+int host_finish(ouster_hip_ctx* ctx, const HostArg& out) {
+    if (out.staged) HIP_TRY(hipMemcpyAsync(out.host, out.dev, out.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return OUSTER_HIP_OK;
+}
+}  // namespace
+
+int ouster_hip_destagger_host(ouster_hip_ctx* ctx, const void* src, void* dst, uint32_t h, uint32_t w,
+                              uint32_t elem_bytes, const int32_t* shifts, uint32_t n_shifts, int inverse) {
+    if (!ctx || !shifts) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_shifts != h) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "image height does not match shifts size");
+    if (h == 0 || w == 0) return OUSTER_HIP_OK;
+    if (!src || !dst || elem_bytes == 0) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "bad image arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)h * w * elem_bytes;
+    HostArg in, out;
+    int rc = host_arg(ctx, src, bytes, 0, true, in);
+    if (rc == OUSTER_HIP_OK) rc = host_arg(ctx, dst, bytes, 1, false, out);
+    if (rc != OUSTER_HIP_OK) return rc;
+    // in place (src == dst) in the reference copies rows through each other: not a supported call there either; go through scratch
+    if (in.dev == out.dev) {
+        if (ctx->user_scratch[1].ensure(bytes)) return fail(OUSTER_HIP_ERR_RUNTIME, "out of device memory (scratch)");
+        out.dev = ctx->user_scratch[1].p;
+        out.staged = true;
+    }
+    rc = ouster_hip_destagger(ctx, in.dev, out.dev, h, w, elem_bytes, shifts, n_shifts, inverse, 1);
+    if (rc != OUSTER_HIP_OK) return rc;
+    return host_finish(ctx, out);
+}
+
+int ouster_hip_cartesian_host(ouster_hip_ctx* ctx, const ouster_hip_lut* lut, const uint32_t* range, void* xyz,
+                              int xyz_dtype) {
+    if (!ctx || !lut) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (xyz_dtype != OUSTER_HIP_F32 && xyz_dtype != OUSTER_HIP_F64)
+        return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "xyz_dtype must be F32 or F64");
+    const size_t npx = (size_t)lut->w * lut->h;
+    if (npx == 0) return OUSTER_HIP_OK;
+    if (!range || !xyz) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL image pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HostArg in, out;
+    int rc = host_arg(ctx, range, npx * 4, 0, true, in);
+    if (rc == OUSTER_HIP_OK) rc = host_arg(ctx, xyz, npx * 3 * (xyz_dtype == OUSTER_HIP_F64 ? 8 : 4), 1, false, out);
+    if (rc != OUSTER_HIP_OK) return rc;
+    rc = ouster_hip_cartesian(ctx, lut, (const uint32_t*)in.dev, out.dev, xyz_dtype, 1);
+    if (rc != OUSTER_HIP_OK) return rc;
+    return host_finish(ctx, out);
+}
+
+int ouster_hip_dewarp_host(ouster_hip_ctx* ctx, const void* points, const double* poses, void* dewarped, int dtype,
+                           uint32_t h, uint32_t w) {
+    if (!ctx) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (dtype != OUSTER_HIP_F32 && dtype != OUSTER_HIP_F64) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "dtype must be F32 or F64");
+    if (h == 0 || w == 0) return OUSTER_HIP_OK;
+    if (!points || !poses || !dewarped) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t pbytes = (size_t)h * w * 3 * (dtype == OUSTER_HIP_F64 ? 8 : 4);
+    HostArg in, po, out;
+    int rc = host_arg(ctx, points, pbytes, 0, true, in);
+    if (rc == OUSTER_HIP_OK) rc = host_arg(ctx, poses, (size_t)w * 128, 2, true, po);
+    if (rc == OUSTER_HIP_OK) rc = host_arg(ctx, dewarped, pbytes, 1, false, out);
+    if (rc != OUSTER_HIP_OK) return rc;
+    rc = ouster_hip_dewarp(ctx, in.dev, (const double*)po.dev, out.dev, dtype, h, w, 1);
+    if (rc != OUSTER_HIP_OK) return rc;
+    return host_finish(ctx, out);
 }
 
 // ---- range-gated, compacting frame dewarp ------------------------------------------------------

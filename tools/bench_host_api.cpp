@@ -1,16 +1,30 @@
-// bench_host_api.cpp -- latency of the drop-in, frame-at-a-time host API (host LidarFrame in,
-// host results out; every call crosses PCIe): FrameBatcher::batch x128 -> destagger<uint32_t>
-// -> XYZLut::operator().  This is what an unmodified reference caller gets; the batched,
-// device-resident path (bench.py, DeviceFrameBatch) is two orders of magnitude faster.
-// Build: make -C tests/cpp ../../tools/bench_host_api   (or see tools/Makefile rule below)
+// bench_host_api.cpp -- what an UNMODIFIED caller of the reference's frame-at-a-time API gets (host LidarFrame in, host
+// results out, every call crosses PCIe), the calls of /root/reference/examples/representations_example.cpp:38-54,85-87 and
+// examples/helpers.cpp:16-39 on one 128 x 2048 dual-return frame:
+//     FrameBatcher::batch x 128 packets  ->  destagger<T> of RANGE, RANGE2 (u32), REFLECTIVITY, REFLECTIVITY2 (u8)
+//     ->  XYZLut()(RANGE), XYZLut()(RANGE2)   (double clouds, as XYZLut = XYZLutT<double>)
+// Reported per call and as frame_total (all seven calls + the batcher), with the library's allocation counters over the
+// timed frames (the steady state allocates nothing: include/ouster_hip.h, "host containers").  The batched, device-resident
+// path (bench.py, DeviceFrameBatch) is three orders of magnitude faster; this is the drop-in view.
+// Build: make -C tests/cpp
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <random>
+#include <vector>
 
 #include "ouster/core/lidar_scan.h"
+#include "ouster/hip/device_buffer.h"
 
 using namespace ouster::sdk::core;
 using clk = std::chrono::steady_clock;
+
+static double ms(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+static double median(std::vector<double> v) {
+    std::sort(v.begin(), v.end());
+    return v[v.size() / 2];
+}
 
 int main(int argc, char** argv) {
     const int frames = argc > 1 ? std::atoi(argv[1]) : 20;
@@ -48,28 +62,54 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < src.packet_count(); ++i) src.packet_timestamp()[i] = 1 + i;
     XYZLut lut(info, false);
     LidarFrame frame(sinfo);
+    const LidarFrame& cframe = frame;   // a reader of the released frame
     FrameBatcher batcher(sinfo);
-    double t_batch = 0, t_dst = 0, t_xyz = 0;
-    for (int f = -2; f < frames; ++f) {  // two warm-up frames
-        src.frame_id = 100 + f + 2;
+    std::vector<double> t_batch, t_d32, t_d8, t_xyz, t_total;
+    ouster::sdk::hip::AllocStats a0{}, a1{};
+    bool same = true;
+    for (int f = -3; f < frames; ++f) {  // three warm-up frames (the pool and the scratch see every size once)
+        if (f == 0) a0 = ouster::sdk::hip::alloc_stats();
+        src.frame_id = 100 + f + 3;
         auto packets = impl::frame_to_packets(src, pf, info.init_id, 1);
         auto t0 = clk::now();
         bool done = false;
         for (auto& p : packets) done = batcher(p, frame);
         auto t1 = clk::now();
-        auto d = destagger<uint32_t>(info, frame.field<uint32_t>("RANGE"));
+        auto d1 = destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE));
         auto t2 = clk::now();
-        auto pts = lut(frame);
+        auto d2 = destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE2));
         auto t3 = clk::now();
-        if (!done || pts.rows() != 128 * 2048 || d.rows() != 128) return 1;
+        auto d3 = destagger<uint8_t>(info, cframe.field<uint8_t>(ChanField::REFLECTIVITY));
+        auto d4 = destagger<uint8_t>(info, cframe.field<uint8_t>(ChanField::REFLECTIVITY2));
+        auto t4 = clk::now();
+        auto pts = lut(cframe);
+        auto t5 = clk::now();
+        auto pts2 = lut(cframe.field<uint32_t>(ChanField::RANGE2));
+        auto t6 = clk::now();
+        if (!done || pts.rows() != 128 * 2048 || pts2.rows() != 128 * 2048 || d1.rows() != 128 || d2.rows() != 128 ||
+            d3.rows() != 128 || d4.rows() != 128)
+            return 1;
+        if (f == frames - 1) {   // the released frame is the frame that was sent
+            for (auto it = pf->begin(); it != pf->end(); ++it)
+                if (src.has_field(it->first)) same = same && src.field(it->first) == cframe.field(it->first);
+        }
         if (f >= 0) {
-            t_batch += std::chrono::duration<double, std::milli>(t1 - t0).count();
-            t_dst += std::chrono::duration<double, std::milli>(t2 - t1).count();
-            t_xyz += std::chrono::duration<double, std::milli>(t3 - t2).count();
+            t_batch.push_back(ms(t0, t1));
+            t_d32.push_back((ms(t1, t2) + ms(t2, t3)) / 2);
+            t_d8.push_back(ms(t3, t4) / 2);
+            t_xyz.push_back((ms(t4, t5) + ms(t5, t6)) / 2);
+            t_total.push_back(ms(t0, t6));
         }
     }
-    std::printf("{\"frames\": %d, \"ms_per_frame\": {\"FrameBatcher_128_packets\": %.3f, \"destagger_u32\": %.3f, "
-                "\"XYZLut_f64\": %.3f}, \"note\": \"host containers in/out, one PCIe round trip per call\"}\n",
-                frames, t_batch / frames, t_dst / frames, t_xyz / frames);
-    return 0;
+    a1 = ouster::sdk::hip::alloc_stats();
+    auto mean = [&](const std::vector<double>& v) { double s = 0; for (double x : v) s += x; return s / v.size(); };
+    std::printf("{\"frames\": %d, \"ms_per_frame\": {\"FrameBatcher_128_packets\": %.4f, \"destagger_u32\": %.4f, \"destagger_u8\": %.4f, "
+                "\"XYZLut_f64\": %.4f, \"frame_total\": %.4f}, \"median_ms\": {\"FrameBatcher_128_packets\": %.4f, \"destagger_u32\": %.4f, "
+                "\"XYZLut_f64\": %.4f, \"frame_total\": %.4f}, \"frame_total_is\": \"batch x128 + destagger RANGE RANGE2 REFLECTIVITY REFLECTIVITY2 + XYZLut() of RANGE and RANGE2 (f64)\", "
+                "\"frame_matches_source\": %s, \"allocations_in_timed_frames\": {\"device\": %llu, \"pinned\": %llu, \"pool_requests\": %llu, \"pool_hits\": %llu}, "
+                "\"note\": \"host containers in/out; planes, images and clouds are pool (page-locked) memory the kernels read and write in place\"}\n",
+                frames, mean(t_batch), mean(t_d32), mean(t_d8), mean(t_xyz), mean(t_total), median(t_batch), median(t_d32), median(t_xyz), median(t_total),
+                same ? "true" : "false", (unsigned long long)(a1.device_allocs - a0.device_allocs), (unsigned long long)(a1.pinned_allocs - a0.pinned_allocs),
+                (unsigned long long)(a1.pool_requests - a0.pool_requests), (unsigned long long)(a1.pool_hits - a0.pool_hits));
+    return same ? 0 : 2;
 }
