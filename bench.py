@@ -653,7 +653,7 @@ def time_drop_in():
     import subprocess
     res = {}
     bdir = os.path.join(ROOT, "tests", "cpp", "_build")
-    for key, argv in (("host_api", ["bench_host_api", "12"]), ("frame_stream", ["bench_stream", "768", "32", "3", "xyz"])):
+    for key, argv in (("host_api", ["bench_host_api", "40"]), ("frame_stream", ["bench_stream", "768", "32", "3", "xyz"])):
         exe = os.path.join(bdir, argv[0])
         try:
             o = subprocess.run([exe] + argv[1:], capture_output=True, text=True, timeout=120)
@@ -664,9 +664,20 @@ def time_drop_in():
                    "FrameStream: host packets in, XYZ of both returns out, batches of 32 frames, 3 in flight"}
     ha = res.get("host_api", {})
     if "ms_per_frame" in ha:
-        out["frame_batcher_ms"] = ha["ms_per_frame"]["FrameBatcher_128_packets"]
-        out["destagger_ms"] = ha["ms_per_frame"]["destagger_u32"]
-        out["xyzlut_ms"] = ha["ms_per_frame"]["XYZLut_f64"]
+        m = ha["ms_per_frame"]
+        out["frame_batcher_ms"] = m["FrameBatcher_128_packets"]
+        out["frame_batcher_release_call_ms"] = m.get("FrameBatcher_release_call")
+        out["destagger_ms"] = m["destagger_u32"]
+        out["destagger_u8_ms"] = m.get("destagger_u8")
+        out["xyzlut_ms"] = m["XYZLut_f64"]
+        out["frame_total_ms"] = m.get("frame_total")
+        out["frame_total_is"] = ha.get("frame_total_is")
+        out["frame_matches_source"] = ha.get("frame_matches_source")
+        out["allocations_in_timed_frames"] = ha.get("allocations_in_timed_frames")
+        out["how"] = ("Field / img_t / PointCloudXYZ are pool (page-locked) memory: the decode, cartesian and inverse-destagger kernels "
+                      "read and write them in place (one launch, no staging copy, no allocation); destagger() of a plane the "
+                      "FrameBatcher has just released is one copy out of the HBM mirror its release launch left behind "
+                      "(DESIGN 5; link measurements: profiles/r06_dropin/copybench.json)")
     else:
         out["host_api_error"] = ha.get("error")
     fs = res.get("frame_stream", {})

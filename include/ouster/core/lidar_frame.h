@@ -80,6 +80,17 @@ std::string to_string(const FieldType& field_type);              ///< lidar_fram
 std::string to_string(const LidarFrameFieldTypes& field_types);
 
 /** Owning, zero-initialised, typed n-d buffer (field.h:828-905, field.cpp:247-296). */
+namespace impl {
+/** Device-resident by-products of a FrameBatcher's release (host_internal.h: FrameMirror): the destaggered form of every
+ *  plane the batcher just decoded stays in HBM, keyed by the plane's host storage, so that destagger(plane) of the released
+ *  frame is one copy out instead of a round trip.  An entry dies the moment the plane's storage can change: a writable
+ *  pointer or view is handed out, the storage is freed or replaced, the batcher (or another one) decodes into it again.
+ *  A Field that has EVER handed out a writable pointer is never mirrored -- such a pointer may be written through at any
+ *  time without the library noticing.  mirrors_live() keeps the hooks at one relaxed load when nothing is mirrored. */
+bool mirrors_live() noexcept;
+void mirror_forget(const void* host_storage) noexcept;
+}  // namespace impl
+
 class Field {
    public:
     Field() = default;
@@ -95,12 +106,12 @@ class Field {
     size_t element_size() const { return field_type_size(tag_); }
     size_t size() const { return count_; }   ///< number of elements
     size_t bytes() const { return count_ * element_size(); }
-    void* get() { return ptr_; }
+    void* get() { return writable_(); }
     const void* get() const { return ptr_; }
     /** Typed pointer. @throw std::invalid_argument on element type mismatch. */
     template <typename T> T* get() {
         check<T>();
-        return static_cast<T*>(ptr_);
+        return static_cast<T*>(writable_());
     }
     template <typename T> const T* get() const {
         check<T>();
@@ -110,7 +121,7 @@ class Field {
     template <typename T> ImgRef<T> img() {
         check<T>();
         if (shape_.size() != 2) throw std::invalid_argument("Field: cannot convert to 2d image");
-        return ImgRef<T>(static_cast<T*>(ptr_), shape_[0], shape_[1]);
+        return ImgRef<T>(static_cast<T*>(writable_()), shape_[0], shape_[1]);
     }
     template <typename T> ImgRef<const T> img() const {
         check<T>();
@@ -124,12 +135,12 @@ class Field {
     // ---- the reference's FieldView conversions (ouster_core/include/ouster/core/field.h:374-470) ----
     /** Typed pointer; `void` always converts.
      *  @throw std::invalid_argument("FieldView: ineligible dereference type ...") on a type mismatch */
-    template <typename T> operator T*() { return conv_ptr<T>(); }
+    template <typename T> operator T*() { return conv_ptr<T>(std::is_const<T>::value); }
     template <typename T> operator const T*() const { return conv_ptr<const T>(); }
     /** n-d view.  @throw std::invalid_argument on a type or dimension mismatch */
     template <typename T, size_t Dim> operator ArrayView<T, Dim>() {
         check_rank<Dim>();
-        return ArrayView<T, Dim>(conv_ptr<T>(), shape_);
+        return ArrayView<T, Dim>(conv_ptr<T>(std::is_const<T>::value), shape_);
     }
     template <typename T, size_t Dim> operator ConstArrayView<T, Dim>() const {
         check_rank<Dim>();
@@ -138,7 +149,7 @@ class Field {
     /** 2-D image view (the stand-in for the reference's `operator Eigen::Ref<img_t<T>>`). */
     template <typename T> operator ImgRef<T>() {
         check_2d();
-        return ImgRef<T>(conv_ptr<T>(), shape_[0], shape_[1]);
+        return ImgRef<T>(conv_ptr<T>(std::is_const<T>::value), shape_[0], shape_[1]);
     }
     template <typename T> operator ImgRef<const T>() const {
         check_2d();
@@ -147,7 +158,7 @@ class Field {
 #ifdef OUSTER_HIP_USE_EIGEN
     template <typename T> operator Eigen::Ref<EigenImg<T>>() {
         check_2d();
-        return Eigen::Map<EigenImg<T>>(conv_ptr<T>(), static_cast<Eigen::Index>(shape_[0]),
+        return Eigen::Map<EigenImg<T>>(conv_ptr<T>(false), static_cast<Eigen::Index>(shape_[0]),
                                        static_cast<Eigen::Index>(shape_[1]));
     }
     template <typename T> operator Eigen::Ref<const EigenImg<T>>() const {
@@ -162,12 +173,26 @@ class Field {
         if (FieldTag<T>::tag != tag_)
             throw std::invalid_argument("Field: ineligible dereference type");
     }
-    template <typename T> T* conv_ptr() const {
+   public:
+    /** Library-internal: the storage, without declaring a caller-held writable pointer (FrameBatcher decodes through it
+     *  and settles the mirror itself). */
+    void* storage_() const { return ptr_; }
+    bool writable_escaped_() const { return escaped_; }
+
+   private:
+    template <typename T> T* conv_ptr(bool read_only = true) const {
         using NC = typename std::remove_const<T>::type;
         if (!std::is_void<NC>::value && FieldTag<NC>::tag != tag_)
             throw std::invalid_argument("FieldView: ineligible dereference type for field of element type " +
                                         to_string(tag_) + ". Dereference type must match or be void.");
+        if (!read_only) const_cast<Field*>(this)->writable_();
         return static_cast<T*>(ptr_);
+    }
+    /** a writable pointer leaves the Field: from now on its contents may change behind the library's back */
+    void* writable_() {
+        escaped_ = true;
+        if (impl::mirrors_live()) impl::mirror_forget(ptr_);
+        return ptr_;
     }
     template <size_t Dim> void check_rank() const {
         if (shape_.size() != Dim)
@@ -185,6 +210,7 @@ class Field {
     FieldClass class_ = FieldClass::NONE;
     size_t count_ = 0;
     void* ptr_ = nullptr;
+    bool escaped_ = false;   ///< a writable pointer / view of the storage was handed out at some point (travels with the storage)
 };
 
 /** 1-D header view (stands in for the Eigen headers returned by the reference): a contiguous VecRef. */

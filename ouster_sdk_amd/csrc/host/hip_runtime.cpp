@@ -182,6 +182,18 @@ void destagger_bytes(const void* img, void* out, size_t h, size_t w, size_t elem
     if (h != out_h || w != out_w)
         throw std::invalid_argument{"image and destaggered must have the same shape"};
     if (h == 0 || w == 0) return;
+    // a plane of a frame a FrameBatcher has just released: its destaggered form is still in HBM (impl::MirrorPlane) -- one copy out
+    if (!inverse && mirrors_live()) {
+        MirrorPlane m;
+        if (mirror_find(img, m) && m.h == h && m.w == w && m.elem == elem_bytes && img != out && *m.shifts == shifts) {
+            const std::shared_ptr<hip::Context> cur = hip::Context::current();
+            hip::ScopedContext on_device(cur->device() == m.device ? cur : hip::Context::for_device(m.device));
+            ouster_hip_ctx* ctx = hip::default_ctx();
+            hip::check(ouster_hip_copy_out(ctx, out, m.d_destaggered, h * w * elem_bytes));
+            hip::check(ouster_hip_sync(ctx));
+            return;
+        }
+    }
     static_assert(sizeof(int) == sizeof(int32_t), "pixel_shift_by_row is handed over as int32");
     hip::check(ouster_hip_destagger_host(hip::default_ctx(), img, out, static_cast<uint32_t>(h),
                                          static_cast<uint32_t>(w), static_cast<uint32_t>(elem_bytes),

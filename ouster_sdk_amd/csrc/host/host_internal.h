@@ -17,6 +17,20 @@ namespace core {
 namespace impl {
 /** default LidarFrame planes of a (built-in or custom) profile */
 std::vector<std::pair<std::string, ChanFieldType>> default_planes(UDPProfileLidar profile);
+
+/** One plane of a released frame whose destaggered form is still in HBM (include/ouster/core/lidar_frame.h, impl::mirrors_live):
+ *  written by the FrameBatcher's release launch as a by-product (the fused decode kernel has the pixels in LDS anyway),
+ *  served by destagger() as one copy out.  Keyed by the plane's host storage. */
+struct MirrorPlane {
+    const void* host = nullptr;
+    const void* d_destaggered = nullptr;
+    size_t h = 0, w = 0, elem = 0;
+    int device = 0;
+    std::shared_ptr<const std::vector<int>> shifts;   ///< the pixel_shift_by_row the destaggered form was made with
+    std::shared_ptr<void> keep;                       ///< the device block
+};
+void mirror_register(const MirrorPlane& m);
+bool mirror_find(const void* host_storage, MirrorPlane& out);
 }  // namespace impl
 }  // namespace core
 

@@ -12,8 +12,11 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <deque>
+#include <mutex>
 #include <sstream>
+#include <unordered_map>
 
 #include "host_internal.h"
 #include "ouster/core/lidar_frame.h"
@@ -22,6 +25,48 @@
 namespace ouster {
 namespace sdk {
 namespace core {
+
+// ---------------------------------------------------------------------------------------
+// mirror registry (impl::mirrors_live / mirror_forget / mirror_register / mirror_find)
+// ---------------------------------------------------------------------------------------
+namespace impl {
+namespace {
+struct MirrorRegistry {
+    std::mutex mu;
+    std::unordered_map<const void*, MirrorPlane> planes;
+    std::atomic<int> live{0};
+};
+MirrorRegistry& mirrors() {
+    static MirrorRegistry* r = new MirrorRegistry();   // leaked: Field destructors of static frames may run late
+    return *r;
+}
+}  // namespace
+bool mirrors_live() noexcept { return mirrors().live.load(std::memory_order_relaxed) != 0; }
+void mirror_forget(const void* host) noexcept {
+    MirrorRegistry& r = mirrors();
+    std::shared_ptr<void> drop;   // released outside the lock
+    std::lock_guard<std::mutex> g(r.mu);
+    auto it = r.planes.find(host);
+    if (it == r.planes.end()) return;
+    drop = std::move(it->second.keep);
+    r.planes.erase(it);
+    r.live.store(static_cast<int>(r.planes.size()), std::memory_order_relaxed);
+}
+void mirror_register(const MirrorPlane& m) {
+    MirrorRegistry& r = mirrors();
+    std::lock_guard<std::mutex> g(r.mu);
+    r.planes[m.host] = m;
+    r.live.store(static_cast<int>(r.planes.size()), std::memory_order_relaxed);
+}
+bool mirror_find(const void* host, MirrorPlane& out) {
+    MirrorRegistry& r = mirrors();
+    std::lock_guard<std::mutex> g(r.mu);
+    auto it = r.planes.find(host);
+    if (it == r.planes.end()) return false;
+    out = it->second;
+    return true;
+}
+}  // namespace impl
 
 // ---------------------------------------------------------------------------------------
 // Field
@@ -44,8 +89,9 @@ Field::Field(const Field& o) : tag_(o.tag_), shape_(o.shape_), class_(o.class_),
     }
 }
 Field::Field(Field&& o) noexcept
-    : tag_(o.tag_), shape_(std::move(o.shape_)), class_(o.class_), count_(o.count_), ptr_(o.ptr_) {
+    : tag_(o.tag_), shape_(std::move(o.shape_)), class_(o.class_), count_(o.count_), ptr_(o.ptr_), escaped_(o.escaped_) {
     o.ptr_ = nullptr;
+    o.escaped_ = false;
     o.count_ = 0;
     o.tag_ = ChanFieldType::VOID;
 }
@@ -55,10 +101,15 @@ Field& Field::operator=(Field o) noexcept {
     std::swap(class_, o.class_);
     std::swap(count_, o.count_);
     std::swap(ptr_, o.ptr_);
+    std::swap(escaped_, o.escaped_);
     return *this;
 }
-Field::~Field() { impl::host_free(ptr_, bytes()); }
+Field::~Field() {
+    if (ptr_ && impl::mirrors_live()) impl::mirror_forget(ptr_);   // the block goes back to the pool: its address will be reused
+    impl::host_free(ptr_, bytes());
+}
 void Field::set_zero() {
+    if (ptr_ && impl::mirrors_live()) impl::mirror_forget(ptr_);
     if (ptr_) std::memset(ptr_, 0, bytes());
 }
 bool Field::operator==(const Field& o) const {
@@ -273,16 +324,16 @@ void cast_into(D* dst, const Field& src) {
 }
 void copy_and_cast(Field& dst, const Field& src) {
     switch (dst.tag()) {
-        case ChanFieldType::UINT8: cast_into(static_cast<uint8_t*>(dst.get()), src); break;
-        case ChanFieldType::UINT16: cast_into(static_cast<uint16_t*>(dst.get()), src); break;
-        case ChanFieldType::UINT32: cast_into(static_cast<uint32_t*>(dst.get()), src); break;
-        case ChanFieldType::UINT64: cast_into(static_cast<uint64_t*>(dst.get()), src); break;
-        case ChanFieldType::INT8: cast_into(static_cast<int8_t*>(dst.get()), src); break;
-        case ChanFieldType::INT16: cast_into(static_cast<int16_t*>(dst.get()), src); break;
-        case ChanFieldType::INT32: cast_into(static_cast<int32_t*>(dst.get()), src); break;
-        case ChanFieldType::INT64: cast_into(static_cast<int64_t*>(dst.get()), src); break;
-        case ChanFieldType::FLOAT32: cast_into(static_cast<float*>(dst.get()), src); break;
-        case ChanFieldType::FLOAT64: cast_into(static_cast<double*>(dst.get()), src); break;
+        case ChanFieldType::UINT8: cast_into(static_cast<uint8_t*>(dst.storage_()), src); break;
+        case ChanFieldType::UINT16: cast_into(static_cast<uint16_t*>(dst.storage_()), src); break;
+        case ChanFieldType::UINT32: cast_into(static_cast<uint32_t*>(dst.storage_()), src); break;
+        case ChanFieldType::UINT64: cast_into(static_cast<uint64_t*>(dst.storage_()), src); break;
+        case ChanFieldType::INT8: cast_into(static_cast<int8_t*>(dst.storage_()), src); break;
+        case ChanFieldType::INT16: cast_into(static_cast<int16_t*>(dst.storage_()), src); break;
+        case ChanFieldType::INT32: cast_into(static_cast<int32_t*>(dst.storage_()), src); break;
+        case ChanFieldType::INT64: cast_into(static_cast<int64_t*>(dst.storage_()), src); break;
+        case ChanFieldType::FLOAT32: cast_into(static_cast<float*>(dst.storage_()), src); break;
+        case ChanFieldType::FLOAT64: cast_into(static_cast<double*>(dst.storage_()), src); break;
         default: throw std::invalid_argument("LidarFrame: cannot cast to element type " + to_string(dst.tag()));
     }
 }
@@ -303,7 +354,7 @@ LidarFrame::LidarFrame(const LidarFrame& other, const LidarFrameFieldTypes& fiel
         if (src.shape() != dst.shape())
             throw std::invalid_argument("Field '" + ft.name +
                                         "' from source frame has dimensions that don't match desired.");
-        if (src.tag() == dst.tag()) std::memcpy(dst.get(), src.get(), src.bytes());
+        if (src.tag() == dst.tag()) std::memcpy(dst.storage_(), src.get(), src.bytes());
         else copy_and_cast(dst, src);
     }
 }
@@ -580,6 +631,10 @@ struct FrameBatcher::State : std::enable_shared_from_this<FrameBatcher::State> {
     std::vector<std::string> fmt_fields;
     std::vector<uint32_t> fmt_elems;
     hip::DeviceBuffer d_packets, d_out;
+    // destaggered planes of the last released frame, kept in HBM (impl::MirrorPlane) and the host planes they belong to
+    std::shared_ptr<hip::DeviceBuffer> d_mirror;
+    std::vector<const void*> mirror_keys;
+    std::shared_ptr<const std::vector<int>> mirror_shifts;
     FrameBatcher::PacketSink sink;  // set: released frames go here instead of being decoded
     // this batcher's own context (stream + scratch) on the GPU that was current when it first needed
     // one: distinct batchers never share mutable GPU state, like the reference's CPU batchers
@@ -591,6 +646,7 @@ struct FrameBatcher::State : std::enable_shared_from_this<FrameBatcher::State> {
     }
 
     ~State() {
+        for (const void* k : mirror_keys) impl::mirror_forget(k);
         if (fmt) ouster_hip_format_destroy(fmt);
     }
 };
@@ -801,6 +857,11 @@ struct BatcherOps {
         void* h_ts = frame.timestamp().data();
         void* h_st = frame.status().data();
         void* h_mid = frame.measurement_id().data();
+        // the planes are about to change: nothing mirrored from them (by this batcher's last release, or anybody's) stays valid
+        for (const void* k : s.mirror_keys) impl::mirror_forget(k);
+        s.mirror_keys.clear();
+        if (impl::mirrors_live())
+            for (Field* f : dst) impl::mirror_forget(f->storage_());
 
         // (1) The frame's planes and headers and the staged packets are pool memory (what LidarFrame and this batcher
         // allocate): ONE launch that reads the packets and writes the frame where they lie.  Input and output cross the link
@@ -808,15 +869,50 @@ struct BatcherOps {
         bool in_place = col_limit >= W && s.staged_count && hip::is_device_accessible(s.staged.data(), s.staged_count * s.stride) &&
                         hip::is_device_accessible(h_ts, W * 8) && hip::is_device_accessible(h_st, W * 4) &&
                         hip::is_device_accessible(h_mid, W * 2);
-        for (size_t i = 0; i < dst.size() && in_place; ++i) in_place = hip::is_device_accessible(dst[i]->get(), H * W * elems[i]);
+        for (size_t i = 0; i < dst.size() && in_place; ++i) in_place = hip::is_device_accessible(dst[i]->storage_(), H * W * elems[i]);
         if (in_place) {
-            for (size_t i = 0; i < dst.size(); ++i) out.planes[i] = dst[i]->get();
+            for (size_t i = 0; i < dst.size(); ++i) out.planes[i] = dst[i]->storage_();
             out.timestamp = static_cast<uint64_t*>(h_ts);
             out.status = static_cast<uint32_t*>(h_st);
             out.measurement_id = static_cast<uint16_t*>(h_mid);
+            // By-product kept in HBM: the destaggered form of every plane nobody holds a writable pointer to (the kernel has
+            // the tile in LDS; the extra stores are HBM stores).  destagger(plane) of the released frame is then one copy out
+            // (26 us per MB) instead of a kernel over the link in both directions (50 us per MB, tools/copybench).
+            static const bool mirror_on = [] { const char* e = std::getenv("OUSTER_HIP_MIRROR"); return !e || std::atoi(e) != 0; }();
+            const std::vector<int>& shifts = s.info->format.pixel_shift_by_row;
+            std::vector<size_t> moff(dst.size(), SIZE_MAX);
+            size_t mtotal = 0;
+            if (mirror_on && shifts.size() == H) {
+                for (size_t i = 0; i < dst.size(); ++i) {
+                    if (dst[i]->writable_escaped_() || (elems[i] != 1 && elems[i] != 2 && elems[i] != 4 && elems[i] != 8)) continue;
+                    moff[i] = mtotal;
+                    mtotal += (H * W * elems[i] + 255) & ~size_t{255};
+                }
+            }
+            if (mtotal) {
+                if (!s.d_mirror || s.d_mirror->size() < mtotal) s.d_mirror = std::make_shared<hip::DeviceBuffer>(mtotal);
+                if (!s.mirror_shifts || *s.mirror_shifts != shifts) s.mirror_shifts = std::make_shared<const std::vector<int>>(shifts);
+                for (size_t i = 0; i < dst.size(); ++i)
+                    if (moff[i] != SIZE_MAX) out.destaggered[i] = static_cast<uint8_t*>(s.d_mirror->data()) + moff[i];
+            }
+            static_assert(sizeof(int) == sizeof(int32_t), "pixel_shift_by_row is handed over as int32");
             hip::check(ouster_hip_decode(ctx, s.fmt, s.staged.data(), s.stride, static_cast<uint32_t>(slots), &count, 1, nullptr,
-                                         &out, nullptr, nullptr, 0));
+                                         &out, mtotal ? reinterpret_cast<const int32_t*>(shifts.data()) : nullptr, nullptr, 0));
             hip::check(ouster_hip_sync(ctx));
+            for (size_t i = 0; i < dst.size() && mtotal; ++i) {
+                if (moff[i] == SIZE_MAX) continue;
+                impl::MirrorPlane m;
+                m.host = dst[i]->storage_();
+                m.d_destaggered = out.destaggered[i];
+                m.h = H;
+                m.w = W;
+                m.elem = elems[i];
+                m.device = s.context()->device();
+                m.shifts = s.mirror_shifts;
+                m.keep = s.d_mirror;
+                impl::mirror_register(m);
+                s.mirror_keys.push_back(m.host);
+            }
             return;
         }
 
@@ -851,7 +947,7 @@ struct BatcherOps {
         s.d_out.download_async(h_st, W * 4, off_st);
         s.d_out.download_async(h_mid, W * 2, off_mid);
         if (col_limit >= W) {
-            for (size_t i = 0; i < dst.size(); ++i) s.d_out.download_async(dst[i]->get(), H * W * elems[i], off[i]);
+            for (size_t i = 0; i < dst.size(); ++i) s.d_out.download_async(dst[i]->storage_(), H * W * elems[i], off[i]);
             hip::check(ouster_hip_sync(ctx));
         } else if (col_limit > 0) {
             hip::check(ouster_hip_sync(ctx));
@@ -859,7 +955,7 @@ struct BatcherOps {
             for (size_t i = 0; i < dst.size(); ++i) {
                 tmp.resize(H * W * elems[i]);
                 s.d_out.download(tmp.data(), tmp.size(), off[i]);
-                uint8_t* out_plane = static_cast<uint8_t*>(dst[i]->get());
+                uint8_t* out_plane = static_cast<uint8_t*>(dst[i]->storage_());
                 for (size_t r = 0; r < H; ++r)
                     std::memcpy(out_plane + r * W * elems[i], tmp.data() + r * W * elems[i], col_limit * elems[i]);
             }

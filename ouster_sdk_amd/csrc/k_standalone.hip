@@ -36,20 +36,125 @@ const FieldC* spec_fields(int spec_id, int* nf, uint32_t* chan, int* r1, int* r2
 
 // ------------------------------------------------------------------------------------
 // k_destagger: dst[img][u][(v + off[u]) % w] = src[img][u][v], element = elem bytes.
-// One workgroup per (row, image); lanes walk the DESTINATION row in 16 B chunks so every
-// store is an aligned, coalesced 16 B vector; the source bytes for a chunk start at an
-// arbitrary byte offset of the source row and are fetched with three aligned dword loads
-// per output dword pair (the row is L1/L2 resident after first touch).
+// One workgroup per (row, image).  The source row is fetched ONCE with aligned 16 B loads into LDS
+// (every byte crosses the memory system -- or, for a host image worked on in place, the PCIe link --
+// exactly once); lanes then walk the DESTINATION row in 16 B chunks so every store is an aligned,
+// coalesced 16 B vector, and assemble each chunk from the LDS image of the row at an arbitrary byte
+// offset (five dword reads and a funnel shift; the wrap point of the rotation is just an index modulo).
+// Rows that do not fit the LDS budget (or are not 16 B granular) take the direct path below.
 //   offset arithmetic: destagger_into, impl/lidar_frame_impl.h:753-759
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_destagger(DestaggerArgs a) {
+constexpr uint32_t DESTAGGER_LDS_MAX = 64u << 10;
+// k_destagger_rows: the same for rows of up to 16 KB, several consecutive rows per workgroup, software pipelined: the
+// aligned 16 B loads of row j + 1 are in flight while row j is assembled from its LDS image and stored.  Matters where the
+// image is host memory worked on in place: with one row per workgroup every workgroup of a one-image launch reads, then every
+// workgroup writes, and the two directions of the link are used one after the other (1 MB: 50 us); pipelined, they overlap.
+template <int CH>
+__global__ __launch_bounds__(256) void k_destagger_rows(DestaggerArgs a, uint32_t rows_per_wg) {
+    extern __shared__ uint4 s_row[];   // 2 x row
+    const uint32_t img = blockIdx.y;
+    const size_t row_bytes = (size_t)a.w * a.elem;
+    const uint32_t nchunk = (uint32_t)(row_bytes >> 4), ndw = nchunk * 4;
+    const uint32_t r0 = blockIdx.x * rows_per_wg, r1 = min(a.h, r0 + rows_per_wg);
+    const uint8_t* sbase = (const uint8_t*)a.src + (size_t)img * a.h * row_bytes;
+    uint8_t* dbase = (uint8_t*)a.dst + (size_t)img * a.h * row_bytes;
+    uint4 regs[CH];
+    auto fetch = [&](uint32_t u) {
+        const uint4* srow = (const uint4*)(sbase + (size_t)u * row_bytes);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const uint32_t i = threadIdx.x + k * 256;
+            if (i < nchunk) regs[k] = srow[i];
+        }
+    };
+    if (r0 < r1) fetch(r0);
+    for (uint32_t u = r0; u < r1; ++u) {
+        uint4* buf = s_row + ((u - r0) & 1) * nchunk;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const uint32_t i = threadIdx.x + k * 256;
+            if (i < nchunk) buf[i] = regs[k];
+        }
+        __syncthreads();
+        if (u + 1 < r1) fetch(u + 1);
+        const uint32_t* s_dw = (const uint32_t*)buf;
+        const uint32_t sb0 = (uint32_t)(row_bytes - (size_t)a.offsets[u] * a.elem);
+        const uint32_t sh = (sb0 & 3) * 8;
+        uint8_t* drow = dbase + (size_t)u * row_bytes;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const uint32_t i = threadIdx.x + k * 256;
+            if (i >= nchunk) break;
+            uint32_t dw = (sb0 >> 2) + i * 4;
+            if (dw >= ndw) dw -= ndw;
+            uint32_t d[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                uint32_t j = dw + q;
+                if (j >= ndw) j -= ndw;
+                d[q] = s_dw[j];
+            }
+            typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+            v4 o;
+            if (sh == 0) {
+                o = v4{d[0], d[1], d[2], d[3]};
+            } else {
+                o = v4{(d[0] >> sh) | (d[1] << (32 - sh)), (d[1] >> sh) | (d[2] << (32 - sh)),
+                       (d[2] >> sh) | (d[3] << (32 - sh)), (d[3] >> sh) | (d[4] << (32 - sh))};
+            }
+#if OUSTER_NT_STANDALONE
+            __builtin_nontemporal_store(o, (v4*)(drow + ((size_t)i << 4)));
+#else
+            *(v4*)(drow + ((size_t)i << 4)) = o;
+#endif
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_destagger(DestaggerArgs a, uint32_t lds_row) {
+    extern __shared__ uint4 s_row[];
     const uint32_t u = blockIdx.x, img = blockIdx.y;
     const size_t row_bytes = (size_t)a.w * a.elem;
     const uint8_t* srow = (const uint8_t*)a.src + ((size_t)img * a.h + u) * row_bytes;
     uint8_t* drow = (uint8_t*)a.dst + ((size_t)img * a.h + u) * row_bytes;
     const size_t shift_bytes = (size_t)a.offsets[u] * a.elem;  // dst byte b <- src byte (b - shift) mod row
     const bool fast = ((row_bytes & 15) == 0) && ((((uintptr_t)a.src | (uintptr_t)a.dst) & 15) == 0);
-    if (fast) {
+    if (fast && lds_row) {
+        const uint32_t nchunk = (uint32_t)(row_bytes >> 4), ndw = nchunk * 4;
+        for (uint32_t i = threadIdx.x; i < nchunk; i += blockDim.x) s_row[i] = ((const uint4*)srow)[i];
+        __syncthreads();
+        const uint32_t* s_dw = (const uint32_t*)s_row;
+        const uint32_t sb0 = (uint32_t)(row_bytes - shift_bytes);   // source byte of destination byte 0 (== row_bytes: no shift)
+        const uint32_t sh = (sb0 & 3) * 8;
+        for (uint32_t i = threadIdx.x; i < nchunk; i += blockDim.x) {
+            uint32_t dw = (sb0 >> 2) + i * 4;     // first source dword of this chunk, before the wrap
+            if (dw >= ndw) dw -= ndw;
+            uint32_t d[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                uint32_t j = dw + k;
+                if (j >= ndw) j -= ndw;
+                d[k] = s_dw[j];
+            }
+            uint4 o;
+            if (sh == 0) {
+                o = make_uint4(d[0], d[1], d[2], d[3]);
+            } else {
+                o.x = (d[0] >> sh) | (d[1] << (32 - sh));
+                o.y = (d[1] >> sh) | (d[2] << (32 - sh));
+                o.z = (d[2] >> sh) | (d[3] << (32 - sh));
+                o.w = (d[3] >> sh) | (d[4] << (32 - sh));
+            }
+#if OUSTER_NT_STANDALONE
+            {
+                typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(v4{o.x, o.y, o.z, o.w}, (v4*)(drow + ((size_t)i << 4)));
+            }
+#else
+            *(uint4*)(drow + ((size_t)i << 4)) = o;
+#endif
+        }
+    } else if (fast) {
         const uint32_t nchunk = (uint32_t)(row_bytes >> 4);
         for (uint32_t i = threadIdx.x; i < nchunk; i += blockDim.x) {
             const size_t db = (size_t)i << 4;
@@ -79,14 +184,7 @@ __global__ __launch_bounds__(256) void k_destagger(DestaggerArgs a) {
                     o[k] = b[4 * k] | (b[4 * k + 1] << 8) | (b[4 * k + 2] << 16) |
                            ((uint32_t)b[4 * k + 3] << 24);
             }
-#if OUSTER_NT_STANDALONE
-            {
-                typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(v4{o[0], o[1], o[2], o[3]}, (v4*)(drow + db));
-            }
-#else
             *(uint4*)(drow + db) = make_uint4(o[0], o[1], o[2], o[3]);
-#endif
         }
     } else {
         for (size_t b = threadIdx.x; b < row_bytes; b += blockDim.x) {
@@ -1717,7 +1815,24 @@ hipError_t launch_slotmap(const DecodeArgs& a, int device, hipStream_t st) {
 
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st) {
     dim3 grid(a.h, n_images);
-    hipLaunchKernelGGL(k_destagger, grid, dim3(256), 0, st, a);
+    const size_t row_bytes = (size_t)a.w * a.elem;
+    const bool al = (row_bytes % 16 == 0) && ((((uintptr_t)a.src | (uintptr_t)a.dst) & 15) == 0);
+    static const int rows_env = [] { const char* e = getenv("OUSTER_HIP_DESTAGGER_ROWS"); return e ? atoi(e) : -1; }();   // A/B
+    if (al && row_bytes <= (16u << 10) && rows_env != 0) {
+        // rows per workgroup: 4 for a single image (32 workgroups keep both directions of a PCIe link busy); large batches
+        // keep >= 2048 workgroups for the HBM case
+        uint32_t rpw = rows_env > 0 ? (uint32_t)rows_env : 4u;
+        while (rpw > 1 && (size_t)((a.h + rpw - 1) / rpw) * n_images < 2048 && n_images > 1) rpw /= 2;
+        const uint32_t nchunk = (uint32_t)(row_bytes >> 4), ch = (nchunk + 255) / 256;
+        dim3 g2((a.h + rpw - 1) / rpw, n_images);
+        const uint32_t lds2 = 2u * (uint32_t)row_bytes;
+        if (ch <= 1) hipLaunchKernelGGL(k_destagger_rows<1>, g2, dim3(256), lds2, st, a, rpw);
+        else if (ch <= 2) hipLaunchKernelGGL(k_destagger_rows<2>, g2, dim3(256), lds2, st, a, rpw);
+        else hipLaunchKernelGGL(k_destagger_rows<4>, g2, dim3(256), lds2, st, a, rpw);
+        return hipGetLastError();
+    }
+    const uint32_t lds = (al && row_bytes <= DESTAGGER_LDS_MAX) ? (uint32_t)row_bytes : 0u;
+    hipLaunchKernelGGL(k_destagger, grid, dim3(256), lds, st, a, lds);
     return hipGetLastError();
 }
 

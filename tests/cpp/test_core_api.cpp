@@ -1449,7 +1449,201 @@ static void test_frame_under_assembly() {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// round 6: the frame-at-a-time API on host containers -- pool memory worked on in place, the HBM mirror of a released
+// frame's destaggered planes, foreign memory through the context's scratch, and the steady-state allocation contract
+// ---------------------------------------------------------------------------------------
+template <typename T>
+static bool is_roll(const ImgRef<const T>& img, const img_t<T>& d, const std::vector<int>& shifts) {
+    const size_t h = img.rows(), w = img.cols();
+    if (d.rows() != h || d.cols() != w) return false;
+    for (size_t r = 0; r < h; ++r) {
+        const size_t off = (w + static_cast<size_t>(static_cast<long long>(shifts[r])) % w) % w;   // the reference's size_t arithmetic
+        for (size_t c = 0; c < w; ++c)
+            if (d(r, (c + off) % w) != img(r, c)) return false;
+    }
+    return true;
+}
+static bool cloud_matches(const PointCloudXYZd& pts, const ImgRef<const uint32_t>& range, const XYZLut& lut) {
+    for (size_t i = 0; i < range.size(); ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double want = range(i) ? range(i) * lut.direction(i, k) + lut.offset(i, k) : 0.0;
+            if (std::fabs(pts(i, k) - want) > 1e-4 || (!range(i) && pts(i, k) != 0.0)) return false;
+        }
+    return true;
+}
+
+static void test_dropin_host_containers() {
+    std::printf("drop-in: pool containers, mirror, steady-state allocations\n");
+    auto info = make_info(UDPProfileLidar::RNG15_RFL8_NIR8_DUAL, HeaderType::STANDARD, 128, 1024);
+    auto sinfo = std::make_shared<SensorInfo>(info);
+    auto pf = std::make_shared<PacketFormat>(info);
+    const std::vector<int>& shifts = info.format.pixel_shift_by_row;
+    XYZLut lut(info, false);
+    LidarFrame src(sinfo);
+    LidarFrame frame(sinfo);
+    const LidarFrame& cframe = frame;
+    // the library's containers are pool memory the GPU reaches in place
+    CHECK(ouster::sdk::hip::is_device_accessible(cframe.field(ChanField::RANGE).get(), 128 * 1024 * 4));
+    {
+        img_t<uint32_t> probe(128, 1024);
+        CHECK(ouster::sdk::hip::is_device_accessible(probe.data(), probe.size() * 4));
+        std::vector<uint32_t> heap(128 * 1024);
+        CHECK(!ouster::sdk::hip::is_device_accessible(heap.data(), heap.size() * 4));
+    }
+    FrameBatcher batcher(sinfo);
+    int64_t next_frame_id = 100;
+    auto release = [&](uint64_t seed) {
+        randomize(src, *pf, seed);
+        src.frame_id = next_frame_id++;   // a frame id that went backwards would be a late frame: dropped
+        bool done = false;
+        for (auto& p : impl::frame_to_packets(src, pf, info.init_id, info.sn)) done = batcher(p, frame);
+        return done;
+    };
+    // -- steady state: no device allocation, no page-locking call, every container out of the pool ------------------
+    ouster::sdk::hip::AllocStats a0{}, a1{};
+    bool all_ok = true;
+    for (int f = 0; f < 104; ++f) {
+        if (f == 4) a0 = ouster::sdk::hip::alloc_stats();
+        all_ok &= release(1000 + f);
+        auto d1 = destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE));          // served from the mirror
+        auto d2 = destagger<uint8_t>(info, cframe.field<uint8_t>(ChanField::REFLECTIVITY2));
+        auto d3 = destagger<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE2), shifts, true);  // inverse: the kernel, in place
+        auto pts = lut(cframe);
+        if (f % 13 == 0 || f == 103) {
+            all_ok &= planes_equal(src, cframe, *pf);
+            all_ok &= is_roll<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE), d1, shifts);
+            all_ok &= is_roll<uint8_t>(cframe.field<uint8_t>(ChanField::REFLECTIVITY2), d2, shifts);
+            {   // stagger then destagger gives the plane back
+                const auto back = destagger<uint32_t>(d3, shifts);
+                all_ok &= std::memcmp(back.data(), cframe.field<uint32_t>(ChanField::RANGE2).data(), back.size() * 4) == 0;
+            }
+            all_ok &= cloud_matches(pts, cframe.field<uint32_t>(ChanField::RANGE), lut);
+        }
+    }
+    a1 = ouster::sdk::hip::alloc_stats();
+    CHECK(all_ok);
+    CHECK(a1.device_allocs == a0.device_allocs);     // 100 frames x (batch + 3 destaggers + XYZLut): nothing allocated on the device
+    CHECK(a1.pinned_allocs == a0.pinned_allocs);     // ... no hipHostMalloc either
+    CHECK(a1.pool_requests - a0.pool_requests == a1.pool_hits - a0.pool_hits);
+    CHECK(a1.pool_requests - a0.pool_requests >= 400);
+    std::printf("  100 steady-state frames: device allocs +%llu, pinned allocs +%llu, pool %llu / %llu hits\n",
+                (unsigned long long)(a1.device_allocs - a0.device_allocs), (unsigned long long)(a1.pinned_allocs - a0.pinned_allocs),
+                (unsigned long long)(a1.pool_hits - a0.pool_hits), (unsigned long long)(a1.pool_requests - a0.pool_requests));
+
+    // -- the mirror never outlives the data it was made from -----------------------------------------------------------
+    CHECK(release(7));
+    CHECK(impl::mirrors_live());
+    auto before = destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE));
+    CHECK(is_roll<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE), before, shifts));
+    // (a) other shifts than the sensor's: not the mirrored form
+    std::vector<int> other(shifts);
+    other[5] += 3;
+    CHECK(is_roll<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE), destagger<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE), other), other));
+    // (b) a writable view is handed out and written through: the next destagger sees the new contents
+    {
+        auto rw = frame.field<uint32_t>(ChanField::RANGE);
+        rw(3, 17) ^= 0x5a5a;
+        rw(127, 1023) = 424242;
+    }
+    auto after = destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE));
+    CHECK(is_roll<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE), after, shifts));
+    CHECK(!(after == before));
+    // ... and that field is never mirrored again (the view may still be around), the others are
+    CHECK(release(8));
+    {
+        auto d = destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE));
+        CHECK(is_roll<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE), d, shifts));
+        CHECK(cframe.field(ChanField::RANGE).writable_escaped_() && !cframe.field(ChanField::RANGE2).writable_escaped_());
+    }
+    // (c) a pointer taken BEFORE the release and written through AFTER it
+    {
+        LidarFrame fr2(sinfo);
+        uint16_t* nir = fr2.field(ChanField::NEAR_IR);   // FieldView conversion: writable
+        FrameBatcher b2(sinfo);
+        randomize(src, *pf, 99);
+        bool done = false;
+        for (auto& p : impl::frame_to_packets(src, pf, info.init_id, info.sn)) done = b2(p, fr2);
+        CHECK(done);
+        nir[1024 * 5 + 9] = 0xbeef;
+        const LidarFrame& c2 = fr2;
+        auto d = destagger<uint16_t>(info, c2.field<uint16_t>(ChanField::NEAR_IR));
+        CHECK(is_roll<uint16_t>(c2.field<uint16_t>(ChanField::NEAR_IR), d, shifts));
+        const size_t off = (1024 + static_cast<size_t>(static_cast<long long>(shifts[5])) % 1024) % 1024;
+        CHECK(d(5, (9 + off) % 1024) == 0xbeef);
+        // (d) set_zero, copies and moved frames
+        auto dr2 = destagger<uint32_t>(info, c2.field<uint32_t>(ChanField::RANGE2));
+        LidarFrame copy(fr2);
+        const LidarFrame& ccopy = copy;
+        CHECK(destagger<uint32_t>(info, ccopy.field<uint32_t>(ChanField::RANGE2)) == dr2);
+        LidarFrame moved(std::move(fr2));
+        const LidarFrame& cmoved = moved;
+        CHECK(destagger<uint32_t>(info, cmoved.field<uint32_t>(ChanField::RANGE2)) == dr2);   // the storage moved with its mirror
+        moved.field(ChanField::RANGE2).set_zero();
+        CHECK(destagger<uint32_t>(info, cmoved.field<uint32_t>(ChanField::RANGE2)) == img_t<uint32_t>(128, 1024));
+    }   // (e) b2 and its frames are gone: their storage goes back to the pool and is handed out again below
+    {
+        img_t<uint32_t> fresh(128, 1024);
+        for (size_t i = 0; i < fresh.size(); ++i) fresh.data()[i] = static_cast<uint32_t>(i * 2654435761u);
+        CHECK(is_roll<uint32_t>(ImgRef<const uint32_t>(fresh), destagger<uint32_t>(fresh, shifts), shifts));
+    }
+    // (f) the batcher decodes the next frame into the same LidarFrame: new contents, new mirror
+    CHECK(release(9));
+    auto r2a = destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE2));
+    CHECK(release(10));
+    auto r2b = destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE2));
+    CHECK(is_roll<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE2), r2b, shifts) && !(r2a == r2b));
+    // (g) a second batcher decodes into the frame the first one mirrored
+    {
+        FrameBatcher b3(sinfo);
+        randomize(src, *pf, 11);
+        src.frame_id = 4242;   // b3 has seen no frame yet
+        bool done = false;
+        for (auto& p : impl::frame_to_packets(src, pf, info.init_id, info.sn)) done = b3(p, frame);
+        CHECK(done && planes_equal(src, cframe, *pf));
+        CHECK(is_roll<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE2), destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE2)), shifts));
+    }
+    CHECK(is_roll<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE2), destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE2)), shifts));
+
+    // -- memory the pool has never seen: a caller's own arrays go through the context's scratch, same results ----------
+    {
+        std::mt19937 g(5);
+        std::vector<uint32_t> own(128 * 1024), own_out(128 * 1024);
+        for (auto& v : own) v = (g() % 4 == 0) ? 0 : g() % (1u << 19);
+        destagger_into<uint32_t>(ImgRef<const uint32_t>(own.data(), 128, 1024), shifts, false, ImgRef<uint32_t>(own_out.data(), 128, 1024));
+        img_t<uint32_t> as_img(128, 1024);
+        std::memcpy(as_img.data(), own_out.data(), own_out.size() * 4);
+        CHECK(is_roll<uint32_t>(ImgRef<const uint32_t>(own.data(), 128, 1024), as_img, shifts));
+        auto pts = lut(ImgRef<const uint32_t>(own.data(), 128, 1024));
+        CHECK(cloud_matches(pts, ImgRef<const uint32_t>(own.data(), 128, 1024), lut));
+        ouster::sdk::hip::AllocStats s0{};
+        for (int i = 0; i < 21; ++i) {
+            if (i == 1) s0 = ouster::sdk::hip::alloc_stats();   // the first pass sizes the context's scratch
+            destagger_into<uint32_t>(ImgRef<const uint32_t>(own.data(), 128, 1024), shifts, false, ImgRef<uint32_t>(own_out.data(), 128, 1024));
+            std::vector<double> cloud(128 * 1024 * 3);
+            impl::cartesian_device(lut.device(), own.data(), own.size(), cloud.data(), true);
+        }
+        const auto s1 = ouster::sdk::hip::alloc_stats();
+        CHECK(s1.device_allocs == s0.device_allocs && s1.pinned_allocs == s0.pinned_allocs);
+    }
+    // a frame too small for pool blocks (plain heap memory) still batches and destaggers
+    {
+        auto tiny = make_info(UDPProfileLidar::RNG19_RFL8_SIG16_NIR16, HeaderType::STANDARD, 16, 64);
+        auto tinfo = std::make_shared<SensorInfo>(tiny);
+        auto tpf = std::make_shared<PacketFormat>(tiny);
+        LidarFrame a(tinfo), b(tinfo);
+        randomize(a, *tpf, 3);
+        FrameBatcher tb(tinfo);
+        bool done = false;
+        for (auto& p : impl::frame_to_packets(a, tpf, tiny.init_id, tiny.sn)) done = tb(p, b);
+        const LidarFrame& cb = b;
+        CHECK(done && planes_equal(a, cb, *tpf));
+        CHECK(is_roll<uint32_t>(cb.field<uint32_t>(ChanField::RANGE), destagger<uint32_t>(tiny, cb.field<uint32_t>(ChanField::RANGE)), tiny.format.pixel_shift_by_row));
+    }
+}
+
 int main() {
+    test_dropin_host_containers();
     test_frame_under_assembly();
     test_threads_and_contexts();
     test_field_conversions();

@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
     LidarFrame frame(sinfo);
     const LidarFrame& cframe = frame;   // a reader of the released frame
     FrameBatcher batcher(sinfo);
-    std::vector<double> t_batch, t_d32, t_d8, t_xyz, t_total;
+    std::vector<double> t_batch, t_release, t_d32, t_d8, t_xyz, t_total;
     ouster::sdk::hip::AllocStats a0{}, a1{};
     bool same = true;
     for (int f = -3; f < frames; ++f) {  // three warm-up frames (the pool and the scratch see every size once)
@@ -73,7 +73,9 @@ int main(int argc, char** argv) {
         auto packets = impl::frame_to_packets(src, pf, info.init_id, 1);
         auto t0 = clk::now();
         bool done = false;
-        for (auto& p : packets) done = batcher(p, frame);
+        for (size_t k = 0; k + 1 < packets.size(); ++k) done = batcher(packets[k], frame);
+        auto t0r = clk::now();
+        done = batcher(packets.back(), frame);   // the call that releases the frame: the one GPU launch
         auto t1 = clk::now();
         auto d1 = destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE));
         auto t2 = clk::now();
@@ -95,6 +97,7 @@ int main(int argc, char** argv) {
         }
         if (f >= 0) {
             t_batch.push_back(ms(t0, t1));
+            t_release.push_back(ms(t0r, t1));
             t_d32.push_back((ms(t1, t2) + ms(t2, t3)) / 2);
             t_d8.push_back(ms(t3, t4) / 2);
             t_xyz.push_back((ms(t4, t5) + ms(t5, t6)) / 2);
@@ -103,12 +106,12 @@ int main(int argc, char** argv) {
     }
     a1 = ouster::sdk::hip::alloc_stats();
     auto mean = [&](const std::vector<double>& v) { double s = 0; for (double x : v) s += x; return s / v.size(); };
-    std::printf("{\"frames\": %d, \"ms_per_frame\": {\"FrameBatcher_128_packets\": %.4f, \"destagger_u32\": %.4f, \"destagger_u8\": %.4f, "
+    std::printf("{\"frames\": %d, \"ms_per_frame\": {\"FrameBatcher_128_packets\": %.4f, \"FrameBatcher_release_call\": %.4f, \"destagger_u32\": %.4f, \"destagger_u8\": %.4f, "
                 "\"XYZLut_f64\": %.4f, \"frame_total\": %.4f}, \"median_ms\": {\"FrameBatcher_128_packets\": %.4f, \"destagger_u32\": %.4f, "
                 "\"XYZLut_f64\": %.4f, \"frame_total\": %.4f}, \"frame_total_is\": \"batch x128 + destagger RANGE RANGE2 REFLECTIVITY REFLECTIVITY2 + XYZLut() of RANGE and RANGE2 (f64)\", "
                 "\"frame_matches_source\": %s, \"allocations_in_timed_frames\": {\"device\": %llu, \"pinned\": %llu, \"pool_requests\": %llu, \"pool_hits\": %llu}, "
                 "\"note\": \"host containers in/out; planes, images and clouds are pool (page-locked) memory the kernels read and write in place\"}\n",
-                frames, mean(t_batch), mean(t_d32), mean(t_d8), mean(t_xyz), mean(t_total), median(t_batch), median(t_d32), median(t_xyz), median(t_total),
+                frames, mean(t_batch), mean(t_release), mean(t_d32), mean(t_d8), mean(t_xyz), mean(t_total), median(t_batch), median(t_d32), median(t_xyz), median(t_total),
                 same ? "true" : "false", (unsigned long long)(a1.device_allocs - a0.device_allocs), (unsigned long long)(a1.pinned_allocs - a0.pinned_allocs),
                 (unsigned long long)(a1.pool_requests - a0.pool_requests), (unsigned long long)(a1.pool_hits - a0.pool_hits));
     return same ? 0 : 2;

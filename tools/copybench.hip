@@ -71,6 +71,22 @@ int main() {
         hipLaunchKernelGGL(k_copy16, 256, 256, 0, st, (const uint4*)d_a, (uint4*)d_b, (size_t)(1u << 16));
         CK(hipMemcpyAsync(pin, d_b, 1u << 20, hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st)); }));
+    {   // host -> host through a kernel (what destagger on pool containers is), and how the wait is done
+        uint8_t* pin2;
+        CK(hipHostMalloc((void**)&pin2, maxb, hipHostMallocDefault));
+        const size_t n16 = (1u << 20) / 16;
+        for (int wg : {32, 128, 512}) {
+            std::printf(" \"inplace_1MB_host_to_host_%dwg_sync_us\": %.2f,\n", wg, mean_of(100, [&] { hipLaunchKernelGGL(k_copy16, wg, 256, 0, st, (const uint4*)pin, (uint4*)pin2, n16); CK(hipStreamSynchronize(st)); }));
+            std::printf(" \"inplace_1MB_host_to_host_%dwg_queryspin_us\": %.2f,\n", wg, mean_of(100, [&] { hipLaunchKernelGGL(k_copy16, wg, 256, 0, st, (const uint4*)pin, (uint4*)pin2, n16); while (hipStreamQuery(st) == hipErrorNotReady) {} }));
+        }
+        std::printf(" \"launch_queryspin_us\": %.2f,\n", mean_of(200, [&] { hipLaunchKernelGGL(k_empty, 1, 64, 0, st); while (hipStreamQuery(st) == hipErrorNotReady) {} }));
+        hipEvent_t e;
+        CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        std::printf(" \"inplace_1MB_host_to_host_128wg_eventsync_us\": %.2f,\n", mean_of(100, [&] { hipLaunchKernelGGL(k_copy16, 128, 256, 0, st, (const uint4*)pin, (uint4*)pin2, n16); CK(hipEventRecord(e, st)); CK(hipEventSynchronize(e)); }));
+        std::printf(" \"inplace_6MB_dev_to_host_sync_us\": %.2f,\n", mean_of(50, [&] { hipLaunchKernelGGL(k_copy16, 1024, 256, 0, st, (const uint4*)d_a, (uint4*)pin2, (size_t)6291456 / 16); CK(hipStreamSynchronize(st)); }));
+        std::printf(" \"inplace_6MB_dev_to_host_queryspin_us\": %.2f,\n", mean_of(50, [&] { hipLaunchKernelGGL(k_copy16, 1024, 256, 0, st, (const uint4*)d_a, (uint4*)pin2, (size_t)6291456 / 16); while (hipStreamQuery(st) == hipErrorNotReady) {} }));
+        CK(hipHostFree(pin2));
+    }
     {
         void* p = nullptr;
         std::printf(" \"hipMalloc_free_1MB_us\": %.2f,\n", mean_of(50, [&] { CK(hipMalloc(&p, 1u << 20)); CK(hipFree(p)); }));
