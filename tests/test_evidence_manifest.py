@@ -15,7 +15,7 @@ CPP_TESTS = ("packet_format_test", "frame_batcher_test", "profile_extension_test
              "cartesian_test", "lidar_frame_test", "parsing_benchmark_test", "pcap_test")
 PY_TESTS = ("test_xyzlut.py", "test_destagger.py", "test_batching.py", "test_parsing.py", "test_data.py", "test_core.py",
             "test_extended_profiles.py", "test_pcap.py", "multi.py", "examples/reference.py", "core/_digest.py")
-LIBS = ("libcore_ref.so", "libdecode_ref.so", "libdewarp_ref.so", "libzpng_ref.so")
+LIBS = ("libcore_ref.so", "libdecode_ref.so", "libdewarp_ref.so", "libzpng_ref.so", "libhotpath_ref.so", "libcore_ref_omp.so")
 
 
 def _built_from_reference():
