@@ -132,6 +132,36 @@ def algorithmic_bytes_per_frame(workload: str = "dual") -> int:
     return pkts + H * W * plane_b + H * W * dst_b + len(xyz_names) * H * W * 3 * 4
 
 
+def usable_cores():
+    """Host cores this process may actually keep busy: the affinity mask capped by the cgroup CPU quota.  (os.cpu_count() says
+    256 on the GPU boxes; round 6's first all-core run got 3 x one core out of 256 spinning threads and 2 Mpoints/s out of the
+    reference's OpenMP cartesian -- a quota a fraction of the machine wide throttles a team that size.)  Returns
+    (threads to use, {how it was derived})."""
+    n_aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    info = {"cpu_count": os.cpu_count(), "affinity": n_aff, "cgroup_quota_cores": None}
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:            # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:   # cgroup v1
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    n = n_aff
+    if quota is not None:
+        info["cgroup_quota_cores"] = round(quota, 2)
+        n = max(1, min(n_aff, int(quota + 0.5)))
+    return n, info
+
+
 def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 8.0):
     """The reference's CPU path on a bounded sample, timed on this box's host cores.
 
@@ -152,7 +182,7 @@ def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 8.0):
     flat = np.ascontiguousarray(pool)
     sh = np.ascontiguousarray(shifts, dtype=np.int32)
     cks = C.c_uint64()
-    cores = os.cpu_count() or 1
+    cores, core_info = usable_cores()
     pts_per_frame = H * W * 2
     bpp = algorithmic_bytes_per_frame("dual") / pts_per_frame
 
@@ -223,7 +253,7 @@ def cpu_baseline(pool: np.ndarray, shifts, target_s: float = 8.0):
         ta = run_all(ra, 3)
         cp_bytes, cp_reps = 64 << 20, 8
         tcopy = O.lib().ora_bench_stream_copy(cp_bytes, cp_reps, threads)
-        allc = {"cores": threads, "host_cores": cores,
+        allc = {"cores": threads, "host_cores": core_info,
                 "port_value": round(nv * ra * pts_per_frame / ta / 1e6, 1),
                 "stream_copy_GBps_same_threads": round(2.0 * cp_bytes * cp_reps * threads / tcopy / 1e9, 1),
                 "note": "GBps counts SURVEY 8(d)'s algorithmic bytes; the f64 path also reads 2 x 24 B of LUT per point, so its "

@@ -45,10 +45,10 @@ const FieldC* spec_fields(int spec_id, int* nf, uint32_t* chan, int* r1, int* r2
 //   offset arithmetic: destagger_into, impl/lidar_frame_impl.h:753-759
 // ------------------------------------------------------------------------------------
 constexpr uint32_t DESTAGGER_LDS_MAX = 64u << 10;
-// k_destagger_rows: the same for rows of up to 16 KB, several consecutive rows per workgroup, software pipelined: the
-// aligned 16 B loads of row j + 1 are in flight while row j is assembled from its LDS image and stored.  Matters where the
-// image is host memory worked on in place: with one row per workgroup every workgroup of a one-image launch reads, then every
-// workgroup writes, and the two directions of the link are used one after the other (1 MB: 50 us); pipelined, they overlap.
+// k_destagger_rows: the same for short rows, several consecutive rows per workgroup, software pipelined: the aligned 16 B
+// loads of row j + 1 are in flight while row j is assembled from its LDS image and stored.  (Built to overlap the two
+// directions of the PCIe link for a host image worked on in place; it does not -- a kernel that reads and writes host memory
+// gets 1 MB in + 1 MB out in 50 us whatever its shape, tools/copybench -- but it is the faster form for 8 / 16-bit planes in HBM.)
 template <int CH>
 __global__ __launch_bounds__(256) void k_destagger_rows(DestaggerArgs a, uint32_t rows_per_wg) {
     extern __shared__ uint4 s_row[];   // 2 x row
@@ -1818,11 +1818,11 @@ hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream
     const size_t row_bytes = (size_t)a.w * a.elem;
     const bool al = (row_bytes % 16 == 0) && ((((uintptr_t)a.src | (uintptr_t)a.dst) & 15) == 0);
     static const int rows_env = [] { const char* e = getenv("OUSTER_HIP_DESTAGGER_ROWS"); return e ? atoi(e) : -1; }();   // A/B
-    if (al && row_bytes <= (16u << 10) && rows_env != 0) {
-        // rows per workgroup: 4 for a single image (32 workgroups keep both directions of a PCIe link busy); large batches
-        // keep >= 2048 workgroups for the HBM case
-        uint32_t rpw = rows_env > 0 ? (uint32_t)rows_env : 4u;
-        while (rpw > 1 && (size_t)((a.h + rpw - 1) / rpw) * n_images < 2048 && n_images > 1) rpw /= 2;
+    if (al && row_bytes <= (rows_env > 0 ? (16u << 10) : (4u << 10)) && rows_env != 0) {
+        // rows of up to 4 KB (8 / 16-bit planes of a 2048-column frame): two rows per workgroup, pipelined -- 0.77 / 0.79 of the HBM
+        // roofline on 256 images against 0.72 / 0.75 for one row per workgroup (round 6, same box); 8 KB rows (32-bit planes)
+        // lose with this form (0.50 against 0.76) and stay on k_destagger
+        uint32_t rpw = rows_env > 0 ? (uint32_t)rows_env : 2u;
         const uint32_t nchunk = (uint32_t)(row_bytes >> 4), ch = (nchunk + 255) / 256;
         dim3 g2((a.h + rpw - 1) / rpw, n_images);
         const uint32_t lds2 = 2u * (uint32_t)row_bytes;
