@@ -890,10 +890,20 @@ def main():
                                                     stride_gb=args.placement_stride_gb)
         placement["mode"] = "draws"
     elif args.placement == "refine":
-        t_setup = time.perf_counter()
-        out, placement = hp.refine_placement(packets, out, draws=args.placement_draws, ballast_gb=args.placement_ballast_gb)
-        placement["mode"] = "refine"
-        placement["setup_s"] = round(time.perf_counter() - t_setup, 3)
+        # the search holds (draws - 1) more copies of the output set (+ ballast): not where the device memory left to this rank
+        # is short (N ranks of a test on one device; a shared GPU) -- then the first allocation stands and the line says so
+        out_bytes = sum(v.numel() * v.element_size() for v in out.values())
+        need = (args.placement_draws - 1) * (out_bytes + int(args.placement_ballast_gb * (1 << 30)))
+        free_b, total_b = torch.cuda.mem_get_info()
+        share = free_b // (world if one_device else 1)
+        if share < need + need // 4 + (2 << 30):
+            placement = {"mode": "first", "skipped": f"placement search needs {need >> 20} MB transient, {share >> 20} MB of device "
+                                                     f"memory free for this rank ({free_b >> 20} MB free in all): first allocation kept"}
+        else:
+            t_setup = time.perf_counter()
+            out, placement = hp.refine_placement(packets, out, draws=args.placement_draws, ballast_gb=args.placement_ballast_gb)
+            placement["mode"] = "refine"
+            placement["setup_s"] = round(time.perf_counter() - t_setup, 3)
     for _ in range(args.warmup):
         hp.decode(packets, out)
     torch.cuda.synchronize()
@@ -958,10 +968,26 @@ def main():
                 "what": "pinned H2D packets + decode + D2H XYZ f32, serialized"}
 
     elapsed = t1 - t0
+    per_rank = None
     if world > 1:
+        # every rank's own view next to the max the line is computed from: a slow rank, or one whose tuner settled on another
+        # kernel, must be visible in a SCALE record (rank 0 would otherwise speak for all of them)
+        mine = {"rank": rank, "ms_per_step": round((t1 - t0) / args.steps * 1e3, 4), "kernel_ms": round(kern_ms, 4),
+                "kernel": f"{kern} {tc}x{tr}", "device": torch.cuda.current_device(),
+                "placement": (placement or {}).get("mode", "first") + (":skipped" if (placement or {}).get("skipped") else "")}
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        kernels = {}
+        for r_ in rows:
+            kernels[r_["kernel"]] = kernels.get(r_["kernel"], 0) + 1
+        per_rank = {"ms_min": min(r_["ms_per_step"] for r_ in rows), "ms_max": max(r_["ms_per_step"] for r_ in rows),
+                    "kernel_ms_min": min(r_["kernel_ms"] for r_ in rows), "kernel_ms_max": max(r_["kernel_ms"] for r_ in rows),
+                    "kernel": kernels, "slowest_rank": max(rows, key=lambda r_: r_["ms_per_step"])["rank"],
+                    "placement": sorted({r_["placement"] for r_ in rows}),
+                    "note": "ms_* are each rank's own timed region (its barrier wait included); `ms_per_step` of the line is the max"}
 
     exchange = None
     if args.exchange:
@@ -1146,6 +1172,8 @@ def main():
             line["roofline"]["searched_placement_frac_step"] = round(bytes_per_launch / (rep["kept_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         line["rccl_ranks"] = rccl_ranks
         line["collective_backend"] = coll
+        if per_rank:
+            line["per_rank"] = per_rank
         if exchange:
             line["exchange"] = exchange
         if pcie:

@@ -1137,6 +1137,7 @@ static void test_sharded_batch() {
     const int ndev = ouster::sdk::hip::device_count();
     std::vector<std::vector<int>> layouts = {{}};               // one shard per visible GPU
     layouts.push_back({0, 0, 0});                               // three shards on GPU 0: the exchange path on a one-GPU box
+    layouts.push_back({0, 0, 0, 0, 0, 0, 0, 0});                // the shape of a full node (8 shards of 8 frames), all on GPU 0
     if (ndev >= 2) layouts.push_back({1, 0});                   // root on another GPU than shard 0
     for (const auto& devs : layouts) {
         ouster::sdk::hip::ShardedBatch sb(sensors, n, opt, devs);

@@ -136,6 +136,42 @@ def test_batch512_exchange_checksum_does_not_depend_on_the_number_of_ranks():
     assert a["exchange"]["xyz_checksum"] == b["exchange"]["xyz_checksum"] != 0, (a["exchange"], b["exchange"])
 
 
+def test_eight_ranks_dry_run_batch512_exchange_on_whatever_is_here():
+    """the launch the driver's SCALE run makes on an 8-GPU node -- `bench.py --gpus 8 --workload batch512
+    --exchange`, eight ranks started by bench.py itself -- before there is such a node: with eight or more GPUs visible over RCCL,
+    one rank per GPU (no fallback); otherwise all eight ranks on cuda:0 over gloo (BENCH_ONE_DEVICE=1: same code, the exchange
+    tensors travel through host memory).  The 512 frames scattered from rank 0, decoded by eight ranks and gathered back must
+    leave the clouds ONE rank leaves; the line carries every rank's own timing and kernel."""
+    base = ["--steps", "2", "--warmup", "1", "--workload", "batch512", "--no-cpu", "--exchange", "--no-loss-paths", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_ONE_DEVICE", "BENCH_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--placement", "first"] + base, capture_output=True, text=True,
+                         cwd=ROOT, timeout=900, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a = _last_json(one.stdout)
+    if _n_gpus() >= 8:
+        env8 = dict(env, BENCH_BACKEND="nccl")
+    else:
+        env8 = dict(env, BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + base, capture_output=True, text=True, cwd=ROOT, timeout=1500, env=env8)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    b = _last_json(p.stdout)
+    assert b["n_gpus"] == 8 and b["validated"] is True and b["value"] > 0, b
+    assert b["scaling"] == "strong" and b["config"]["sharding"].startswith("frames x8")
+    assert a["exchange"]["frames_total"] == b["exchange"]["frames_total"] == 512
+    assert a["exchange"]["xyz_checksum"] == b["exchange"]["xyz_checksum"] != 0, (a["exchange"], b["exchange"])
+    pr = b["per_rank"]
+    assert sum(pr["kernel"].values()) == 8 and 0 < pr["ms_min"] <= pr["ms_max"] and 0 <= pr["slowest_rank"] < 8, pr
+    assert abs(b["ms_per_step"] - pr["ms_max"]) <= 0.25 * pr["ms_max"] + 0.05, (b["ms_per_step"], pr)   # the line is the slowest rank's time
+    if _n_gpus() >= 8:
+        assert b["rccl_ranks"] == 8
+    else:
+        # eight ranks share one device: the placement search (two more output sets per rank) stands down where memory is short,
+        # and says so; with 288 GB it normally runs
+        assert all(x in ("refine", "first:skipped") for x in pr["placement"]), pr
+    print("eight ranks:", b["collective_backend"], pr, b["exchange"])
+
+
 def test_config4_recorded_frames_same_result_for_1_and_2_ranks():
     one = subprocess.run([sys.executable, "tools/config4_recorded.py", "--frames", "64", "--reps", "1"],
                          capture_output=True, text=True, cwd=ROOT, timeout=600)
