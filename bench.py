@@ -924,6 +924,10 @@ def main():
     spec_name = "SpecSingle" if args.workload in ("single", "batch512") else "SpecDualLB"
     kern = hp.ctx.last_decode_kernel() or ("k_decode_wide" if tr < H else "k_decode")
     kernel_name = f"{kern}<{spec_name},{tc},sep-f32> ({tc}x{tr} tiles)"
+    tuner = {"source": hp.ctx.last_decode_tuner(), "kernel": kern, "tile": [tc, tr],
+             "cache_file": os.environ.get("OUSTER_HIP_TUNING_CACHE"),
+             "note": "measured: this process timed the candidates during setup (24 calls before the warm-up); cache: read from "
+                     "OUSTER_HIP_TUNING_CACHE / BatchOptions::tuning_cache, nothing timed (tests/test_gpu_tuning_cache.py)"}
     hp.ctx.timing(False)
 
 
@@ -1170,6 +1174,7 @@ def main():
             rep = placement["search_after_timed_region"]
             line["roofline"]["searched_placement_ms_per_call"] = rep["kept_ms"]
             line["roofline"]["searched_placement_frac_step"] = round(bytes_per_launch / (rep["kept_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        line["tuner"] = tuner
         line["rccl_ranks"] = rccl_ranks
         line["collective_backend"] = coll
         if per_rank:

@@ -51,9 +51,16 @@ struct BatchOptions {
     /// buffers (+8.7 % on the box of profiles/r05).  Set it to false where construction time or the transient
     /// memory matter more; placement_ballast_bytes > 0 / placement_draws = 4 is the thorough (tens of GB) form.
     /// Pointers handed out afterwards stay valid for the life of the batch.
+    /// Only a batch that OWNS its context searches (`context` below left empty): the search re-times kernel variants and would
+    /// otherwise reset the tuner state of other batches sharing the context.
     bool auto_placement = true;
     int placement_draws = 3;
     size_t placement_ballast_bytes = 0;
+    /// File with the kernel-variant tuner's verdicts of earlier processes (include/ouster_hip.h,
+    /// ouster_hip_ctx_set_tuning_cache): a batch that finds its workload there launches the recorded variant from its first
+    /// decode() and times nothing; one that has to measure appends its verdict.  Empty: the process-wide
+    /// OUSTER_HIP_TUNING_CACHE, if set, else none.
+    std::string tuning_cache;
     int device = -1;                      ///< GPU to work on (-1: hip::current_device() of the constructing thread)
     std::shared_ptr<Context> context;     ///< share this context (stream + scratch) instead of owning one
 };

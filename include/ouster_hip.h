@@ -452,6 +452,19 @@ int ouster_hip_last_decode_tile(ouster_hip_ctx* ctx, int* tile_cols, int* tile_r
  * loader waves, the default) or "k_decode_stream" (every wave fetches; knob "stream_loader" = 0). */
 const char* ouster_hip_last_decode_kernel(ouster_hip_ctx* ctx);
 
+/* Persisted verdicts of the variant tuner.  ouster_hip_decode picks its kernel variant per workload shape by timing up to
+ * five candidates four times each on the first calls (above); with a cache file a process that finds its workload -- keyed by
+ * device (arch, CU count, name), library version, profile, H, W, channel bytes, batch-size class and output set -- launches the
+ * recorded variant from its FIRST call and times nothing, and a process that had to measure appends its verdict (one O_APPEND
+ * write per verdict: the ranks of one job may share the file).  path NULL or "": no cache (the default; the environment
+ * variable OUSTER_HIP_TUNING_CACHE, read in ouster_hip_ctx_create, sets one for every context of the process).  Results do
+ * not depend on the variant, only the speed does.  What is NOT persisted: where output buffers live (the placement search of
+ * hip::DeviceFrameBatch) -- that is a property of the physical pages an allocation drew, gone with the process. */
+int ouster_hip_ctx_set_tuning_cache(ouster_hip_ctx* ctx, const char* path);
+/* How the last ouster_hip_decode chose its variant: "cache" (read from the file), "measured" (timed by this context),
+ * "measuring" (still timing: the call ran a candidate) or "none" (forced by a knob / a shape with one variant). */
+const char* ouster_hip_last_decode_tuner(ouster_hip_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

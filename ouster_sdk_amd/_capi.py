@@ -93,6 +93,7 @@ ABI_SYMBOLS = [
     "ouster_hip_alloc_stats_read", "ouster_hip_device_alloc", "ouster_hip_device_free",
     "ouster_hip_destagger_host", "ouster_hip_cartesian_host", "ouster_hip_dewarp_host",
     "ouster_hip_copy_in", "ouster_hip_copy_out", "ouster_hip_ctx_scratch",
+    "ouster_hip_ctx_set_tuning_cache", "ouster_hip_last_decode_tuner",
 ]
 
 _hip = None
@@ -182,6 +183,10 @@ def load_hip(private_path: Optional[str] = None):
         L.ouster_hip_copy_in.argtypes = [vp, vp, vp, C.c_size_t]
         L.ouster_hip_copy_out.argtypes = [vp, vp, vp, C.c_size_t]
         L.ouster_hip_ctx_scratch.argtypes = [vp, C.c_uint32, C.c_size_t, C.POINTER(vp)]
+    if hasattr(L, "ouster_hip_ctx_set_tuning_cache"):
+        L.ouster_hip_ctx_set_tuning_cache.argtypes = [vp, C.c_char_p]
+        L.ouster_hip_last_decode_tuner.restype = C.c_char_p
+        L.ouster_hip_last_decode_tuner.argtypes = [vp]
     if private_path is None:
         _hip = L
     return L
@@ -299,6 +304,16 @@ class Context:
         if not hasattr(self.L, "ouster_hip_last_decode_kernel"):
             return ""
         return (self.L.ouster_hip_last_decode_kernel(self.h) or b"").decode()
+
+    def set_tuning_cache(self, path: Optional[str]):
+        """Persisted verdicts of the kernel-variant tuner (include/ouster_hip.h, ouster_hip_ctx_set_tuning_cache)."""
+        check(self.L.ouster_hip_ctx_set_tuning_cache(self.h, path.encode() if path else None))
+
+    def last_decode_tuner(self) -> str:
+        """"cache" | "measured" | "measuring" | "none": how the last decode chose its kernel variant."""
+        if not hasattr(self.L, "ouster_hip_last_decode_tuner"):
+            return ""
+        return (self.L.ouster_hip_last_decode_tuner(self.h) or b"").decode()
 
     def timing_read(self) -> Tuple[float, int]:
         ms = C.c_double()

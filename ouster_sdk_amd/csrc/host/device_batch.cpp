@@ -23,6 +23,7 @@ DeviceFrameBatch::DeviceFrameBatch(const std::vector<SensorInfo>& sensors, uint3
       pf_(sensors.at(0)), n_frames_(n_frames), opt_(options) {
     ScopedContext on_my_context(ctx_);
     if (n_frames == 0) throw std::invalid_argument("DeviceFrameBatch: n_frames must be > 0");
+    if (!opt_.tuning_cache.empty()) check(ouster_hip_ctx_set_tuning_cache(ctx_->handle(), opt_.tuning_cache.c_str()));
     const SensorInfo& s0 = sensors[0];
     h_ = s0.format.pixels_per_column;
     w_ = s0.format.columns_per_frame;
@@ -90,7 +91,7 @@ DeviceFrameBatch::DeviceFrameBatch(const std::vector<SensorInfo>& sensors, uint3
     d_mid_.resize(static_cast<size_t>(n_frames_) * w_ * 2);
     d_status_.resize(static_cast<size_t>(n_frames_) * w_ * 4);
     counts_.assign(n_frames_, 0);
-    if (opt_.auto_placement && n_frames_ >= 64) {
+    if (opt_.auto_placement && n_frames_ >= 64 && !options.context) {   // a shared context's tuner state is not ours to reset
         if (hipMemsetAsync(d_packets_.data(), 0, d_packets_.size(), static_cast<hipStream_t>(ctx_->stream())) != hipSuccess)
             throw std::runtime_error("ouster_hip: hipMemset(packets) failed");
         refine_placement(opt_.placement_draws, nullptr, opt_.placement_ballast_bytes);

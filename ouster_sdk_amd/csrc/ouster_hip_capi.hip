@@ -11,9 +11,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
 #include <map>
 #include <new>
 #include <string>
+#include <unistd.h>
 #include <vector>
 
 #include "host_pool.h"
@@ -127,11 +129,16 @@ struct ouster_hip_ctx {
     struct Tune {
         int best = -2;  // -2: still measuring; 0: narrow; 128 / 256: wide; 1000 + tile width: the persistent kernel
         int calls = 0;
+        bool from_cache = false;   // `best` was read from the tuning cache file, not timed by this context
         static constexpr int ROUNDS = 4, NCAND = 5, SAMPLES = NCAND * ROUNDS;
         hipEvent_t ev[SAMPLES][2] = {};  // up to five candidates x ROUNDS consecutive launches
         float ms[NCAND] = {0, 0, 0, 0, 0};  // fastest warm sample of each candidate
     };
     std::map<uint64_t, Tune> tune;
+    // verdicts of earlier processes (ouster_hip_ctx_set_tuning_cache): workload key -> chosen variant, for THIS device and library
+    std::string tune_cache_path, tune_cache_id;
+    std::map<uint64_t, int> tune_cache;
+    const char* last_tuner = "none";     // how the last ouster_hip_decode chose its variant
     int last_tile_cols = 0, last_tile_rows = 0;  // tile of the last k_decode launch
 };
 
@@ -311,6 +318,7 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.hdr_words = env_int("OUSTER_HIP_HDR_WORDS", k.hdr_words);
         k.fixup_rows = env_int("OUSTER_HIP_FIXUP_ROWS", k.fixup_rows);
     }
+    if (const char* e = getenv("OUSTER_HIP_TUNING_CACHE")) (void)ouster_hip_ctx_set_tuning_cache(c, e);
     if (stream == OUSTER_HIP_STREAM_NULL) {
         c->stream = nullptr;  // the null stream
     } else if (stream) {
@@ -379,6 +387,7 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
                     for (hipEvent_t e : pr)
                         if (e) (void)hipEventDestroy(e);
             c->tune.clear();
+            c->tune_cache.clear();   // what this context read from the cache file is void as well: it re-measures and appends anew
         }
     }
     else if (n == "xcd") k.xcd = value;
@@ -400,6 +409,48 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "unknown knob '%s'", name);
     return OUSTER_HIP_OK;
 }
+
+// ---- persisted verdicts of the variant tuner -----------------------------------------------------------------------------
+// One text line per verdict: "v1 <device and library id> <workload key, hex> <variant> <its fastest sample, ms>".  Lines are
+// appended with one write() each (O_APPEND: ranks of one job may share the file), the last line of a key wins at load.
+int ouster_hip_ctx_set_tuning_cache(ouster_hip_ctx* c, const char* path) {
+    if (!c) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    c->tune_cache.clear();
+    c->tune_cache_path = path ? path : "";
+    if (c->tune_cache_path.empty()) return OUSTER_HIP_OK;
+    hipDeviceProp_t prop{};
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) {
+        (void)hipGetLastError();
+        c->tune_cache_path.clear();
+        return fail(OUSTER_HIP_ERR_RUNTIME, "hipGetDeviceProperties failed");
+    }
+    std::string id = std::string(prop.gcnArchName) + ":" + std::to_string(prop.multiProcessorCount) + ":" + prop.name + ":" + ouster_hip_version();
+    for (char& ch : id) if (ch == ' ' || ch == '\t') ch = '_';
+    c->tune_cache_id = id;
+    if (FILE* f = fopen(c->tune_cache_path.c_str(), "r")) {
+        char line[512], ver[8], dev[320];
+        unsigned long long key = 0;
+        int best = 0;
+        float ms = 0;
+        while (fgets(line, sizeof line, f))
+            if (sscanf(line, "%7s %319s %llx %d %f", ver, dev, &key, &best, &ms) == 5 && !strcmp(ver, "v1") && id == dev)
+                c->tune_cache[(uint64_t)key] = best;
+        fclose(f);
+    }
+    return OUSTER_HIP_OK;
+}
+static void tune_cache_append(ouster_hip_ctx* c, uint64_t key, int best, float ms) {
+    if (c->tune_cache_path.empty()) return;
+    c->tune_cache[key] = best;
+    char line[512];
+    const int n = snprintf(line, sizeof line, "v1 %s %016llx %d %.4f\n", c->tune_cache_id.c_str(), (unsigned long long)key, best, ms);
+    if (n <= 0 || n >= (int)sizeof line) return;
+    const int fd = open(c->tune_cache_path.c_str(), O_WRONLY | O_APPEND | O_CREAT, 0644);
+    if (fd < 0) return;   // a cache that cannot be written is not an error of the decode
+    (void)!write(fd, line, (size_t)n);
+    close(fd);
+}
+const char* ouster_hip_last_decode_tuner(ouster_hip_ctx* c) { return c ? c->last_tuner : ""; }
 
 int ouster_hip_sync(ouster_hip_ctx* c) {
     if (!c) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "ctx is NULL");
@@ -1051,6 +1102,7 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     }
     ouster_hip_ctx::Tune* tuning = nullptr;
     int tune_slot = -1;
+    ctx->last_tuner = "none";   // forced by a knob, or a shape with nothing to choose
     if (stream || resolved || small_wide) {
         // forced / nothing to choose
     } else if (kn.wide >= 0) {  // forced (experiments, tests)
@@ -1085,9 +1137,18 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
                             if (e) (void)hipEventDestroy(e);
                 ctx->tune.clear();
             }
+            const bool fresh = !ctx->tune.count(key);
             ouster_hip_ctx::Tune& t = ctx->tune[key];
             const int cand[ouster_hip_ctx::Tune::NCAND] = {256, 128, 0, 1000 + stream_auto, 1000 + stream_alt};
             const int nc = stream_auto ? (stream_alt ? 5 : 4) : 3;
+            if (fresh) {   // an earlier process (or rank) has timed this workload on this device: launch its choice from call 1
+                auto hit = ctx->tune_cache.find(key);
+                if (hit != ctx->tune_cache.end()) {
+                    bool known = false;
+                    for (int c = 0; c < nc; ++c) known = known || cand[c] == hit->second;
+                    if (known) { t.best = hit->second; t.from_cache = true; }
+                }
+            }
             // Four launches of each candidate, back to back (a launch that follows a different variant
             // is not representative of the steady state: alternating the candidates made the 64-column
             // kernel look 8 % faster than it then ran).  Single launches vary by ~10 %, mostly upwards,
@@ -1115,15 +1176,20 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
                     float best_ms = 0;
                     for (int c = 0; c < nc; ++c)
                         if (t.ms[c] > 0 && (best_ms == 0 || t.ms[c] < best_ms)) { t.best = cand[c]; best_ms = t.ms[c]; }
+                    tune_cache_append(ctx, key, t.best, best_ms);
                 }
             }
             if (t.best != -2) {
                 sel = t.best;
+                ctx->last_tuner = t.from_cache ? "cache" : "measured";
             } else if (t.calls < NS) {
                 tune_slot = t.calls;
                 sel = cand[tune_slot / R];
                 tuning = &t;
                 ++t.calls;
+                ctx->last_tuner = "measuring";
+            } else {
+                ctx->last_tuner = "measuring";   // every sample is queued, not all have landed: the default variant runs
             }
         }
         if (sel >= 1000 && setup_stream(sel - 1000)) stream = sel - 1000;
