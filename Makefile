@@ -7,7 +7,8 @@ CXX ?= g++
 LIB := ouster_sdk_amd/lib
 CSRC := ouster_sdk_amd/csrc
 HOST_SRC := $(wildcard $(CSRC)/host/*.cpp)
-HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result
+# EXPERIMENTS=1 also compiles the measured-slower kernel forms kept for A/B work (k_decode_wide_resolved, k_dwf_single, k_dwf_fused)
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++20 -fPIC -Wno-unused-result $(if $(EXPERIMENTS),-DOUSTER_EXPERIMENTS,)
 # the fused decode kernels are compiled once per packet-profile specialisation (parallel with -j)
 OBJ := $(CSRC)/_build
 SPEC_IDS := 0 1 2 3 4 5

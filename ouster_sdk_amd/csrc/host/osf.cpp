@@ -582,6 +582,9 @@ struct OsfFrameDecoder::Impl {
                           size_t total, uint8_t* base, void* dev, hipStream_t st) {
         const size_t n = plans.size(), G = std::min<size_t>(8, n);
         if (!n) return;
+        // `base` is this decoder's reused pinned buffer: a copy queued from it by an earlier call that ended in an exception
+        // (after its uploads, before the synchronisation at the end of the unpack) may still be reading it
+        if (hipStreamSynchronize(st) != hipSuccess) throw std::runtime_error("ouster_hip: hipStreamSynchronize failed");
         std::vector<uint32_t> grp(n);
         std::vector<size_t> first(G + 1);
         std::unique_ptr<std::atomic<uint32_t>[]> left(new std::atomic<uint32_t>[G]);

@@ -634,6 +634,8 @@ static hipError_t launch_decode_wide_t(const DecodeArgs& a, int xyzm, dim3 grid,
     }
 }
 
+#ifdef OUSTER_EXPERIMENTS   // the one-launch form for small batches: measured slower than the optimistic pass + fix-up launch
+                            // (profiles/r05/one_launch_ab.json); out of the default build since round 6 (make EXPERIMENTS=1)
 // ------------------------------------------------------------------------------------
 // k_decode_wide_resolved: ONE launch for small batches (a tick of a few sensors, a single frame): every workgroup resolves
 // its frame's column maps itself (resolve_frame: one round of header reads that hit L2 after the first tile, then LDS work)
@@ -715,6 +717,7 @@ static hipError_t launch_wide_resolved_t(const DecodeArgs& a, int xyzm, dim3 gri
         default: return launch_wide_resolved_x<S, TW, 3>(a, grid, lds, device, st);
     }
 }
+#endif  // OUSTER_EXPERIMENTS
 
 template <class S, int TW, int XYZM>
 static hipError_t launch_wide_fixup_x(const DecodeArgs& a, dim3 grid, size_t lds, int device, hipStream_t st) {
@@ -774,11 +777,15 @@ hipError_t OUSTER_SPEC_FN(launch_decode_wide)(const DecodeArgs& a_in, int tw, in
     const uint32_t nblocks = a.xcd_map ? ((a.n_frames + 7) / 8) * 8 * bpf : a.n_frames * bpf;
     const dim3 grid(nblocks);
     if (resolved) {
+#ifdef OUSTER_EXPERIMENTS
         switch (tw) {
             case 128: return launch_wide_resolved_t<SpecT, 128>(a, xyzm, grid, lds, device, st);
             case 256: return launch_wide_resolved_t<SpecT, 256>(a, xyzm, grid, lds, device, st);
             default: return hipErrorInvalidValue;
         }
+#else
+        return hipErrorInvalidValue;   // MODE_RESOLVED is never chosen by a default build
+#endif
     }
     switch (tw) {
         case 64: return launch_decode_wide_t<SpecT, 64>(a, xyzm, grid, lds, device, st);

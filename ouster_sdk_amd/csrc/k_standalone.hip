@@ -957,6 +957,8 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
     }
 }
 
+#ifdef OUSTER_EXPERIMENTS   // the two single-pass forms of the frame dewarp: measured slower than count / scan / emit (DESIGN_HISTORY.md H3);
+                            // out of the default build since round 6 (make EXPERIMENTS=1)
 // ------------------------------------------------------------------------------------
 // k_dwf_single: the same range-gated, compacting frame dewarp in ONE pass over the range planes.
 // A workgroup owns a 64-column tile of one frame for ALL rows (H x 65 dwords of LDS), counts the kept
@@ -1377,6 +1379,7 @@ __global__ __launch_bounds__(256) void k_dwf_fused(DewarpFramesArgs a) {
     else
         dwf_column_loop<T, SEP, TILE, ROWS, false>(a, lut, s_rng, s_meta, f, c0, ncol, fbase, row, bt, m_run);
 }
+#endif  // OUSTER_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------
 // k_osf_unpack: the device half of the OSF field decode.  One workgroup per
@@ -1418,11 +1421,6 @@ __device__ __forceinline__ uint32_t block_incl_scan_u8(uint32_t v, uint32_t* s_w
 // (bpp = 1, 2, 3, 4 or 8 of them in one 64-bit register).  Input rows start at odd addresses (the filter byte), hence byte
 // loads; output pixels are stored whole.  2300 images of a 256-frame batch are 2300 independent waves: 9 per CU.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t shift_up_1(uint64_t v) {   // lane r receives lane r-1's value (lane 0: its own)
-    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, 64);
-    return (uint64_t)lo | ((uint64_t)hi << 32);
-}
-
 // Memory never sits inside a step: every lane keeps a RING of three 64-pixel blocks of its own row in LDS.  Block m+1 is read
 // from global memory into registers when window m (64 steps) starts and copied to the ring when it ends; a step reads its raw
 // pixel from the ring and writes the reconstructed one over it; block m-2 -- finished by every row -- leaves for global memory
@@ -1458,6 +1456,9 @@ __device__ __forceinline__ void uf_px_store(l_u8* p, uint64_t v) {
     else if (BPP == 8) *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(p) = v;
     else { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); }
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_osf_png_unfilter relies on the gfx9 DPP row control wave_shr:1 and on more than 64 KB of LDS per workgroup: build for gfx950"
+#endif
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {   // lane r receives lane r-1's value (lane 0: zero)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
@@ -1923,6 +1924,7 @@ hipError_t launch_dewarp(const DewarpArgs& a_in, hipStream_t st) {
 hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st) {
     const uint32_t tiles = (a.w + 63) / 64;
     const size_t lds = (size_t)a.h * 65 * 4;
+#ifdef OUSTER_EXPERIMENTS
     if (a.tile_state && lds <= 96 * 1024) {
         // single pass with a decoupled look-back over the tiles (the state buffer must be zero)
         hipError_t e = hipMemsetAsync(a.tile_state, 0, ((size_t)a.n_frames * tiles + DWF_WORDS) * 8, st);
@@ -1954,6 +1956,7 @@ hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipSt
             return separable ? go(k_dwf_single<float, true, DWF_NT>) : go(k_dwf_single<float, false, DWF_NT>);
         return separable ? go(k_dwf_single<double, true, DWF_NT>) : go(k_dwf_single<double, false, DWF_NT>);
     }
+#endif
     if (!a.gate_counts) hipLaunchKernelGGL(k_dwf_count, dim3(tiles, a.n_frames), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dwf_scan, dim3(a.n_frames), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dwf_frame_scan, dim3(1), dim3(256), 0, st, a);

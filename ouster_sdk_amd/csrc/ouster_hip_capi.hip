@@ -275,7 +275,11 @@ static void fill_geometry(const ouster_hip_format_desc& d, Geometry& g) {
 extern "C" {
 
 const char* ouster_hip_last_error(void) { return g_err.c_str(); }
-const char* ouster_hip_version(void) { return "ouster_hip 0.2 (gfx950)"; }
+#ifdef OUSTER_EXPERIMENTS
+const char* ouster_hip_version(void) { return "ouster_hip 0.3 (gfx950) +experiments"; }
+#else
+const char* ouster_hip_version(void) { return "ouster_hip 0.3 (gfx950)"; }
+#endif
 
 int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
     if (!out) return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "out is NULL");
@@ -1075,12 +1079,18 @@ int ouster_hip_decode(ouster_hip_ctx* ctx, const ouster_hip_format* fmt, const u
     // before they can start: 14 us against the 3 us a second launch costs).  So: a buffer with one slot per column takes the
     // optimistic wide tiles, any other shape the one-launch form (kn.small = 2 forces it for both).
     bool resolved = false, small_wide = false;
-    if (kn.small && kn.stream <= 0 && kn.wide < 0 && kn.tile == 0 && kn.fast) {
+#ifdef OUSTER_EXPERIMENTS
+    constexpr bool may_resolve = true;
+#else
+    constexpr bool may_resolve = false;   // default build: a small batch whose buffer is not "one slot per column" takes the general
+                                          // mapping like a large one (k_slotmap + k_decode_wide); k_decode_wide_resolved is not compiled
+#endif
+    if (kn.small && kn.stream <= 0 && kn.wide < 0 && kn.tile == 0 && kn.fast && (fast || may_resolve)) {
         for (int tw : {256, 128})
             if (W >= (uint32_t)tw) {
                 if (setup_wide(tw, false, true)) {
                     wide = tw;
-                    resolved = !fast || kn.small == 2;
+                    resolved = may_resolve && (!fast || kn.small == 2);
                     small_wide = !resolved;
                 }
                 break;
@@ -1577,7 +1587,11 @@ static int dewarp_frames_impl(ouster_hip_ctx* ctx, const ouster_hip_lut* const* 
     a.dtype = dtype;
     a.col_off = (uint32_t*)ctx->scratch.p;
     a.gate_counts = gate_counts;
+#ifdef OUSTER_EXPERIMENTS
     a.tile_state = (ctx->knobs.dewarp_single_pass && !gate_counts && !pose_rows) ? (uint64_t*)((uint8_t*)ctx->scratch.p + col_off_bytes) : nullptr;
+#else
+    a.tile_state = nullptr;   // the single-pass kernels are not in a default build (knob "dewarp_single_pass" is then without effect)
+#endif
     a.frame_off = frame_offsets;
     a.points = points;
     a.frame_idxs = frame_idxs;
