@@ -733,12 +733,15 @@ struct __attribute__((aligned(16))) DwfColMeta {
 // column metadata (count, output base, pose, table row), lane = row (NR rows per lane).  EASY: everything the tile emits lies
 // below `capacity` and no kept range can be zero (the gate's lower bound is at least 1) -- then the loop carries neither the
 // per-point room check nor the zero-range select.
-template <class T, bool SEP, int TILE, int ROWS, bool EASY>
+// SWZ: the tile image came by LDS-DMA (k_dwf_emit_stream): lane-linear, so it cannot be padded per row; instead the 16 B
+// cell of columns 4k..4k+3 of row r sits at cell position k ^ (r & 15) of its row -- a wave reading one column over 64 rows
+// then spreads over 16 four-bank groups (4-way conflicts on two reads per column, against 64-way for the plain layout).
+template <class T, bool SEP, int TILE, int ROWS, bool EASY, int NWAVES = 4, bool SWZ = false>
 __device__ __forceinline__ void dwf_column_loop(const DewarpFramesArgs& a, const LutDev& lut, const uint32_t* s_rng,
                                                 const DwfColMeta<T>* s_meta, uint32_t f, uint32_t c0, uint32_t ncol,
                                                 uint64_t fbase, const uint32_t (&row)[ROWS / 64],
                                                 const double (&bt)[ROWS / 64][9], uint32_t& m_run) {
-    constexpr int PITCH = TILE + 1, CPW = TILE / 4, NR = ROWS / 64;
+    constexpr int PITCH = SWZ ? TILE : TILE + 1, CPW = TILE / NWAVES, NR = ROWS / 64;
     constexpr bool roomy = EASY, no_zero = EASY;
     const uint32_t W = a.w, H = a.h;
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -749,7 +752,10 @@ __device__ __forceinline__ void dwf_column_loop(const DewarpFramesArgs& a, const
         const uint32_t jn = min(wave * CPW + jj_next, (uint32_t)TILE - 1u);
         cntn = s_meta[jn].cnt;
 #pragma unroll
-        for (int hh = 0; hh < NR; ++hh) rn[hh] = s_rng[(lane + 64 * hh) * PITCH + jn];
+        for (int hh = 0; hh < NR; ++hh) {
+            const uint32_t rr = lane + 64 * hh;
+            rn[hh] = SWZ ? s_rng[rr * PITCH + ((((jn >> 2) ^ (rr & 15u)) << 2) | (jn & 3u))] : s_rng[rr * PITCH + jn];
+        }
     };
     fetch_col(0);
     for (uint32_t jj = 0; jj < (uint32_t)CPW; ++jj) {
@@ -957,6 +963,133 @@ __global__ __launch_bounds__(256) void k_dwf_emit(DewarpFramesArgs a) {
     }
 }
 
+#ifdef OUSTER_EXPERIMENTS
+// ------------------------------------------------------------------------------------
+// k_dwf_emit_stream: k_dwf_emit as a PERSISTENT kernel with a loader wave (round 6; k_decode_stream2's skeleton).
+// k_dwf_emit's time is the sum of its read side and its write side (0.127 ms without the stores, 0.19 with them, 256 frames):
+// a workgroup asks for its 32 KB range tile, waits, and only then computes and stores, and four such workgroups per CU do not
+// hide one another's wait behind a saturated memory system.  Here two workgroups per CU live for the whole launch and walk
+// the (frame, column tile) list; each has TWO tile contexts in LDS: while eight waves rank, project and store tile i, the
+// ninth has tile i+1 arriving by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip; nothing for the column loop to wait on) and
+// writes its column metadata.  One workgroup barrier per tile.  Same outputs, order and arithmetic as k_dwf_emit.
+// Needs whole tiles (W % 64 == 0), ROWS == H, 16 B aligned range planes and the separable tables; anything else: k_dwf_emit.
+// MEASURED (round 6, 256 frames of 128 x 2048, same box, same process): bit-identical output, 0.2173 ms for the chain against
+// 0.2143 ms with k_dwf_emit -- hiding the tile's read latency buys nothing, so the emit kernel's time is NOT the sum of an
+// exposed read side and a write side (the reading of DESIGN r05 section 10.2); 94 VGPRs, 2 x 79 KB of LDS, 18 waves per CU.
+// Kept for A/B work only (make EXPERIMENTS=1, knob "dwf_stream" = 1); a default build does not compile it.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void dwf_glds16(const void* g, uint32_t lds) {   // one LDS-DMA wave instruction (k_decode_stream.hip: glds16)
+    uint32_t keep;
+    lds = __builtin_amdgcn_readfirstlane(lds);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+struct __attribute__((aligned(16))) DwfTileHdr {
+    uint64_t fbase;
+    uint32_t f, c0, any, easy, pad0, pad1;
+};
+template <class T, int ROWS>
+constexpr uint32_t dwf_stream_ctx_bytes() { return (uint32_t)(ROWS * 64 * 4 + 64 * sizeof(DwfColMeta<T>) + sizeof(DwfTileHdr)); }
+
+template <class T, int ROWS>
+__global__ __launch_bounds__(576, 2) void k_dwf_emit_stream(DewarpFramesArgs a, uint32_t n_items) {
+    constexpr int TILE = 64, NCW = 8, NR = ROWS / 64;
+    constexpr uint32_t RNG_BYTES = ROWS * TILE * 4, META_BYTES = TILE * sizeof(DwfColMeta<T>), CTX = dwf_stream_ctx_bytes<T, ROWS>();
+    extern __shared__ __align__(16) uint32_t smem[];
+    const uint32_t W = a.w, H = a.h, tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tiles = W / TILE;
+    const uint32_t G = gridDim.x;
+    if (blockIdx.x >= n_items) return;
+    const uint32_t n_mine = (n_items - blockIdx.x + G - 1) / G;
+    auto item = [&](uint32_t i) { return blockIdx.x + G * i; };
+    auto ctx_rng = [&](uint32_t b) { return (uint32_t*)((uint8_t*)smem + b * CTX); };
+    auto ctx_meta = [&](uint32_t b) { return (DwfColMeta<T>*)((uint8_t*)smem + b * CTX + RNG_BYTES); };
+    auto ctx_hdr = [&](uint32_t b) { return (DwfTileHdr*)((uint8_t*)smem + b * CTX + RNG_BYTES + META_BYTES); };
+
+    if (wave >= (uint32_t)NCW) {
+        // ================= the loader wave: lane = column of the tile for the metadata, 16 B cell for the ranges =================
+        const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+        auto fetch = [&](uint32_t it, uint32_t b) {
+            const uint32_t f = it / tiles, c0 = (it - f * tiles) * TILE;
+            const uint32_t* off = a.col_off + (size_t)f * (W + 1);
+            const uint32_t mx = c0 + lane;
+            const uint32_t base = off[mx], next = off[mx + 1];
+            const uint32_t first = __builtin_amdgcn_readfirstlane(base), last = (uint32_t)__builtin_amdgcn_readlane((int)next, 63);
+            const bool any = last != first;
+            const uint64_t fbase = a.frame_off[f];
+            if (any) {
+                // ranges: instruction k brings rows 4k..4k+3; lane l -> row 4k + l/16, LDS cell l%16, i.e. columns 4*(cell ^ (row & 15))..
+                const uint8_t* rp = (const uint8_t*)(a.range + (size_t)f * W * H) + (size_t)c0 * 4;
+                const uint32_t r_in = lane >> 4, cell = lane & 15u;
+#pragma unroll 8
+                for (uint32_t k = 0; k < (uint32_t)ROWS / 4u; ++k) {
+                    const uint32_t r = 4u * k + r_in;
+                    dwf_glds16(rp + (size_t)r * W * 4 + ((cell ^ (r & 15u)) << 4), lds0 + b * CTX + k * 1024u);
+                }
+            }
+            DwfColMeta<T> m;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) m.pose[k] = (T)0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) m.col[k] = 0.0;
+            m.base = base;
+            m.cnt = next - base;
+            m.ts = 0;
+            if (m.cnt) {
+                load_pose_rows<T>(a, (size_t)f * W + mx, m.pose);
+                const LutDev* lp = a.luts + f % a.n_luts;
+                const double* ct = lp->col_tab;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) m.col[k] = as_global(ct)[(size_t)mx * 5 + k];
+                if (a.timestamps_ns) m.ts = a.timestamp[(size_t)f * W + mx];
+            }
+            ctx_meta(b)[lane] = m;
+            if (lane == 0) {
+                DwfTileHdr h;
+                h.fbase = fbase; h.f = f; h.c0 = c0; h.any = any ? 1u : 0u;
+                h.easy = (fbase + last <= a.capacity && a.min_r > 0) ? 1u : 0u;
+                h.pad0 = h.pad1 = 0;
+                *ctx_hdr(b) = h;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile has landed (this wave's queue holds nothing else)
+        };
+        fetch(item(0), 0);
+        for (uint32_t i = 0; i < n_mine; ++i) {
+            __syncthreads();   // tile i is in its context; the other one is free (the column loops are done with tile i-1)
+            if (i + 1 < n_mine) fetch(item(i + 1), (i + 1) & 1u);
+        }
+        return;
+    }
+
+    // ================= the eight column-loop waves: wave = 8 columns of the tile, lane = row =================
+    uint32_t row[NR];
+    double bt[NR][9];
+    uint32_t cur_lut = 0xffffffffu;
+    LutDev lut{};
+#pragma unroll
+    for (int hh = 0; hh < NR; ++hh) row[hh] = lane + 64 * hh;
+    for (uint32_t i = 0; i < n_mine; ++i) {
+        const uint32_t b = i & 1u;
+        __syncthreads();
+        const DwfTileHdr h = *ctx_hdr(b);
+        if (!h.any) continue;
+        const uint32_t li = h.f % a.n_luts;
+        if (li != cur_lut) {   // the lane's rows of the beam table: once per launch for a one-sensor batch
+            cur_lut = li;
+            lut = a.luts[li];
+#pragma unroll
+            for (int hh = 0; hh < NR; ++hh)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) bt[hh][k] = as_global(lut.beam_tab)[(size_t)min(row[hh], H - 1u) * 9 + k];
+        }
+        uint32_t m_run = 0;
+        if (h.easy) dwf_column_loop<T, true, TILE, ROWS, true, NCW, true>(a, lut, ctx_rng(b), ctx_meta(b), h.f, h.c0, TILE, h.fbase, row, bt, m_run);
+        else dwf_column_loop<T, true, TILE, ROWS, false, NCW, true>(a, lut, ctx_rng(b), ctx_meta(b), h.f, h.c0, TILE, h.fbase, row, bt, m_run);
+    }
+}
+
+#endif  // OUSTER_EXPERIMENTS (k_dwf_emit_stream)
 #ifdef OUSTER_EXPERIMENTS   // the two single-pass forms of the frame dewarp: measured slower than count / scan / emit (DESIGN_HISTORY.md H3);
                             // out of the default build since round 6 (make EXPERIMENTS=1)
 // ------------------------------------------------------------------------------------
@@ -1921,7 +2054,7 @@ hipError_t launch_dewarp(const DewarpArgs& a_in, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st) {
+hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st, int stream_mode) {
     const uint32_t tiles = (a.w + 63) / 64;
     const size_t lds = (size_t)a.h * 65 * 4;
 #ifdef OUSTER_EXPERIMENTS
@@ -1962,6 +2095,35 @@ hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipSt
     hipLaunchKernelGGL(k_dwf_frame_scan, dim3(1), dim3(256), 0, st, a);
     // 64-column emit tiles (32-column ones measured 15 % slower); 128 rows per pass when the sensor has
     // more than 64 beams: the per-column overhead is paid once per column instead of once per 64 rows
+#ifdef OUSTER_EXPERIMENTS
+    // the persistent form (k_dwf_emit_stream) where it applies: whole 64-column tiles of exactly h rows, 16 B aligned planes,
+    // the separable tables, and enough tiles to give every persistent workgroup a run of them
+    {
+        static const uint32_t wgs = [] {
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return (uint32_t)(2 * (cus > 0 ? cus : 256));
+        }();
+        const uint32_t n_items = a.n_frames * tiles;
+        const bool ok = stream_mode != 0 && separable && a.dtype == OUSTER_HIP_F32 && a.w % 64 == 0 && (a.h == 64 || a.h == 128) &&
+                        ((uintptr_t)a.range & 15) == 0 && n_items >= (stream_mode > 0 ? 1u : 4u * wgs);
+        if (ok) {
+            const uint32_t g = std::min(n_items, wgs);
+            auto go = [&](auto kernel, uint32_t ctx_bytes) -> hipError_t {
+                const size_t lds = 2 * (size_t)ctx_bytes;
+                hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kernel, dim3(g), dim3(576), lds, st, a, n_items);
+                return hipGetLastError();
+            };
+            return a.h == 128 ? go(k_dwf_emit_stream<float, 128>, dwf_stream_ctx_bytes<float, 128>())
+                              : go(k_dwf_emit_stream<float, 64>, dwf_stream_ctx_bytes<float, 64>());
+        }
+    }
+#else
+    (void)stream_mode;
+#endif
     const dim3 grid(tiles, a.n_frames);
     auto emit = [&](auto rows) {
         constexpr int R = decltype(rows)::value;

@@ -95,6 +95,7 @@ struct Knobs {
     int stream_order = 0;     // OUSTER_HIP_STREAM_ORDER: item order of k_decode_stream's groups (experiments)
     int slotmap = 1;          // OUSTER_HIP_SLOTMAP: 0 = buffers without one slot per column go through k_decode's general tiles
                               //   (every tile scans the frame's headers) instead of k_slotmap + k_decode_wide
+    int dwf_stream = -1;      // OUSTER_HIP_DWF_STREAM: the frame dewarp's emit kernel: -1 auto | 0 k_dwf_emit | 1 the persistent k_dwf_emit_stream where eligible
     int stream_loader = 4;    // OUSTER_HIP_STREAM_LOADER: loader waves of k_decode_stream2 (0 = k_decode_stream: every wave fetches)
 };
 
@@ -316,6 +317,7 @@ int ouster_hip_ctx_create(int device, void* stream, ouster_hip_ctx** out) {
         k.stream_min_tiles = env_int("OUSTER_HIP_STREAM_MIN_TILES", k.stream_min_tiles);
         k.stream_order = env_int("OUSTER_HIP_STREAM_ORDER", k.stream_order);
         k.stream_loader = env_int("OUSTER_HIP_STREAM_LOADER", k.stream_loader);
+        k.dwf_stream = env_int("OUSTER_HIP_DWF_STREAM", k.dwf_stream);
         k.slotmap = env_int("OUSTER_HIP_SLOTMAP", k.slotmap);
         k.fixup_wide = env_int("OUSTER_HIP_FIXUP_WIDE", k.fixup_wide);
         k.small = env_int("OUSTER_HIP_SMALL", k.small);
@@ -403,6 +405,7 @@ int ouster_hip_ctx_set_knob(ouster_hip_ctx* c, const char* name, int value) {
     else if (n == "fixup_rows") k.fixup_rows = value;
     else if (n == "beam_lds") k.beam_lds = value;
     else if (n == "dewarp_single_pass") k.dewarp_single_pass = value;
+    else if (n == "dwf_stream") k.dwf_stream = value;
     else if (n == "stream") k.stream = value;
     else if (n == "stream_rows") k.stream_rows = value;
     else if (n == "stream_wait") k.stream_wait = value;
@@ -1598,7 +1601,7 @@ static int dewarp_frames_impl(ouster_hip_ctx* ctx, const ouster_hip_lut* const* 
     a.col_idxs = col_idxs;
     a.timestamps_ns = timestamps_ns;
     a.capacity = capacity;
-    HIP_TRY(launch_dewarp_frames(a, luts[0]->separable, ctx->stream));
+    HIP_TRY(launch_dewarp_frames(a, luts[0]->separable, ctx->stream, ctx->knobs.dwf_stream));
     return OUSTER_HIP_OK;
 }
 

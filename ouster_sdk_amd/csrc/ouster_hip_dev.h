@@ -230,7 +230,8 @@ hipError_t launch_slotmap(const DecodeArgs& a, int device, hipStream_t st);
 hipError_t launch_destagger(const DestaggerArgs& a, uint32_t n_images, hipStream_t st);
 hipError_t launch_cartesian(const CartesianArgs& a, int mode, hipStream_t st);
 hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);
-hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st);
+// stream_mode: -1 auto | 0 never | 1 always where eligible -- the persistent k_dwf_emit_stream instead of k_dwf_emit (knob "dwf_stream")
+hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st, int stream_mode = -1);
 hipError_t launch_osf_unpack(const OsfUnpackArgs& a, uint32_t n_planes, hipStream_t st);
 hipError_t launch_osf_png_unfilter(const OsfUnfilterArgs& a, uint32_t n_jobs, uint32_t max_row_bytes, hipStream_t st);
 

@@ -386,22 +386,25 @@ def test_dense_dewarp_matches_oracle(oracle):
     assert torch.equal(hp.dewarp(p32, ident), p32)
 
 
-@pytest.mark.parametrize("path", ["runs", "single"])
-@pytest.mark.parametrize("h,w,n", [(128, 1024, 3), (32, 512, 2), (9, 100, 2), (70, 130, 2), (130, 64, 1), (260, 72, 2)])
+@pytest.mark.parametrize("path", ["runs", "single", "stream"])
+@pytest.mark.parametrize("h,w,n", [(128, 1024, 3), (64, 512, 4), (32, 512, 2), (9, 100, 2), (70, 130, 2), (130, 64, 1), (260, 72, 2)])
 def test_dewarp_frames_matches_oracle(oracle, h, w, n, path):
     """dewarp(LidarFrame / FrameSet, XYZLut, min_range, max_range) with provenance
     (impl/dewarp_impl.h:23-115): order, counts, col/frame indices and timestamps bit-exact;
     points within the XYZ bar."""
     O = oracle
     from ouster_sdk_amd import _capi
-    if path == "single" and b"experiments" not in _capi.load_hip().ouster_hip_version():
-        pytest.skip("the single-pass dewarp kernels are only in a build made with `make EXPERIMENTS=1` (round 6 hygiene)")
+    if path in ("single", "stream") and b"experiments" not in _capi.load_hip().ouster_hip_version():
+        pytest.skip("the single-pass and the persistent dewarp kernels are only in a build made with `make EXPERIMENTS=1` (round 6 hygiene)")
     rng = np.random.default_rng(h * 31 + w)
     cal = O.synthetic_calib(h=h, w=w, b2l_x=15.806)
     ldir, lofs = cal.xyz_lut(True)
     hp = HotPath("RNG15_RFL8_NIR8", h, w, 4 if w % 4 == 0 else 1)
     # count / scan / emit (the default) or k_dwf_single (one pass, decoupled look-back)
     hp.ctx.set_knob("dewarp_single_pass", 1 if path == "single" else 0)
+    # "stream": the persistent, LDS-DMA double-buffered k_dwf_emit_stream wherever the shape allows it (whole 64-column tiles of
+    # exactly h = 64 / 128 rows, float output, separable tables; by itself it only takes batches of >= 2048 tiles), else k_dwf_emit
+    hp.ctx.set_knob("dwf_stream", 1 if path == "stream" else 0)
     hp.add_lut(cal.beam_to_lidar, cal.lut_transform(True), cal.beam_azimuth_angles,
                cal.beam_altitude_angles)
     r = rng.integers(0, 2 ** 17, size=(n, h, w)).astype(np.uint32)
@@ -438,6 +441,21 @@ def test_dewarp_frames_matches_oracle(oracle, h, w, n, path):
             if tot:
                 wp = np.concatenate([x[0] for x in want]).astype(np.float64)
                 assert np.abs(_np(got["points"])[:tot].astype(np.float64) - wp).max() <= tol
+            if tdt == torch.float32 and path == "stream":
+                # the two emit kernels share their arithmetic: every byte of every output is the same; also where the result
+                # does not fit (capacity: the per-point room check of the column loop instead of its easy path)
+                hp.ctx.set_knob("dwf_stream", 0)
+                plain = hp.dewarp_frames(d_r, d_st, d_po, lo, hi, timestamp=d_ts, dtype=tdt)
+                hp.ctx.set_knob("dwf_stream", 1)
+                for k in got:
+                    n_k = tot if k != "frame_offsets" else len(offs)
+                    assert torch.equal(plain[k][:n_k], got[k][:n_k]), (k, lo, hi)
+                if tot > 3:
+                    cap = tot // 2
+                    part = hp.dewarp_frames(d_r, d_st, d_po, lo, hi, timestamp=d_ts, dtype=tdt, capacity=cap)
+                    assert np.array_equal(_np(part["frame_offsets"]), offs)
+                    for k in ("points", "col_idxs", "frame_idxs", "timestamps_ns"):
+                        assert torch.equal(part[k][:cap], got[k][:cap]), (k, lo, hi, "capacity")
             if tdt == torch.float32:
                 # the poses as float rows (ouster_hip_dewarp_frames_rows: 48 B per column): dewarp<float> casts the pose to
                 # float before it multiplies, so every byte of every output is the same
