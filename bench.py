@@ -712,7 +712,8 @@ def time_drop_in():
     import subprocess
     res = {}
     bdir = os.path.join(ROOT, "tests", "cpp", "_build")
-    for key, argv in (("host_api", ["bench_host_api", "40"]), ("frame_stream", ["bench_stream", "768", "32", "3", "xyz"])):
+    for key, argv in (("host_api", ["bench_host_api", "40"]), ("frame_stream", ["bench_stream", "768", "32", "3", "xyz"]),
+                      ("frame_stream_compact", ["bench_stream", "1536", "16", "4", "compact"])):
         exe = os.path.join(bdir, argv[0])
         try:
             o = subprocess.run([exe] + argv[1:], capture_output=True, text=True, timeout=120)
@@ -746,6 +747,17 @@ def time_drop_in():
         out["frame_stream_D2H_GBps"] = fs.get("D2H_GBps")
     else:
         out["frame_stream_error"] = fs.get("error")
+    fc = res.get("frame_stream_compact", {})
+    if "frames_per_s" in fc:   # round 6: the range-gated compacting route as what comes back (StreamOptions::dewarp_*)
+        out["frame_stream_compact"] = {"frames_per_s": fc["frames_per_s"], "Gpixels_per_s": round(fc["Mpixels_per_s"] / 1e3, 3),
+                                       "kept_points_per_frame": fc.get("kept_points_per_frame"), "H2D_GBps": fc.get("H2D_GBps"),
+                                       "D2H_GBps": fc.get("D2H_GBps"), "frames_per_batch": 16, "in_flight": 4,
+                                       "what": "host packets in, the gated (0.5 - 400 m) point list of the first return out: 12 B per kept "
+                                               "point instead of 24 B per pixel; bound by the one host thread that stages the packets "
+                                               "(its memcpy rate is H2D_GBps), no longer by the link from the device",
+                                       "dense_xyz_frames_per_s": fs.get("frames_per_s")}
+    elif fc:
+        out["frame_stream_compact_error"] = fc.get("error")
     return out
 
 

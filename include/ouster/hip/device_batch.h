@@ -158,6 +158,14 @@ class DeviceFrameBatch {
      *  float (or double with xyz_f64), frames concatenated in index order.  Needs the RANGE plane
      *  and options.xyz (for the LUTs).  Synchronous; returns the number of points. */
     uint64_t dewarp(double min_range, double max_range, bool provenance = false);
+    /** The same without the wait: the kernels are queued on the batch's stream and the per-frame offsets stay on the device
+     *  (`dewarped_offsets_device()`, [n_frames + 1] u64, the last one the total) -- for pipelines that copy them out with
+     *  their own stream (hip::FrameStream).  dewarped_frame_offsets() is NOT updated. */
+    void dewarp_async(double min_range, double max_range, bool provenance = false);
+    uint64_t* dewarped_offsets_device() { return static_cast<uint64_t*>(d_dw_off_.data()); }
+    uint32_t* dewarped_frame_idxs_device() { return static_cast<uint32_t*>(d_dw_fi_.data()); }
+    uint32_t* dewarped_col_idxs_device() { return static_cast<uint32_t*>(d_dw_ci_.data()); }
+    uint64_t* dewarped_timestamps_device() { return static_cast<uint64_t*>(d_dw_ts_.data()); }
     /** Results of the last dewarp(): device pointers and per-frame exclusive offsets [n_frames+1]. */
     void* dewarped_points_device() { return d_dw_pts_.data(); }
     const std::vector<uint64_t>& dewarped_frame_offsets() const { return dw_offsets_; }

@@ -31,6 +31,15 @@ struct StreamOptions {
     std::vector<std::string> download_destaggered;
     bool download_headers = true;     ///< timestamp / measurement_id / status per column
     int device = -1;                  ///< GPU to stream through (-1: hip::current_device())
+    /// Round 6: the range-gated, COMPACTING route (core::dewarp(FrameSet, luts, min_range, max_range),
+    /// impl/dewarp_impl.h:23-115) as what comes back: with max >= min every batch is also run through
+    /// DeviceFrameBatch::dewarp on the device and the compacted point list (points of the first return inside the gate, frames
+    /// in push order, the reference's order inside a frame; 12 B per KEPT point instead of 24 B per pixel for two dense
+    /// clouds) is returned in BatchResult::points -- the stream is bound by the link from the device, and this is the route
+    /// that moves fewer bytes over it (set download_xyz = false with it).  Poses are the identity: the points are in the frame
+    /// of the LUT (sensor, or body with the extrinsics folded in).
+    double dewarp_min_range = 0.0, dewarp_max_range = -1.0;
+    bool dewarp_provenance = false;   ///< also frame / column index and timestamp per point
 };
 
 /** One finished batch; the pointers stay valid during the callback only. */
@@ -43,6 +52,14 @@ struct BatchResult {
     const uint64_t* timestamp = nullptr;                     ///< [n_frames][w]
     const uint16_t* measurement_id = nullptr;
     const uint32_t* status = nullptr;
+    // the compacting route (StreamOptions::dewarp_*): n_points points [3] float (double with outputs.xyz_f64), the points of
+    // frame i of this batch are [frame_offsets[i], frame_offsets[i + 1]); provenance arrays [n_points] when asked for
+    const void* points = nullptr;
+    uint64_t n_points = 0;
+    const uint64_t* frame_offsets = nullptr;                 ///< [frames_per_batch + 1]
+    const uint32_t* point_frame_idxs = nullptr;              ///< index within the batch
+    const uint32_t* point_col_idxs = nullptr;
+    const uint64_t* point_timestamps_ns = nullptr;
 };
 
 class FrameStream {
@@ -81,6 +98,8 @@ class FrameStream {
     struct Slot;
     void submit(Slot& s);
     void deliver(Slot& s);
+    void request_points(Slot& s);   // compacting route: queue the copy of a batch's point list once its size is known
+    void poll_points();
 
     std::shared_ptr<Context> ctx_;    // compute stream + scratch, shared by the buffer sets
     StreamOptions opt_;

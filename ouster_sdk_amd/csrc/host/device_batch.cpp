@@ -452,6 +452,14 @@ void DeviceFrameBatch::upload_poses(uint32_t frame, const double* poses) {
 }
 
 uint64_t DeviceFrameBatch::dewarp(double min_range, double max_range, bool provenance) {
+    dewarp_async(min_range, max_range, provenance);
+    ScopedContext on_my_context(ctx_);
+    dw_offsets_.resize(static_cast<size_t>(n_frames_) + 1);
+    d_dw_off_.download(dw_offsets_.data(), dw_offsets_.size() * 8);  // synchronous
+    return dw_offsets_.back();
+}
+
+void DeviceFrameBatch::dewarp_async(double min_range, double max_range, bool provenance) {
     ScopedContext on_my_context(ctx_);
     auto rp = d_planes_.find(ChanField::RANGE);
     if (rp == d_planes_.end() || luts_.empty())
@@ -489,9 +497,6 @@ uint64_t DeviceFrameBatch::dewarp(double min_range, double max_range, bool prove
         provenance ? static_cast<uint32_t*>(d_dw_ci_.data()) : nullptr,
         provenance ? static_cast<uint64_t*>(d_dw_ts_.data()) : nullptr, cap,
         static_cast<uint64_t*>(d_dw_off_.data()), counted ? static_cast<const uint16_t*>(d_gate_.data()) : nullptr));
-    dw_offsets_.resize(static_cast<size_t>(n_frames_) + 1);
-    d_dw_off_.download(dw_offsets_.data(), dw_offsets_.size() * 8);  // synchronous
-    return dw_offsets_.back();
 }
 
 void DeviceFrameBatch::download_dewarped(void* points, uint32_t* fi, uint32_t* ci, uint64_t* ts) {

@@ -39,7 +39,9 @@ struct FrameStream::Slot {
     Pinned packets;                      // [frames][slots][stride]
     Pinned xyz[2], ts, mid, status;
     std::map<std::string, Pinned> planes, destaggered;
-    hipEvent_t e_h2d = nullptr, e_dec = nullptr, e_done = nullptr;
+    Pinned dw_pts, dw_off, dw_fi, dw_ci, dw_ts;   // the compacting route: capacity H * W points per frame
+    hipEvent_t e_h2d = nullptr, e_dec = nullptr, e_done = nullptr, e_pts = nullptr;
+    bool points_requested = false;       // the compacted list's copy has been queued (its size is known once the offsets are here)
     uint32_t filled = 0;                 // frames copied into `packets`
     bool in_flight = false;
     uint64_t first_frame = 0;
@@ -63,6 +65,12 @@ FrameStream::FrameStream(const std::vector<core::SensorInfo>& sensors, const Str
     if (opt_.batches_in_flight == 0) throw std::invalid_argument("FrameStream: batches_in_flight must be > 0");
     opt_.outputs.all_slots = true;
     if (opt_.download_xyz) opt_.outputs.xyz = true;
+    const bool compact = opt_.dewarp_max_range >= opt_.dewarp_min_range;
+    if (compact) {   // the decode leaves the gate's per-column counts behind (no counting pass), and the LUTs are needed
+        opt_.outputs.xyz = true;
+        opt_.outputs.gate_min_range = opt_.dewarp_min_range;
+        opt_.outputs.gate_max_range = opt_.dewarp_max_range;
+    }
     opt_.outputs.context = ctx_;
     hipStream_t a = nullptr, b = nullptr;
     ok(hipStreamCreateWithFlags(&a, hipStreamNonBlocking), "hipStreamCreate");
@@ -84,6 +92,16 @@ FrameStream::FrameStream(const std::vector<core::SensorInfo>& sensors, const Str
             (void)bt.destaggered_device(name);  // throws if it is not produced
             s->destaggered[name].alloc(n * bt.plane_bytes_per_frame(name));
         }
+        if (compact) {
+            const size_t cap = n * bt.h() * bt.w();
+            s->dw_pts.alloc(cap * (opt_.outputs.xyz_f64 ? 24 : 12));
+            s->dw_off.alloc((n + 1) * 8);
+            if (opt_.dewarp_provenance) {
+                s->dw_fi.alloc(cap * 4);
+                s->dw_ci.alloc(cap * 4);
+                s->dw_ts.alloc(cap * 8);
+            }
+        }
         if (opt_.download_headers) {
             s->ts.alloc(n * bt.w() * 8);
             s->mid.alloc(n * bt.w() * 2);
@@ -92,6 +110,7 @@ FrameStream::FrameStream(const std::vector<core::SensorInfo>& sensors, const Str
         ok(hipEventCreateWithFlags(&s->e_h2d, hipEventDisableTiming), "hipEventCreate");
         ok(hipEventCreateWithFlags(&s->e_dec, hipEventDisableTiming), "hipEventCreate");
         ok(hipEventCreateWithFlags(&s->e_done, hipEventDisableTiming), "hipEventCreate");
+        ok(hipEventCreateWithFlags(&s->e_pts, hipEventDisableTiming), "hipEventCreate");
         slots_.push_back(std::move(s));
     }
 }
@@ -100,7 +119,7 @@ FrameStream::~FrameStream() {
     ScopedContext on_my_context(ctx_);
     for (auto& s : slots_) {
         if (s->in_flight) (void)hipEventSynchronize(s->e_done);
-        for (hipEvent_t e : {s->e_h2d, s->e_dec, s->e_done})
+        for (hipEvent_t e : {s->e_h2d, s->e_dec, s->e_done, s->e_pts})
             if (e) (void)hipEventDestroy(e);
     }
     if (stream_h2d_) (void)hipStreamDestroy(static_cast<hipStream_t>(stream_h2d_));
@@ -109,6 +128,7 @@ FrameStream::~FrameStream() {
 
 void FrameStream::push_frame(const std::vector<const uint8_t*>& lidar_packets) {
     ScopedContext on_my_context(ctx_);
+    poll_points();
     Slot& s = *slots_[cur_];
     if (s.in_flight) deliver(s);  // every buffer set busy: the oldest batch has to come home first
     DeviceFrameBatch& bt = *s.batch;
@@ -200,6 +220,7 @@ void FrameStream::submit(Slot& s) {
     ok(hipEventRecord(s.e_h2d, h2d), "hipEventRecord");
     ok(hipStreamWaitEvent(comp, s.e_h2d, 0), "hipStreamWaitEvent");
     bt.decode();
+    if (s.dw_off.p) bt.dewarp_async(opt_.dewarp_min_range, opt_.dewarp_max_range, opt_.dewarp_provenance);
     ok(hipEventRecord(s.e_dec, comp), "hipEventRecord");
     ok(hipStreamWaitEvent(d2h, s.e_dec, 0), "hipStreamWaitEvent");
     const size_t n = opt_.frames_per_batch;
@@ -217,8 +238,12 @@ void FrameStream::submit(Slot& s) {
         ok(hipMemcpyAsync(s.mid.p, bt.measurement_id_device(), s.mid.n, hipMemcpyDeviceToHost, d2h), "D2H m_id");
         ok(hipMemcpyAsync(s.status.p, bt.status_device(), s.status.n, hipMemcpyDeviceToHost, d2h), "D2H status");
     }
+    // the compacted list: only its offsets now; how many points there are is known when they have arrived (deliver())
+    if (s.dw_off.p)
+        ok(hipMemcpyAsync(s.dw_off.p, bt.dewarped_offsets_device(), s.dw_off.n, hipMemcpyDeviceToHost, d2h), "D2H offsets");
     ok(hipEventRecord(s.e_done, d2h), "hipEventRecord");
     s.in_flight = true;
+    s.points_requested = false;
     s.n_frames = s.filled;
     s.filled = 0;
     cur_ = (cur_ + 1) % slots_.size();
@@ -239,8 +264,54 @@ void FrameStream::deliver(Slot& s) {
     r.timestamp = static_cast<const uint64_t*>(s.ts.p);
     r.measurement_id = static_cast<const uint16_t*>(s.mid.p);
     r.status = static_cast<const uint32_t*>(s.status.p);
+    if (s.dw_off.p) {
+        request_points(s);                                   // no-op when poll_points() already did it
+        ok(hipEventSynchronize(s.e_pts), "hipEventSynchronize");
+        const uint64_t* off = static_cast<const uint64_t*>(s.dw_off.p);
+        r.points = s.dw_pts.p;
+        r.n_points = off[opt_.frames_per_batch];
+        r.frame_offsets = off;
+        if (opt_.dewarp_provenance) {
+            r.point_frame_idxs = static_cast<const uint32_t*>(s.dw_fi.p);
+            r.point_col_idxs = static_cast<const uint32_t*>(s.dw_ci.p);
+            r.point_timestamps_ns = static_cast<const uint64_t*>(s.dw_ts.p);
+        }
+    }
     delivered_ += s.n_frames;
     if (cb_) cb_(r);
+}
+
+// The compacted list of a batch: exactly the kept points cross the link.  How many there are is known when the batch's offsets
+// have arrived (e_done); the copy is queued as soon as somebody notices -- every push looks (poll_points), so it normally runs
+// under the host's staging of later frames -- and waited for when the batch is delivered.
+void FrameStream::request_points(Slot& s) {
+    if (s.points_requested) return;
+    ok(hipEventSynchronize(s.e_done), "hipEventSynchronize");
+    const uint64_t total = static_cast<const uint64_t*>(s.dw_off.p)[opt_.frames_per_batch];
+    auto d2h = static_cast<hipStream_t>(stream_d2h_);
+    DeviceFrameBatch& bt = *s.batch;
+    if (total) {
+        ok(hipMemcpyAsync(s.dw_pts.p, bt.dewarped_points_device(), total * (opt_.outputs.xyz_f64 ? 24 : 12), hipMemcpyDeviceToHost, d2h),
+           "D2H points");
+        if (opt_.dewarp_provenance) {
+            ok(hipMemcpyAsync(s.dw_fi.p, bt.dewarped_frame_idxs_device(), total * 4, hipMemcpyDeviceToHost, d2h), "D2H frame idx");
+            ok(hipMemcpyAsync(s.dw_ci.p, bt.dewarped_col_idxs_device(), total * 4, hipMemcpyDeviceToHost, d2h), "D2H col idx");
+            ok(hipMemcpyAsync(s.dw_ts.p, bt.dewarped_timestamps_device(), total * 8, hipMemcpyDeviceToHost, d2h), "D2H timestamps");
+        }
+    }
+    ok(hipEventRecord(s.e_pts, d2h), "hipEventRecord");
+    s.points_requested = true;
+}
+
+void FrameStream::poll_points() {
+    for (auto& sp : slots_) {
+        Slot& s = *sp;
+        if (!s.in_flight || !s.dw_off.p || s.points_requested) continue;
+        const hipError_t q = hipEventQuery(s.e_done);
+        if (q == hipSuccess) request_points(s);
+        else if (q != hipErrorNotReady) ok(q, "hipEventQuery");
+        else (void)hipGetLastError();
+    }
 }
 
 void FrameStream::finish() {

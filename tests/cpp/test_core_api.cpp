@@ -1263,6 +1263,55 @@ static void test_frame_stream() {
         }
         CHECK(same);
     }
+    {   // round 6: the compacting route -- what comes back is the range-gated point list of every frame (dewarp_impl.h:23-81)
+        ouster::sdk::hip::StreamOptions o3;
+        o3.frames_per_batch = 4;
+        o3.batches_in_flight = 2;
+        o3.download_xyz = false;
+        o3.download_headers = false;
+        o3.dewarp_min_range = 1.5;
+        o3.dewarp_max_range = 90.0;
+        o3.dewarp_provenance = true;
+        XYZLutT<float> lf{XYZLut(a, true)};
+        bool counts_ok = true, prov_ok = true;
+        float worst32 = 0;
+        uint64_t seen = 0, points = 0;
+        ouster::sdk::hip::FrameStream s3({a}, o3, [&](const ouster::sdk::hip::BatchResult& r) {
+            counts_ok &= r.frame_offsets && r.frame_offsets[0] == 0 && r.n_points == r.frame_offsets[4] && r.xyz[0] == nullptr;
+            for (uint32_t i = 0; i < r.n_frames; ++i) {
+                const size_t f = r.first_frame + i;
+                LidarFrame fr(src[f]);                     // what the stream decoded: frame f (frame 5 without its packet 2)
+                if (f == 5)
+                    for (size_t c = 32; c < 48; ++c) fr.status()[c] = 0;
+                std::vector<uint32_t> wf, wc;
+                std::vector<uint64_t> wt;
+                FrameSet one{std::make_shared<LidarFrame>(fr)};
+                const auto want = impl::dewarp_impl<float>(one, std::vector<XYZLutT<float>>{lf}, 1.5, 90.0, &wf, &wc, &wt);
+                const uint64_t b = r.frame_offsets[i], e = r.frame_offsets[i + 1];
+                counts_ok &= e - b == want.size();
+                if (e - b != want.size()) continue;
+                const float* p = static_cast<const float*>(r.points) + b * 3;
+                for (size_t k = 0; k < want.size(); ++k) {
+                    for (int d = 0; d < 3; ++d) worst32 = std::max(worst32, std::abs(p[3 * k + d] - want[k][d]));
+                    prov_ok &= r.point_col_idxs[b + k] == wc[k] && r.point_timestamps_ns[b + k] == wt[k] && r.point_frame_idxs[b + k] == i;
+                }
+                points += want.size();
+            }
+            for (uint32_t i = r.n_frames; i < 4; ++i) counts_ok &= r.frame_offsets[i + 1] == r.frame_offsets[i];   // unused frames of a partial batch
+            seen += r.n_frames;
+        });
+        for (uint32_t f = 0; f < n; ++f) {
+            std::vector<const uint8_t*> ptrs;
+            for (size_t i = 0; i < pk[f].size(); ++i)
+                if (!(f == 5 && i == 2)) ptrs.push_back(pk[f][i].buf.data());
+            s3.push_frame(ptrs);
+        }
+        s3.finish();
+        CHECK(seen == n && points > 1000);
+        CHECK(counts_ok);
+        CHECK(prov_ok);
+        CHECK(worst32 <= 1e-4f);
+    }
     CHECK(throws_with<std::invalid_argument>([&] {
         ouster::sdk::hip::StreamOptions bad; bad.frames_per_batch = 3;
         ouster::sdk::hip::FrameStream s2({a, a}, bad, nullptr); }, "multiple of the sensor count"));

@@ -1,6 +1,7 @@
 // bench_stream.cpp -- PCIe-inclusive throughput of the hot path: host packets in, host results out,
 // through ouster::sdk::hip::FrameStream (pinned staging, H2D / decode / D2H overlapped).
-// Usage: bench_stream [frames=2048] [frames_per_batch=32] [in_flight=3] [what=xyz|xyz+planes|none]
+// Usage: bench_stream [frames=2048] [frames_per_batch=32] [in_flight=3] [what=xyz|xyz+planes|none|compact]
+// compact: the range-gated compacting route (StreamOptions::dewarp_*, gate 0.5 - 400 m): the kept points of the first return
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -64,16 +65,24 @@ int main(int argc, char** argv) {
     opt.download_xyz = what != "none";
     opt.download_headers = what != "none";
     if (what == "none") opt.outputs.xyz = true;
+    if (what == "compact") {
+        opt.download_xyz = false;
+        opt.download_headers = false;
+        opt.dewarp_min_range = 0.5;
+        opt.dewarp_max_range = 400.0;
+    }
     if (what == "xyz+planes") {
         opt.outputs.destagger = {"RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"};
         opt.download_planes = {"RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2", "NEAR_IR"};
         opt.download_destaggered = {"RANGE", "RANGE2", "REFLECTIVITY", "REFLECTIVITY2"};
     }
     double checksum = 0;
-    uint64_t got = 0;
+    uint64_t got = 0, kept = 0;
     ouster::sdk::hip::FrameStream stream({info}, opt, [&](const ouster::sdk::hip::BatchResult& r) {
         got += r.n_frames;
+        kept += r.n_points;
         if (r.xyz[0]) checksum += static_cast<const float*>(r.xyz[0])[12345];
+        if (r.points && r.n_points > 12345) checksum += static_cast<const float*>(r.points)[12345];
     });
     std::vector<std::vector<const uint8_t*>> ptrs(pool.size());
     for (size_t f = 0; f < pool.size(); ++f)
@@ -81,15 +90,16 @@ int main(int argc, char** argv) {
     for (uint32_t f = 0; f < 4 * fpb; ++f) stream.push_frame(ptrs[f % ptrs.size()]);  // warm-up (tuner, allocs)
     stream.finish();
     const uint64_t warm = got;
+    kept = 0;
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t f = 0; f < total; ++f) stream.push_frame(ptrs[f % ptrs.size()]);
     stream.finish();
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double in_b = 128.0 * 16640, xyz_b = 2.0 * 128 * 2048 * 12, pl_b = what == "xyz+planes" ? 128.0 * 2048 * (4 + 4 + 1 + 1 + 2 + 10) : 0;
-    const double out_b = what == "none" ? 0 : xyz_b + pl_b + 2048 * 14;
+    const double out_b = what == "none" ? 0 : what == "compact" ? 12.0 * kept / total + (fpb + 1) * 8.0 / fpb : xyz_b + pl_b + 2048 * 14;
     std::printf("{\"frames\": %u, \"frames_per_batch\": %u, \"in_flight\": %u, \"download\": \"%s\", \"seconds\": %.4f, "
-                "\"frames_per_s\": %.1f, \"Mpoints_per_s\": %.1f, \"H2D_GBps\": %.2f, \"D2H_GBps\": %.2f, \"delivered\": %llu, \"checksum\": %.3f}\n",
+                "\"frames_per_s\": %.1f, \"Mpoints_per_s\": %.1f, \"H2D_GBps\": %.2f, \"D2H_GBps\": %.2f, \"delivered\": %llu, \"checksum\": %.3f, \"Mpixels_per_s\": %.1f, \"kept_points_per_frame\": %.0f}\n",
                 total, fpb, depth, what.c_str(), s, total / s, total / s * 524288 / 1e6, total / s * in_b / 1e9,
-                total / s * out_b / 1e9, (unsigned long long)(got - warm), checksum);
+                total / s * out_b / 1e9, (unsigned long long)(got - warm), checksum, total / s * 262144 / 1e6, (double)kept / total);
     return 0;
 }
