@@ -747,6 +747,12 @@ def time_drop_in():
         out["frame_stream_D2H_GBps"] = fs.get("D2H_GBps")
     else:
         out["frame_stream_error"] = fs.get("error")
+    try:   # the same three calls through the pybind11 module (numpy in, numpy out; results are numpy arrays over pool memory)
+        o = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_python_api.py"), "30"], capture_output=True, text=True, timeout=180)
+        pj = json.loads(o.stdout.strip().splitlines()[-1]) if o.returncode == 0 else {"error": (o.stderr or o.stdout)[-200:]}
+    except Exception as e:   # noqa: BLE001
+        pj = {"error": str(e)[:200]}
+    out["python_core_ms"] = pj.get("ms_per_frame", pj)
     fc = res.get("frame_stream_compact", {})
     if "frames_per_s" in fc:   # round 6: the range-gated compacting route as what comes back (StreamOptions::dewarp_*)
         out["frame_stream_compact"] = {"frames_per_s": fc["frames_per_s"], "Gpixels_per_s": round(fc["Mpixels_per_s"] / 1e3, 3),

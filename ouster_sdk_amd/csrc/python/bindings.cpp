@@ -163,23 +163,45 @@ bool try_set_field(const PacketFormat& pf, LidarPacket& p, const std::string& na
     return true;
 }
 
+// A numpy array over memory of the library's pool (include/ouster_hip.h, ouster_hip_host_alloc): the kernels write the result
+// in place (no staging copy, no first-touch faults) and the block goes back to the pool when the array dies.
+py::array pool_array(const py::dtype& dt, const std::vector<py::ssize_t>& shape) {
+    size_t bytes = static_cast<size_t>(dt.itemsize());
+    for (py::ssize_t d : shape) bytes *= static_cast<size_t>(d);
+    struct Block { void* p; size_t n; };
+    auto* blk = new Block{impl::host_alloc(bytes ? bytes : 1, false), bytes ? bytes : 1};
+    if (!blk->p) {
+        delete blk;
+        throw std::bad_alloc();
+    }
+    py::capsule owner(blk, [](void* q) {
+        auto* b = static_cast<Block*>(q);
+        impl::host_free(b->p, b->n);
+        delete b;
+    });
+    return py::array(dt, shape, blk->p, owner);
+}
+
 template <typename T>
 py::array lut_call(const XYZLutT<T>& lut, const py::object& arg) {
-    PointCloudXYZ<T> pts;
+    // the cloud is written straight into the array that is returned (pool memory: one launch, nothing copied)
+    py::array out = pool_array(py::dtype::of<T>(), {static_cast<py::ssize_t>(lut.h), static_cast<py::ssize_t>(lut.w), py::ssize_t{3}});
+    const uint32_t* range = nullptr;
+    py::array_t<uint32_t, py::array::c_style | py::array::forcecast> r;
     if (py::isinstance<LidarFrame>(arg)) {
         const LidarFrame& fr = arg.cast<const LidarFrame&>();
         if (fr.w != lut.w || fr.h != lut.h) throw std::invalid_argument("unexpected image dimensions");
-        pts = lut(fr);
+        range = fr.field<uint32_t>(ChanField::RANGE).data();
     } else {
-        auto r = py::array_t<uint32_t, py::array::c_style | py::array::forcecast>::ensure(arg);
+        r = py::array_t<uint32_t, py::array::c_style | py::array::forcecast>::ensure(arg);
         if (!r || r.ndim() != 2) throw std::invalid_argument("Incompatible argument: expected a 2d range image");
         if (static_cast<size_t>(r.shape(0)) != lut.h || static_cast<size_t>(r.shape(1)) != lut.w)
             throw std::invalid_argument("unexpected image dimensions");
-        pts = lut(ImgRef<const uint32_t>(r.data(), r.shape(0), r.shape(1)));
+        range = r.data();
     }
-    py::array_t<T> out({static_cast<py::ssize_t>(lut.h), static_cast<py::ssize_t>(lut.w), py::ssize_t{3}});
-    std::memcpy(out.mutable_data(), pts.data(), pts.size() * sizeof(T));
-    return std::move(out);
+    if (lut.h * lut.w != static_cast<size_t>(lut.direction.rows())) throw std::invalid_argument("unexpected image dimensions");
+    impl::cartesian_device(lut.device(), range, lut.h * lut.w, out.mutable_data(), sizeof(T) == 8);
+    return out;
 }
 
 template <typename T>
@@ -689,7 +711,7 @@ PYBIND11_MODULE(core, m) {
                 throw std::invalid_argument("Image resolution must match SensorInfo.");
             size_t extra = 1;
             for (py::ssize_t i = 2; i < src.ndim(); ++i) extra *= static_cast<size_t>(src.shape(i));
-            py::array out(src.dtype(), std::vector<py::ssize_t>(src.shape(), src.shape() + src.ndim()));
+            py::array out = pool_array(src.dtype(), std::vector<py::ssize_t>(src.shape(), src.shape() + src.ndim()));
             impl::destagger_bytes(src.data(), out.mutable_data(), h, w,
                                   static_cast<size_t>(src.itemsize()) * extra,
                                   info.format.pixel_shift_by_row, inverse, h, w);
