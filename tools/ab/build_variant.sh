@@ -12,6 +12,7 @@ for i in 0 1 2 3 4 5; do hipcc $F -DOUSTER_SPEC_ID=$i -c -o $B/k_decode_$i.o $C/
 for i in 1 2 3 4 5; do hipcc $F -DOUSTER_SPEC_ID=$i -c -o $B/k_decode_stream_$i.o $C/k_decode_stream.hip & done
 hipcc $F -c -o $B/k_standalone.o $C/k_standalone.hip &
 hipcc $F -c -o $B/ouster_hip_capi.o $C/ouster_hip_capi.hip &
+hipcc $F -c -o $B/host_pool.o $C/host_pool.hip &
 wait
 hipcc $F -shared -o tools/ab/libouster_hip_$NAME.so $B/*.o
 ls -la tools/ab/libouster_hip_$NAME.so
