@@ -994,11 +994,21 @@ def main():
     if world > 1:
         # every rank's own view next to the max the line is computed from: a slow rank, or one whose tuner settled on another
         # kernel, must be visible in a SCALE record (rank 0 would otherwise speak for all of them)
-        mine = {"rank": rank, "ms_per_step": round((t1 - t0) / args.steps * 1e3, 4), "kernel_ms": round(kern_ms, 4),
-                "kernel": f"{kern} {tc}x{tr}", "device": torch.cuda.current_device(),
-                "placement": (placement or {}).get("mode", "first") + (":skipped" if (placement or {}).get("skipped") else "")}
-        rows = [None] * world
-        dist.all_gather_object(rows, mine)
+        # (plain tensors through the same all-gather path as the reduction below: no pickling, nothing RCCL has not done before)
+        KERNELS = ["k_decode", "k_decode_wide", "k_decode_stream", "k_decode_stream2", "other"]
+        pl_mode = (placement or {}).get("mode", "first")
+        pl_code = {"first": 0, "refine": 1, "draws": 2}.get(pl_mode, 0) + (10 if (placement or {}).get("skipped") else 0)
+        mine_t = torch.tensor([(t1 - t0) / args.steps * 1e3, kern_ms, float(KERNELS.index(kern) if kern in KERNELS else 4), float(tc), float(tr),
+                               float(pl_code), float(torch.cuda.current_device())], dtype=torch.float64, device=red_device)
+        all_t = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(all_t, mine_t)
+        rows = []
+        for r_i, v in enumerate(all_t):
+            v = v.cpu().tolist()
+            pc = int(v[5])
+            rows.append({"rank": r_i, "ms_per_step": round(v[0], 4), "kernel_ms": round(v[1], 4),
+                         "kernel": f"{KERNELS[int(v[2])]} {int(v[3])}x{int(v[4])}", "device": int(v[6]),
+                         "placement": ["first", "refine", "draws"][pc % 10] + (":skipped" if pc >= 10 else "")})
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
