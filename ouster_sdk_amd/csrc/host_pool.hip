@@ -4,13 +4,15 @@
 // Why a pool: one hipHostMalloc + hipHostFree of a 6 MB cloud costs 1.1 ms on the round-6 boxes
 // (tools/copybench), eight times the PCIe time of the cloud itself; a block that is handed out
 // again costs a mutex and a map lookup.  Why page-locked at all: a kernel reaches such memory in
-// place, so a frame-at-a-time call is ONE launch whose reads and writes share the full-duplex link
-// (1 MB in + 1 MB out: 40 us, against 64 us for copy-in / kernel / copy-out and 177 us for what round
-// 5 did) -- and pages that stay resident are never first-touched again.
+// place, so a frame-at-a-time call is ONE launch with no staging copy on either side (1 MB in + 1 MB
+// out: 50 us -- the link's two directions do not overlap for a kernel --, against 64 us for copy-in /
+// kernel / copy-out and 177 us for what round 5 did), a copy out of HBM into it runs at the full link
+// rate (26.5 us per MB), and pages that stay resident are never first-touched again.
 //
 // Blocks are never returned to the system at process exit (the HIP runtime may be gone by then).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -30,6 +32,8 @@ AllocCounters& alloc_counters() {
 using ouster_hip_dev::alloc_counters;
 
 namespace {
+
+std::atomic<bool> g_exiting{false};   // set by an atexit handler: from then on nothing is handed back to the HIP runtime
 
 struct Block {
     size_t cap;   // bytes of the block (its size class)
@@ -58,6 +62,9 @@ struct Pool {
                 n = 0;
             }
             have_gpu = n > 0;
+            // registered AFTER the probe above has initialised the runtime (and with it the runtime's own exit handlers):
+            // handlers run in reverse order, so this one runs before the runtime is torn down
+            std::atexit([] { g_exiting.store(true); });
             if (const char* e = std::getenv("OUSTER_HIP_HOST_POOL_MB")) cache_limit = (size_t)std::atoll(e) << 20;
             if (const char* e = std::getenv("OUSTER_HIP_HOST_POOL")) if (std::atoi(e) == 0) have_gpu = 0;   // A/B: plain memory
         }
@@ -131,7 +138,7 @@ void ouster_hip_host_free(void* p) {
             release = true;
         }
     }
-    if (release) {
+    if (release && !g_exiting.load()) {   // a container freed by a static destructor at exit: the runtime may be gone
         (void)hipHostFree(p);
         alloc_counters().pinned_frees.fetch_add(1, std::memory_order_relaxed);
     }
@@ -163,6 +170,7 @@ void ouster_hip_host_pool_trim(size_t keep_bytes) {
             }
     }
     for (void* p : drop) {
+        if (g_exiting.load()) break;
         (void)hipHostFree(p);
         alloc_counters().pinned_frees.fetch_add(1, std::memory_order_relaxed);
     }
