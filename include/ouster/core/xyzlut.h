@@ -30,7 +30,7 @@ using XYZLut = XYZLutT<double>;
 
 namespace impl {
 /** Shared handle to the device-side tables of a LUT. */
-struct DeviceLut {
+struct DeviceLut : std::enable_shared_from_this<DeviceLut> {
     ::ouster_hip_lut* handle = nullptr;
     int device = 0;  ///< GPU the tables live on (ouster::sdk::hip::set_device at creation time)
     ~DeviceLut();

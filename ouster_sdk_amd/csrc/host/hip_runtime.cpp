@@ -293,6 +293,29 @@ void cartesian_device(const DeviceLut& dev, const uint32_t* range, size_t n, voi
     if (n == 0) return;
     hip::ScopedContext on_lut_device(hip::Context::current()->device() == dev.device
                                          ? hip::Context::current() : hip::Context::for_device(dev.device));
+    // the range plane of a frame a FrameBatcher has just released: its cloud may already be in HBM (impl::XyzWish) -- one copy
+    // out; if not, the batcher learns which LUT its frames are projected with and its next release produces it
+    if (mirrors_live()) {
+        MirrorPlane m;
+        if (mirror_find(range, m) && m.elem == 4 && m.h * m.w == n && m.device == dev.device) {
+            if (m.d_xyz && m.xyz_lut == dev.handle && m.xyz_f64 == points_f64) {
+                ouster_hip_ctx* ctx = hip::default_ctx();
+                hip::check(ouster_hip_copy_out(ctx, points, m.d_xyz, n * 3 * (points_f64 ? 8 : 4)));
+                hip::check(ouster_hip_sync(ctx));
+                return;
+            }
+            if (m.wish) {
+                std::lock_guard<std::mutex> g(m.wish->mu);
+                if (m.wish->lut.get() != &dev || m.wish->f64 != points_f64) {
+                    try {
+                        m.wish->lut = dev.shared_from_this();
+                        m.wish->f64 = points_f64;
+                    } catch (const std::bad_weak_ptr&) {   // a DeviceLut that is not owned by a shared_ptr: nothing to remember
+                    }
+                }
+            }
+        }
+    }
     hip::check(ouster_hip_cartesian_host(hip::default_ctx(), dev.handle, range, points,
                                          points_f64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32));
 }

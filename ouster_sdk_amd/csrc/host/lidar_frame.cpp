@@ -20,6 +20,7 @@
 
 #include "host_internal.h"
 #include "ouster/core/lidar_frame.h"
+#include "ouster/core/xyzlut.h"
 #include "ouster/hip/device_buffer.h"
 
 namespace ouster {
@@ -635,6 +636,7 @@ struct FrameBatcher::State : std::enable_shared_from_this<FrameBatcher::State> {
     std::shared_ptr<hip::DeviceBuffer> d_mirror;
     std::vector<const void*> mirror_keys;
     std::shared_ptr<const std::vector<int>> mirror_shifts;
+    std::shared_ptr<impl::XyzWish> xyz_wish = std::make_shared<impl::XyzWish>();   // the LUT the caller projects released frames with
     FrameBatcher::PacketSink sink;  // set: released frames go here instead of being decoded
     // this batcher's own context (stream + scratch) on the GPU that was current when it first needed
     // one: distinct batchers never share mutable GPU state, like the reference's CPU batchers
@@ -889,15 +891,46 @@ struct BatcherOps {
                     mtotal += (H * W * elems[i] + 255) & ~size_t{255};
                 }
             }
+            // ... and the clouds of the range planes, when the caller has been projecting this batcher's frames (XyzWish)
+            std::shared_ptr<const impl::DeviceLut> xl;
+            bool xf64 = true;
+            {
+                std::lock_guard<std::mutex> g(s.xyz_wish->mu);
+                xl = s.xyz_wish->lut;
+                xf64 = s.xyz_wish->f64;
+            }
+            size_t xoff[2] = {SIZE_MAX, SIZE_MAX};
+            int xfield[2] = {-1, -1};
+            const ouster_hip_lut* xl_handle = nullptr;
+            if (mtotal && xl && xl->handle && xl->device == s.context()->device()) {
+                int k = 0;
+                for (size_t i = 0; i < dst.size() && k < 2; ++i)
+                    if (moff[i] != SIZE_MAX && elems[i] == 4 && (names[i] == ChanField::RANGE || names[i] == ChanField::RANGE2)) {
+                        xfield[k] = static_cast<int>(i);
+                        xoff[k] = mtotal;
+                        mtotal += (H * W * 3 * (xf64 ? 8 : 4) + 255) & ~size_t{255};
+                        ++k;
+                    }
+                if (k) xl_handle = xl->handle;
+            }
             if (mtotal) {
                 if (!s.d_mirror || s.d_mirror->size() < mtotal) s.d_mirror = std::make_shared<hip::DeviceBuffer>(mtotal);
                 if (!s.mirror_shifts || *s.mirror_shifts != shifts) s.mirror_shifts = std::make_shared<const std::vector<int>>(shifts);
                 for (size_t i = 0; i < dst.size(); ++i)
                     if (moff[i] != SIZE_MAX) out.destaggered[i] = static_cast<uint8_t*>(s.d_mirror->data()) + moff[i];
             }
+            if (xl_handle) {
+                for (int k = 0; k < 2; ++k)
+                    if (xfield[k] >= 0) {
+                        out.xyz[k] = static_cast<uint8_t*>(s.d_mirror->data()) + xoff[k];
+                        out.xyz_field[k] = xfield[k];
+                    }
+                out.xyz_dtype = xf64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32;
+            }
             static_assert(sizeof(int) == sizeof(int32_t), "pixel_shift_by_row is handed over as int32");
             hip::check(ouster_hip_decode(ctx, s.fmt, s.staged.data(), s.stride, static_cast<uint32_t>(slots), &count, 1, nullptr,
-                                         &out, mtotal ? reinterpret_cast<const int32_t*>(shifts.data()) : nullptr, nullptr, 0));
+                                         &out, mtotal ? reinterpret_cast<const int32_t*>(shifts.data()) : nullptr,
+                                         xl_handle ? &xl_handle : nullptr, xl_handle ? 1 : 0));
             hip::check(ouster_hip_sync(ctx));
             for (size_t i = 0; i < dst.size() && mtotal; ++i) {
                 if (moff[i] == SIZE_MAX) continue;
@@ -910,6 +943,13 @@ struct BatcherOps {
                 m.device = s.context()->device();
                 m.shifts = s.mirror_shifts;
                 m.keep = s.d_mirror;
+                m.wish = s.xyz_wish;
+                for (int k = 0; k < 2; ++k)
+                    if (xl_handle && xfield[k] == static_cast<int>(i)) {
+                        m.d_xyz = out.xyz[k];
+                        m.xyz_lut = xl_handle;
+                        m.xyz_f64 = xf64;
+                    }
                 impl::mirror_register(m);
                 s.mirror_keys.push_back(m.host);
             }

@@ -1655,6 +1655,64 @@ static void test_dropin_host_containers() {
     }
     CHECK(is_roll<uint32_t>(cframe.field<uint32_t>(ChanField::RANGE2), destagger<uint32_t>(info, cframe.field<uint32_t>(ChanField::RANGE2)), shifts));
 
+    // -- the cloud of a released frame: the first lut(frame) tells the batcher which LUT its frames are projected with, the next
+    //    release launch projects ahead of the call and lut(frame) is one copy out; always the cloud of the CURRENT range plane
+    {
+        LidarFrame fx(sinfo);   // a frame nobody has taken a writable pointer from
+        const LidarFrame& cfx = fx;
+        FrameBatcher bx(sinfo);
+        int64_t fid = 5000;
+        auto rel = [&](uint64_t seed) {
+            randomize(src, *pf, seed);
+            src.frame_id = fid++;
+            bool done = false;
+            for (auto& p : impl::frame_to_packets(src, pf, info.init_id, info.sn)) done = bx(p, fx);
+            return done;
+        };
+        XYZLut lut_ext(info, true);
+        XYZLutT<float> lut_f{XYZLut(info, false)};
+        bool ok = true;
+        for (int round = 0; round < 4; ++round) {
+            ok &= rel(7000 + round);
+            const auto pts = lut(cfx);                                                  // round 0: the kernel; later: the mirror
+            ok &= cloud_matches(pts, cfx.field<uint32_t>(ChanField::RANGE), lut);
+            const auto pts2 = lut(cfx.field<uint32_t>(ChanField::RANGE2));
+            ok &= cloud_matches(pts2, cfx.field<uint32_t>(ChanField::RANGE2), lut);
+            const auto pe = lut_ext(cfx);                                               // another LUT: never the mirrored cloud
+            ok &= cloud_matches(pe, cfx.field<uint32_t>(ChanField::RANGE), lut_ext);
+            if (round == 2) {                                                           // switch the wish to float and back
+                const auto pf32 = lut_f(cfx);
+                float worst = 0;
+                for (size_t i = 0; i < pf32.size(); ++i) worst = std::max(worst, std::abs(pf32.data()[i] - static_cast<float>(pts.data()[i])));
+                ok &= worst <= 1e-4f;
+            }
+        }
+        CHECK(ok);
+        CHECK(rel(7100));
+        const auto a1 = lut(cfx);
+        { auto rw = fx.field<uint32_t>(ChanField::RANGE); rw(5, 5) = 77777; rw(100, 900) = 0; }   // written after the release
+        const auto a2 = lut(cfx);
+        CHECK(cloud_matches(a2, cfx.field<uint32_t>(ChanField::RANGE), lut) && !(a1 == a2));
+        CHECK(a2(100 * 1024 + 900, 0) == 0.0 && a2(100 * 1024 + 900, 2) == 0.0);
+        // steady state of the mirrored cloud: still nothing allocated
+        const auto s0 = ouster::sdk::hip::alloc_stats();
+        LidarFrame fy(sinfo);
+        const LidarFrame& cfy = fy;
+        FrameBatcher by(sinfo);
+        bool ok2 = true;
+        ouster::sdk::hip::AllocStats s1{};
+        for (int i = 0; i < 12; ++i) {
+            if (i == 4) s1 = ouster::sdk::hip::alloc_stats();
+            randomize(src, *pf, 7200 + i);
+            src.frame_id = 9000 + i;
+            bool done = false;
+            for (auto& p : impl::frame_to_packets(src, pf, info.init_id, info.sn)) done = by(p, fy);
+            ok2 &= done && cloud_matches(lut(cfy), cfy.field<uint32_t>(ChanField::RANGE), lut);
+        }
+        const auto s2 = ouster::sdk::hip::alloc_stats();
+        CHECK(ok2 && s2.device_allocs == s1.device_allocs && s2.pinned_allocs == s1.pinned_allocs && s1.device_allocs >= s0.device_allocs);
+    }
+
     // -- memory the pool has never seen: a caller's own arrays go through the context's scratch, same results ----------
     {
         std::mt19937 g(5);
