@@ -737,7 +737,7 @@ def time_drop_in():
         out["how"] = ("Field / img_t / PointCloudXYZ are pool (page-locked) memory: the decode, cartesian and inverse-destagger kernels "
                       "read and write them in place (one launch, no staging copy, no allocation); destagger() of a plane the "
                       "FrameBatcher has just released is one copy out of the HBM mirror its release launch left behind "
-                      "(DESIGN 5; link measurements: profiles/r06_dropin/copybench.json)")
+                      "and, once the batcher has seen which LUT the caller projects with, so is XYZLut()(frame) (DESIGN 4.1; link measurements: profiles/r06_dropin/copybench.json)")
     else:
         out["host_api_error"] = ha.get("error")
     fs = res.get("frame_stream", {})
@@ -747,6 +747,17 @@ def time_drop_in():
         out["frame_stream_D2H_GBps"] = fs.get("D2H_GBps")
     else:
         out["frame_stream_error"] = fs.get("error")
+    try:   # the same calls with the HBM mirror switched off: every destagger / XYZLut() is a kernel on the host containers in place
+        o = subprocess.run([os.path.join(bdir, "bench_host_api"), "40"], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, OUSTER_HIP_MIRROR="0"))
+        mo = json.loads(o.stdout.strip().splitlines()[-1])["ms_per_frame"] if o.returncode == 0 else None
+        if mo:
+            out["without_mirror"] = {"frame_batcher_ms": mo["FrameBatcher_128_packets"], "destagger_ms": mo["destagger_u32"],
+                                     "destagger_u8_ms": mo.get("destagger_u8"), "xyzlut_ms": mo["XYZLut_f64"],
+                                     "frame_total_ms": mo.get("frame_total"),
+                                     "what": "OUSTER_HIP_MIRROR=0: nothing is served from what the release launch left in HBM"}
+    except Exception as e:   # noqa: BLE001
+        out["without_mirror"] = {"error": str(e)[:200]}
     try:   # the same three calls through the pybind11 module (numpy in, numpy out; results are numpy arrays over pool memory)
         o = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_python_api.py"), "30"], capture_output=True, text=True, timeout=180)
         pj = json.loads(o.stdout.strip().splitlines()[-1]) if o.returncode == 0 else {"error": (o.stderr or o.stdout)[-200:]}
