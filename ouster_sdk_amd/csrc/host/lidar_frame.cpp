@@ -632,6 +632,13 @@ struct FrameBatcher::State : std::enable_shared_from_this<FrameBatcher::State> {
     std::vector<std::string> fmt_fields;
     std::vector<uint32_t> fmt_elems;
     hip::DeviceBuffer d_packets, d_out;
+    // Frames of 64 packets or more: the staged packets are also sent to the device in pieces of UPLOAD_CHUNK while the rest
+    // of the frame is still arriving (asynchronous copies out of the page-locked staging buffer), so that the release launch
+    // reads them from HBM and only its stores cross the link: a copy-engine upload and a kernel's stores to host memory share
+    // the link (2.1 MB up + 3.96 MB down together 93 us, tools/copybench), a kernel's own reads and stores do not (0.145 ms).
+    static constexpr size_t UPLOAD_CHUNK = 32;
+    size_t uploaded = 0;           // packets of the frame under assembly already queued for upload into d_packets
+    bool chunked() const { return expected_lidar_packets >= 64 && !sink; }
     // destaggered planes of the last released frame, kept in HBM (impl::MirrorPlane) and the host planes they belong to
     std::shared_ptr<hip::DeviceBuffer> d_mirror;
     std::vector<const void*> mirror_keys;
@@ -678,6 +685,7 @@ void FrameBatcher::reset() {
     s_->finished_frame_id = -1;
     s_->batched_lidar_packets = 0;
     s_->staged_count = 0;
+    s_->uploaded = 0;
     s_->next_valid_m_id = s_->next_headers_m_id = 0;
     s_->pending.reset();
     s_->cache.clear();
@@ -698,6 +706,7 @@ struct BatcherOps {
         s.finished_frame_id = -1;
         s.batched_lidar_packets = 0;
         s.staged_count = 0;
+        s.uploaded = 0;
         s.next_valid_m_id = s.next_headers_m_id = 0;
         s.pending.reset();              // notes left on frames of an earlier assembly are void: their packets are gone
         frame.clear_pending_decode();
@@ -728,6 +737,10 @@ struct BatcherOps {
                                                              (s.expected_lidar_packets + 4) * s.stride}),
                                            impl::uninitialized);
             if (s.staged_count) std::memcpy(grown.data(), s.staged.data(), s.staged_count * s.stride);
+            if (s.uploaded) {   // copies may still be reading the block that is about to go back to the pool
+                hip::ScopedContext on_my_context(s.context());
+                hip::check(ouster_hip_sync(hip::default_ctx()));
+            }
             s.staged = std::move(grown);
         }
         uint8_t* dst = s.staged.data() + s.staged_count * s.stride;
@@ -737,6 +750,21 @@ struct BatcherOps {
         s.batched_lidar_packets++;
         track_columns(s, pf, dst, frame);
         if (!s.sink) frame.set_pending_decode(pending_note(s, pf));
+        if (s.chunked() && s.staged_count - s.uploaded >= FrameBatcher::State::UPLOAD_CHUNK && s.staged_count < s.expected_lidar_packets)
+            upload_staged(s, s.staged_count);
+    }
+    // queue staged packets [uploaded, upto) for upload (asynchronous, the batcher's stream; the staging block is page-locked)
+    static void upload_staged(FrameBatcher::State& s, size_t upto) {
+        if (upto <= s.uploaded) return;
+        hip::ScopedContext on_my_context(s.context());
+        const size_t need = std::max<size_t>(s.staged.size(), (s.expected_lidar_packets + 4) * s.stride);
+        if (s.d_packets.size() < need) {
+            if (s.uploaded) hip::check(ouster_hip_sync(hip::default_ctx()));
+            s.d_packets.resize(need);
+            s.uploaded = 0;       // a new buffer: everything staged so far goes up again
+        }
+        s.d_packets.upload_async(s.staged.data() + s.uploaded * s.stride, (upto - s.uploaded) * s.stride, s.uploaded * s.stride);
+        s.uploaded = upto;
     }
     static std::shared_ptr<impl::PendingDecode> pending_note(FrameBatcher::State& s, const PacketFormat& pf);
 
@@ -816,6 +844,7 @@ struct BatcherOps {
         s.last_frame_id = frame.frame_id;
         s.batched_lidar_packets = 0;
         s.staged_count = 0;
+        s.uploaded = 0;
     }
 
     // one GPU launch: every plane the frame shares with the packet format + column headers
@@ -928,7 +957,12 @@ struct BatcherOps {
                 out.xyz_dtype = xf64 ? OUSTER_HIP_F64 : OUSTER_HIP_F32;
             }
             static_assert(sizeof(int) == sizeof(int32_t), "pixel_shift_by_row is handed over as int32");
-            hip::check(ouster_hip_decode(ctx, s.fmt, s.staged.data(), s.stride, static_cast<uint32_t>(slots), &count, 1, nullptr,
+            const uint8_t* pk = s.staged.data();
+            if (s.chunked()) {   // most of the frame is in HBM already: the rest follows, the launch reads all of it there
+                upload_staged(s, s.staged_count);
+                pk = static_cast<const uint8_t*>(s.d_packets.data());
+            }
+            hip::check(ouster_hip_decode(ctx, s.fmt, pk, s.stride, static_cast<uint32_t>(slots), &count, 1, nullptr,
                                          &out, mtotal ? reinterpret_cast<const int32_t*>(shifts.data()) : nullptr,
                                          xl_handle ? &xl_handle : nullptr, xl_handle ? 1 : 0));
             hip::check(ouster_hip_sync(ctx));
@@ -973,8 +1007,13 @@ struct BatcherOps {
         const size_t off_mid = total;
         total += al(W * 2);
         s.d_out.resize(total);
-        s.d_packets.resize(slots * s.stride);
-        if (s.staged_count) s.d_packets.upload_async(s.staged.data(), s.staged_count * s.stride);
+        if (s.chunked()) {
+            upload_staged(s, s.staged_count);
+            if (s.d_packets.size() < slots * s.stride) s.d_packets.resize(slots * s.stride);
+        } else {
+            s.d_packets.resize(slots * s.stride);
+            if (s.staged_count) s.d_packets.upload_async(s.staged.data(), s.staged_count * s.stride);
+        }
         uint8_t* base = static_cast<uint8_t*>(s.d_out.data());
         for (size_t i = 0; i < dst.size(); ++i) out.planes[i] = base + off[i];
         out.timestamp = reinterpret_cast<uint64_t*>(base + off_ts);

@@ -114,13 +114,30 @@ int main(int argc, char** argv) {
         }
     }
     a1 = ouster::sdk::hip::alloc_stats();
+    // The release call when the packets do NOT arrive back to back: a sensor spreads a frame's 128 packets over 100 ms, this
+    // loop merely leaves 150 us before the last one -- enough for the pieces the batcher uploads while a frame is arriving to
+    // have landed, so that the release launch finds all but the last piece in HBM (back to back, above, the copy engine is still
+    // busy with them when the last packet comes).
+    std::vector<double> t_release_paced;
+    for (int f = 0; f < std::min(frames, 20); ++f) {
+        src.frame_id = 200 + frames + f;   // (16-bit frame ids: keep counting forward)
+        auto packets = impl::frame_to_packets(src, pf, info.init_id, 1);
+        bool done = false;
+        for (size_t k = 0; k + 1 < packets.size(); ++k) done = batcher(packets[k], frame);
+        const auto w0 = clk::now();
+        while (ms(w0, clk::now()) < 0.15) {}
+        const auto r0 = clk::now();
+        done = batcher(packets.back(), frame);
+        t_release_paced.push_back(ms(r0, clk::now()));
+        if (!done) return 3;
+    }
     auto mean = [&](const std::vector<double>& v) { double s = 0; for (double x : v) s += x; return s / v.size(); };
-    std::printf("{\"frames\": %d, \"ms_per_frame\": {\"FrameBatcher_128_packets\": %.4f, \"FrameBatcher_release_call\": %.4f, \"destagger_u32\": %.4f, \"destagger_u8\": %.4f, "
+    std::printf("{\"frames\": %d, \"ms_per_frame\": {\"FrameBatcher_128_packets\": %.4f, \"FrameBatcher_release_call\": %.4f, \"FrameBatcher_release_call_paced\": %.4f, \"destagger_u32\": %.4f, \"destagger_u8\": %.4f, "
                 "\"XYZLut_f64\": %.4f, \"frame_total\": %.4f}, \"median_ms\": {\"FrameBatcher_128_packets\": %.4f, \"destagger_u32\": %.4f, "
                 "\"XYZLut_f64\": %.4f, \"frame_total\": %.4f}, \"frame_total_is\": \"batch x128 + destagger RANGE RANGE2 REFLECTIVITY REFLECTIVITY2 + XYZLut() of RANGE and RANGE2 (f64)\", "
                 "\"frame_matches_source\": %s, \"allocations_in_timed_frames\": {\"device\": %llu, \"pinned\": %llu, \"pool_requests\": %llu, \"pool_hits\": %llu}, "
                 "\"LidarFrame_construction_ms\": {\"first_of_the_process\": %.3f, \"from_cached_pool_blocks\": %.3f}, \"note\": \"host containers in/out; planes, images and clouds are pool (page-locked) memory the kernels read and write in place\"}\n",
-                frames, mean(t_batch), mean(t_release), mean(t_d32), mean(t_d8), mean(t_xyz), mean(t_total), median(t_batch), median(t_d32), median(t_xyz), median(t_total),
+                frames, mean(t_batch), mean(t_release), mean(t_release_paced), mean(t_d32), mean(t_d8), mean(t_xyz), mean(t_total), median(t_batch), median(t_d32), median(t_xyz), median(t_total),
                 same ? "true" : "false", (unsigned long long)(a1.device_allocs - a0.device_allocs), (unsigned long long)(a1.pinned_allocs - a0.pinned_allocs),
                 (unsigned long long)(a1.pool_requests - a0.pool_requests), (unsigned long long)(a1.pool_hits - a0.pool_hits), t_first_frame, t_reused_frame);
     return same ? 0 : 2;

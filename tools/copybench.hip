@@ -85,6 +85,21 @@ int main() {
         std::printf(" \"inplace_1MB_host_to_host_128wg_eventsync_us\": %.2f,\n", mean_of(100, [&] { hipLaunchKernelGGL(k_copy16, 128, 256, 0, st, (const uint4*)pin, (uint4*)pin2, n16); CK(hipEventRecord(e, st)); CK(hipEventSynchronize(e)); }));
         std::printf(" \"inplace_6MB_dev_to_host_sync_us\": %.2f,\n", mean_of(50, [&] { hipLaunchKernelGGL(k_copy16, 1024, 256, 0, st, (const uint4*)d_a, (uint4*)pin2, (size_t)6291456 / 16); CK(hipStreamSynchronize(st)); }));
         std::printf(" \"inplace_6MB_dev_to_host_queryspin_us\": %.2f,\n", mean_of(50, [&] { hipLaunchKernelGGL(k_copy16, 1024, 256, 0, st, (const uint4*)d_a, (uint4*)pin2, (size_t)6291456 / 16); while (hipStreamQuery(st) == hipErrorNotReady) {} }));
+        // do a copy-engine upload and a kernel's stores to host memory share the link at the same time?
+        hipStream_t st2;
+        CK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        const size_t up = 2129920, down = 3960832;
+        std::printf(" \"dma_h2d_2MB_alone_us\": %.2f,\n", mean_of(50, [&] { CK(hipMemcpyAsync(d_b, pin, up, hipMemcpyHostToDevice, st2)); CK(hipStreamSynchronize(st2)); }));
+        std::printf(" \"kernel_writes_host_4MB_alone_us\": %.2f,\n", mean_of(50, [&] { hipLaunchKernelGGL(k_copy16, 256, 256, 0, st, (const uint4*)d_a, (uint4*)pin2, down / 16); CK(hipStreamSynchronize(st)); }));
+        std::printf(" \"dma_h2d_2MB_and_kernel_writes_host_4MB_together_us\": %.2f,\n", mean_of(50, [&] {
+            CK(hipMemcpyAsync(d_b, pin, up, hipMemcpyHostToDevice, st2));
+            hipLaunchKernelGGL(k_copy16, 256, 256, 0, st, (const uint4*)d_a, (uint4*)pin2, down / 16);
+            CK(hipStreamSynchronize(st)); CK(hipStreamSynchronize(st2)); }));
+        std::printf(" \"dma_h2d_2MB_and_dma_d2h_4MB_together_us\": %.2f,\n", mean_of(50, [&] {
+            CK(hipMemcpyAsync(d_b, pin, up, hipMemcpyHostToDevice, st2));
+            CK(hipMemcpyAsync(pin2, d_a, down, hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st)); CK(hipStreamSynchronize(st2)); }));
+        CK(hipStreamDestroy(st2));
         CK(hipHostFree(pin2));
     }
     {
