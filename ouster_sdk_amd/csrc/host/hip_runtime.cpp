@@ -298,7 +298,7 @@ void cartesian_device(const DeviceLut& dev, const uint32_t* range, size_t n, voi
     if (mirrors_live()) {
         MirrorPlane m;
         if (mirror_find(range, m) && m.elem == 4 && m.h * m.w == n && m.device == dev.device) {
-            if (m.d_xyz && m.xyz_lut == dev.handle && m.xyz_f64 == points_f64) {
+            if (m.d_xyz && m.xyz_lut.get() == &dev && m.xyz_f64 == points_f64) {
                 ouster_hip_ctx* ctx = hip::default_ctx();
                 hip::check(ouster_hip_copy_out(ctx, points, m.d_xyz, n * 3 * (points_f64 ? 8 : 4)));
                 hip::check(ouster_hip_sync(ctx));

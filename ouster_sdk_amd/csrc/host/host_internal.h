@@ -41,7 +41,8 @@ struct MirrorPlane {
     std::shared_ptr<void> keep;                       ///< the device block
     // a 32-bit range plane may also have its cloud in HBM: lut(plane) with `xyz_lut`, element type per xyz_f64
     const void* d_xyz = nullptr;
-    const void* xyz_lut = nullptr;                    ///< the ouster_hip_lut handle it was projected with
+    std::shared_ptr<const DeviceLut> xyz_lut;         ///< the LUT it was projected with; owned, so that its address cannot be
+                                                      ///< handed to another LUT while this entry lives
     bool xyz_f64 = true;
     std::shared_ptr<XyzWish> wish;                    ///< where a call that found no cloud leaves its LUT for the next release
 };

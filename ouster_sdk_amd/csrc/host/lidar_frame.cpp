@@ -981,7 +981,7 @@ struct BatcherOps {
                 for (int k = 0; k < 2; ++k)
                     if (xl_handle && xfield[k] == static_cast<int>(i)) {
                         m.d_xyz = out.xyz[k];
-                        m.xyz_lut = xl_handle;
+                        m.xyz_lut = xl;
                         m.xyz_f64 = xf64;
                     }
                 impl::mirror_register(m);
