@@ -61,3 +61,29 @@ def test_no_gpu_fails_loudly():
     from ouster_sdk_amd import device
     with pytest.raises(capi.OusterHipError, match="no CPU fallback"):
         device.HotPath("RNG15_RFL8_NIR8_DUAL", 128, 2048)
+
+
+def test_host_pool_entry_points_work_without_a_gpu_as_plain_memory():
+    """include/ouster_hip.h, "host containers": without a GPU ouster_hip_host_alloc hands out plain heap memory (the C++
+    containers still work), nothing is reported as GPU-addressable, the counters stay at zero and the compute entry points on
+    host arrays refuse like every other one (no CPU fallback).  With a GPU the same calls are exercised by the C++ drop-in test."""
+    L = capi.load_hip()
+    st0 = capi.alloc_stats()
+    for n in (1, 100, 4096, 1 << 20):
+        p = L.ouster_hip_host_alloc(n, 1)
+        assert p
+        buf = (C.c_uint8 * n).from_address(p)
+        assert not any(buf[:: max(1, n // 64)])          # zeroed
+        buf[n - 1] = 7
+        if not has_gpu():
+            assert L.ouster_hip_host_is_pinned(p, n) == 0
+        elif n >= 2048:
+            assert L.ouster_hip_host_is_pinned(p, n) == 1 and L.ouster_hip_host_is_pinned(p + 1, n) == 0
+        L.ouster_hip_host_free(p)
+    L.ouster_hip_host_free(None)
+    L.ouster_hip_host_pool_trim(0)
+    st1 = capi.alloc_stats()
+    if not has_gpu():
+        assert st1["pinned_allocs"] == st0["pinned_allocs"] == 0 and st1["device_allocs"] == 0 and st1["pool_requests"] == 0
+        a = (C.c_uint32 * 16)()
+        assert L.ouster_hip_destagger_host(None, a, a, 4, 4, 4, a, 4, 0) == capi.ERR_INVALID_ARGUMENT   # no context can exist

@@ -447,3 +447,29 @@ def test_multi_sensor_ticks_do_not_wait_for_a_silent_sensor(oracle):
             assert not b["RANGE"][k].any() and not b["status"][k].any()
     with pytest.raises(IndexError):
         stream.push_packet(2, core.LidarPacket(size))
+
+
+def test_results_are_pool_backed_arrays_that_outlive_everything(meta):
+    """Round 6: destagger() / XYZLut() return numpy arrays over blocks of the library's pinned pool that the kernels wrote in
+    place; the array owns its block (a capsule), so it stays valid after the LUT, the frame and every other array are gone, and
+    a later call may be handed a recycled block without touching it."""
+    import gc
+    w, h = meta.format.columns_per_frame, meta.format.pixels_per_column
+    rng = np.random.default_rng(3)
+    r = rng.integers(0, 1 << 17, size=(h, w)).astype(np.uint32)
+    lut = core.XYZLut(meta, False)
+    xyz = lut(r)
+    d = core.destagger(meta, r)
+    assert xyz.shape == (h, w, 3) and xyz.dtype == np.float64 and d.shape == (h, w)
+    assert xyz.flags.writeable and not xyz.flags.owndata and xyz.base is not None
+    want_xyz, want_d = xyz.copy(), d.copy()
+    del lut
+    gc.collect()
+    for _ in range(4):                                  # blocks of the same size class come and go
+        tmp = core.destagger(meta, r[::-1].copy())
+        del tmp
+    gc.collect()
+    assert np.array_equal(xyz, want_xyz) and np.array_equal(d, want_d)
+    assert np.array_equal(d, np.stack([np.roll(row, s) for row, s in zip(r, meta.format.pixel_shift_by_row)]))
+    xyz[0, 0, 0] = 42.0                                 # the caller's array to write
+    assert xyz[0, 0, 0] == 42.0
