@@ -404,7 +404,7 @@ void ouster_hip_host_pool_trim(size_t keep_bytes);
 /* Process-wide allocation counters of this library (device memory: every hipMalloc / hipFree it makes,
  * ouster_hip_device_alloc included; pinned: the pool's hipHostMalloc / hipHostFree calls).  The
  * steady-state contract of the frame-at-a-time calls -- no allocation once the shapes have been
- * seen -- is checked by reading these before and after (tests/test_gpu_dropin.py). */
+ * seen -- is checked by reading these before and after (tests/cpp/test_core_api.cpp, test_dropin_host_containers). */
 typedef struct ouster_hip_alloc_stats {
     uint64_t device_allocs, device_frees;
     uint64_t pinned_allocs, pinned_frees;

@@ -406,7 +406,12 @@ FieldPlan plan_field(const EncodedField& f, size_t h, size_t w, bool device_unfi
     out.h = h;
     out.bpp = bpp;
     out.stride = w * bpp;
-    out.filtered = device_unfilter;   // the GPU reverses the filters (k_osf_png_unfilter)
+    // the GPU reverses the filters (k_osf_png_unfilter) -- unless a scanline is too long for its LDS (64 per-lane rings of 192
+    // pixels, sized by the widest pixel a batch may hold, 8 bytes, plus one row: 160 KB per workgroup, i.e. rows up to ~61 KB);
+    // such a field is unfiltered on the host as in rounds 2 - 4 (it used to fail in the launch)
+    const size_t device_lds = 64 * (size_t{192} * 8 + 16) + ((out.stride + 15) & ~size_t{15});
+    if (device_unfilter && device_lds > size_t{160} * 1024) device_unfilter = false;
+    out.filtered = device_unfilter;
     out.staged_bytes = device_unfilter ? h * (out.stride + 1) : h * out.stride;
     return out;
 }

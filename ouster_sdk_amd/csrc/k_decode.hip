@@ -481,10 +481,10 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
     constexpr int NT = 256;
     extern __shared__ __align__(16) uint32_t smem[];
     CrewLds* C = (CrewLds*)((uint8_t*)smem + a.crew_lds_off);
-    const uint64_t tag = a.frame_state[FS_TAG];
+    const uint64_t tag = a.frame_state[FS_TAG], any = a.frame_state[FS_ANY];   // both asked for at once: one round trip
     // the next call's ticket counters (tag parity; k_decode_fixup does the same)
     if (blockIdx.x < 8 && threadIdx.x == 0) a.frame_state[FS_TICKET + ((tag + 1u) & 1u) * 8u + blockIdx.x] = 0;
-    if (a.frame_state[FS_ANY] == tag) fixup_crew<S, TW, XYZM, POSES>(a, smem, C, tag);
+    if (any == tag) fixup_crew<S, TW, XYZM, POSES>(a, smem, C, tag);
     // valid-column counts of the clean frames (flagged ones got theirs from their LEAD ticket), then the sequence word
     sum_valid_columns<NT>(a, tag, blockIdx.x, gridDim.x);
     if (blockIdx.x == 0 && threadIdx.x == 0) a.frame_state[FS_SEQ] = tag;  // the next call tags with tag + 1

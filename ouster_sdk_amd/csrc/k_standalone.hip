@@ -2142,9 +2142,13 @@ hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipSt
     return hipGetLastError();
 }
 
+size_t osf_png_unfilter_lds_bytes(uint32_t w, uint32_t max_row_bytes) {
+    const uint32_t bpp = w ? (max_row_bytes + w - 1) / w : 1u;   // the widest pixel of the batch sizes everybody's LDS
+    return uf_ring_bytes(bpp) + (((size_t)max_row_bytes + 15) & ~(size_t)15);
+}
+
 hipError_t launch_osf_png_unfilter(const OsfUnfilterArgs& a, uint32_t n_jobs, uint32_t max_row_bytes, hipStream_t st) {
-    const uint32_t bpp = a.w ? (max_row_bytes + a.w - 1) / a.w : 1u;   // the widest pixel of the batch sizes everybody's LDS
-    const size_t lds = uf_ring_bytes(bpp) + (((size_t)max_row_bytes + 15) & ~(size_t)15);
+    const size_t lds = osf_png_unfilter_lds_bytes(a.w, max_row_bytes);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k_osf_png_unfilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1659,8 +1659,9 @@ int ouster_hip_osf_unpack(ouster_hip_ctx* ctx, const ouster_hip_osf_plane* plane
             return fail(OUSTER_HIP_ERR_INVALID_ARGUMENT, "plane %u: unknown encoding %u", i, p.encoding);
         }
     }
-    if (n_filtered && (uint64_t)max_row_bytes > 64u * 1024u)
-        return fail(OUSTER_HIP_ERR_UNSUPPORTED, "a PNG scanline of %u bytes does not fit in LDS", max_row_bytes);
+    if (n_filtered && osf_png_unfilter_lds_bytes(w, max_row_bytes) > 160u * 1024u)   // the launcher's own figure
+        return fail(OUSTER_HIP_ERR_UNSUPPORTED, "a PNG scanline of %u bytes needs %zu bytes of LDS for the device filters (160 KB per workgroup): "
+                    "hand the planes over unfiltered (flags = 0)", max_row_bytes, osf_png_unfilter_lds_bytes(w, max_row_bytes));
     HIP_TRY(hipSetDevice(ctx->device));
     OsfUnpackArgs a{};
     a.h = h;

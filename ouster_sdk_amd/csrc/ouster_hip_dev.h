@@ -234,5 +234,7 @@ hipError_t launch_dewarp(const DewarpArgs& a, hipStream_t st);
 hipError_t launch_dewarp_frames(const DewarpFramesArgs& a, bool separable, hipStream_t st, int stream_mode = -1);
 hipError_t launch_osf_unpack(const OsfUnpackArgs& a, uint32_t n_planes, hipStream_t st);
 hipError_t launch_osf_png_unfilter(const OsfUnfilterArgs& a, uint32_t n_jobs, uint32_t max_row_bytes, hipStream_t st);
+// dynamic LDS that launch needs (per-lane rings sized by the widest pixel + the band's last row): what ouster_hip_osf_unpack checks
+size_t osf_png_unfilter_lds_bytes(uint32_t w, uint32_t max_row_bytes);
 
 }  // namespace ouster_hip_dev
