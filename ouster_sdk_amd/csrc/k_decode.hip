@@ -481,7 +481,13 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
     constexpr int NT = 256;
     extern __shared__ __align__(16) uint32_t smem[];
     CrewLds* C = (CrewLds*)((uint8_t*)smem + a.crew_lds_off);
-    const uint64_t tag = a.frame_state[FS_TAG], any = a.frame_state[FS_ANY];   // both asked for at once: one round trip
+#ifdef OUSTER_PHASE_TIMING
+    if (a.phase_times && threadIdx.x == 0) a.phase_times[(size_t)blockIdx.x * 64 + 62] = PT_NOW();
+#endif
+    // both asked for at once: one round trip.  (Round 6: also asking for this thread's frame word and tile counts here -- the clean
+    // batch's second dependent trip -- shortened this kernel from 1.8 to 1.3 us on the chip-wide clock and made the pipelined
+    // one-frame call 0.3 us SLOWER, 14.10 against 13.80 us in alternating runs on one box: profiles/r06_latency.)
+    const uint64_t tag = a.frame_state[FS_TAG], any = a.frame_state[FS_ANY];
     // the next call's ticket counters (tag parity; k_decode_fixup does the same)
     if (blockIdx.x < 8 && threadIdx.x == 0) a.frame_state[FS_TICKET + ((tag + 1u) & 1u) * 8u + blockIdx.x] = 0;
     if (any == tag) fixup_crew<S, TW, XYZM, POSES>(a, smem, C, tag);
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(256) void k_decode_wide_fixup(DecodeArgs a) {
     sum_valid_columns<NT>(a, tag, blockIdx.x, gridDim.x);
     if (blockIdx.x == 0 && threadIdx.x == 0) a.frame_state[FS_SEQ] = tag;  // the next call tags with tag + 1
 #ifdef OUSTER_PHASE_TIMING
-    if (a.phase_times && threadIdx.x == 0) a.phase_times[(size_t)blockIdx.x * 64 + 63] = __builtin_readcyclecounter();
+    if (a.phase_times && threadIdx.x == 0) a.phase_times[(size_t)blockIdx.x * 64 + 63] = PT_NOW();
 #endif
 }
 

@@ -70,7 +70,12 @@ __device__ __forceinline__ void wide_tile(const DecodeArgs& a, uint32_t* smem, u
     if (a.packet_counts) count = min(a.packet_counts[f], a.slots_per_frame);
 #ifdef OUSTER_PHASE_TIMING
     uint64_t* pt_ = (a.phase_times && a.mode != MODE_FIXUP) ? a.phase_times + (size_t)blockIdx.x * 16 : nullptr;
-#define PHASE_STAMP(i) do { if (pt_ && tid == 0) pt_[i] = __builtin_readcyclecounter(); } while (0)
+#ifdef OUSTER_PHASE_WALL   // the chip-wide 100 MHz clock: stamps of different workgroups compare (tools/ab/phase_timing.py small)
+#define PT_NOW() wall_clock64()
+#else
+#define PT_NOW() __builtin_readcyclecounter()
+#endif
+#define PHASE_STAMP(i) do { if (pt_ && tid == 0) pt_[i] = PT_NOW(); } while (0)
     if (pt_ && tid == 0) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); pt_[7] = xcc; }
 #else
 #define PHASE_STAMP(i) do {} while (0)
@@ -350,7 +355,7 @@ __device__ __forceinline__ void wide_tile(const DecodeArgs& a, uint32_t* smem, u
 #ifdef OUSTER_PHASE_TIMING
     if (pt_ && tid == 0) {   // the stores of this wave have been issued; when are they done?
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pt_[5] = __builtin_readcyclecounter();
+        pt_[5] = PT_NOW();
     }
 #endif
 }

@@ -1,8 +1,49 @@
 #!/usr/bin/env python3
-"""Phase timeline of k_decode_wide workgroups (instrumented library, see phase_timing.sh)."""
+"""Phase timeline of k_decode_wide workgroups (instrumented library: tools/ab/build_variant.sh <name> -DOUSTER_PHASE_TIMING, run with
+OUSTER_HIP_SO=tools/ab/libouster_hip_<name>.so).
+  phase_timing.py <workload>        a large launch: phase shares per workgroup (per-CU cycle counters)
+  phase_timing.py small [frames=1]  ONE small launch (1 or 4 frames) on the chip-wide 100 MHz clock (build with -DOUSTER_PHASE_WALL
+                                    as well): when workgroups start, where each phase ends, when the fix-up kernel runs"""
 import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def small_launch(n):
+    NWG = 1 << 14
+    buf = torch.zeros((NWG, 16), dtype=torch.int64, device="cuda")
+    os.environ["OUSTER_HIP_PHASE_BUF"] = hex(buf.data_ptr())
+    import bench
+    hp, packets, out, profile, shifts, lut_args, n_ret, _ = bench._workload_setup("fused4" if n == 4 else "dual", n)
+    for _ in range(30):
+        hp.decode(packets, out)
+    torch.cuda.synchronize()
+    rows = []
+    for rep in range(20):
+        buf.zero_()
+        torch.cuda.synchronize()
+        hp.decode(packets, out)
+        torch.cuda.synchronize()
+        t = buf.cpu().numpy()
+        fix = t.reshape(-1, 64)[:, 62:64]
+        fix = fix[fix[:, 0] != 0]
+        wg = t[t[:, 0] != 0][:, :6].astype(np.float64)
+        t0 = wg[:, 0].min()
+        rel = (wg - t0) / 100.0   # us
+        rows.append({"wgs": len(wg), "start_last": rel[:, 0].max(), "p1_med": np.median(rel[:, 1]), "p2_med": np.median(rel[:, 2]), "p3_med": np.median(rel[:, 3]),
+                     "p4_med": np.median(rel[:, 4]), "p4_max": rel[:, 4].max(), "drain_max": rel[:, 5].max(),
+                     "life_med": np.median(rel[:, 5] - rel[:, 0]),
+                     "d01": np.median(rel[:, 1] - rel[:, 0]), "d12": np.median(rel[:, 2] - rel[:, 1]), "d23": np.median(rel[:, 3] - rel[:, 2]),
+                     "d34": np.median(rel[:, 4] - rel[:, 3]), "d45": np.median(rel[:, 5] - rel[:, 4]),
+                     "fix_start": (fix[:, 0].min() - t0) / 100.0 if len(fix) else None, "fix_end": (fix[:, 1].max() - t0) / 100.0 if len(fix) else None})
+    keys = rows[0].keys()
+    med = {k: round(float(np.median([r[k] for r in rows if r[k] is not None])), 2) for k in keys}
+    print(json.dumps({"frames": n, "kernel": hp.ctx.last_decode_kernel(), "tile": hp.ctx.last_decode_tile(), "median_over_20_launches_us": med}))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "small":
+    small_launch(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    sys.exit(0)
 wl = sys.argv[1] if len(sys.argv) > 1 else "single"
 NWG = 1 << 16
 buf = torch.zeros((NWG, 16), dtype=torch.int64, device="cuda")
