@@ -412,17 +412,16 @@ __device__ __forceinline__ void sum_valid_columns(const DecodeArgs& a, uint64_t 
 //                              in which every ticket resolved for itself paid 6 us per ticket at scale (0.60 against 0.63).
 // Maps and ready words are written and read with agent-scope atomics: the XCDs' L2s are not coherent with each other for
 // plain accesses.  Few flagged frames: short tiles (fix_rows_small), so that the damage spreads over the chip; many: the
-// launch's tall tiles.  A workgroup's first ticket is its own number (no atomic on a clean batch: 512 workgroups adding to
-// one word are served one after the other, 4 us on every call); the counter hands out the tickets behind those, each asked
+// launch's tall tiles.  The counter hands out every ticket (a clean batch never gets here: FS_ANY), each asked
 // for when the item before it starts.  The counter lives in frame_state behind the sequence words, one per tag parity: this
 // call's starts at zero (zeroed by the call before), the other is zeroed for the next call; the ready words ([ready_off + f],
 // the buffer's second half) carry the tag and are never cleared.
 // ------------------------------------------------------------------------------------
 #ifdef OUSTER_PHASE_TIMING   // experiment builds (tools/ab/phase_timing.sh): per workgroup 64 words: [0] start, [1] events, then 4 per ticket
-#define FSTAMP_BEGIN() uint64_t fs0_ = __builtin_readcyclecounter(), fs1_ = 0
-#define FSTAMP_MID() do { fs1_ = __builtin_readcyclecounter(); } while (0)
+#define FSTAMP_BEGIN() uint64_t fs0_ = PT_NOW(), fs1_ = 0
+#define FSTAMP_MID() do { fs1_ = PT_NOW(); } while (0)
 #define FSTAMP_END(kind, n) do { if (a.phase_times && tid == 0) { uint64_t* q_ = a.phase_times + (size_t)blockIdx.x * 64; const uint64_t e_ = q_[1]; \
-    if (e_ < 15) { q_[2 + 4 * e_] = (kind) | ((uint64_t)(n) << 8); q_[3 + 4 * e_] = fs0_; q_[4 + 4 * e_] = fs1_; q_[5 + 4 * e_] = __builtin_readcyclecounter(); q_[1] = e_ + 1; } } } while (0)
+    if (e_ < 15) { q_[2 + 4 * e_] = (kind) | ((uint64_t)(n) << 8); q_[3 + 4 * e_] = fs0_; q_[4 + 4 * e_] = fs1_; q_[5 + 4 * e_] = PT_NOW(); q_[1] = e_ + 1; } } } while (0)
 #else
 #define FSTAMP_BEGIN() do {} while (0)
 #define FSTAMP_MID() do {} while (0)
@@ -440,11 +439,15 @@ __device__ __forceinline__ void fixup_crew(const DecodeArgs& a, uint32_t* smem, 
     // to an eighth of the chip's bandwidth: 115 us for a frame with eight dirty column tiles, tools/ab/fixup_kinds2.py.)
     unsigned long long* ctr = (unsigned long long*)&a.frame_state[FS_TICKET + (tag & 1u) * 8u];
     unsigned long long* ready = (unsigned long long*)&a.frame_state[a.ready_off];
-    // first ticket = the workgroup's own number (no atomic at all where few frames are flagged), the counter hands out the tickets
-    // behind those.  The next ticket is asked for when an item starts and looked at when it ends.
-    const unsigned long long tick0 = (unsigned long long)gridDim.x;
+    // Every ticket comes from the counter, the first one too -- asked for on entry, looked at behind the listing of the flagged
+    // frames (which hides the 4 us that 512 workgroups adding to one word take).  Round 6: with "first ticket = my own number"
+    // the pass waited for workgroups that were not there yet: of the 512 workgroups of this launch a quarter to a half start at
+    // once, the rest 17 - 59 us later (kernel-entry stamps on the chip-wide clock, tools/ab/phase_timing.py fixup), and the
+    // late ones held low-numbered tickets -- every frame's first wrong tile.  In arrival order the workgroups that are there
+    // take the tickets with work and the late ones find the tail.
     unsigned long long ahead = 0;
-    auto pull_ahead = [&]() { if (tid == 0) ahead = atomicAdd(ctr, 1ull) + tick0; };
+    auto pull_ahead = [&]() { if (tid == 0) ahead = atomicAdd(ctr, 1ull); };
+    pull_ahead();
     auto take_ahead = [&]() -> unsigned long long {
         __syncthreads();
         if (tid == 0) C->ticket = ahead;
@@ -452,7 +455,7 @@ __device__ __forceinline__ void fixup_crew(const DecodeArgs& a, uint32_t* smem, 
         return C->ticket;
     };
 #ifdef OUSTER_PHASE_TIMING
-    if (a.phase_times && tid == 0) { a.phase_times[(size_t)blockIdx.x * 64] = __builtin_readcyclecounter(); a.phase_times[(size_t)blockIdx.x * 64 + 1] = 0; }
+    if (a.phase_times && tid == 0) { a.phase_times[(size_t)blockIdx.x * 64] = PT_NOW(); a.phase_times[(size_t)blockIdx.x * 64 + 1] = 0; }
 #endif
     const ResolveLds L(smem, W, npo, a.slots_per_frame);
     // the frame's maps in LDS (L.pix / L.hdr); `lead`: also its packet-level outputs, frame-level values and valid-column count
@@ -508,7 +511,7 @@ __device__ __forceinline__ void fixup_crew(const DecodeArgs& a, uint32_t* smem, 
             a.frame_meta[f] = m;
         }
     };
-    unsigned long long ticket = blockIdx.x, done = 0;
+    unsigned long long ticket = 0, done = 0;
     for (uint32_t base = 0; base < a.n_frames; base += FIXUP_CHUNK) {
         // The flagged frames of this chunk.  The list must come out in the SAME order in every workgroup -- the workgroups
         // share the items out by index -- so it is compacted in frame order (ballots + a prefix over the 64-frame groups),
@@ -540,6 +543,7 @@ __device__ __forceinline__ void fixup_crew(const DecodeArgs& a, uint32_t* smem, 
             C->n = n;
         }
         __syncthreads();
+        if (base == 0) ticket = take_ahead();
         const uint32_t n_flagged = C->n;
         // few damaged frames: short tiles, one ticket per dirty tile (the chip is idle, latency counts); many: the launch's
         // tall tiles (a workgroup moves 1.8 x the bytes per microsecond through a 32-row tile than through four 8-row ones)
@@ -548,14 +552,22 @@ __device__ __forceinline__ void fixup_crew(const DecodeArgs& a, uint32_t* smem, 
         // took as long as its unluckiest ticket -- 228 us for 64 compacted frames, tools/ab/fixup_kinds.py; a ticket that finds
         // no work costs 2 us)
         const uint32_t SPLIT = min(a.tiles_per_frame, SPLIT_MAX);
+        // (round 6: short tiles for up to gridDim / 16 flagged frames instead of 8 -- every frame's first wrong tile in one round of
+        // the grid -- made bench.py's stray10 pass 99 us instead of 66: an 8-row tile takes 18.5 us where a 32-row one takes 42)
         TRd = n_flagged <= 8u ? min(a.fix_rows_small, a.rows_per_tile) : a.rows_per_tile;
         nchd = (a.g.pixels_per_column + TRd - 1u) / TRd;
         const uint32_t bpf = nchd * SPLIT;
         const unsigned long long items = (unsigned long long)n_flagged * (1u + bpf);
         if (items == 0) continue;
+        // Few tickets per workgroup: the next one is asked for when this one is DONE.  Asked for at the start (which hides the
+        // atomic's 1 - 2 us, and is what many flagged frames want), the tickets behind the first gridDim are all handed out at once
+        // to workgroups that have just started a 38 us tile, while the workgroups whose first ticket found no work run out of
+        // tickets and leave: bench.py's stray10 (26 flagged frames, 858 tickets, 304 with work, 512 workgroups) had tiles starting
+        // 87 us into a pass that could be over by then -- 117 us per pass (tools/ab/phase_timing.py fixup, profiles/r06_latency).
+        const bool prefetch = items > 4ull * gridDim.x;
         while (ticket < done + items) {
             const uint32_t it = (uint32_t)(ticket - done);
-            pull_ahead();
+            if (prefetch) pull_ahead();
             FSTAMP_BEGIN();
             if (it < n_flagged) {
                 resolve(base + C->list[it], true);
@@ -597,6 +609,7 @@ __device__ __forceinline__ void fixup_crew(const DecodeArgs& a, uint32_t* smem, 
                 }
                 FSTAMP_END(2u, ntl);
             }
+            if (!prefetch) pull_ahead();
             ticket = take_ahead();
         }
         done += items;

@@ -3,7 +3,9 @@
 OUSTER_HIP_SO=tools/ab/libouster_hip_<name>.so).
   phase_timing.py <workload>        a large launch: phase shares per workgroup (per-CU cycle counters)
   phase_timing.py small [frames=1]  ONE small launch (1 or 4 frames) on the chip-wide 100 MHz clock (build with -DOUSTER_PHASE_WALL
-                                    as well): when workgroups start, where each phase ends, when the fix-up kernel runs"""
+                                    as well): when workgroups start, where each phase ends, when the fix-up kernel runs
+  phase_timing.py fixup             the fix-up pass behind bench.py's stray10 batch (26 of 256 frames flagged) on the same clock
+                                    (OUSTER_HIP_PHASE_FIXUP_ONLY=1 is set here): LEAD / REDO tickets, when they start, how long they take"""
 import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -41,6 +43,72 @@ def small_launch(n):
     print(json.dumps({"frames": n, "kernel": hp.ctx.last_decode_kernel(), "tile": hp.ctx.last_decode_tile(), "median_over_20_launches_us": med}))
 
 
+def fixup_pass():
+    os.environ["OUSTER_HIP_PHASE_FIXUP_ONLY"] = "1"
+    NWG = 1 << 12
+    buf = torch.zeros((NWG, 64), dtype=torch.int64, device="cuda")
+    os.environ["OUSTER_HIP_PHASE_BUF"] = hex(buf.data_ptr())
+    import bench
+    F = 256
+    hp, packets, out, profile, shifts, lut_args, n_ret, _ = bench._workload_setup("dual", F)
+    for k, v in [kv.split("=") for kv in sys.argv[2:]]:
+        hp.ctx.set_knob(k, int(v))
+    slots = packets.shape[1]
+    f_idx = torch.arange(F, device="cuda")
+    lost = (f_idx * 7 + 3) % slots
+    keep = torch.arange(slots, device="cuda").unsqueeze(0).expand(F, slots)
+    keep = keep[keep != lost.unsqueeze(1)].reshape(F, slots - 1)
+    pk = packets.clone()
+    counts = torch.full((F,), slots, dtype=torch.int32, device="cuda")
+    comp = f_idx[f_idx % 20 == 3]
+    pk[comp, :slots - 1] = packets[comp.unsqueeze(1), keep[comp]]
+    pk[comp, slots - 1] = 0
+    counts[comp] = slots - 1
+    swp = f_idx[f_idx % 20 == 13]
+    a, b = packets[swp, 10].clone(), packets[swp, 11].clone()
+    pk[swp, 10], pk[swp, 11] = b, a
+    for _ in range(30):
+        hp.decode(pk, out, packet_counts=counts)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        hp.decode(pk, out, packet_counts=counts)
+    e1.record()
+    torch.cuda.synchronize()
+    step_ms = e0.elapsed_time(e1) / 20
+    runs = []
+    for rep in range(10):
+        buf.zero_()
+        torch.cuda.synchronize()
+        hp.decode(pk, out, packet_counts=counts)
+        torch.cuda.synchronize()
+        t = buf.cpu().numpy().astype(np.float64)
+        t = t[t[:, 62] != 0]
+        k0 = t[:, 62].min()
+        ev = {"lead": [], "redo_work": [], "redo_idle": []}
+        for w in t:
+            for e in range(int(w[1])):
+                kind, n = int(w[2 + 4 * e]) & 0xff, int(w[2 + 4 * e]) >> 8
+                b0, mid, end = (w[3 + 4 * e] - k0) / 100, (w[4 + 4 * e] - k0) / 100, (w[5 + 4 * e] - k0) / 100
+                ev["lead" if kind == 1 else ("redo_work" if n else "redo_idle")].append((b0, end - b0, n))
+        def summ(v):
+            if not v: return None
+            st, du = np.array([x[0] for x in v]), np.array([x[1] for x in v])
+            return {"n": len(v), "start_med": round(float(np.median(st)), 1), "start_max": round(float(st.max()), 1), "dur_med": round(float(np.median(du)), 1),
+                    "dur_max": round(float(du.max()), 1), "end_max": round(float((st + du).max()), 1), "tiles": int(sum(x[2] for x in v))}
+        pct = lambda v: [round(float(x) / 100, 1) for x in np.percentile(v, [0, 25, 50, 75, 90, 100])]
+        ws = sorted(x[0] for x in ev["redo_work"])
+        runs.append({"wgs": len(t), "kernel_entry_pct_us": pct(t[:, 62] - k0), "crew_start_pct_us": pct(t[:, 0] - k0), "wg_exit_pct_us": pct(t[:, 63] - k0),
+                     "kernel_end": round(float((t[:, 63] - k0).max()) / 100, 1), "redo_work_start_pct_us": [round(float(x), 1) for x in np.percentile(ws, [0, 25, 50, 75, 90, 100])],
+                     **{k: summ(v) for k, v in ev.items()}})
+    runs.sort(key=lambda r: r["kernel_end"])
+    print(json.dumps({"step_ms": round(step_ms, 4), "tile": hp.ctx.last_decode_tile(), "kernel": hp.ctx.last_decode_kernel(), "median_run_us": runs[len(runs) // 2]}))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "fixup":
+    fixup_pass()
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "small":
     small_launch(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     sys.exit(0)
