@@ -3,8 +3,8 @@
 # summaries): SUMMARY.md, both bench lines, pmc_traffic.json, the kernel-trace stats, the two PMC passes and
 # decode_dispatches.csv (every k_decode* / k_slotmap dispatch of the traced process in start order).
 set -e
-for t in "$@"; do
-    src=gpurun_out/prof_$t; dst=profiles/$t; mkdir -p $dst
+for t in "$@"; do   # <tag>, or <tag>:<directory under profiles/> to keep a recording under another name
+    src=gpurun_out/prof_${t%%:*}; dst=profiles/${t##*:}; mkdir -p $dst
     cp $src/SUMMARY.md $src/bench_plain.json $src/bench_under_rocprof.json $src/pmc_traffic.json $dst/
     cp $src/trace/bench_kernel_stats.csv $dst/kernel_stats.csv
     cp $src/pmc_fetch/bench_counter_collection.csv $dst/pmc_fetch_size.csv
