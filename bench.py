@@ -467,7 +467,7 @@ def _workload_setup(name, n_frames, pool_frames=4, seed=0xC0FFEE):
     return hp, packets, out, profile, shifts, lut_args, len(xyz_names), label
 
 
-def time_other_workloads(steps=12, placement="refine"):
+def time_other_workloads(steps=12, placement="refine", scan_tries=10, scan_stride_gb=4.0):
     """The BASELINE configs the metric is not quoted on, each timed like the headline (tuner settled, the same frugal
     placement search -- two more output sets back to back -- unless `placement` is "first", two input batches in turn, HIP
     events around the decode kernel) and checked against the oracle -- report rows, never `value`:
@@ -480,10 +480,23 @@ def time_other_workloads(steps=12, placement="refine"):
         for _ in range(24):
             hp.decode(packets, out)
         torch.cuda.synchronize()
-        first_ms = None
+        first_ms, scanned = None, 0
         if placement == "refine":
             out, rep = hp.refine_placement(packets, out, draws=3, ballast_gb=0.0)
             first_ms = rep["first_allocation_ms"]
+            if scan_tries >= 2:   # the headline's sequence: whole sets drawn, then the group-wise search again in the memory they gave back
+                prof_, bits_, chan_, dst_, xyz_ = WORKLOADS[name][:5]
+                out_bytes = sum(v.numel() * v.element_size() for v in out.values())
+                free_b, _ = torch.cuda.mem_get_info()
+                tries = min(scan_tries, int(free_b * 0.6) // (out_bytes + int(scan_stride_gb * (1 << 30))) - 1)
+                if tries >= 2:
+                    try:
+                        packets, out, srep = hp.pick_placement(packets, lambda: hp.alloc_outputs(F, destagger=dst_, xyz=xyz_), tries=tries,
+                                                               launches=8, stride_gb=scan_stride_gb, incumbent=out, slab=False)
+                        out, rep = hp.refine_placement(packets, out, draws=3, ballast_gb=0.0)
+                        scanned = len(srep["output_sets_ms"])
+                    except Exception:
+                        torch.cuda.empty_cache()
         inputs = [packets, packets.clone()]
         hp.ctx.timing(True)
         torch.cuda.synchronize()
@@ -505,7 +518,9 @@ def time_other_workloads(steps=12, placement="refine"):
                      "frac_step": round(nbytes / dt / 1e9 / HBM_PEAK_GBPS, 4),
                      "algorithmic_bytes_per_launch": int(nbytes), "validated": bool(ok), "max_abs_dxyz_m": worst,
                      "validated_frames": checked,
-                     "buffer_placement": "first allocation" if first_ms is None else "fastest of 3 back-to-back locations per buffer group",
+                     "buffer_placement": "first allocation" if first_ms is None else
+                                         ("fastest of 3 back-to-back locations per buffer group" +
+                                          (f", then of that and {scanned} further whole output sets, then per group again (like the headline)" if scanned else "")),
                      "first_allocation_ms_per_call": first_ms}
         del hp, packets, out, inputs
         torch.cuda.empty_cache()
@@ -811,6 +826,12 @@ def main():
     ap.add_argument("--placement-ballast-gb", type=float, default=0.0,
                     help="--placement refine: device memory held between two locations (0: back-to-back draws; 8 with 4 draws "
                          "is round 3's 35 GB form)")
+    ap.add_argument("--placement-scan-tries", type=int, default=10,
+                    help="--placement refine: whole output sets (one allocation per array, back to back) drawn AFTER the group-wise search, "
+                         "which stays a candidate (HotPath.pick_placement(slab=False) = DeviceFrameBatch::tune_placement).  About one process in "
+                         "three gets nothing but slow placements for its first allocations and the three back-to-back draws of the frugal "
+                         "search do not leave them (DESIGN.md 3.2).  0: the frugal search alone")
+    ap.add_argument("--placement-scan-stride-gb", type=float, default=4.0, help="device memory held (allocated, never touched) between two draws of the scan")
     ap.add_argument("--placement-stride-gb", type=float, default=4.0,
                     help="--placement draws: ballast held between two draws (they scan the device memory)")
     ap.add_argument("--placement-tries", type=int, default=24,
@@ -864,6 +885,14 @@ def main():
             coll = "RCCL %s via torch.distributed 'nccl', one rank per GPU" % ".".join(str(x) for x in torch.cuda.nccl.version())
         else:
             coll = f"{backend} (test transport, {int(ones.item())} ranks): RCCL was not used"
+
+    # The host-API rows (child processes: bench_host_api, bench_stream) are taken FIRST, while this process owns nothing on the GPU:
+    # measured behind the placement search -- tens of device-to-device clones and tens of GB allocated and freed by this process --
+    # the child's copy stream from the device ran at 27.8 GB/s instead of 50.7 (round 6; the headline and every resident row are
+    # unaffected either way)
+    drop_in_early = None
+    if rank == 0 and world == 1 and args.workload == "dual" and args.outputs == "full" and not args.no_extras:
+        drop_in_early = _report_row(time_drop_in)
 
     profile, bits, chan, dst_names, xyz_names, _, _, wl_label = WORKLOADS[args.workload]
     alt, az, shifts, b2l, l2s = synth_calibration()
@@ -932,6 +961,26 @@ def main():
             t_setup = time.perf_counter()
             out, placement = hp.refine_placement(packets, out, draws=args.placement_draws, ballast_gb=args.placement_ballast_gb)
             placement["mode"] = "refine"
+            # then whole output sets, one allocation per array, back to back (HotPath.pick_placement(slab=False) = what
+            # DeviceFrameBatch::tune_placement does): a process whose first allocations all landed badly -- about one in three --
+            # usually has a good set among its next ten; what the group-wise search kept is a candidate
+            per_draw = out_bytes + int(args.placement_scan_stride_gb * (1 << 30))
+            tries = min(args.placement_scan_tries, int(share * 0.6) // per_draw - 1) if world == 1 or not one_device else 0
+            if tries >= 2:
+                try:
+                    packets, out2, scan = hp.pick_placement(packets, make_outputs, tries=tries, launches=8,
+                                                            stride_gb=args.placement_scan_stride_gb, incumbent=out, slab=False)
+                    placement["scan"] = scan
+                    out = out2
+                    # ... and the group-wise search once more: its copies now land in the memory the scan has just given back,
+                    # which is where a process whose fresh allocations were all slow found its fast groups
+                    # (profiles/r06_latency/placement_notes.txt)
+                    out, rep2 = hp.refine_placement(packets, out, draws=args.placement_draws, ballast_gb=args.placement_ballast_gb)
+                    placement["after_scan"] = {k: rep2[k] for k in ("first_allocation_ms", "kept_ms", "groups")}
+                    placement["kept_ms"] = rep2["kept_ms"]
+                except Exception as e:   # what the group-wise search kept stands
+                    placement["scan"] = {"error": str(e)[:200]}
+                    torch.cuda.empty_cache()
             placement["setup_s"] = round(time.perf_counter() - t_setup, 3)
     for _ in range(args.warmup):
         hp.decode(packets, out)
@@ -1114,15 +1163,15 @@ def main():
     # every other BASELINE config and the small-batch latency view, in the driver-visible line
     other_workloads, latency, latency_python, standalone, drop_in = None, None, None, None, None
     if rank == 0 and world == 1 and args.workload == "dual" and args.outputs == "full" and not args.no_extras:
-        other_workloads = _report_row(time_other_workloads, placement="first" if args.placement == "first" else "refine")   # same default
+        other_workloads = _report_row(time_other_workloads, placement="first" if args.placement == "first" else "refine",
+                                      scan_tries=args.placement_scan_tries, scan_stride_gb=args.placement_scan_stride_gb)   # same default
         latency_python = _report_row(time_small_batches)
         latency = _report_row(time_latency_cpp, latency_python)
         if "error" in latency:      # the C++ helper is missing: the Python-timed rows are the only ones
             latency = latency_python
         torch.cuda.empty_cache()
         standalone = _report_row(time_standalone)
-        torch.cuda.empty_cache()
-        drop_in = _report_row(time_drop_in)
+        drop_in = drop_in_early
     # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot wrap a run from inside):
     # only quoted when the committed profile is of exactly this workload and output set.
     traffic, traffic_src = None, None
@@ -1179,8 +1228,15 @@ def main():
                        "buffer_placement": ("first allocation: the buffers as the allocator returned them "
                                             "(BatchOptions::auto_placement = false)"
                                             if (not placement or placement.get("mode") == "first") else
-                                            ("each buffer group at the fastest of %d locations %g GB apart (HotPath.refine_placement = what "
-                                             "DeviceFrameBatch does at construction with BatchOptions::auto_placement = true, the library's default)"
+                                            ((("each buffer group at the fastest of %d back-to-back locations, then the fastest of that and %d further "
+                                               "whole output sets and of up to 10 locations of the packet buffer (HotPath.pick_placement(slab=False) = "
+                                               "DeviceFrameBatch::tune_placement, a setup-time option of the library: about one process in three gets only "
+                                               "slow placements for its first allocations, DESIGN.md 3.2); with the library's default alone: "
+                                               % (placement["draws_per_group"], len(placement["scan"].get("output_sets_ms", []))))
+                                              if placement.get("scan") and "error" not in placement["scan"] else "") +
+                                             "each buffer group at the fastest of %d locations %g GB apart (HotPath.refine_placement = what "
+                                             "DeviceFrameBatch does at construction with BatchOptions::auto_placement = true, the library's default); "
+                                             "roofline.first_allocation_* is the same run on the buffers as the allocator first returned them"
                                              % (placement["draws_per_group"], args.placement_ballast_gb)) if placement["mode"] == "refine" else
                                             "DIAGNOSTIC: best of %d allocations of the output set (%.0f GB of ballast between "
                                             "two draws) and of up to 10 of the packet buffer (HotPath.pick_placement)"

@@ -96,7 +96,7 @@ class HotPath:
         return out
 
     def pick_placement(self, packets: torch.Tensor, make_outputs, tries: int = 16, launches: int = 12,
-                       stride_gb: float = 0.0):
+                       stride_gb: float = 0.0, incumbent: Optional[Dict[str, torch.Tensor]] = None, slab: bool = True):
         """Output buffers that live for the life of a pipeline are worth choosing: on MI355X the achieved
         write rate of the decode differs by 10 - 20 % between allocations of the SAME size made by the SAME
         process (tools/ab/alloc_lottery.py: the physical placement of an allocation is drawn when it is made
@@ -106,7 +106,11 @@ class HotPath:
         (packets, outputs, report).  Everything but the winners is freed.
         stride_gb > 0: hold that much ballast between two draws, so that `tries` draws scan the device memory
         instead of its first tries x (set size) -- which mode a draw gets follows where it lands
-        (tools/ab/ballast.py), and the fast regions can be tens of GB apart."""
+        (tools/ab/ballast.py), and the fast regions can be tens of GB apart.
+        incumbent: an output set the caller already has; it is timed first and is a candidate like every draw (the
+        result is then never slower than what the caller came with; report["incumbent_ms"]).
+        slab=False: a draw is make_outputs() as it is (one allocation per array) -- round 6: one slab per set is one physical
+        draw, but slabs themselves are 5 - 8 % slower than separately allocated arrays (tools/ab/_phase notes in DESIGN 3.2)."""
         def slab_set():
             tmpl = make_outputs()
             names = list(tmpl)
@@ -136,9 +140,18 @@ class HotPath:
         # the rejected draws stay allocated until the search is over: memory that has just been freed is what
         # the next allocation of the same size gets back, and it would be the same draw again
         best_out, best_ms, out_ms, held = None, None, [], []
-        for _ in range(max(1, tries)):
+        incumbent_ms = None
+        if incumbent is not None:
+            incumbent_ms = clock(packets, incumbent)
+            best_out, best_ms = incumbent, incumbent_ms
+            if stride_gb > 0:
+                try:
+                    held.append(torch.empty(int(stride_gb * (1 << 30)), dtype=torch.uint8, device="cuda"))
+                except RuntimeError:
+                    pass
+        for _ in range(max(1, tries) if incumbent is None else max(0, tries)):
             try:
-                cand = slab_set()
+                cand = slab_set() if slab else make_outputs()
             except RuntimeError:        # out of device memory: choose among the draws made so far
                 if best_out is None:
                     raise
@@ -186,8 +199,10 @@ class HotPath:
             for _ in range(24):
                 self.decode(best_pk, best_out)
             torch.cuda.synchronize()
-        return best_pk, best_out, {"tries": tries, "stride_gb": stride_gb, "output_sets_ms": out_ms,
-                                   "packet_buffers_ms": pk_ms}
+        rep = {"tries": tries, "stride_gb": stride_gb, "output_sets_ms": out_ms, "packet_buffers_ms": pk_ms}
+        if incumbent_ms is not None:
+            rep["incumbent_ms"] = round(incumbent_ms, 4)
+        return best_pk, best_out, rep
 
     def refine_placement(self, packets: torch.Tensor, out: Dict[str, torch.Tensor], draws: int = 4, launches: int = 10,
                          ballast_gb: float = 8.0):
