@@ -410,6 +410,33 @@ def test_pick_placement_returns_equivalent_buffers(oracle):
     _compare(O, cal, hp, out, [src[f % 4] for f in range(32)], ["RANGE", "REFLECTIVITY2"], ["RANGE", "RANGE2"])
 
 
+def test_placement_setup_sequence_keeps_the_bytes(oracle):
+    """bench.py's round-6 setup: refine_placement, pick_placement with per-array draws and the caller's set as a candidate
+    (slab=False, incumbent=out), refine_placement again.  Whatever wins is an ordinary set of buffers and decodes to the same
+    bytes; the report names the caller's set's time."""
+    O = oracle
+    cal = O.synthetic_calib(h=64, w=1024, profile="RNG15_RFL8_NIR8_DUAL")
+    packets, src = O.synth_packets(cal, 4, with_window=True)
+    hp = _hotpath(cal, "RNG15_RFL8_NIR8_DUAL")
+    d_pk = torch.from_numpy(packets).cuda().repeat(8, 1, 1).contiguous()
+    make = lambda: hp.alloc_outputs(32, destagger=["RANGE", "REFLECTIVITY2"], xyz=["RANGE", "RANGE2"])  # noqa: E731
+    plain = make()
+    hp.decode(d_pk, plain)
+    out = make()
+    out, rep1 = hp.refine_placement(d_pk, out, draws=2, launches=2, ballast_gb=0.0)
+    pk2, out, rep = hp.pick_placement(d_pk, make, tries=2, launches=2, stride_gb=0.0, incumbent=out, slab=False)
+    assert "incumbent_ms" in rep and len(rep["output_sets_ms"]) == 2
+    out, rep2 = hp.refine_placement(pk2, out, draws=2, launches=2, ballast_gb=0.0)
+    assert list(out) == list(plain)
+    for t in out.values():
+        t.view(torch.uint8).fill_(0x3C)
+    hp.decode(pk2, out)
+    hp.sync()
+    for k in plain:
+        assert out[k].dtype == plain[k].dtype and out[k].shape == plain[k].shape, k
+        assert torch.equal(out[k].view(torch.uint8), plain[k].view(torch.uint8)), k
+
+
 @pytest.mark.parametrize("label,wide", VARIANTS)
 @pytest.mark.parametrize("dt", ["f32", "f64"])
 def test_poses_fused_behind_the_cartesian(oracle, label, wide, dt):
