@@ -56,6 +56,13 @@ struct BatchOptions {
     bool auto_placement = true;
     int placement_draws = 3;
     size_t placement_ballast_bytes = 0;
+    /// Round 6, off by default (2 - 9 s and ~75 GB transient at construction): behind the search above, tune_placement(10, nullptr,
+    /// 4 GB) -- ten whole output sets drawn, the memory given back -- and the group-wise search once more.  About one fresh process
+    /// in three gets only slow placements for its first allocations (0.645 of the HBM roofline per decode where the same GPU
+    /// gives 0.70 - 0.75) and back-to-back draws do not leave them; the group-wise search run again in the memory the whole-set
+    /// draws gave back is what finds the fast groups (profiles/r06_latency/placement_notes.txt).  For pipelines
+    /// that live long enough to pay for it; needs auto_placement and an owned context like the search above.
+    bool placement_thorough = false;
     /// File with the kernel-variant tuner's verdicts of earlier processes (include/ouster_hip.h,
     /// ouster_hip_ctx_set_tuning_cache): a batch that finds its workload there launches the recorded variant from its first
     /// decode() and times nothing; one that has to measure appends its verdict.  Empty: the process-wide

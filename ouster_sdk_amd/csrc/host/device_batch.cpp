@@ -95,6 +95,10 @@ DeviceFrameBatch::DeviceFrameBatch(const std::vector<SensorInfo>& sensors, uint3
         if (hipMemsetAsync(d_packets_.data(), 0, d_packets_.size(), static_cast<hipStream_t>(ctx_->stream())) != hipSuccess)
             throw std::runtime_error("ouster_hip: hipMemset(packets) failed");
         refine_placement(opt_.placement_draws, nullptr, opt_.placement_ballast_bytes);
+        if (opt_.placement_thorough) {
+            tune_placement(10, nullptr, size_t{4} << 30);
+            refine_placement(opt_.placement_draws, nullptr, opt_.placement_ballast_bytes);
+        }
     }
 }
 
