@@ -110,7 +110,7 @@ class HotPath:
         incumbent: an output set the caller already has; it is timed first and is a candidate like every draw (the
         result is then never slower than what the caller came with; report["incumbent_ms"]).
         slab=False: a draw is make_outputs() as it is (one allocation per array) -- round 6: one slab per set is one physical
-        draw, but slabs themselves are 5 - 8 % slower than separately allocated arrays (tools/ab/alloc_lottery.py slab, profiles/r06_latency/placement_notes.txt)."""
+        draw, but slabs themselves tend to be slower than separately allocated arrays (tools/ab/alloc_lottery.py slab, profiles/r06_latency/placement_notes.txt)."""
         def slab_set():
             tmpl = make_outputs()
             names = list(tmpl)
