@@ -22,10 +22,16 @@ Setup before the W warm-up steps (none of it inside the timed region, all of it 
   * buffer placement, `--placement refine` (default): the frugal search that ouster::sdk::hip::DeviceFrameBatch runs by itself
     when it is constructed (BatchOptions::auto_placement = true, the library's default since round 5): two more copies of
     the output set are allocated back to back (6.6 GB transient for 256 dual-return frames, 0.1 s) and every buffer group (XYZ
-    pair, 32-bit planes, destaggered planes, narrow planes) is kept at the fastest of its three locations.  "placement" and
-    roofline.first_allocation_* report the first allocation's time next to the kept one (1 - 9 % slower).  `--placement
-    first` takes the first allocation as it comes (auto_placement = false) and reports the search beside it
-    (roofline.searched_placement_*); `--placement draws` is the round-2 diagnostic;
+    pair, 32-bit planes, destaggered planes, narrow planes) is kept at the fastest of its three locations -- then, since round 6
+    (`--placement-scan-tries`, default 10; 0 switches it off), what BatchOptions::placement_thorough adds: ten whole output sets
+    drawn 4 GB apart (the set kept so far is a candidate), their memory given back, the group-wise search once more (2 - 9 s,
+    ~75 GB transient).  One fresh process in three draws only slow placements for its first allocations (0.645 of the roofline per
+    step where the same GPU gives 0.70 - 0.75) and the back-to-back draws never leave them; the second group-wise search, in the
+    memory the whole sets gave back, does (profiles/r06_latency/placement_notes.txt).  "placement" reports every
+    draw and roofline.first_allocation_* the first allocation's time next to the kept one.  `--placement first` takes the first
+    allocation as it comes (auto_placement = false) and reports the search beside it (roofline.searched_placement_*);
+    `--placement draws` is the round-2 diagnostic;
+  * the host-API rows ("drop_in": child processes) are taken before this process owns anything on the GPU;
   * after the K timed steps the outputs are compared with the oracle ("validated", "max_abs_dxyz_m").
 The timed steps rotate over `--rotate-inputs` copies of the packet batch (default 2: no step finds its input in the
 256 MB Infinity Cache).  After the timed region the paths the metric never touches are timed on the same buffers and
