@@ -980,6 +980,32 @@ static void test_device_batch() {
         }
         CHECK(wworst <= 1e-4f);
     }
+    {   // BatchOptions::placement_thorough (round 6): a batch of 64 frames settles its buffers at construction -- group-wise search,
+        // whole sets drawn, group-wise search again -- and decodes to the same bytes as the plain one
+        ouster::sdk::hip::BatchOptions topt = opt;
+        topt.placement_thorough = true;
+        ouster::sdk::hip::DeviceFrameBatch tb(sensors, 64, topt);
+        for (uint32_t f = 0; f < 64; ++f) {
+            auto packets = impl::frame_to_packets(src[f % n], pf, a.init_id, a.sn);
+            std::vector<const uint8_t*> ptrs;
+            for (size_t i = 0; i < packets.size(); ++i)
+                if (!(f % n == 2 && i == 5)) ptrs.push_back(packets[i].buf.data());
+            tb.upload_frame_packets(f, ptrs);
+        }
+        tb.decode();
+        bool same = true;
+        for (uint32_t f : {0u, 2u, 63u}) {
+            img_t<uint32_t> r0(128, 1024), r1(128, 1024);
+            PointCloudXYZf x0(128 * 1024), x1(128 * 1024);
+            batch.download_plane("RANGE", f % n, r0.data(), true);
+            tb.download_plane("RANGE", f, r1.data(), true);
+            batch.download_xyz(0, f % n, x0.data());
+            tb.download_xyz(0, f, x1.data());
+            same &= r0 == r1;
+            if ((f % n) % 2 == f % 2) same &= std::memcmp(x0.data(), x1.data(), x0.size() * sizeof(float)) == 0;   // same sensor's LUT
+        }
+        CHECK(same);
+    }
     const uint64_t total = batch.dewarp(1.0, 150.0, true);
     CHECK(total > 0 && batch.dewarped_frame_offsets().size() == n + 1 &&
           batch.dewarped_frame_offsets().back() == total);
