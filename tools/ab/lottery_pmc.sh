@@ -15,9 +15,18 @@ if [ -n "$LOTTERY_CHANNELS" ]; then
   python $R/tools/ab/lottery_pmc.py --channels $O
   exit 0
 fi
-for set in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_PENDING_STALL_CYCLES_sum" \
-           "TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_sum TCC_TAG_STALL_sum" \
-           "GRBM_GUI_ACTIVE TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
+# round 6: LOTTERY_TRANSLATION=1 looks at the second level of address translation instead (UTCL2 busy cycles, first-level misses
+# under a miss, stalls for UTCL2 credits): profiles/r06_latency/placement_notes.txt items 7 - 9
+if [ -n "$LOTTERY_TRANSLATION" ]; then
+  SETS=("GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum" \
+        "TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_REQUEST_sum" \
+        "TCP_UTCL1_SERIALIZATION_STALL_sum TCP_UTCL1_THRASHING_STALL_sum TCP_UTCL1_LFIFO_FULL_sum TCP_PENDING_STALL_CYCLES_sum")
+else
+  SETS=("TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_PENDING_STALL_CYCLES_sum" \
+        "TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_sum TCC_TAG_STALL_sum" \
+        "GRBM_GUI_ACTIVE TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum")
+fi
+for set in "${SETS[@]}"; do
   i=$((i+1))
   timeout 120 rocprofv3 --pmc $set --output-format csv -d $O/p$i -o p -- python $R/tools/ab/lottery_pmc.py > $O/out$i.txt 2> $O/err$i.txt || tail -3 $O/err$i.txt
   tail -1 $O/out$i.txt
