@@ -1271,6 +1271,12 @@ def main():
             line["roofline"]["first_allocation_ms_per_call"] = placement["first_allocation_ms"]
             line["roofline"]["first_allocation_frac_step"] = round(
                 bytes_per_launch / (placement["first_allocation_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        if placement and isinstance(placement.get("scan"), dict) and placement["scan"].get("incumbent_ms"):
+            # ... and what the library's default search alone had reached before the whole sets were drawn (same clock: 8 back-to-back
+            # decodes into the buffers it kept) -- three numbers for one run: first allocation, library default, this setup
+            line["roofline"]["library_default_search_ms_per_call"] = placement["scan"]["incumbent_ms"]
+            line["roofline"]["library_default_search_frac_step"] = round(
+                bytes_per_launch / (placement["scan"]["incumbent_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         if placement and "search_after_timed_region" in placement:   # default: what the opt-in search would have given
             rep = placement["search_after_timed_region"]
             line["roofline"]["searched_placement_ms_per_call"] = rep["kept_ms"]
